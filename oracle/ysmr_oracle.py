@@ -1,0 +1,421 @@
+"""CPU oracle for the YSMR detect-and-link hot path -- TEST INFRASTRUCTURE, never product code.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  ``ysmr_amd`` (the product) never does; it fails loudly without its HIP library.
+
+Two halves:
+
+* image half (a1-a6): ctypes wrapper around ``oracle/ysmr_oracle.c`` (see its header for the
+  restated OpenCV algorithms and the "parity unpinned" note for a1/a2/a3/a5/a6; a4 is pinned
+  against ``scipy.ndimage.binary_propagation`` in tests/test_oracle_image.py);
+* link half (a7-a19): NumPy/SciPy restatement of ``ysmr/tracker.py:27-230`` and
+  ``ysmr/gsff.py:28-347``, pinned bit-for-bit against the imported reference by
+  ``tests/golden/gen_golden.py`` (fixtures committed under tests/golden/).
+
+The link half deliberately keeps the reference's per-track Python loop structure (it is also the
+CPU baseline timed by bench.py), but holds state in flat lists/arrays instead of OrderedDicts.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+from scipy.spatial.distance import cdist
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libysmr_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/ysmr_oracle.c with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "ysmr_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def _c():
+    global _lib
+    if _lib is None:
+        build()
+        lib = ctypes.CDLL(_SO)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        ci = ctypes.c_int
+        lib.yo_bgr2gray.argtypes = [u8p, ci, ci, u8p]
+        lib.yo_blur3.argtypes = [u8p, ci, ci, u8p]
+        lib.yo_gauss11.argtypes = [f32p]
+        lib.yo_adaptive_mean.argtypes = [u8p, ci, ci, u8p]
+        lib.yo_classify.argtypes = [u8p, u8p, ctypes.c_long, ci, ci, ci, ci, u8p]
+        lib.yo_propagate.argtypes = [u8p, ci, ci, u8p]
+        lib.yo_label8.argtypes = [u8p, ci, ci, i32p]
+        lib.yo_min_area_rect_xy.argtypes = [i32p, ci, f32p]
+        lib.yo_components.argtypes = [u8p, ci, ci, i32p, f32p, i32p, ci]
+        lib.yo_components.restype = ci
+        lib.yo_detect_frame.argtypes = [u8p, ci, ci, ci, ci, ci, ci, ci, u8p, u8p, i32p, f32p,
+                                        i32p, ci]
+        lib.yo_detect_frame.restype = ci
+        for f in (lib.yo_bgr2gray, lib.yo_blur3, lib.yo_gauss11, lib.yo_adaptive_mean,
+                  lib.yo_classify, lib.yo_propagate, lib.yo_label8, lib.yo_min_area_rect_xy):
+            f.restype = None
+        _lib = lib
+    return _lib
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(ctypes.POINTER(ty))
+
+
+# ------------------------------------------------------------------------------------------------
+# image half
+# ------------------------------------------------------------------------------------------------
+def threshold_params(white_on_dark: bool, offset, adt):
+    """Integer form of the two cv2.adaptiveThreshold calls (ysmr/track_eval.py:127-132, 185-208).
+
+    cv2 computes ``idelta = ceil(C)`` (THRESH_BINARY) or ``floor(C)`` (THRESH_BINARY_INV) and sets a
+    pixel iff ``s - m > -idelta`` resp. ``s - m <= -idelta``.  The reference negates
+    the offset for dark-on-bright videos before use (track_eval.py:132).
+    Returns (inv, t_low, t_high, use_high) with use_high False when adt == 0;
+    adt < 0 selects the out-of-scope mean-gray branch and raises.
+    """
+    if adt < 0:
+        raise ValueError("adaptive double threshold < 0: mean-gray branch is out of scope")
+    inv = not white_on_dark
+    off = -offset if inv else offset
+    c1 = off * -1
+    c2 = (off + adt) * -1
+    if inv:
+        t_low, t_high = -math.floor(c1), -math.floor(c2)
+    else:
+        t_low, t_high = -math.ceil(c1), -math.ceil(c2)
+    return int(inv), int(t_low), int(t_high), int(adt > 0)
+
+
+def gauss11():
+    k = np.zeros(11, np.float32)
+    _c().yo_gauss11(_p(k, ctypes.c_float))
+    return k
+
+
+def bgr2gray(bgr):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w = bgr.shape[:2]
+    out = np.empty((h, w), np.uint8)
+    _c().yo_bgr2gray(_p(bgr, ctypes.c_uint8), h, w, _p(out, ctypes.c_uint8))
+    return out
+
+
+def blur3(gray):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    out = np.empty_like(gray)
+    _c().yo_blur3(_p(gray, ctypes.c_uint8), gray.shape[0], gray.shape[1], _p(out, ctypes.c_uint8))
+    return out
+
+
+def adaptive_mean(blurred):
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    out = np.empty_like(blurred)
+    _c().yo_adaptive_mean(_p(blurred, ctypes.c_uint8), blurred.shape[0], blurred.shape[1],
+                          _p(out, ctypes.c_uint8))
+    return out
+
+
+def classify(blurred, mean, inv, t_low, t_high, use_high):
+    out = np.empty_like(blurred)
+    _c().yo_classify(_p(blurred, ctypes.c_uint8), _p(mean, ctypes.c_uint8), blurred.size, inv,
+                     t_low, t_high, use_high, _p(out, ctypes.c_uint8))
+    return out
+
+
+def propagate(cls):
+    cls = np.ascontiguousarray(cls, np.uint8)
+    out = np.empty_like(cls)
+    _c().yo_propagate(_p(cls, ctypes.c_uint8), cls.shape[0], cls.shape[1], _p(out, ctypes.c_uint8))
+    return out
+
+
+def label8(fg):
+    fg = np.ascontiguousarray(fg, np.uint8)
+    out = np.empty(fg.shape, np.int32)
+    _c().yo_label8(_p(fg, ctypes.c_uint8), fg.shape[0], fg.shape[1], _p(out, ctypes.c_int32))
+    return out
+
+
+def min_area_rect(points_xy):
+    """points_xy: (n, 2) integer pixel coordinates -> (cx, cy, w, h, angle) float32."""
+    xy = np.ascontiguousarray(points_xy, np.int32).reshape(-1, 2)
+    rect = np.zeros(5, np.float32)
+    _c().yo_min_area_rect_xy(_p(xy, ctypes.c_int32), xy.shape[0], _p(rect, ctypes.c_float))
+    return rect
+
+
+def components(fg, max_det=None):
+    fg = np.ascontiguousarray(fg, np.uint8)
+    h, w = fg.shape
+    if max_det is None:
+        max_det = h * w // 2 + 1
+    labels = np.empty((h, w), np.int32)
+    det = np.zeros((max_det, 5), np.float32)
+    anchors = np.zeros(max_det, np.int32)
+    n = _c().yo_components(_p(fg, ctypes.c_uint8), h, w, _p(labels, ctypes.c_int32),
+                           _p(det, ctypes.c_float), _p(anchors, ctypes.c_int32), max_det)
+    m = min(n, max_det)
+    return labels, det[:m].copy(), anchors[:m].copy(), n
+
+
+@dataclass
+class FrameDetections:
+    cls: np.ndarray
+    mask: np.ndarray
+    labels: np.ndarray
+    det: np.ndarray       # (M, 5) float32: cx, cy, w, h, angle
+    anchors: np.ndarray   # (M,) int32
+    count: int
+
+
+def detect_frame(frame, inv=0, t_low=5, t_high=7, use_high=1, max_det=None) -> FrameDetections:
+    """The image half of one loop iteration (track_eval.py:180-303) on an (H,W) or (H,W,3) frame."""
+    frame = np.ascontiguousarray(frame, np.uint8)
+    h, w = frame.shape[:2]
+    ch = 1 if frame.ndim == 2 else frame.shape[2]
+    if max_det is None:
+        max_det = 65536
+    cls = np.empty((h, w), np.uint8)
+    mask = np.empty((h, w), np.uint8)
+    labels = np.empty((h, w), np.int32)
+    det = np.zeros((max_det, 5), np.float32)
+    anchors = np.zeros(max_det, np.int32)
+    n = _c().yo_detect_frame(_p(frame, ctypes.c_uint8), h, w, ch, inv, t_low, t_high, use_high,
+                             _p(cls, ctypes.c_uint8), _p(mask, ctypes.c_uint8),
+                             _p(labels, ctypes.c_int32), _p(det, ctypes.c_float),
+                             _p(anchors, ctypes.c_int32), max_det)
+    m = min(n, max_det)
+    return FrameDetections(cls, mask, labels, det[:m].copy(), anchors[:m].copy(), n)
+
+
+def det_to_rects(det):
+    """(M,5) float32 -> the reference's rects list [((x, y), (w, h, deg)), ...]
+    (reshape_result, ysmr/helper_file.py:1336-1347); values become Python floats like cv2's."""
+    return [((float(d[0]), float(d[1])), (float(d[2]), float(d[3]), float(d[4]))) for d in det]
+
+
+# ------------------------------------------------------------------------------------------------
+# link half: GaussianSumFIR (ysmr/gsff.py) and CentroidTracker (ysmr/tracker.py)
+# ------------------------------------------------------------------------------------------------
+def horizon_sizes(n_min, n_max, n_f):
+    """gsff.py:87-109: n_i = int(n_min + p*i), p = (n_max - n_min)/n_f, i = 1..n_f."""
+    step = (n_max - n_min) / n_f
+    return [int(n_min + step * i) for i in range(1, n_f + 1)]
+
+
+def lsf_gain(size, dt, a=None, c=None):
+    """gsff.py:111-153: gain = (L^T L)^-1 L^T with L = H_bar A^-N, H_bar = [C; CA; ...; CA^(N-1)]."""
+    if a is None:
+        a = np.array([[1, 0, dt, 0], [0, 1, 0, dt], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    if c is None:
+        c = np.array([[1, 0, 0, 0], [0, 1, 0, 0]])
+    rows = c
+    power = a
+    for _ in range(size - 1):
+        rows = np.concatenate((rows, np.dot(c, power)), axis=0)
+        power = np.dot(power, a)
+    big_l = np.dot(rows, np.linalg.matrix_power(np.linalg.inv(a), size))
+    return np.dot(np.linalg.inv(np.dot(big_l.T, big_l)), big_l.T)
+
+
+@dataclass
+class GsffState:
+    """Per-track filter memory (the kwargs dict the reference threads through correct/predict)."""
+    mode: int = 0
+    history: list | None = None          # list of measurement vectors, newest last
+    weights: np.ndarray | None = None
+    likelihoods: list | None = None
+    x_hat: np.ndarray | None = None      # (dim, mode)
+
+
+class OracleGSFF:
+    def __init__(self, delta_t, n_min=0, n_max=30, n_f=3, a=None, c=None,
+                 likelihood_minimum=10 ** -20, inv_cov=None, x_hat_array_length=2):
+        self.lik_min = likelihood_minimum
+        self.dim = x_hat_array_length
+        self.n_f = n_f
+        self.n_i = horizon_sizes(n_min, n_max, n_f)
+        self.gains = [lsf_gain(n, delta_t, a, c) for n in self.n_i]
+        self.inv_cov = np.linalg.inv(np.eye(2)) if inv_cov is None else inv_cov
+
+    # gsff.py:156-177
+    def _fir(self, idx, history):
+        n = self.n_i[idx]
+        flat = [v for m in history[-n:] for v in m]
+        return np.dot(self.gains[idx], flat)
+
+    # gsff.py:179-202 (the FloatingPointError handlers are dead code under NumPy defaults)
+    def _likelihood(self, z, y_hat):
+        d = z - y_hat
+        lik = np.exp(-0.5 * np.dot(d.T, np.dot(self.inv_cov, d)))
+        return self.lik_min if lik < self.lik_min else lik
+
+    def _refresh(self, st: GsffState):
+        for i in range(st.mode):
+            st.x_hat[:, i] = self._fir(i, st.history)[: self.dim]
+
+    # gsff.py:204-249
+    def predict(self, st: GsffState):
+        if st.history is None:
+            return None
+        self._refresh(st)
+        return np.sum(st.x_hat * st.weights, axis=1)
+
+    # gsff.py:251-347
+    def correct(self, z, st: GsffState):
+        if st.history is None:
+            st.history = [z] * self.n_i[0]
+        grew = False
+        if st.mode < self.n_f:
+            while len(st.history) >= self.n_i[st.mode]:
+                st.mode += 1
+                grew = True
+                if st.mode >= self.n_f:
+                    break
+        if grew:
+            st.likelihoods = [self.lik_min] * st.mode
+            st.x_hat = np.zeros((self.dim, st.mode))
+            st.weights = 1 / st.mode * np.ones(st.mode)
+            self._refresh(st)
+        for i in range(st.mode):
+            st.likelihoods[i] = self._likelihood(z, st.x_hat[:, i][:2])
+        st.history.append(z)
+        keep = self.n_i[-1] + 1
+        if len(st.history) > keep:
+            st.history = st.history[-keep:]
+        total = sum(st.likelihoods * st.weights)
+        for i in range(st.weights.shape[0]):
+            st.weights[i] = st.likelihoods[i] * st.weights[i] / total
+        return np.sum(st.x_hat * st.weights, axis=1)
+
+
+@dataclass
+class _Track:
+    tid: int
+    pos: np.ndarray
+    info: object
+    gone: int = 0
+    gs: GsffState = field(default_factory=GsffState)
+
+
+class OracleTracker:
+    """Restatement of CentroidTracker (ysmr/tracker.py:27-230).
+
+    ``update(rects)`` returns ``(ids, xy, info, claims)``: ids in dict-iteration order of the
+    reference (= ascending id), xy the filtered (or raw) positions (n,2) float64, info the list
+    of (w,h,deg) tuples or [0,0,0] lists, claims the list of (row, col) pairs accepted this frame.
+    Tie order of equal row minima: stable (min, row) -- the reference's default argsort is
+    unspecified there.  New-track id order follows CPython set iteration
+    (see update()); product code reproduces it with an explicit model of CPython's set table.
+    """
+
+    def __init__(self, max_disappeared=50, fps=30, n_min=0, n_max=None, n_f=3, use_gsff=True):
+        self.max_gone = max_disappeared
+        self.use_gsff = use_gsff
+        self.next_id = 0
+        self.tracks: list[_Track] = []
+        if use_gsff:
+            if n_max is None:
+                n_max = fps
+            self.gsff = OracleGSFF(delta_t=1 / fps, n_min=n_min, n_max=n_max, n_f=n_f,
+                                   likelihood_minimum=10 ** -20,
+                                   inv_cov=np.linalg.inv(np.eye(2)), x_hat_array_length=2)
+
+    def _register(self, pos, info):
+        self.tracks.append(_Track(self.next_id, pos, info))
+        self.next_id += 1
+
+    def _age(self, tr: _Track):
+        """tracker.py:100-107 / 204-211; returns True when the track must be dropped."""
+        tr.gone += 1
+        tr.info = [0] * len(tr.info)
+        return tr.gone > self.max_gone
+
+    def update(self, rects):
+        claims = []
+        if len(rects) == 0:
+            self.tracks = [t for t in self.tracks if not self._age(t)]
+        else:
+            pts = np.zeros((len(rects), len(rects[0][0])), dtype="float")
+            infos = []
+            for i, (xy, info) in enumerate(rects):
+                pts[i] = xy
+                infos.append(info)
+            if not self.tracks:
+                for i in range(len(pts)):
+                    self._register(pts[i], infos[i])
+            else:
+                cur = np.array([t.pos for t in self.tracks])
+                d = cdist(cur, pts)
+                order = np.argsort(d.min(axis=1), kind="stable")
+                nearest = d.argmin(axis=1)[order]
+                rows_used, cols_used = set(), set()
+                for r, c in zip(order, nearest):
+                    if r in rows_used or c in cols_used:
+                        continue
+                    tr = self.tracks[r]
+                    tr.pos = pts[c]
+                    tr.info = infos[c]
+                    tr.gone = 0
+                    rows_used.add(r)
+                    cols_used.add(c)
+                    claims.append((int(r), int(c)))
+                n_tr, n_det = d.shape
+                if n_tr >= n_det:
+                    dead = set()
+                    for r in range(n_tr):
+                        if r not in rows_used and self._age(self.tracks[r]):
+                            dead.add(r)
+                    if dead:
+                        self.tracks = [t for i, t in enumerate(self.tracks) if i not in dead]
+                else:
+                    # tracker.py:193,216 iterates a Python *set*: new ids are handed out in
+                    # CPython's hash-table order of set(range(M)).difference(used), which is NOT
+                    # ascending in general (e.g. {5, 40} iterates 40, 5).  Restated literally.
+                    for c in set(range(0, n_det)).difference(cols_used):
+                        self._register(pts[c], infos[c])
+        ids = [t.tid for t in self.tracks]
+        info = [t.info for t in self.tracks]
+        if self.use_gsff:
+            out = np.zeros((len(self.tracks), 2))
+            for i, t in enumerate(self.tracks):
+                out[i] = self.gsff.correct(t.pos, t.gs)
+                t.pos = self.gsff.predict(t.gs)
+        else:
+            out = np.array([t.pos for t in self.tracks], dtype=float).reshape(-1, 2)
+        return ids, out, info, claims
+
+
+# ------------------------------------------------------------------------------------------------
+# whole path: frames -> rows, mirroring the body of track_bacteria (track_eval.py:156-366)
+# ------------------------------------------------------------------------------------------------
+def track_frames(frames, fps=30.0, white_on_dark=True, offset=5, adt=2.0, use_gsff=True,
+                 n_min=0, n_max=30, n_f=3, max_det=65536, tracker=None, frame0=0):
+    """Run detect+link over an iterable of frames.  Returns (rows, tracker) with rows a list of
+    (frame, id, x, y, w, h, deg) -- one per live track per frame (track_eval.py:313-316)."""
+    inv, t_low, t_high, use_high = threshold_params(white_on_dark, offset, adt)
+    if tracker is None:
+        tracker = OracleTracker(max_disappeared=fps, fps=fps, n_min=n_min, n_max=n_max, n_f=n_f,
+                                use_gsff=use_gsff)
+    rows = []
+    for k, frame in enumerate(frames):
+        fd = detect_frame(frame, inv, t_low, t_high, use_high, max_det)
+        ids, xy, info, _ = tracker.update(det_to_rects(fd.det))
+        for i, tid in enumerate(ids):
+            w, h, deg = info[i]
+            rows.append((frame0 + k, tid, float(xy[i][0]), float(xy[i][1]), float(w), float(h),
+                         float(deg)))
+    return rows, tracker
