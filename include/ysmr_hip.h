@@ -1,0 +1,150 @@
+/*
+ * ysmr_hip.h -- C ABI of libysmr_hip.so: the MI355X (gfx950) implementation of YSMR's per-frame
+ * detect-and-link hot path.  Plain pointers and sizes only; every pointer named *_dev is a HIP
+ * device pointer owned by the caller (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  No entry point allocates on the per-frame path
+ * (ysmr_tracker_create/destroy own the tracker state).  Every function returns 0 (YSMR_OK) or a
+ * YSMR_ERR_* code and never throws -- mirroring the reference's "log + return None" convention
+ * (ysmr/track_eval.py:50-77, ysmr/main.py:92-95); ysmr_last_error() gives the message.
+ *
+ * Reference interfaces replaced (files under /root/reference):
+ *   ysmr_threshold_batch  cv2.cvtColor + cv2.GaussianBlur + 2 x cv2.adaptiveThreshold
+ *                         ysmr/track_eval.py:180-208
+ *   ysmr_detect_batch     the above + scipy binary_propagation + cv2.findContours +
+ *                         cv2.minAreaRect + reshape_result
+ *                         ysmr/track_eval.py:180-303, ysmr/helper_file.py:1336-1347
+ *   ysmr_tracker_*        CentroidTracker.__init__/update   ysmr/tracker.py:37-71, 93-230
+ *                         GaussianSumFIR.correct/predict    ysmr/gsff.py:204-347
+ *                         row emission                      ysmr/track_eval.py:313-316
+ *   ysmr_gsff_gains       GaussianSumFIR.generate_n_i/compute_lsf_gain  ysmr/gsff.py:87-153
+ */
+#ifndef YSMR_HIP_H
+#define YSMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YSMR_OK            0
+#define YSMR_ERR_ARG       1   /* bad argument (null pointer, size, unsupported option) */
+#define YSMR_ERR_HIP       2   /* a HIP runtime call failed */
+#define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
+#define YSMR_ERR_STATE     4   /* handle used in the wrong state */
+
+#define YSMR_ABI_VERSION   1
+
+/* per-frame detection status bits (status_dev) */
+#define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
+#define YSMR_DET_ARENA     2   /* geometry scratch arena exhausted: some rectangles missing */
+
+/* One output row: a live track in one frame (ysmr/track_eval.py:313-316,
+ * CSV columns TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE). */
+typedef struct ysmr_row {
+    int32_t frame;        /* POSITION_T */
+    int32_t track_id;     /* TRACK_ID */
+    double  x, y;         /* POSITION_X/Y: GSFF-filtered (or raw when GSFF is disabled) */
+    float   w, h, angle;  /* WIDTH, HEIGHT, DEGREES_ANGLE; all 0 while the track is "disappeared" */
+    int32_t disappeared;  /* consecutive frames without a detection (0 = matched this frame) */
+} ysmr_row;
+
+typedef struct ysmr_tracker ysmr_tracker; /* opaque; bound to one device + used from one thread */
+
+int         ysmr_abi_version(void);
+const char *ysmr_last_error(void);        /* message of the calling thread's last failing call */
+
+/* ---- detection: a1-a6 ------------------------------------------------------------------- */
+
+/* Bytes of scratch ysmr_detect_batch needs for this geometry. */
+size_t ysmr_detect_workspace_bytes(int batch, int height, int width, int max_det);
+
+/* a1-a3 fused.  frames_dev: u8 [batch][height][width][channels], channels 1 (gray) or 3 (BGR).
+ * cls_dev: u8 [batch][height][width] (allocation rounded up to a multiple of 16 bytes):
+ *   bit0 = `thresh`  (1st adaptiveThreshold call), bit1 = `markers` (2nd call).
+ * inv = 0: THRESH_BINARY (bit set iff s - mean > t); inv = 1: THRESH_BINARY_INV (s - mean <= t).
+ * use_high = 0 reproduces "adaptive double threshold = 0": bit1 mirrors bit0. */
+int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
+                         int channels, int inv, int t_low, int t_high, int use_high,
+                         uint8_t *cls_dev);
+
+/* a1-a6.  Outputs (all device):
+ *   cls_dev     u8  [batch][H][W]  class map as above (bit2 is used internally as a flag)
+ *   mask_dev    u8  [batch][H][W]  final mask {0,255} == binary_propagation(markers, mask=thresh)
+ *                                  (may be NULL)
+ *   labels_dev  i32 [batch][H][W]  0 = background, else 1 + raster index of the first pixel of
+ *                                  the 8-connected component of the final mask (required: it is
+ *                                  also the union-find array)
+ *   det_count_dev i32 [batch]      detections per frame (<= max_det written)
+ *   det_dev     f32 [batch][max_det][5]  cx, cy, w, h, angle_deg of cv2.minAreaRect, in
+ *                                  cv2.findContours(RETR_EXTERNAL) order (reverse raster order
+ *                                  of first pixels; components nested in a hole are skipped)
+ *   anchors_dev i32 [batch][max_det]  raster index of each detection's first pixel (may be NULL)
+ *   status_dev  i32 [batch]        YSMR_DET_* bits
+ */
+int ysmr_detect_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
+                      int channels, int inv, int t_low, int t_high, int use_high,
+                      void *workspace_dev, size_t workspace_bytes, uint8_t *cls_dev,
+                      uint8_t *mask_dev, int32_t *labels_dev, int32_t *det_count_dev,
+                      float *det_dev, int32_t *anchors_dev, int max_det, int32_t *status_dev);
+
+/* ---- linking: a7-a19 -------------------------------------------------------------------- */
+
+/* Horizon sizes n_i (gsff.py:87-109) and rows 0/1 of each least-squares gain (gsff.py:111-153,
+ * closed form of the default constant-velocity model).  n_max <= 0 means "None -> fps".
+ * n_i_out: n_f ints.  gains_out (may be NULL): for filter i, 2 rows x 2*n_i[i] doubles, filters
+ * concatenated.  Returns YSMR_ERR_ARG for horizons that are not strictly increasing and >= 1. */
+int ysmr_gsff_gains(double fps, int n_min, double n_max, int n_f, int32_t *n_i_out,
+                    double *gains_out);
+
+/* CentroidTracker(max_disappeared, fps, n_min, n_max, n_f, use_gsff).  capacity = maximum number
+ * of simultaneously live tracks, max_det = maximum detections per frame.  gains_host may be NULL
+ * (closed form) or point to host memory laid out as ysmr_gsff_gains() writes it. */
+int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_max, int n_f,
+                        int use_gsff, int capacity, int max_det, const double *gains_host,
+                        ysmr_tracker **out);
+int ysmr_tracker_destroy(ysmr_tracker *t);
+int ysmr_tracker_reset(ysmr_tracker *t, void *stream);
+
+/* One CentroidTracker.update(rects).  det_dev: [m][5] = cx, cy, w, h, angle; f32 as written by
+ * ysmr_detect_batch (det_is_f64 = 0) or f64 (det_is_f64 = 1; for callers holding float64
+ * centroids, like the reference's input_centroids, tracker.py:111).  m >= 0: detection count known
+ * on the host; m < 0: read it from *m_dev (device i32, clamped to max_det).
+ * Outputs (device, each may be NULL):
+ *   rows_dev      ysmr_row [capacity]  one row per live track after the update, ascending id
+ *   n_rows_dev    i32                  number of rows
+ *   claim_col_dev i32 [capacity]       for each track row BEFORE the update (ascending id):
+ *                                      claimed detection column or -1
+ *   n_before_dev  i32                  number of tracks before the update
+ *   new_cols_dev  i32 [max_det]        detection columns registered as new tracks, in id order
+ *   n_new_dev     i32
+ */
+int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int det_is_f64, int m,
+                        const int32_t *m_dev, int32_t frame_index, ysmr_row *rows_dev,
+                        int32_t *n_rows_dev, int32_t *claim_col_dev, int32_t *n_before_dev,
+                        int32_t *new_cols_dev, int32_t *n_new_dev);
+
+/* The frame loop of track_bacteria for `batch` consecutive frames whose detections are already
+ * on the device: det_dev f32 [batch][max_det][5], det_count_dev i32 [batch].  Rows are appended
+ * to rows_dev (capacity rows_capacity) starting at *row_count_dev, which is advanced; rows of a
+ * frame are contiguous and in ascending id order.  Overflow sets *row_count_dev past capacity
+ * (rows beyond capacity are dropped); the host checks after synchronising. */
+int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev,
+                     const int32_t *det_count_dev, int batch, int32_t first_frame_index,
+                     ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev);
+
+/* Current track table in id order: ids i32 [capacity], positions f64 [capacity][2] (the
+ * CentroidTracker.objects values: GSFF predictions, or raw centroids without GSFF), disappeared
+ * counters, count.  Device outputs, each may be NULL. */
+int ysmr_tracker_peek(ysmr_tracker *t, void *stream, int32_t *ids_dev, double *xy_dev,
+                      int32_t *disappeared_dev, int32_t *n_dev);
+
+/* Host-visible counters (synchronises the stream): live tracks, next id, sticky error bits. */
+int ysmr_tracker_info(ysmr_tracker *t, void *stream, int32_t *n_tracks, int32_t *next_id,
+                      int32_t *error_bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YSMR_HIP_H */

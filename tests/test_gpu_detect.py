@@ -1,0 +1,151 @@
+"""GPU parity (run with -m gpu on the MI355X box): HIP detection path vs the CPU oracle.
+
+Bit-exact: class maps (thresholded masks), final mask, label map, detection count/order
+(anchors), rectangle centre and size.  The rectangle angle goes through a float64 atan2 whose
+device implementation is not correctly rounded; it may differ by one float32 ulp.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def _detect_gpu(torch, frames, params=None, max_det=4096):
+    from ysmr_amd.detect import Detector, threshold_params
+    frames = np.ascontiguousarray(frames)
+    b, h, w = frames.shape[:3]
+    det = Detector(b, h, w, max_det=max_det, params=params or threshold_params(True, 5, 2.0))
+    res = det.detect(torch.from_numpy(frames).cuda())
+    torch.cuda.synchronize()
+    return {k: getattr(res, k).cpu().numpy() for k in ("cls", "mask", "labels", "det_count", "det", "anchors", "status")}
+
+
+def _assert_angle_close(a, b):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    ok = (a == b) | (np.abs(a - b) <= np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)))
+    assert ok.all(), (a[~ok], b[~ok])
+
+
+def _compare(oracle, frames, got, params, max_det=4096):
+    for f in range(frames.shape[0]):
+        ref = oracle.detect_frame(frames[f], params.inv, params.t_low, params.t_high, params.use_high, max_det)
+        assert got["status"][f] == 0
+        np.testing.assert_array_equal(got["cls"][f] & 3, ref.cls, err_msg=f"cls frame {f}")
+        np.testing.assert_array_equal(got["mask"][f], ref.mask, err_msg=f"mask frame {f}")
+        np.testing.assert_array_equal(got["labels"][f], ref.labels, err_msg=f"labels frame {f}")
+        assert got["det_count"][f] == ref.count, f"count frame {f}"
+        n = ref.count
+        np.testing.assert_array_equal(got["anchors"][f][:n], ref.anchors)
+        np.testing.assert_array_equal(got["det"][f][:n, :4], ref.det[:, :4], err_msg=f"rect frame {f}")
+        _assert_angle_close(got["det"][f][:n, 4], ref.det[:, 4])
+
+
+def test_threshold_only_matches_oracle(torch_cuda, oracle):
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    torch = torch_cuda
+    rng = np.random.default_rng(0)
+    for (h, w) in [(1, 1), (5, 7), (13, 300), (64, 64), (97, 131), (200, 260)]:
+        frames = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+        if h >= 64:
+            frames[0] = SyntheticVideo(h, w, 12, seed=h).next_frame()
+        for args in [(True, 5, 2.0), (False, 5, 2.0), (True, 3, 0.0), (True, 5, 2.5)]:
+            p = threshold_params(*args)
+            d = Detector(2, h, w, max_det=64, params=p)
+            cls = d.threshold(torch.from_numpy(frames).cuda()).cpu().numpy()
+            for f in range(2):
+                blur = oracle.blur3(frames[f])
+                ref = oracle.classify(blur, oracle.adaptive_mean(blur), p.inv, p.t_low, p.t_high, p.use_high)
+                np.testing.assert_array_equal(cls[f], ref, err_msg=f"{h}x{w} {args} frame {f}")
+
+
+def test_threshold_bgr(torch_cuda, oracle):
+    from ysmr_amd.detect import Detector
+    torch = torch_cuda
+    rng = np.random.default_rng(1)
+    frames = rng.integers(0, 256, (2, 70, 90, 3), dtype=np.uint8)
+    d = Detector(2, 70, 90, max_det=64)
+    cls = d.threshold(torch.from_numpy(frames).cuda()).cpu().numpy()
+    for f in range(2):
+        blur = oracle.blur3(oracle.bgr2gray(frames[f]))
+        ref = oracle.classify(blur, oracle.adaptive_mean(blur), 0, 5, 7, 1)
+        np.testing.assert_array_equal(cls[f], ref)
+
+
+def test_detect_synthetic_video(torch_cuda, oracle):
+    from ysmr_amd.detect import threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    p = threshold_params(True, 5, 2.0)
+    frames = SyntheticVideo(300, 412, 80, seed=2).frames(5)      # W, H*W not multiples of 16
+    _compare(oracle, frames, _detect_gpu(torch_cuda, frames, p), p)
+    frames = SyntheticVideo(922, 1228, 500, seed=3).frames(2)     # the benchmark geometry
+    _compare(oracle, frames, _detect_gpu(torch_cuda, frames, p), p)
+
+
+def test_detect_dense_noise_stresses_union_find(torch_cuda, oracle):
+    """Uniform noise gives dense, convoluted masks: long union-find chains, holes, nesting."""
+    from ysmr_amd.detect import threshold_params
+    rng = np.random.default_rng(4)
+    frames = rng.integers(0, 256, (3, 150, 201), dtype=np.uint8)
+    frames[1] = (rng.random((150, 201)) < 0.5) * np.uint8(200) + 20
+    for args in [(True, 5, 2.0), (True, 1, 0.0), (False, 5, 2.0)]:
+        p = threshold_params(*args)
+        _compare(oracle, frames, _detect_gpu(torch_cuda, frames, p, max_det=16384), p, max_det=16384)
+
+
+def test_detect_nested_component_is_skipped(torch_cuda, oracle):
+    from ysmr_amd.detect import threshold_params
+    p = threshold_params(True, 5, 2.0)
+    img = np.full((120, 160), 40, np.uint8)
+    yy, xx = np.mgrid[0:120, 0:160]
+    r = np.hypot(yy - 60, xx - 80)
+    img[(r > 14) & (r < 18)] = 210          # ring
+    img[(np.hypot(yy - 60, xx - 80) < 2.5)] = 210   # dot inside the ring's hole
+    img[20:23, 20:28] = 200                 # ordinary blob
+    img[(np.hypot(yy - 100, xx - 30) > 5) & (np.hypot(yy - 100, xx - 30) < 8)] = 220  # small ring, empty hole
+    frames = np.stack([img, np.full_like(img, 40)])
+    got = _detect_gpu(torch_cuda, frames, p)
+    _compare(oracle, frames, got, p)
+    ref = oracle.detect_frame(img)
+    n_comp = len(np.unique(ref.labels)) - 1
+    assert ref.count == n_comp - 1          # exactly the nested dot is dropped
+    assert got["det_count"][1] == 0
+
+
+def test_detect_empty_and_full(torch_cuda, oracle):
+    from ysmr_amd.detect import threshold_params
+    p = threshold_params(True, 5, 2.0)
+    frames = np.stack([np.zeros((40, 50), np.uint8), np.full((40, 50), 255, np.uint8)])
+    got = _detect_gpu(torch_cuda, frames, p)
+    _compare(oracle, frames, got, p)
+    assert list(got["det_count"]) == [0, 0]
+
+
+def test_detect_overflow_is_flagged(torch_cuda):
+    from ysmr_amd import _lib
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (1, 100, 100), dtype=np.uint8)
+    got = _detect_gpu(torch_cuda, frames, max_det=8)
+    assert got["status"][0] & _lib.DET_OVERFLOW
+    assert got["det_count"][0] <= 8
+
+
+def test_large_component_uses_arena(torch_cuda, oracle):
+    """A blob wider than the LDS hull fast path (and one with a big hole) goes through the arena."""
+    from ysmr_amd.detect import threshold_params
+    p = threshold_params(True, 5, 2.0)
+    img = np.full((200, 300), 30, np.uint8)
+    yy, xx = np.mgrid[0:200, 0:300]
+    img[np.abs((yy - 100) * 0.4 + (xx - 150) * 0.2) < 2.0] = 220       # long slanted bar
+    r = np.hypot(yy - 100, xx - 60)
+    img[(r > 35) & (r < 38)] = 220                                     # big ring (window > LDS? no, but wide hull)
+    img[95:99, 55:62] = 220                                            # nested blob
+    frames = img[None]
+    _compare(oracle, frames, _detect_gpu(torch_cuda, frames, p), p)

@@ -1,0 +1,131 @@
+"""GPU parity (run with -m gpu): HIP tracker/GSFF vs (a) fixtures captured from the reference's
+own tracker.py/gsff.py and (b) the CPU oracle.
+
+Integer quantities (ids, claims, counters, disappeared) are exact.  GSFF-smoothed positions:
+north_star allows 1e-5 relative; the device differs from NumPy only through summation order of the
+FIR dot products and exp(), so the tests hold it to 1e-9.
+"""
+import numpy as np
+import pytest
+
+from conftest import compare_rows, golden, rects_of, tracker_frames
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+ATOL = 1e-9   # pixels; positions that are exactly 0 in exact arithmetic come out as rounding noise
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+TRACKER_CASES = [("tracker_small_gsff.npz", None), ("tracker_small_nogsff.npz", None), ("tracker_mid_gsff.npz", None),
+                 ("tracker_gap.npz", 5), ("tracker_2997.npz", 6)]
+
+
+@pytest.mark.parametrize("name,max_gone", TRACKER_CASES)
+def test_centroid_tracker_matches_reference_fixture(torch_cuda, name, max_gone):
+    from ysmr_amd.tracker import CentroidTracker
+    g = golden(name)
+    fps = float(g["fps"])
+    n_max = None if int(g["n_max"]) < 0 else int(g["n_max"])
+    ct = CentroidTracker(max_disappeared=fps if max_gone is None else max_gone, fps=fps, n_min=int(g["n_min"]),
+                         n_max=n_max, n_f=int(g["n_f"]), use_gsff=bool(g["use_gsff"]), capacity=1024, max_det=1024)
+    off, coff = g["off"], g["claim_off"]
+    for f, (det, info) in enumerate(tracker_frames(g)):
+        objs, infos = ct.update(rects_of(det, info))
+        sl = slice(off[f], off[f + 1])
+        assert list(objs.keys()) == list(g["ids"][sl]), f"ids frame {f}"
+        np.testing.assert_allclose(np.array(list(objs.values())).reshape(-1, 2), g["xy"][sl], rtol=RTOL, atol=ATOL,
+                                   err_msg=f"xy frame {f}")
+        got_info = np.array([list(infos[i]) for i in objs.keys()], dtype=float).reshape(-1, 3)
+        np.testing.assert_array_equal(got_info, g["info"][sl], err_msg=f"info frame {f}")
+        assert list(ct.disappeared.values()) == list(g["disappeared"][sl]), f"disappeared frame {f}"
+        assert ct.nextObjectID == g["next_id"][f]
+        assert sorted(ct.last_claims) == sorted(map(tuple, g["claims"][coff[f]:coff[f + 1]].tolist())), f"claims {f}"
+
+
+GSFF_CASES = [("gsff_smooth_default.npz", 30.0, 0, 30, 3), ("gsff_jump_default.npz", 30.0, 0, 30, 3),
+              ("gsff_turn_default.npz", 30.0, 0, 30, 3), ("gsff_lost_default.npz", 30.0, 0, 30, 3),
+              ("gsff_smooth_2997.npz", 29.97, 0, 29.97, 3), ("gsff_jump_nf4.npz", 25.0, 4, 24, 4)]
+
+
+@pytest.mark.parametrize("name,fps,n_min,n_max,n_f", GSFF_CASES)
+def test_gsff_class_matches_reference_fixture(torch_cuda, name, fps, n_min, n_max, n_f):
+    from ysmr_amd.gsff import GaussianSumFIR
+    g = golden(name)
+    f = GaussianSumFIR(delta_t=1 / fps, n_min=n_min, n_max=n_max, n_f=n_f)
+    assert f.n_i == list(g["n_i"])
+    state = {}
+    for k, z in enumerate(g["fed"]):
+        c, state = f.correct(measurement=np.array(z), **state)
+        p, state = f.predict(**state)
+        assert state["mode"] == g["mode"][k]
+        np.testing.assert_allclose(c, g["correct"][k], rtol=RTOL, atol=ATOL, err_msg=f"correct step {k}")
+        np.testing.assert_allclose(p, g["predict"][k], rtol=RTOL, atol=ATOL, err_msg=f"predict step {k}")
+
+
+def test_new_ids_follow_cpython_set_order(torch_cuda, oracle):
+    """tracker.py:216 iterates a set: ids of tracks born in one frame follow CPython's hash-table
+    order.  The device model must reproduce it for every mix of claimed/unclaimed columns."""
+    from ysmr_amd.tracker import CentroidTracker
+    rng = np.random.default_rng(11)
+    for trial in range(25):
+        n0 = int(rng.integers(1, 120))
+        extra = int(rng.integers(1, 200))
+        base = rng.uniform(0, 5000, (n0, 2))
+        ct = CentroidTracker(max_disappeared=30, fps=30.0, use_gsff=False, capacity=1024, max_det=1024)
+        ot = oracle.OracleTracker(max_disappeared=30, fps=30.0, use_gsff=False)
+        info = np.zeros((n0, 3))
+        ct.update(rects_of(base, info)); ot.update(rects_of(base, info))
+        pts = np.vstack([base + rng.normal(0, 0.01, base.shape), rng.uniform(6000, 9000, (extra, 2))])
+        pts = pts[rng.permutation(len(pts))]
+        info = np.zeros((len(pts), 3))
+        objs, _ = ct.update(rects_of(pts, info))
+        ids, xy, _, _ = ot.update(rects_of(pts, info))
+        assert list(objs.keys()) == ids
+        np.testing.assert_array_equal(np.array(list(objs.values())), xy, err_msg=f"trial {trial}")
+
+
+def test_distance_ties_take_lowest_column_and_row(torch_cuda, oracle):
+    from ysmr_amd.tracker import CentroidTracker
+    ct = CentroidTracker(max_disappeared=30, fps=30.0, use_gsff=False, capacity=64, max_det=64)
+    ot = oracle.OracleTracker(max_disappeared=30, fps=30.0, use_gsff=False)
+    start = [((0.0, 0.0), (1, 1, 0)), ((10.0, 0.0), (1, 1, 0)), ((20.0, 5.0), (1, 1, 0))]
+    # detections equidistant from track 0 / two tracks equidistant from one detection
+    nxt = [((3.0, 4.0), (2, 2, 0)), ((-3.0, 4.0), (3, 3, 0)), ((5.0, 0.0), (4, 4, 0)), ((20.0, 5.0), (5, 5, 0))]
+    for rects in (start, nxt, nxt):
+        objs, infos = ct.update(rects)
+        ids, xy, info, claims = ot.update(rects)
+        assert list(objs.keys()) == ids
+        np.testing.assert_array_equal(np.array(list(objs.values())), xy)
+        assert sorted(ct.last_claims) == sorted(claims)
+        assert [list(infos[i]) for i in ids] == [list(i) for i in info]
+
+
+def test_pipeline_rows_match_oracle(torch_cuda, oracle):
+    """frames -> HIP detect -> HIP link (device resident, batched) vs the CPU oracle end to end."""
+    torch = torch_cuda
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    from ysmr_amd import _lib
+    n_frames, h, w = 48, 240, 320
+    frames = SyntheticVideo(h, w, 40, seed=7, dropout=0.05, speckle=0.05).frames(n_frames)
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0)
+    det = Detector(16, h, w, max_det=256, params=threshold_params(True, 5, 2.0))
+    trk = DeviceTracker(max_disappeared=30.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=256, max_det=256)
+    rows = torch.empty(n_frames * 256 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    dev = torch.from_numpy(frames).cuda()
+    for f0 in range(0, n_frames, 16):
+        res = det.detect(dev[f0:f0 + 16])
+        trk.run(res.det, res.det_count, f0, rows, count)
+    torch.cuda.synchronize()
+    assert trk.info()[2] == 0
+    got = rows_to_numpy(rows, int(count.item()))
+    n_loose = compare_rows(got, ref_rows)
+    assert 0 < n_loose < len(got) // 2

@@ -1,0 +1,85 @@
+"""ctypes binding of libysmr_hip.so (include/ysmr_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object has not been
+built (``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C ysmr_amd/csrc``) every
+entry point raises :class:`YsmrLibraryError`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libysmr_hip.so")
+
+YSMR_OK = 0
+DET_OVERFLOW = 1
+DET_ARENA = 2
+
+#: numpy view of ``struct ysmr_row`` (40 bytes)
+ROW_DTYPE = np.dtype([("frame", "<i4"), ("track_id", "<i4"), ("x", "<f8"), ("y", "<f8"),
+                      ("w", "<f4"), ("h", "<f4"), ("angle", "<f4"), ("disappeared", "<i4")])
+
+EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_threshold_batch",
+           "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
+           "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_peek",
+           "ysmr_tracker_info")
+
+
+class YsmrLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle with argtypes set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YsmrLibraryError(
+            f"{LIB_PATH} is missing: build the HIP library first (make -C ysmr_amd/csrc, or "
+            "__graft_entry__.build()). ysmr_amd has no CPU fallback.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover
+        raise YsmrLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    L.ysmr_abi_version.restype = ci
+    L.ysmr_last_error.restype = ctypes.c_char_p
+    L.ysmr_detect_workspace_bytes.argtypes = [ci, ci, ci, ci]
+    L.ysmr_detect_workspace_bytes.restype = ctypes.c_size_t
+    L.ysmr_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.ysmr_detect_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, vp, vp,
+                                    vp, vp, vp, ci, vp]
+    L.ysmr_gsff_gains.argtypes = [cd, ci, cd, ci, vp, vp]
+    L.ysmr_tracker_create.argtypes = [cd, cd, ci, cd, ci, ci, ci, ci, vp, ctypes.POINTER(vp)]
+    L.ysmr_tracker_destroy.argtypes = [vp]
+    L.ysmr_tracker_reset.argtypes = [vp, vp]
+    L.ysmr_tracker_update.argtypes = [vp, vp, vp, ci, ci, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp]
+    L.ysmr_tracker_peek.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ysmr_tracker_run.argtypes = [vp, vp, vp, vp, ci, ctypes.c_int32, vp, ctypes.c_int64, vp]
+    L.ysmr_tracker_info.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                    ctypes.POINTER(ctypes.c_int32)]
+    for name in EXPORTS:
+        if name not in ("ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_abi_version"):
+            getattr(L, name).restype = ci
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    """Map a non-zero status to an exception carrying ysmr_last_error()."""
+    if rc != YSMR_OK:
+        msg = lib().ysmr_last_error().decode("utf-8", "replace")
+        raise YsmrLibraryError(f"{what} failed (code {rc}): {msg}")
+
+
+def stream_ptr():
+    """The current torch HIP stream as a hipStream_t value."""
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

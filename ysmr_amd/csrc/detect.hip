@@ -1,0 +1,917 @@
+// detect.hip -- a1-a6 of the YSMR hot path on gfx950: fused gray -> 3x3 blur -> 11x11 Gaussian
+// adaptive double threshold (k_threshold), 4-connected hysteresis + 8-connected component
+// labelling on a lock-free union-find that lives in the label map (k_union4 .. k_flatten),
+// RETR_EXTERNAL ordering/nesting (k_rank, k_bbox_euler, k_outside_*), and per-component
+// minAreaRect (k_geometry).  Reference call sites: ysmr/track_eval.py:180-303.
+//
+// All kernels are batched over frames (detection is frame-parallel); the per-pixel passes walk
+// the batch as one flat byte array in 16-byte chunks so that any H, W is handled with aligned
+// 128-bit accesses, and do work only for the (sparse) foreground.
+//
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
+#include "common.h"
+#include <cfloat>
+#include <cmath>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// k_threshold: a1-a3
+// ------------------------------------------------------------------------------------------
+constexpr int TW = 64, TH = 32;            // output tile per 256-thread block
+constexpr int GW = TW + 12, GH = TH + 12;  // gray halo   (blur 1 + gaussian 5 on each side)
+constexpr int BW = TW + 10, BH = TH + 10;  // blurred halo
+
+struct Gauss11 { float k[11]; };
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ frames,
+                                                   uint8_t *__restrict__ cls, int H, int W,
+                                                   Gauss11 gk, int inv, int t_low, int t_high,
+                                                   int use_high)
+{
+    __shared__ uint8_t s_gray[GH][GW + 4];
+    __shared__ uint8_t s_blur[BH][BW + 2];
+    __shared__ float s_row[BH][TW + 1];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const size_t frame_px = (size_t)H * W;
+    const uint8_t *src = frames + (size_t)blockIdx.z * frame_px * CH;
+
+    // gray halo at absolute coordinates (y0-6.., x0-6..); out-of-image entries are never read
+    for (int i = tid; i < GH * GW; i += 256) {
+        int r = i / GW, c = i - r * GW;
+        int gy = y0 - 6 + r, gx = x0 - 6 + c;
+        uint8_t v = 0;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (CH == 1) {
+                v = src[(size_t)gy * W + gx];
+            } else {
+                const uint8_t *p = src + ((size_t)gy * W + gx) * 3;
+                v = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + 16384) >> 15);
+            }
+        }
+        s_gray[r][c] = v;
+    }
+    __syncthreads();
+
+    // 3x3 blur (REFLECT_101) evaluated at coordinates clamped to the image (REPLICATE for the 11x11)
+    for (int i = tid; i < BH * BW; i += 256) {
+        int r = i / BW, c = i - r * BW;
+        int yy = clampi(y0 - 5 + r, 0, H - 1), xx = clampi(x0 - 5 + c, 0, W - 1);
+        int ym = reflect101(yy - 1, H) - (y0 - 6), yc = yy - (y0 - 6), yp = reflect101(yy + 1, H) - (y0 - 6);
+        int xm = reflect101(xx - 1, W) - (x0 - 6), xc = xx - (x0 - 6), xp = reflect101(xx + 1, W) - (x0 - 6);
+        int s = s_gray[ym][xm] + 2 * s_gray[ym][xc] + s_gray[ym][xp] +
+                2 * (s_gray[yc][xm] + 2 * s_gray[yc][xc] + s_gray[yc][xp]) +
+                s_gray[yp][xm] + 2 * s_gray[yp][xc] + s_gray[yp][xp];
+        s_blur[r][c] = (uint8_t)((s + 8) >> 4);
+    }
+    __syncthreads();
+
+    // row pass: ascending FMA chain from zero
+    for (int i = tid; i < BH * TW; i += 256) {
+        int r = i / TW, c = i - r * TW;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) s = fmaf((float)s_blur[r][c + k], gk.k[k], s);
+        s_row[r][c] = s;
+    }
+    __syncthreads();
+
+    // column pass (symmetric form), round-half-even, compare
+    for (int i = tid; i < TH * TW; i += 256) {
+        int r = i / TW, c = i - r * TW;
+        int y = y0 + r, x = x0 + c;
+        if (y >= H || x >= W) continue;
+        float s = fmaf(s_row[r + 5][c], gk.k[5], 0.0f);
+#pragma unroll
+        for (int j = 1; j <= 5; ++j) s = fmaf(s_row[r + 5 + j][c] + s_row[r + 5 - j][c], gk.k[5 + j], s);
+        int m = clampi((int)rintf(s), 0, 255);
+        int d = (int)s_blur[r + 5][c + 5] - m;
+        int lo = inv ? (d <= t_low) : (d > t_low);
+        int hi = use_high ? (inv ? (d <= t_high) : (d > t_high)) : lo;
+        cls[(size_t)blockIdx.z * frame_px + (size_t)y * W + x] = (uint8_t)(lo | (hi << 1));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Union-find in the label map.  labels[p] holds (parent index + 1); 0 = not a node.
+// The smaller raster index always becomes the root, so a component's root is its first pixel.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t DEAD = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t ld_node(const uint32_t *L, uint32_t i)
+{
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t find_root(const uint32_t *L, uint32_t p)
+{
+    uint32_t v = ld_node(L, p);
+    while (true) {
+        if (v == 0) return DEAD;
+        if (v - 1 == p) return p;
+        p = v - 1;
+        v = ld_node(L, p);
+    }
+}
+
+__device__ __forceinline__ void unite(uint32_t *L, uint32_t a, uint32_t b)
+{
+    while (true) {
+        a = find_root(L, a);
+        b = find_root(L, b);
+        if (a == b || a == DEAD || b == DEAD) return;
+        if (a < b) { uint32_t t = a; a = b; b = t; }
+        uint32_t old = atomicMin(&L[a], b + 1);
+        if (old == a + 1) return;
+        a = old - 1;
+    }
+}
+
+struct Geo {
+    int H, W;
+    uint32_t HW;
+    size_t total;  // batch * H * W
+};
+
+// flat batch index -> frame, pixel, y, x
+__device__ __forceinline__ void locate(const Geo &g, size_t flat, uint32_t &f, uint32_t &p, int &y, int &x)
+{
+    f = (uint32_t)(flat / g.HW);
+    p = (uint32_t)(flat - (size_t)f * g.HW);
+    y = (int)(p / (uint32_t)g.W);
+    x = (int)(p - (uint32_t)y * (uint32_t)g.W);
+}
+
+// Load the 16 class bytes of chunk `c` (zero beyond the end of the batch).
+__device__ __forceinline__ uint4 load_chunk(const uint8_t *cls, size_t c, size_t total)
+{
+    size_t base = c * 16;
+    if (base + 16 <= total) return *reinterpret_cast<const uint4 *>(cls + base);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16 && base + i < total; ++i) w[i >> 2] |= (uint32_t)cls[base + i] << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint32_t chunk_byte(const uint4 &v, int i)
+{
+    uint32_t w = (i < 8) ? (i < 4 ? v.x : v.y) : (i < 12 ? v.z : v.w);
+    return (w >> (8 * (i & 3))) & 0xFFu;
+}
+
+// Pass A: every pixel with a class bit becomes its own root.
+__global__ __launch_bounds__(256) void k_init_labels(const uint8_t *__restrict__ cls,
+                                                     uint32_t *__restrict__ labels, Geo g, size_t nchunks)
+{
+    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    uint4 v = load_chunk(cls, c, g.total);
+    size_t base = c * 16;
+    uint32_t out[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint32_t b = chunk_byte(v, i) & 3u;
+        size_t flat = base + i;
+        uint32_t f = (uint32_t)(flat / g.HW);
+        out[i] = b ? (uint32_t)(flat - (size_t)f * g.HW) + 1u : 0u;
+    }
+    if (base + 16 <= g.total) {
+        uint4 *dst = reinterpret_cast<uint4 *>(labels + base);
+        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+        dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
+        dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
+    } else {
+        for (int i = 0; i < 16 && base + i < g.total; ++i) labels[base + i] = out[i];
+    }
+}
+
+// Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
+__global__ __launch_bounds__(256) void k_union4(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
+                                                size_t nchunks)
+{
+    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    uint4 v = load_chunk(cls, c, g.total);
+    if (((v.x | v.y | v.z | v.w) & 0x01010101u) == 0) return;
+    size_t base = c * 16;
+    for (int i = 0; i < 16; ++i) {
+        if (!(chunk_byte(v, i) & 1u)) continue;
+        size_t flat = base + i;
+        uint32_t f, p; int y, x;
+        locate(g, flat, f, p, y, x);
+        uint32_t *L = labels + (size_t)f * g.HW;
+        if (x > 0 && (cls[flat - 1] & 1u)) unite(L, p, p - 1);
+        if (y > 0 && (cls[flat - g.W] & 1u)) unite(L, p, p - (uint32_t)g.W);
+    }
+}
+
+__device__ __forceinline__ void set_flag(uint8_t *cls, size_t flat)
+{
+    uint32_t *w = reinterpret_cast<uint32_t *>(cls) + (flat >> 2);
+    atomicOr(w, 4u << (8 * (flat & 3)));
+}
+
+// Pass C: flag (bit2 on the root's class byte) every thresh-component that holds a marker pixel
+// or touches (4-neighbourhood) a marker pixel lying outside the mask.
+__global__ __launch_bounds__(256) void k_flag(uint8_t *cls, const uint32_t *labels, Geo g, size_t nchunks)
+{
+    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    uint4 v = load_chunk(cls, c, g.total);
+    if (((v.x | v.y | v.z | v.w) & 0x02020202u) == 0) return;
+    size_t base = c * 16;
+    for (int i = 0; i < 16; ++i) {
+        uint32_t b = chunk_byte(v, i);
+        if (!(b & 2u)) continue;
+        size_t flat = base + i;
+        uint32_t f, p; int y, x;
+        locate(g, flat, f, p, y, x);
+        const uint32_t *L = labels + (size_t)f * g.HW;
+        size_t fbase = (size_t)f * g.HW;
+        if (b & 1u) {
+            set_flag(cls, fbase + find_root(L, p));
+        } else {
+            if (x > 0 && (cls[flat - 1] & 1u)) set_flag(cls, fbase + find_root(L, p - 1));
+            if (x < g.W - 1 && (cls[flat + 1] & 1u)) set_flag(cls, fbase + find_root(L, p + 1));
+            if (y > 0 && (cls[flat - g.W] & 1u)) set_flag(cls, fbase + find_root(L, p - g.W));
+            if (y < g.H - 1 && (cls[flat + g.W] & 1u)) set_flag(cls, fbase + find_root(L, p + g.W));
+        }
+    }
+}
+
+// Membership in the final mask R = binary_propagation(markers, mask=thresh).
+__device__ __forceinline__ bool in_result(const uint8_t *cls_frame, const uint32_t *L, uint32_t p, uint32_t b)
+{
+    if (b & 2u) return true;
+    if (!(b & 1u)) return false;
+    uint32_t r = find_root(L, p);
+    return r != DEAD && (cls_frame[r] & 6u) != 0;
+}
+
+// Pass D: 8-connected components of R (what cv2.findContours traces).
+__global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
+                                                size_t nchunks)
+{
+    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    uint4 v = load_chunk(cls, c, g.total);
+    if (((v.x | v.y | v.z | v.w) & 0x03030303u) == 0) return;
+    size_t base = c * 16;
+    for (int i = 0; i < 16; ++i) {
+        uint32_t b = chunk_byte(v, i);
+        if (!(b & 3u)) continue;
+        size_t flat = base + i;
+        uint32_t f, p; int y, x;
+        locate(g, flat, f, p, y, x);
+        uint32_t *L = labels + (size_t)f * g.HW;
+        const uint8_t *cf = cls + (size_t)f * g.HW;
+        if (!in_result(cf, L, p, b)) continue;
+        const int W = g.W;
+        // W, NW, N, NE
+        if (x > 0) { uint32_t q = p - 1, bq = cf[q]; if ((bq & 3u) && !((b & bq) & 1u) && in_result(cf, L, q, bq)) unite(L, p, q); }
+        if (y > 0) {
+            uint32_t q = p - W, bq = cf[q];
+            if ((bq & 3u) && !((b & bq) & 1u) && in_result(cf, L, q, bq)) unite(L, p, q);
+            if (x > 0) { q = p - W - 1; bq = cf[q]; if ((bq & 3u) && in_result(cf, L, q, bq)) unite(L, p, q); }
+            if (x < W - 1) { q = p - W + 1; bq = cf[q]; if ((bq & 3u) && in_result(cf, L, q, bq)) unite(L, p, q); }
+        }
+    }
+}
+
+// Pass E: final labels (root + 1), final mask, list of roots per frame.
+__global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls, uint32_t *labels,
+                                                 uint8_t *__restrict__ mask, Geo g, size_t nchunks,
+                                                 int32_t *nroots, int32_t *roots, int max_det)
+{
+    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    uint4 v = load_chunk(cls, c, g.total);
+    size_t base = c * 16;
+    uint32_t mw[4] = {0, 0, 0, 0};
+    if (((v.x | v.y | v.z | v.w) & 0x03030303u) != 0) {
+        for (int i = 0; i < 16; ++i) {
+            uint32_t b = chunk_byte(v, i);
+            if (!(b & 3u)) continue;
+            size_t flat = base + i;
+            uint32_t f = (uint32_t)(flat / g.HW);
+            uint32_t p = (uint32_t)(flat - (size_t)f * g.HW);
+            uint32_t *L = labels + (size_t)f * g.HW;
+            const uint8_t *cf = cls + (size_t)f * g.HW;
+            uint32_t r = find_root(L, p);
+            bool inr = (r != DEAD) && ((b & 2u) || (cf[r] & 6u));
+            if (inr) {
+                if (r != p) __hip_atomic_store(&L[p], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mw[i >> 2] |= 0xFFu << (8 * (i & 3));
+                if (r == p) {
+                    int idx = atomicAdd(&nroots[f], 1);
+                    if (idx < max_det) roots[(size_t)f * max_det + idx] = (int32_t)p;
+                }
+            } else {
+                __hip_atomic_store(&L[p], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (mask) {
+        if (base + 16 <= g.total) *reinterpret_cast<uint4 *>(mask + base) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+        else for (int i = 0; i < 16 && base + i < g.total; ++i) mask[base + i] = (uint8_t)(mw[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Ordering (reverse raster order of first pixels), bounding boxes, Euler numbers
+// ------------------------------------------------------------------------------------------
+struct CompTables {
+    int32_t *nroots;   // [B]
+    int32_t *roots;    // [B][max_det] unordered
+    int32_t *order;    // [B][max_det] roots sorted descending (= findContours order)
+    int32_t *bbox;     // [B][max_det][4] minx, maxx, miny, maxy
+    int32_t *euler4;   // [B][max_det] 4 * Euler number (8-connectivity)
+    int32_t *nested;   // [B][max_det] component lies in a hole of another one
+    int max_det;
+};
+
+__global__ __launch_bounds__(256) void k_rank(CompTables t, int W, int H, int32_t *status)
+{
+    const int f = blockIdx.x;
+    int n = t.nroots[f];
+    if (n > t.max_det) {
+        if (threadIdx.x == 0) atomicOr(&status[f], YSMR_DET_OVERFLOW);
+        n = t.max_det;
+    }
+    const int32_t *roots = t.roots + (size_t)f * t.max_det;
+    __shared__ int32_t tile[1024];
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        int i = i0 + threadIdx.x;
+        int32_t mine = i < n ? roots[i] : -1;
+        int rank = 0;
+        for (int j0 = 0; j0 < n; j0 += 1024) {
+            __syncthreads();
+            for (int j = threadIdx.x; j < 1024 && j0 + j < n; j += 256) tile[j] = roots[j0 + j];
+            __syncthreads();
+            int m = min(1024, n - j0);
+            for (int j = 0; j < m; ++j) rank += tile[j] > mine;
+        }
+        if (i < n) {
+            size_t o = (size_t)f * t.max_det + rank;
+            t.order[o] = mine;
+            t.bbox[o * 4 + 0] = W; t.bbox[o * 4 + 1] = -1; t.bbox[o * 4 + 2] = H; t.bbox[o * 4 + 3] = -1;
+            t.euler4[o] = 0;
+            t.nested[o] = 0;
+        }
+    }
+}
+
+// index of `root` in the descending list order[0..n)
+__device__ __forceinline__ int find_rank(const int32_t *order, int n, int32_t root)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (order[mid] > root) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && order[lo] == root) ? lo : -1;
+}
+
+// Per final-mask pixel: bounding box of its component; bit-quad counts for the Euler number
+// (E8 = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows, each window counted by its first set pixel).
+__global__ __launch_bounds__(256) void k_bbox_euler(const uint32_t *__restrict__ labels, Geo g, size_t nchunks,
+                                                    CompTables t)
+{
+    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    size_t base = c * 16;
+    uint32_t lab[16];
+    if (base + 16 <= g.total) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(labels + base);
+        uint4 a = src[0], b = src[1], cc = src[2], d = src[3];
+        if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | cc.x | cc.y | cc.z | cc.w | d.x | d.y | d.z | d.w) == 0) return;
+        lab[0] = a.x; lab[1] = a.y; lab[2] = a.z; lab[3] = a.w; lab[4] = b.x; lab[5] = b.y; lab[6] = b.z; lab[7] = b.w;
+        lab[8] = cc.x; lab[9] = cc.y; lab[10] = cc.z; lab[11] = cc.w; lab[12] = d.x; lab[13] = d.y; lab[14] = d.z; lab[15] = d.w;
+    } else {
+        for (int i = 0; i < 16; ++i) lab[i] = (base + i < g.total) ? labels[base + i] : 0u;
+    }
+    for (int i = 0; i < 16; ++i) {
+        if (!lab[i]) continue;
+        size_t flat = base + i;
+        uint32_t f, p; int y, x;
+        locate(g, flat, f, p, y, x);
+        int n = min(t.nroots[f], t.max_det);
+        int k = find_rank(t.order + (size_t)f * t.max_det, n, (int32_t)(lab[i] - 1));
+        if (k < 0) continue;  // component beyond max_det (overflow already flagged)
+        size_t o = (size_t)f * t.max_det + k;
+        const uint32_t *L = labels + (size_t)f * g.HW;
+        const int W = g.W, H = g.H;
+        auto at = [&](int yy, int xx) -> int {
+            return (yy >= 0 && yy < H && xx >= 0 && xx < W && L[(size_t)yy * W + xx] != 0) ? 1 : 0;
+        };
+        int nw = at(y - 1, x - 1), nn = at(y - 1, x), ne = at(y - 1, x + 1);
+        int ww = at(y, x - 1), ee = at(y, x + 1);
+        int sw = at(y + 1, x - 1), ss = at(y + 1, x), se = at(y + 1, x + 1);
+        // bbox: only extreme candidates issue atomics
+        if (!ww) atomicMin(&t.bbox[o * 4 + 0], x);
+        if (!ee) atomicMax(&t.bbox[o * 4 + 1], x);
+        if (!nn) atomicMin(&t.bbox[o * 4 + 2], y);
+        if (!ss) atomicMax(&t.bbox[o * 4 + 3], y);
+        // the four 2x2 windows containing (y,x); window order of pixels: TL, TR, BL, BR
+        int q = 0;
+        auto quad = [&](int tl, int tr, int bl, int br) {
+            int cnt = tl + tr + bl + br;
+            if (cnt == 1) q += 1;
+            else if (cnt == 3) q -= 1;
+            else if (cnt == 2 && ((tl && br) || (tr && bl))) q -= 2;
+        };
+        quad(1, ee, ss, se);                        // (y,x) is TL: always first
+        if (!ww) quad(ww, 1, sw, ss);               // TR: first iff TL clear
+        if (!nn && !ne) quad(nn, ne, 1, ee);        // BL: first iff TL, TR clear
+        if (!nw && !nn && !ww) quad(nw, nn, ww, 1); // BR: first iff all others clear
+        if (q) atomicAdd(&t.euler4[o], q);
+    }
+}
+
+// One thread per component: components whose Euler number is not 1 have holes and may enclose
+// other components (RETR_EXTERNAL skips those); queue them for k_nested.
+constexpr int HOLED_CAP = 4096;
+
+__global__ __launch_bounds__(256) void k_holes(CompTables t, int batch, int32_t *n_holed, int2 *holed, int32_t *status)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int f = i / t.max_det, k = i - f * t.max_det;
+    if (f >= batch) return;
+    int n = min(t.nroots[f], t.max_det);
+    if (k < n && t.euler4[(size_t)f * t.max_det + k] != 4) {
+        int idx = atomicAdd(n_holed, 1);
+        if (idx < HOLED_CAP) holed[idx] = make_int2(f, k);
+        else atomicOr(&status[f], YSMR_DET_ARENA);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// RETR_EXTERNAL nesting, one workgroup per holed component D.  Window = D's bounding box grown
+// by one cell (cells outside the image count as outside background).  Background cells that
+// cannot be reached (4-connected) from the window margin are enclosed by foreground; a component
+// whose first pixel has such a cell as its west neighbour lies in a hole and is not a detection.
+// Cell states: 0 foreground, 1 reached background, 2 unreached background.
+// ------------------------------------------------------------------------------------------
+constexpr int NEST_LDS_CELLS = 48 * 1024;
+
+__global__ __launch_bounds__(256) void k_nested(const uint32_t *__restrict__ labels, Geo g, CompTables t,
+                                                const int32_t *n_holed, const int2 *holed, float *arena,
+                                                uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
+{
+    __shared__ uint8_t s_cell[NEST_LDS_CELLS];
+    __shared__ int s_changed;
+    __shared__ uint32_t s_off;
+    const int idx = blockIdx.x;
+    if (idx >= min(*n_holed, HOLED_CAP)) return;
+    const int f = holed[idx].x, k = holed[idx].y;
+    const size_t o = (size_t)f * t.max_det + k;
+    const int wx0 = t.bbox[o * 4 + 0] - 1, wy0 = t.bbox[o * 4 + 2] - 1;
+    const int ww = t.bbox[o * 4 + 1] - t.bbox[o * 4 + 0] + 3, wh = t.bbox[o * 4 + 3] - t.bbox[o * 4 + 2] + 3;
+    const int cells = ww * wh;
+    const uint32_t *L = labels + (size_t)f * g.HW;
+    const int W = g.W, H = g.H;
+    uint8_t *cell = s_cell;
+    if (cells > NEST_LDS_CELLS) {
+        if (threadIdx.x == 0) {
+            uint32_t need = (uint32_t)(cells + 3) / 4;
+            uint32_t off = atomicAdd(arena_used, need);
+            s_off = (off + need > arena_floats) ? 0xFFFFFFFFu : off;
+        }
+        __syncthreads();
+        if (s_off == 0xFFFFFFFFu) {
+            if (threadIdx.x == 0) atomicOr(&status[f], YSMR_DET_ARENA);
+            return;
+        }
+        cell = reinterpret_cast<uint8_t *>(arena + s_off);
+    }
+    for (int i = threadIdx.x; i < cells; i += 256) {
+        int r = i / ww, c = i - r * ww;
+        int y = wy0 + r, x = wx0 + c;
+        bool inimg = (y >= 0 && y < H && x >= 0 && x < W);
+        bool fg = inimg && L[(size_t)y * W + x] != 0;
+        bool margin = (r == 0 || c == 0 || r == wh - 1 || c == ww - 1);
+        cell[i] = fg ? 0 : ((!inimg || margin) ? 1 : 2);
+    }
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_changed = 0;
+        __syncthreads();
+        bool any = false;
+        for (int r = threadIdx.x; r < wh; r += 256) {
+            uint8_t *row = cell + (size_t)r * ww;
+            uint8_t prev = 0;
+            for (int c = 0; c < ww; ++c) { uint8_t v = row[c]; if (v == 2 && prev == 1) { row[c] = 1; v = 1; any = true; } prev = v; }
+            prev = 0;
+            for (int c = ww - 1; c >= 0; --c) { uint8_t v = row[c]; if (v == 2 && prev == 1) { row[c] = 1; v = 1; any = true; } prev = v; }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int c = threadIdx.x; c < ww; c += 256) {
+            uint8_t prev = 0;
+            for (int r = 0; r < wh; ++r) { uint8_t v = cell[(size_t)r * ww + c]; if (v == 2 && prev == 1) { cell[(size_t)r * ww + c] = 1; v = 1; any = true; } prev = v; }
+            prev = 0;
+            for (int r = wh - 1; r >= 0; --r) { uint8_t v = cell[(size_t)r * ww + c]; if (v == 2 && prev == 1) { cell[(size_t)r * ww + c] = 1; v = 1; any = true; } prev = v; }
+        }
+        if (any) s_changed = 1;
+        __threadfence_block();
+        __syncthreads();
+        if (!s_changed) break;
+    }
+    const int n = min(t.nroots[f], t.max_det);
+    for (int i = threadIdx.x; i < cells; i += 256) {
+        int r = i / ww, c = i - r * ww;
+        if (c == 0 || cell[i] != 0) continue;
+        int y = wy0 + r, x = wx0 + c;
+        uint32_t p = (uint32_t)y * (uint32_t)W + (uint32_t)x;
+        if (L[p] != p + 1u || cell[i - 1] != 2) continue;
+        int kk = find_rank(t.order + (size_t)f * t.max_det, n, (int32_t)p);
+        if (kk >= 0) t.nested[(size_t)f * t.max_det + kk] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_geometry: a6, one thread per component
+// ------------------------------------------------------------------------------------------
+constexpr int GEO_THREADS = 64;
+constexpr int LDS_POINTS = 32;  // hull capacity of the in-LDS fast path
+
+struct HullStore {
+    float *base;
+    int stride;  // in floats
+    __device__ __forceinline__ float &px(int i) const { return base[(size_t)(i * 5 + 0) * stride]; }
+    __device__ __forceinline__ float &py(int i) const { return base[(size_t)(i * 5 + 1) * stride]; }
+    __device__ __forceinline__ float &vx(int i) const { return base[(size_t)(i * 5 + 2) * stride]; }
+    __device__ __forceinline__ float &vy(int i) const { return base[(size_t)(i * 5 + 3) * stride]; }
+    __device__ __forceinline__ float &il(int i) const { return base[(size_t)(i * 5 + 4) * stride]; }
+};
+
+// monotone-chain push with strict turns (collinear points are dropped); coordinates are small
+// integers, so the cross product is exact in int64
+__device__ __forceinline__ void chain_push(const HullStore &s, int start, int &n, int x, int y)
+{
+    if (n > start && (int)s.px(n - 1) == x && (int)s.py(n - 1) == y) return;
+    while (n - start >= 2) {
+        long long ox = (long long)s.px(n - 2), oy = (long long)s.py(n - 2);
+        long long ax = (long long)s.px(n - 1), ay = (long long)s.py(n - 1);
+        long long cr = (ax - ox) * ((long long)y - oy) - (ay - oy) * ((long long)x - ox);
+        if (cr <= 0) --n; else break;
+    }
+    s.px(n) = (float)x;
+    s.py(n) = (float)y;
+    ++n;
+}
+
+#define YSMR_PI 3.1415926535897932384626433832795
+
+__device__ void min_area_rect_hull(const HullStore &s, int n, float *rect)
+{
+    float cx = 0.f, cy = 0.f, bw = 0.f, bh = 0.f, ang = 0.f;
+    if (n > 2) {
+        float minarea = FLT_MAX;
+        int best_left = 0, best_bottom = 0;
+        float best_a = 0.f, best_b = 0.f, best_w = 0.f, best_h = 0.f;
+        int left = 0, bottom = 0, right = 0, top = 0;
+        float ptx = s.px(0), pty = s.py(0);
+        float left_x = ptx, right_x = ptx, top_y = pty, bottom_y = pty;
+        for (int i = 0; i < n; ++i) {
+            if (ptx < left_x) { left_x = ptx; left = i; }
+            if (ptx > right_x) { right_x = ptx; right = i; }
+            if (pty > top_y) { top_y = pty; top = i; }
+            if (pty < bottom_y) { bottom_y = pty; bottom = i; }
+            int nx = (i + 1 < n) ? i + 1 : 0;
+            float qx = s.px(nx), qy = s.py(nx);
+            double dx = (double)qx - (double)ptx, dy = (double)qy - (double)pty;
+            s.vx(i) = (float)dx;
+            s.vy(i) = (float)dy;
+            s.il(i) = (float)(1. / sqrt(dx * dx + dy * dy));
+            ptx = qx; pty = qy;
+        }
+        float orientation = 0.f;
+        {
+            double ax = s.vx(n - 1), ay = s.vy(n - 1);
+            for (int i = 0; i < n; ++i) {
+                double bx = s.vx(i), by = s.vy(i);
+                double convexity = ax * by - ay * bx;
+                if (convexity != 0) { orientation = (convexity > 0) ? 1.f : -1.f; break; }
+                ax = bx; ay = by;
+            }
+        }
+        float base_a = orientation, base_b = 0.f;
+        int seq[4] = {bottom, right, top, left};
+        for (int k = 0; k < n; ++k) {
+            float dp0 = +base_a * s.vx(seq[0]) + base_b * s.vy(seq[0]);
+            float dp1 = -base_b * s.vx(seq[1]) + base_a * s.vy(seq[1]);
+            float dp2 = -base_a * s.vx(seq[2]) - base_b * s.vy(seq[2]);
+            float dp3 = +base_b * s.vx(seq[3]) - base_a * s.vy(seq[3]);
+            float maxcos = dp0 * s.il(seq[0]);
+            int main_element = 0;
+            float c1 = dp1 * s.il(seq[1]);
+            if (c1 > maxcos) { main_element = 1; maxcos = c1; }
+            float c2 = dp2 * s.il(seq[2]);
+            if (c2 > maxcos) { main_element = 2; maxcos = c2; }
+            float c3 = dp3 * s.il(seq[3]);
+            if (c3 > maxcos) { main_element = 3; maxcos = c3; }
+            int pindex = main_element == 0 ? seq[0] : main_element == 1 ? seq[1] : main_element == 2 ? seq[2] : seq[3];
+            float lead_x = s.vx(pindex) * s.il(pindex);
+            float lead_y = s.vy(pindex) * s.il(pindex);
+            if (main_element == 0) { base_a = lead_x; base_b = lead_y; }
+            else if (main_element == 1) { base_a = lead_y; base_b = -lead_x; }
+            else if (main_element == 2) { base_a = -lead_x; base_b = -lead_y; }
+            else { base_a = -lead_y; base_b = lead_x; }
+            int nxt = pindex + 1;
+            if (nxt == n) nxt = 0;
+            if (main_element == 0) seq[0] = nxt; else if (main_element == 1) seq[1] = nxt;
+            else if (main_element == 2) seq[2] = nxt; else seq[3] = nxt;
+
+            float dx = s.px(seq[1]) - s.px(seq[3]);
+            float dy = s.py(seq[1]) - s.py(seq[3]);
+            float width = dx * base_a + dy * base_b;
+            dx = s.px(seq[2]) - s.px(seq[0]);
+            dy = s.py(seq[2]) - s.py(seq[0]);
+            float height = -dx * base_b + dy * base_a;
+            float area = width * height;
+            if (area <= minarea) {
+                minarea = area;
+                best_left = seq[3]; best_a = base_a; best_w = width;
+                best_b = base_b; best_h = height; best_bottom = seq[0];
+            }
+        }
+        float A1 = best_a, B1 = best_b, A2 = -best_b, B2 = best_a;
+        float C1 = A1 * s.px(best_left) + s.py(best_left) * B1;
+        float C2 = A2 * s.px(best_bottom) + s.py(best_bottom) * B2;
+        float idet = 1.f / (A1 * B2 - A2 * B1);
+        float o0 = (C1 * B2 - C2 * B1) * idet;
+        float o1 = (A1 * C2 - A2 * C1) * idet;
+        float o2 = A1 * best_w, o3 = B1 * best_w, o4 = A2 * best_h, o5 = B2 * best_h;
+        cx = o0 + (o2 + o4) * 0.5f;
+        cy = o1 + (o3 + o5) * 0.5f;
+        bw = (float)sqrt((double)o2 * o2 + (double)o3 * o3);
+        bh = (float)sqrt((double)o4 * o4 + (double)o5 * o5);
+        ang = (float)atan2((double)o3, (double)o2);
+    } else if (n == 2) {
+        cx = (s.px(0) + s.px(1)) * 0.5f;
+        cy = (s.py(0) + s.py(1)) * 0.5f;
+        double dx = s.px(1) - s.px(0), dy = s.py(1) - s.py(0);
+        bw = (float)sqrt(dx * dx + dy * dy);
+        bh = 0.f;
+        ang = (float)atan2(dy, dx);
+    } else if (n == 1) {
+        cx = s.px(0);
+        cy = s.py(0);
+    }
+    ang = (float)((double)(ang * 180.f) / YSMR_PI);
+    rect[0] = cx; rect[1] = cy; rect[2] = bw; rect[3] = bh; rect[4] = ang;
+}
+
+// det slots are compacted afterwards (nested components dropped) by k_compact.
+__global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__restrict__ labels, Geo g, CompTables t,
+                                                          int batch, float *det_tmp, float *arena,
+                                                          uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
+{
+    __shared__ float lds[LDS_POINTS * 5 * GEO_THREADS];
+    int i = blockIdx.x * GEO_THREADS + threadIdx.x;
+    int f = i / t.max_det, k = i - f * t.max_det;
+    if (f >= batch) return;
+    int n = min(t.nroots[f], t.max_det);
+    if (k >= n) return;
+    size_t o = (size_t)f * t.max_det + k;
+    if (t.nested[o]) return;
+    const uint32_t want = (uint32_t)t.order[o] + 1u;
+    const int minx = t.bbox[o * 4 + 0], maxx = t.bbox[o * 4 + 1], miny = t.bbox[o * 4 + 2], maxy = t.bbox[o * 4 + 3];
+    const int bwid = maxx - minx + 1;
+    const uint32_t *L = labels + (size_t)f * g.HW;
+    const int W = g.W;
+
+    HullStore s;
+    const int need_pts = 2 * bwid + 3;
+    if (need_pts <= LDS_POINTS) {
+        s.base = lds + threadIdx.x;
+        s.stride = GEO_THREADS;
+    } else {
+        uint32_t need = (uint32_t)need_pts * 5u;
+        uint32_t off = atomicAdd(arena_used, need);
+        if (off + need > arena_floats) {
+            atomicOr(&status[f], YSMR_DET_ARENA);
+            float *d = det_tmp + o * 5;
+            d[0] = d[1] = d[2] = d[3] = d[4] = 0.f;
+            return;
+        }
+        s.base = arena + off;
+        s.stride = 1;
+    }
+    // max-y side: columns right -> left, within a column bottom first then top
+    int nh = 0;
+    for (int x = maxx; x >= minx; --x) {
+        int top = -1, bot = -1;
+        for (int y = miny; y <= maxy; ++y)
+            if (L[(size_t)y * W + x] == want) { if (top < 0) top = y; bot = y; }
+        if (top < 0) continue;
+        chain_push(s, 0, nh, x, bot);
+        chain_push(s, 0, nh, x, top);
+    }
+    // nh >= 1; the last point is the lexicographically first pixel, where the min-y side starts
+    int start = nh - 1;
+    int nl = start;
+    for (int x = minx; x <= maxx; ++x) {
+        int top = -1, bot = -1;
+        for (int y = miny; y <= maxy; ++y)
+            if (L[(size_t)y * W + x] == want) { if (top < 0) top = y; bot = y; }
+        if (top < 0) continue;
+        chain_push(s, start, nl, x, top);
+        chain_push(s, start, nl, x, bot);
+    }
+    // drop the closing point (== point 0) unless the hull is a single point
+    int hn = nl - 1;
+    if (hn < 1) hn = 1;
+    min_area_rect_hull(s, hn, det_tmp + o * 5);
+}
+
+// Drop nested components, write final detection list / count / anchors.
+__global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__restrict__ det_tmp, float *det,
+                                                 int32_t *det_count, int32_t *anchors)
+{
+    const int f = blockIdx.x;
+    int n = min(t.nroots[f], t.max_det);
+    __shared__ int s_scan[256];
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        int i = i0 + threadIdx.x;
+        size_t o = (size_t)f * t.max_det + i;
+        int keep = (i < n && !t.nested[o]) ? 1 : 0;
+        s_scan[threadIdx.x] = keep;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+            __syncthreads();
+            s_scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int pos = s_base + s_scan[threadIdx.x] - keep;
+        if (keep) {
+            size_t q = (size_t)f * t.max_det + pos;
+            for (int j = 0; j < 5; ++j) det[q * 5 + j] = det_tmp[o * 5 + j];
+            if (anchors) anchors[q] = t.order[o];
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) s_base += s_scan[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) det_count[f] = s_base;
+}
+
+Gauss11 make_gauss11()
+{
+    Gauss11 g;
+    const double sigma = 0.3 * ((11 - 1) * 0.5 - 1.0) + 0.8;
+    const double scale2x = -0.5 / (sigma * sigma);
+    double t[11], sum = 0.0;
+    for (int i = 0; i < 11; ++i) {
+        double x = i - 5.0;
+        t[i] = std::exp(scale2x * x * x);
+        sum += t[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < 11; ++i) g.k[i] = (float)(t[i] * sum);
+    return g;
+}
+
+struct Workspace {
+    int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed;
+    int2 *holed;
+    uint32_t *arena_used;
+    float *det_tmp, *arena;
+    uint32_t arena_floats;
+    size_t bytes;
+};
+
+Workspace carve(void *base, int batch, int H, int W, int max_det)
+{
+    Workspace w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return (char *)base + o; };
+    size_t bm = (size_t)batch * max_det;
+    // counters first: one memset clears nroots, n_holed, arena_used
+    w.nroots = (int32_t *)take(sizeof(int32_t) * ((size_t)batch + 4));
+    w.n_holed = w.nroots + batch;
+    w.arena_used = (uint32_t *)(w.n_holed + 1);
+    w.holed = (int2 *)take(sizeof(int2) * HOLED_CAP);
+    w.roots = (int32_t *)take(sizeof(int32_t) * bm);
+    w.order = (int32_t *)take(sizeof(int32_t) * bm);
+    w.bbox = (int32_t *)take(sizeof(int32_t) * bm * 4);
+    w.euler4 = (int32_t *)take(sizeof(int32_t) * bm);
+    w.nested = (int32_t *)take(sizeof(int32_t) * bm);
+    w.det_tmp = (float *)take(sizeof(float) * bm * 5);
+    // scratch arena shared by k_geometry (hulls wider than the LDS fast path) and k_nested (windows
+    // larger than LDS): room for 16 full-width hulls per frame, and at least one full-frame window
+    size_t arena_floats = (size_t)batch * std::max<size_t>(16 * 5 * (2 * (size_t)W + 3), ((size_t)(H + 2) * (W + 2) + 3) / 4);
+    if (arena_floats > 0x7FFFFFFFull) arena_floats = 0x7FFFFFFFull;
+    w.arena_floats = (uint32_t)arena_floats;
+    w.arena = (float *)take(sizeof(float) * arena_floats);
+    w.bytes = off;
+    return w;
+}
+
+int check_geometry(int batch, int H, int W, int channels, int max_det)
+{
+    if (batch <= 0 || H <= 0 || W <= 0 || max_det <= 0)
+        return ysmr::fail(YSMR_ERR_ARG, "batch, height, width, max_det must be positive (got %d, %d, %d, %d)", batch, H, W, max_det);
+    if (channels != 1 && channels != 3)
+        return ysmr::fail(YSMR_ERR_ARG, "channels must be 1 (gray) or 3 (BGR), got %d", channels);
+    if ((size_t)H * W >= 0x7FFFFFF0ull || (size_t)batch * H * W >= (1ull << 40))
+        return ysmr::fail(YSMR_ERR_ARG, "frame too large");
+    return YSMR_OK;
+}
+
+int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, int W, int channels, int inv, int t_low,
+                     int t_high, int use_high, uint8_t *cls)
+{
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, batch);
+    Gauss11 gk = make_gauss11();
+    if (channels == 1)
+        hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high);
+    else
+        hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high);
+    YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ysmr_detect_workspace_bytes(int batch, int height, int width, int max_det)
+{
+    if (batch <= 0 || height <= 0 || width <= 0 || max_det <= 0) return 0;
+    return carve(nullptr, batch, height, width, max_det).bytes;
+}
+
+int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels,
+                         int inv, int t_low, int t_high, int use_high, uint8_t *cls_dev)
+{
+    if (int rc = check_geometry(batch, height, width, channels, 1)) return rc;
+    if (!frames_dev || !cls_dev) return ysmr::fail(YSMR_ERR_ARG, "frames_dev and cls_dev must not be NULL");
+    return launch_threshold((hipStream_t)stream, frames_dev, batch, height, width, channels, inv, t_low, t_high,
+                            use_high, cls_dev);
+}
+
+int ysmr_detect_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels, int inv,
+                      int t_low, int t_high, int use_high, void *workspace_dev, size_t workspace_bytes,
+                      uint8_t *cls_dev, uint8_t *mask_dev, int32_t *labels_dev, int32_t *det_count_dev, float *det_dev,
+                      int32_t *anchors_dev, int max_det, int32_t *status_dev)
+{
+    if (int rc = check_geometry(batch, height, width, channels, max_det)) return rc;
+    if (!frames_dev || !cls_dev || !labels_dev || !det_count_dev || !det_dev || !status_dev || !workspace_dev)
+        return ysmr::fail(YSMR_ERR_ARG, "a required device pointer is NULL");
+    if (((uintptr_t)cls_dev & 15) || ((uintptr_t)labels_dev & 15) || (mask_dev && ((uintptr_t)mask_dev & 15)))
+        return ysmr::fail(YSMR_ERR_ARG, "cls_dev, labels_dev and mask_dev must be 16-byte aligned");
+    Workspace w = carve(workspace_dev, batch, height, width, max_det);
+    if (workspace_bytes < w.bytes)
+        return ysmr::fail(YSMR_ERR_CAPACITY, "workspace too small: %zu < %zu bytes", workspace_bytes, w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    Geo g{height, width, (uint32_t)((size_t)height * width), (size_t)batch * height * width};
+    const size_t nchunks = (g.total + 15) / 16;
+    const unsigned cgrid = (unsigned)((nchunks + 255) / 256);
+    uint32_t *labels = reinterpret_cast<uint32_t *>(labels_dev);
+
+    YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch + 4), st));
+    YSMR_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t) * batch, st));
+    if (int rc = launch_threshold(st, frames_dev, batch, height, width, channels, inv, t_low, t_high, use_high, cls_dev))
+        return rc;
+    hipLaunchKernelGGL(k_init_labels, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
+    hipLaunchKernelGGL(k_union4, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
+    hipLaunchKernelGGL(k_flag, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
+    hipLaunchKernelGGL(k_union8, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
+    hipLaunchKernelGGL(k_flatten, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, mask_dev, g, nchunks, w.nroots,
+                       w.roots, max_det);
+    YSMR_LAUNCH_CHECK();
+    CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, max_det};
+    hipLaunchKernelGGL(k_rank, dim3(batch), dim3(256), 0, st, t, width, height, status_dev);
+    hipLaunchKernelGGL(k_bbox_euler, dim3(cgrid), dim3(256), 0, st, labels, g, nchunks, t);
+    const unsigned comp_threads = (unsigned)((size_t)batch * max_det);
+    hipLaunchKernelGGL(k_holes, dim3((comp_threads + 255) / 256), dim3(256), 0, st, t, batch, w.n_holed, w.holed, status_dev);
+    hipLaunchKernelGGL(k_nested, dim3(HOLED_CAP), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
+                       w.arena_floats, w.arena_used, status_dev);
+    YSMR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_geometry, dim3((comp_threads + GEO_THREADS - 1) / GEO_THREADS), dim3(GEO_THREADS), 0, st,
+                       labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
+    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev);
+    YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,713 @@
+// track.hip -- a7-a19 of the YSMR hot path on gfx950: CentroidTracker.update (ysmr/tracker.py:93-230)
+// with the Gaussian-sum FIR filter (ysmr/gsff.py:204-347) and row emission
+// (ysmr/track_eval.py:313-316), device-resident across frames.
+//
+// Per frame two launches, no host round trip:
+//   k_rowmin  (one wave per track)  nearest detection of every track: fused row-min / arg-min of
+//                                   the N x M float64 distance matrix, which is never stored
+//                                   (tracker.py:151-163 only ever reads D.min(1), D.argmin(1))
+//   k_link    (one workgroup)       claim resolution, ageing / deregistration, registration in
+//                                   CPython set order, GSFF correct+predict per track, rows
+//
+// Claim rule (tracker.py:158-189): proposals are visited in ascending (row minimum, row); a
+// proposal is accepted iff its column is still free.  Each row occurs once, so the winner of a
+// column is simply the proposer with the smallest (distance, row) -- resolved with two atomicMin
+// rounds instead of a sort and a sequential loop.
+//
+// All arithmetic is float64 like the reference; -ffp-contract=off keeps mul/add unfused.
+#include "common.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#define YSMR_MAX_FILTERS 8
+
+struct TrackerDev {
+    int capacity, max_det, n_f, use_gsff, hist_cap, table_cap;
+    double max_gone, lik_min;
+    int n_i[YSMR_MAX_FILTERS];
+    int gain_off[YSMR_MAX_FILTERS];  // filter i: row0 at gains[gain_off[i]], row1 at +2*n_i[i]
+    const double *gains;
+    // persistent state
+    int *n_tracks, *next_id, *err, *n_free;
+    int *order, *order_tmp, *free_slots;
+    int *id, *gone, *mode, *hist_len, *hist_head;
+    double *pos;      // [2][cap]
+    float *info;      // [3][cap]
+    double *hist;     // [hist_cap][2][cap]
+    double *weights;  // [n_f][cap]
+    double *liks;     // [n_f][cap]
+    double *xhat;     // [2][n_f][cap]
+    // per-frame scratch
+    unsigned long long *col_key;  // [max_det] smallest row-minimum (as ordered bits) proposing this column
+    int *col_row;                 // [max_det] winning row, INT_MAX = column unused
+    double *row_min;              // [cap]
+    int *row_arg;                 // [cap]
+    int *claim_col;               // [cap]
+    int *dead;                    // [cap]
+    int *new_cols;                // [max_det]
+    int *set_table;               // [2][table_cap] CPython set model
+    int *scalars;                 // n_before, n_new
+};
+
+struct ysmr_tracker {
+    TrackerDev d;
+    void *block;       // the single device allocation
+    size_t block_bytes;
+    std::vector<double> gains_host;
+};
+
+namespace {
+
+constexpr int ERR_TRACK_CAPACITY = 1;  // more live tracks than `capacity`
+constexpr int ERR_ROWS_CAPACITY = 2;   // row buffer full
+constexpr int ERR_DET_CLAMPED = 4;     // detection count exceeded max_det
+
+__device__ __forceinline__ int det_count(int m_host, const int32_t *m_dev, int max_det, int *err)
+{
+    int m = m_host >= 0 ? m_host : *m_dev;
+    if (m > max_det) { m = max_det; if (err) atomicOr(err, ERR_DET_CLAMPED); }
+    return m < 0 ? 0 : m;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rowmin: one wave per track row.
+// scipy cdist('euclidean') on 2-D points is sqrt(dx*dx + dy*dy) in float64; argmin
+// takes the lowest column among equal distances.  sqrt is monotone, so the row minimum is
+// sqrt(min s); two different s can round to the same sqrt, which is resolved exactly in merge().
+// ------------------------------------------------------------------------------------------
+struct Cand { double s; int j; };
+
+__device__ __forceinline__ Cand merge(Cand a, Cand b)
+{
+    // each candidate = (min s of its subset, first index whose sqrt equals sqrt(min s))
+    if (a.j < 0) return b;
+    if (b.j < 0) return a;
+    double lo = fmin(a.s, b.s), hi = fmax(a.s, b.s);
+    bool same = (hi == lo);
+    if (!same && (hi - lo) <= lo * 0x1p-48) same = (sqrt(hi) == sqrt(lo));
+    Cand r;
+    if (same) { r.s = lo; r.j = min(a.j, b.j); }
+    else if (a.s < b.s) r = a;
+    else r = b;
+    return r;
+}
+
+template <typename DetT>
+__global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__restrict__ det, int m_host,
+                                                const int32_t *m_dev)
+{
+    const int n = *t.n_tracks;
+    const int m = det_count(m_host, m_dev, t.max_det, nullptr);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n || m == 0) return;
+    const int slot = t.order[row];
+    const double px = t.pos[slot], py = t.pos[t.capacity + slot];
+    Cand best{0.0, -1};
+    for (int j = lane; j < m; j += 64) {
+        double dx = px - (double)det[(size_t)j * 5 + 0];
+        double dy = py - (double)det[(size_t)j * 5 + 1];
+        double s = dx * dx;
+        s = s + dy * dy;
+        best = merge(best, Cand{s, j});
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Cand o;
+        o.s = __shfl_xor(best.s, off);
+        o.j = __shfl_xor(best.j, off);
+        best = merge(best, o);
+    }
+    if (lane == 0) {
+        double d = sqrt(best.s);
+        t.row_min[row] = d;
+        t.row_arg[row] = best.j;
+        atomicMin(&t.col_key[best.j], (unsigned long long)__double_as_longlong(d));  // d >= 0: bits are ordered
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GSFF (gsff.py).  History is a ring of hist_cap = n_i[-1] + 1 measurements per track slot.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fir(const TrackerDev &t, int slot, int i, int head, double &x0, double &x1)
+{
+    // lsff_calc (gsff.py:156-177): np.dot(gain, flatten(measurements[-N:])), rows 0 and 1
+    const int N = t.n_i[i];
+    const double *g0 = t.gains + t.gain_off[i];
+    const double *g1 = g0 + 2 * N;
+    int e = head - N;
+    if (e < 0) e += t.hist_cap;
+    double a0 = 0.0, a1 = 0.0;
+    for (int j = 0; j < N; ++j) {
+        double yx = t.hist[((size_t)e * 2 + 0) * t.capacity + slot];
+        double yy = t.hist[((size_t)e * 2 + 1) * t.capacity + slot];
+        a0 = a0 + g0[2 * j] * yx;
+        a0 = a0 + g0[2 * j + 1] * yy;
+        a1 = a1 + g1[2 * j] * yx;
+        a1 = a1 + g1[2 * j + 1] * yy;
+        if (++e == t.hist_cap) e = 0;
+    }
+    x0 = a0;
+    x1 = a1;
+}
+
+__device__ void gsff_step(const TrackerDev &t, int slot, double z0, double z1, double &out0, double &out1,
+                          double &pred0, double &pred1)
+{
+    const int cap = t.capacity, nf = t.n_f;
+    int len = t.hist_len[slot], head = t.hist_head[slot], mode = t.mode[slot];
+    // ---- correct (gsff.py:251-347)
+    if (len == 0) {
+        for (int j = 0; j < t.n_i[0]; ++j) {
+            t.hist[((size_t)j * 2 + 0) * cap + slot] = z0;
+            t.hist[((size_t)j * 2 + 1) * cap + slot] = z1;
+        }
+        len = t.n_i[0];
+        head = len % t.hist_cap;
+    }
+    bool grew = false;
+    if (mode < nf) {
+        while (len >= t.n_i[mode]) {
+            ++mode;
+            grew = true;
+            if (mode >= nf) break;
+        }
+    }
+    if (grew) {
+        const double w0 = 1.0 / (double)mode;
+        for (int i = 0; i < mode; ++i) {
+            double a, b;
+            fir(t, slot, i, head, a, b);
+            t.xhat[((size_t)0 * nf + i) * cap + slot] = a;
+            t.xhat[((size_t)1 * nf + i) * cap + slot] = b;
+            t.weights[(size_t)i * cap + slot] = w0;
+        }
+    }
+    double total = 0.0;
+    for (int i = 0; i < mode; ++i) {
+        double d0 = z0 - t.xhat[((size_t)0 * nf + i) * cap + slot];
+        double d1 = z1 - t.xhat[((size_t)1 * nf + i) * cap + slot];
+        double q = d0 * d0;
+        q = q + d1 * d1;
+        double lik = exp(-0.5 * q);
+        if (lik < t.lik_min) lik = t.lik_min;
+        t.liks[(size_t)i * cap + slot] = lik;
+        total = total + lik * t.weights[(size_t)i * cap + slot];
+    }
+    t.hist[((size_t)head * 2 + 0) * cap + slot] = z0;
+    t.hist[((size_t)head * 2 + 1) * cap + slot] = z1;
+    if (++head == t.hist_cap) head = 0;
+    if (len < t.hist_cap) ++len;
+    // np.sum(x_hat * w, axis=1): NumPy seeds the reduction with element 0 and adds the running
+    // sum of the remaining ones, i.e. a0 + ((a1 + a2) + ...)
+    double f0 = 0.0, f1 = 0.0, r0 = 0.0, r1 = 0.0;
+    for (int i = 0; i < mode; ++i) {
+        double w = t.liks[(size_t)i * cap + slot] * t.weights[(size_t)i * cap + slot] / total;
+        t.weights[(size_t)i * cap + slot] = w;
+        double a = t.xhat[((size_t)0 * nf + i) * cap + slot] * w;
+        double b = t.xhat[((size_t)1 * nf + i) * cap + slot] * w;
+        if (i == 0) { f0 = a; f1 = b; }
+        else if (i == 1) { r0 = a; r1 = b; }
+        else { r0 = r0 + a; r1 = r1 + b; }
+    }
+    out0 = mode > 1 ? f0 + r0 : f0;
+    out1 = mode > 1 ? f1 + r1 : f1;
+    // ---- predict (gsff.py:204-249)
+    f0 = f1 = r0 = r1 = 0.0;
+    for (int i = 0; i < mode; ++i) {
+        double a, b;
+        fir(t, slot, i, head, a, b);
+        t.xhat[((size_t)0 * nf + i) * cap + slot] = a;
+        t.xhat[((size_t)1 * nf + i) * cap + slot] = b;
+        double w = t.weights[(size_t)i * cap + slot];
+        if (i == 0) { f0 = a * w; f1 = b * w; }
+        else if (i == 1) { r0 = a * w; r1 = b * w; }
+        else { r0 = r0 + a * w; r1 = r1 + b * w; }
+    }
+    pred0 = mode > 1 ? f0 + r0 : f0;
+    pred1 = mode > 1 ? f1 + r1 : f1;
+    t.hist_len[slot] = len;
+    t.hist_head[slot] = head;
+    t.mode[slot] = mode;
+}
+
+// ------------------------------------------------------------------------------------------
+// CPython set model: iteration order of set(range(m)).difference(used_cols) (tracker.py:193,216).
+// Ints hash to themselves; table sizes, linear probing (LINEAR_PROBES = 9) and perturbation
+// (PERTURB_SHIFT = 5) as in Objects/setobject.c of CPython 3.7-3.12.
+// Runs on one thread; the number of unused columns per frame is small.
+// ------------------------------------------------------------------------------------------
+__device__ void set_insert_clean(int *table, unsigned mask, int key)
+{
+    unsigned long long perturb = (unsigned long long)key;
+    unsigned i = (unsigned)key & mask;
+    while (true) {
+        int probes = (i + 9u <= mask) ? 9 : 0;
+        for (int j = 0; j <= probes; ++j)
+            if (table[i + j] < 0) { table[i + j] = key; return; }
+        perturb >>= 5;
+        i = (unsigned)(((unsigned long long)i * 5ull + 1ull + perturb) & mask);
+    }
+}
+
+__device__ int cpython_unused_order(const TrackerDev &t, int m, int n_used, int *out)
+{
+    int count = 0;
+    if ((m >> 2) > n_used) {  // set_copy_and_difference: a copy of set(range(m)) iterates ascending
+        for (int c = 0; c < m; ++c)
+            if (t.col_row[c] == 0x7FFFFFFF) out[count++] = c;
+        return count;
+    }
+    int *table = t.set_table, *other = t.set_table + t.table_cap;
+    unsigned mask = 7;
+    int fill = 0;
+    for (int i = 0; i < 8; ++i) table[i] = -1;
+    for (int c = 0; c < m; ++c) {
+        if (t.col_row[c] != 0x7FFFFFFF) continue;
+        set_insert_clean(table, mask, c);  // no equal keys, no dummies: add == insert_clean
+        ++fill;
+        if ((unsigned long long)fill * 5ull >= (unsigned long long)mask * 3ull) {
+            unsigned minused = fill > 50000 ? (unsigned)fill * 2u : (unsigned)fill * 4u;
+            unsigned newsize = 8;
+            while (newsize <= minused) newsize <<= 1;
+            if ((int)newsize > t.table_cap) return -1;
+            for (unsigned i = 0; i < newsize; ++i) other[i] = -1;
+            for (unsigned i = 0; i <= mask; ++i)
+                if (table[i] >= 0) set_insert_clean(other, newsize - 1, table[i]);
+            int *tmp = table; table = other; other = tmp;
+            mask = newsize - 1;
+        }
+    }
+    for (unsigned i = 0; i <= mask; ++i)
+        if (table[i] >= 0) out[count++] = table[i];
+    return count;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_link: one workgroup
+// ------------------------------------------------------------------------------------------
+constexpr int LINK_THREADS = 1024;
+
+__device__ int block_exclusive_scan(int v, int *s_scan, int *total)
+{
+    // 1024-thread inclusive scan in LDS (Hillis-Steele); returns exclusive prefix
+    const int tid = threadIdx.x;
+    s_scan[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < LINK_THREADS; d <<= 1) {
+        int add = tid >= d ? s_scan[tid - d] : 0;
+        __syncthreads();
+        s_scan[tid] += add;
+        __syncthreads();
+    }
+    int incl = s_scan[tid];
+    *total = s_scan[LINK_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+template <typename DetT>
+__global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT *__restrict__ det, int m_host,
+                                                       const int32_t *m_dev, int frame, ysmr_row *rows,
+                                                       long long rows_capacity, long long *row_count,
+                                                       int32_t *n_rows_out, int32_t *claim_out, int32_t *n_before_out,
+                                                       int32_t *new_cols_out, int32_t *n_new_out)
+{
+    __shared__ int s_scan[LINK_THREADS];
+    __shared__ int s_n_used, s_n_new, s_any_dead;
+    const int tid = threadIdx.x;
+    const int cap = t.capacity;
+    const int n = *t.n_tracks;
+    const int m = det_count(m_host, m_dev, t.max_det, t.err);
+    if (tid == 0) { s_n_used = 0; s_n_new = 0; s_any_dead = 0; }
+    __syncthreads();
+
+    // ---- claims
+    if (n > 0 && m > 0) {
+        for (int r = tid; r < n; r += LINK_THREADS) {
+            int c = t.row_arg[r];
+            if ((unsigned long long)__double_as_longlong(t.row_min[r]) == t.col_key[c]) atomicMin(&t.col_row[c], r);
+        }
+        __threadfence_block();
+        __syncthreads();
+        int used = 0;
+        for (int r = tid; r < n; r += LINK_THREADS) {
+            int c = t.row_arg[r];
+            int mine = (__hip_atomic_load(&t.col_row[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == r) ? c : -1;
+            t.claim_col[r] = mine;
+            if (mine >= 0) {
+                int slot = t.order[r];
+                t.pos[slot] = (double)det[(size_t)mine * 5 + 0];
+                t.pos[cap + slot] = (double)det[(size_t)mine * 5 + 1];
+                t.info[slot] = (float)det[(size_t)mine * 5 + 2];
+                t.info[cap + slot] = (float)det[(size_t)mine * 5 + 3];
+                t.info[2 * cap + slot] = (float)det[(size_t)mine * 5 + 4];
+                t.gone[slot] = 0;
+                ++used;
+            }
+        }
+        if (used) atomicAdd(&s_n_used, used);
+    } else {
+        for (int r = tid; r < n; r += LINK_THREADS) t.claim_col[r] = -1;
+    }
+    __syncthreads();
+
+    // ---- ageing (tracker.py:95-107, 198-211): only when there are no detections or N >= M
+    const bool age = (m == 0) || (n > 0 && n >= m);
+    for (int r = tid; r < n; r += LINK_THREADS) {
+        int d = 0;
+        if (age && t.claim_col[r] < 0) {
+            int slot = t.order[r];
+            int g = t.gone[slot] + 1;
+            t.gone[slot] = g;
+            t.info[slot] = 0.f; t.info[cap + slot] = 0.f; t.info[2 * cap + slot] = 0.f;
+            if ((double)g > t.max_gone) { d = 1; s_any_dead = 1; }
+        }
+        t.dead[r] = d;
+    }
+    __syncthreads();
+
+    // ---- stable compaction of the ordered track table
+    int n_live = n;
+    if (s_any_dead) {
+        int base = 0;
+        for (int r0 = 0; r0 < n; r0 += LINK_THREADS) {
+            int r = r0 + tid;
+            int keep = (r < n && !t.dead[r]) ? 1 : 0;
+            int total;
+            int ex = block_exclusive_scan(keep, s_scan, &total);
+            if (keep) t.order_tmp[base + ex] = t.order[r];
+            if (r < n && !keep) {
+                int k = atomicAdd(t.n_free, 1);
+                t.free_slots[k] = t.order[r];
+            }
+            base += total;
+        }
+        n_live = base;
+        __threadfence_block();
+        __syncthreads();
+        for (int r = tid; r < n_live; r += LINK_THREADS) t.order[r] = t.order_tmp[r];
+        __syncthreads();
+    }
+
+    // ---- registration (tracker.py:135-137, 212-217)
+    if (m > 0 && (n == 0 || n < m)) {
+        if (n == 0) {
+            for (int c = tid; c < m; c += LINK_THREADS) t.new_cols[c] = c;
+            if (tid == 0) s_n_new = m;
+        } else if (tid == 0) {
+            int cnt = cpython_unused_order(t, m, s_n_used, t.new_cols);
+            if (cnt < 0) { atomicOr(t.err, ERR_TRACK_CAPACITY); cnt = 0; }
+            s_n_new = cnt;
+        }
+        __threadfence_block();
+        __syncthreads();
+        int n_new = s_n_new;
+        if (n_live + n_new > cap) {
+            if (tid == 0) atomicOr(t.err, ERR_TRACK_CAPACITY);
+            n_new = cap - n_live;
+        }
+        const int nfree = *t.n_free;
+        const int id0 = *t.next_id;
+        for (int j = tid; j < n_new; j += LINK_THREADS) {
+            int c = t.new_cols[j];
+            int slot = t.free_slots[nfree - 1 - j];
+            t.order[n_live + j] = slot;
+            t.id[slot] = id0 + j;
+            t.pos[slot] = (double)det[(size_t)c * 5 + 0];
+            t.pos[cap + slot] = (double)det[(size_t)c * 5 + 1];
+            t.info[slot] = (float)det[(size_t)c * 5 + 2];
+            t.info[cap + slot] = (float)det[(size_t)c * 5 + 3];
+            t.info[2 * cap + slot] = (float)det[(size_t)c * 5 + 4];
+            t.gone[slot] = 0;
+            t.mode[slot] = 0;
+            t.hist_len[slot] = 0;
+            t.hist_head[slot] = 0;
+            if (new_cols_out) new_cols_out[j] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            *t.n_free = nfree - n_new;
+            *t.next_id = id0 + s_n_new;  // ids are consumed even for registrations dropped on overflow
+            s_n_new = n_new;
+        }
+        __syncthreads();
+        n_live += n_new;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- GSFF + rows (tracker.py:219-230, track_eval.py:313-316)
+    long long base = row_count ? *row_count : 0;
+    for (int i = tid; i < n_live; i += LINK_THREADS) {
+        int slot = t.order[i];
+        double z0 = t.pos[slot], z1 = t.pos[cap + slot];
+        double o0 = z0, o1 = z1;
+        if (t.use_gsff) {
+            double p0, p1;
+            gsff_step(t, slot, z0, z1, o0, o1, p0, p1);
+            t.pos[slot] = p0;
+            t.pos[cap + slot] = p1;
+        }
+        if (rows && base + i < rows_capacity) {
+            ysmr_row r;
+            r.frame = frame;
+            r.track_id = t.id[slot];
+            r.x = o0; r.y = o1;
+            r.w = t.info[slot]; r.h = t.info[cap + slot]; r.angle = t.info[2 * cap + slot];
+            r.disappeared = t.gone[slot];
+            rows[base + i] = r;
+        }
+    }
+    // ---- bookkeeping, reset of the per-frame column tables
+    for (int c = tid; c < m; c += LINK_THREADS) {
+        t.col_key[c] = ~0ull;
+        t.col_row[c] = 0x7FFFFFFF;
+    }
+    for (int r = tid; r < n; r += LINK_THREADS)
+        if (claim_out) claim_out[r] = t.claim_col[r];
+    if (tid == 0) {
+        *t.n_tracks = n_live;
+        if (rows && base + n_live > rows_capacity) atomicOr(t.err, ERR_ROWS_CAPACITY);
+        if (row_count) *row_count = base + n_live;
+        if (n_rows_out) *n_rows_out = n_live;
+        if (n_before_out) *n_before_out = n;
+        if (n_new_out) *n_new_out = s_n_new;
+    }
+}
+
+__global__ void k_tracker_reset(TrackerDev t)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < t.capacity) t.free_slots[i] = t.capacity - 1 - i;  // slot 0 is handed out first
+    if (i < t.max_det) { t.col_key[i] = ~0ull; t.col_row[i] = 0x7FFFFFFF; }
+    if (i == 0) { *t.n_tracks = 0; *t.next_id = 0; *t.err = 0; *t.n_free = t.capacity; }
+}
+
+int horizons(double fps, int n_min, double n_max, int n_f, int *n_i)
+{
+    // generate_n_i (gsff.py:87-109); CentroidTracker passes n_max = fps when it is None (tracker.py:58-59)
+    if (n_f < 1 || n_f > YSMR_MAX_FILTERS)
+        return ysmr::fail(YSMR_ERR_ARG, "number of LSFFs must be in 1..%d, got %d", YSMR_MAX_FILTERS, n_f);
+    if (!(fps > 0)) return ysmr::fail(YSMR_ERR_ARG, "fps must be positive");
+    double top = n_max > 0 ? n_max : fps;
+    double p = (top - n_min) / n_f;
+    for (int i = 1; i <= n_f; ++i) n_i[i - 1] = (int)(n_min + p * i);
+    for (int i = 0; i < n_f; ++i)
+        if (n_i[i] < 1 || (i && n_i[i] <= n_i[i - 1]))
+            return ysmr::fail(YSMR_ERR_ARG, "filter horizons must be >= 1 and strictly increasing (n_min=%d n_max=%g n_f=%d)",
+                              n_min, top, n_f);
+    return YSMR_OK;
+}
+
+void closed_form_gain(int N, double *g)
+{
+    // rows 0/1 of (L^T L)^-1 L^T for the constant-velocity model: the one-step-ahead
+    // least-squares line fit, c_j = 1/N + t_j * ((N+1)/2) / sum(t^2), t_j = j - (N-1)/2
+    double st2 = 0.0;
+    for (int j = 0; j < N; ++j) { double tj = j - (N - 1) / 2.0; st2 += tj * tj; }
+    std::memset(g, 0, sizeof(double) * 4 * N);
+    for (int j = 0; j < N; ++j) {
+        double tj = j - (N - 1) / 2.0;
+        double c = 1.0 / N + (st2 > 0 ? tj * ((N + 1) / 2.0) / st2 : 0.0);
+        g[2 * j] = c;              // row 0, x columns
+        g[2 * N + 2 * j + 1] = c;  // row 1, y columns
+    }
+}
+
+template <typename DetT>
+int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, const int32_t *m_dev, int frame,
+                    ysmr_row *rows, long long rows_capacity, long long *row_count, int32_t *n_rows, int32_t *claim,
+                    int32_t *n_before, int32_t *new_cols, int32_t *n_new)
+{
+    const TrackerDev &d = t->d;
+    hipLaunchKernelGGL(k_rowmin<DetT>, dim3((d.capacity + 3) / 4), dim3(256), 0, st, d, det, m, m_dev);
+    hipLaunchKernelGGL(k_link<DetT>, dim3(1), dim3(LINK_THREADS), 0, st, d, det, m, m_dev, frame, rows,
+                       rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
+    YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+__global__ void k_peek(TrackerDev t, int32_t *ids, double *xy, int32_t *gone, int32_t *n_out)
+{
+    const int n = *t.n_tracks;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && n_out) *n_out = n;
+    if (i >= n) return;
+    int slot = t.order[i];
+    if (ids) ids[i] = t.id[slot];
+    if (xy) { xy[2 * i] = t.pos[slot]; xy[2 * i + 1] = t.pos[t.capacity + slot]; }
+    if (gone) gone[i] = t.gone[slot];
+}
+
+}  // namespace
+
+extern "C" {
+
+int ysmr_gsff_gains(double fps, int n_min, double n_max, int n_f, int32_t *n_i_out, double *gains_out)
+{
+    int n_i[YSMR_MAX_FILTERS];
+    if (int rc = horizons(fps, n_min, n_max, n_f, n_i)) return rc;
+    if (!n_i_out) return ysmr::fail(YSMR_ERR_ARG, "n_i_out must not be NULL");
+    size_t off = 0;
+    for (int i = 0; i < n_f; ++i) {
+        n_i_out[i] = n_i[i];
+        if (gains_out) closed_form_gain(n_i[i], gains_out + off);
+        off += 4 * (size_t)n_i[i];
+    }
+    return YSMR_OK;
+}
+
+int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_max, int n_f, int use_gsff,
+                        int capacity, int max_det, const double *gains_host, ysmr_tracker **out)
+{
+    if (!out) return ysmr::fail(YSMR_ERR_ARG, "out must not be NULL");
+    *out = nullptr;
+    if (capacity <= 0 || max_det <= 0 || capacity > (1 << 20) || max_det > (1 << 20))
+        return ysmr::fail(YSMR_ERR_ARG, "capacity and max_det must be in 1..2^20");
+    ysmr_tracker *t = new ysmr_tracker();
+    TrackerDev &d = t->d;
+    std::memset(&d, 0, sizeof(d));
+    d.capacity = capacity;
+    d.max_det = max_det;
+    d.use_gsff = use_gsff ? 1 : 0;
+    d.max_gone = max_disappeared;
+    d.lik_min = 1e-20;  // tracker.py:67
+    d.n_f = use_gsff ? n_f : 1;
+    size_t gain_doubles = 0;
+    if (use_gsff) {
+        if (int rc = horizons(fps, n_min, n_max, n_f, d.n_i)) { delete t; return rc; }
+        for (int i = 0; i < n_f; ++i) { d.gain_off[i] = (int)gain_doubles; gain_doubles += 4 * (size_t)d.n_i[i]; }
+        t->gains_host.resize(gain_doubles);
+        if (gains_host) std::memcpy(t->gains_host.data(), gains_host, sizeof(double) * gain_doubles);
+        else for (int i = 0; i < n_f; ++i) closed_form_gain(d.n_i[i], t->gains_host.data() + d.gain_off[i]);
+        d.hist_cap = d.n_i[n_f - 1] + 1;
+    } else {
+        d.n_i[0] = 1;
+        d.hist_cap = 1;
+    }
+    unsigned tc = 8;
+    while (tc <= (unsigned)max_det * 4u) tc <<= 1;
+    d.table_cap = (int)tc;
+
+    const size_t cap = capacity, nf = d.n_f;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return o; };
+    const size_t o_scal = take(sizeof(int) * 16);
+    const size_t o_order = take(sizeof(int) * cap), o_order_tmp = take(sizeof(int) * cap), o_free = take(sizeof(int) * cap);
+    const size_t o_id = take(sizeof(int) * cap), o_gone = take(sizeof(int) * cap), o_mode = take(sizeof(int) * cap);
+    const size_t o_hlen = take(sizeof(int) * cap), o_hhead = take(sizeof(int) * cap);
+    const size_t o_pos = take(sizeof(double) * 2 * cap), o_info = take(sizeof(float) * 3 * cap);
+    const size_t o_hist = take(sizeof(double) * 2 * cap * d.hist_cap);
+    const size_t o_w = take(sizeof(double) * nf * cap), o_l = take(sizeof(double) * nf * cap);
+    const size_t o_x = take(sizeof(double) * 2 * nf * cap);
+    const size_t o_gain = take(sizeof(double) * (gain_doubles ? gain_doubles : 1));
+    const size_t o_ckey = take(sizeof(unsigned long long) * max_det), o_crow = take(sizeof(int) * max_det);
+    const size_t o_rmin = take(sizeof(double) * cap), o_rarg = take(sizeof(int) * cap);
+    const size_t o_claim = take(sizeof(int) * cap), o_dead = take(sizeof(int) * cap);
+    const size_t o_new = take(sizeof(int) * max_det), o_table = take(sizeof(int) * 2 * (size_t)d.table_cap);
+    t->block_bytes = off;
+    hipError_t e = hipMalloc(&t->block, off);
+    if (e != hipSuccess) {
+        delete t;
+        return ysmr::fail(YSMR_ERR_HIP, "hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
+    }
+    char *b = (char *)t->block;
+    int *scal = (int *)(b + o_scal);
+    d.n_tracks = scal; d.next_id = scal + 1; d.err = scal + 2; d.n_free = scal + 3; d.scalars = scal + 4;
+    d.order = (int *)(b + o_order); d.order_tmp = (int *)(b + o_order_tmp); d.free_slots = (int *)(b + o_free);
+    d.id = (int *)(b + o_id); d.gone = (int *)(b + o_gone); d.mode = (int *)(b + o_mode);
+    d.hist_len = (int *)(b + o_hlen); d.hist_head = (int *)(b + o_hhead);
+    d.pos = (double *)(b + o_pos); d.info = (float *)(b + o_info); d.hist = (double *)(b + o_hist);
+    d.weights = (double *)(b + o_w); d.liks = (double *)(b + o_l); d.xhat = (double *)(b + o_x);
+    d.gains = (const double *)(b + o_gain);
+    d.col_key = (unsigned long long *)(b + o_ckey); d.col_row = (int *)(b + o_crow);
+    d.row_min = (double *)(b + o_rmin); d.row_arg = (int *)(b + o_rarg);
+    d.claim_col = (int *)(b + o_claim); d.dead = (int *)(b + o_dead);
+    d.new_cols = (int *)(b + o_new); d.set_table = (int *)(b + o_table);
+    e = hipMemset(t->block, 0, off);
+    if (e == hipSuccess && gain_doubles)
+        e = hipMemcpy(b + o_gain, t->gains_host.data(), sizeof(double) * gain_doubles, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(t->block);
+        delete t;
+        return ysmr::fail(YSMR_ERR_HIP, "tracker state initialisation failed: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return ysmr_tracker_reset(t, nullptr);
+}
+
+int ysmr_tracker_reset(ysmr_tracker *t, void *stream)
+{
+    if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
+    int n = t->d.capacity > t->d.max_det ? t->d.capacity : t->d.max_det;
+    hipLaunchKernelGGL(k_tracker_reset, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d);
+    YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+int ysmr_tracker_destroy(ysmr_tracker *t)
+{
+    if (!t) return YSMR_OK;
+    hipError_t e = hipFree(t->block);
+    delete t;
+    if (e != hipSuccess) return ysmr::fail(YSMR_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
+    return YSMR_OK;
+}
+
+int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int det_is_f64, int m,
+                        const int32_t *m_dev, int32_t frame_index, ysmr_row *rows_dev, int32_t *n_rows_dev,
+                        int32_t *claim_col_dev, int32_t *n_before_dev, int32_t *new_cols_dev, int32_t *n_new_dev)
+{
+    if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
+    if (m < 0 && !m_dev) return ysmr::fail(YSMR_ERR_ARG, "m < 0 requires m_dev");
+    if (m > t->d.max_det) return ysmr::fail(YSMR_ERR_CAPACITY, "m = %d exceeds max_det = %d", m, t->d.max_det);
+    if (!det_dev && m != 0) return ysmr::fail(YSMR_ERR_ARG, "det_dev is NULL");
+    if (det_is_f64)
+        return launch_update_t<double>(t, (hipStream_t)stream, (const double *)det_dev, m, m_dev, frame_index, rows_dev,
+                                       t->d.capacity, nullptr, n_rows_dev, claim_col_dev, n_before_dev, new_cols_dev,
+                                       n_new_dev);
+    return launch_update_t<float>(t, (hipStream_t)stream, (const float *)det_dev, m, m_dev, frame_index, rows_dev,
+                                  t->d.capacity, nullptr, n_rows_dev, claim_col_dev, n_before_dev, new_cols_dev,
+                                  n_new_dev);
+}
+
+int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
+                     int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev)
+{
+    if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
+    if (!det_dev || !det_count_dev || !rows_dev || !row_count_dev || batch <= 0)
+        return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev, rows_dev, row_count_dev must be set and batch > 0");
+    for (int f = 0; f < batch; ++f) {
+        int rc = launch_update_t<float>(t, (hipStream_t)stream, det_dev + (size_t)f * t->d.max_det * 5, -1,
+                                        det_count_dev + f, first_frame_index + f, rows_dev, (long long)rows_capacity,
+                                        (long long *)row_count_dev, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return YSMR_OK;
+}
+
+int ysmr_tracker_peek(ysmr_tracker *t, void *stream, int32_t *ids_dev, double *xy_dev, int32_t *disappeared_dev,
+                      int32_t *n_dev)
+{
+    if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
+    hipLaunchKernelGGL(k_peek, dim3((t->d.capacity + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d, ids_dev,
+                       xy_dev, disappeared_dev, n_dev);
+    YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+int ysmr_tracker_info(ysmr_tracker *t, void *stream, int32_t *n_tracks, int32_t *next_id, int32_t *error_bits)
+{
+    if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
+    int host[4];
+    YSMR_HIP_CHECK(hipMemcpyAsync(host, t->d.n_tracks, sizeof(int) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    YSMR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    if (n_tracks) *n_tracks = host[0];
+    if (next_id) *next_id = host[1];
+    if (error_bits) *error_bits = host[2];
+    return YSMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""Device-side detection (a1-a6): thin host wrapper over ``ysmr_detect_batch``.
+
+PyTorch is used only as the owner of device buffers and streams; all arithmetic happens in the
+HIP kernels of ``csrc/detect.hip``.  Replaces, for a batch of frames at once, the per-frame
+sequence cvtColor -> GaussianBlur -> 2 x adaptiveThreshold -> binary_propagation -> findContours
+-> minAreaRect of the reference (ysmr/track_eval.py:180-303).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+__all__ = ["ThresholdParams", "threshold_params", "Detector", "DetectResult"]
+
+
+@dataclass(frozen=True)
+class ThresholdParams:
+    inv: int
+    t_low: int
+    t_high: int
+    use_high: int
+
+
+def threshold_params(white_on_dark: bool, offset, adt) -> ThresholdParams:
+    """Integer thresholds equivalent to the reference's two ``cv2.adaptiveThreshold`` calls.
+
+    ysmr/track_eval.py:127-132 picks THRESH_BINARY / THRESH_BINARY_INV (negating the offset for
+    dark-on-bright) and :189-208 passes ``C = -offset`` and ``C = -(offset + adt)``.  OpenCV turns
+    C into ``idelta = ceil(C)`` (BINARY) or ``floor(C)`` (INV) and tests ``src - mean > -idelta``
+    resp. ``<= -idelta``.  ``adt == 0`` means a single threshold; ``adt < 0`` selects the
+    reference's mean-gray branch, which this path does not implement.
+    """
+    if adt < 0:
+        raise ValueError("'adaptive double threshold' < 0 (mean-gray threshold) is not supported by the HIP path")
+    inv = not white_on_dark
+    off = offset * -1 if inv else offset
+    c_low, c_high = off * -1, (off + adt) * -1
+    if inv:
+        return ThresholdParams(1, -math.floor(c_low), -math.floor(c_high), int(adt > 0))
+    return ThresholdParams(0, -math.ceil(c_low), -math.ceil(c_high), int(adt > 0))
+
+
+@dataclass
+class DetectResult:
+    """Device tensors of one ``Detector.detect`` call (views into the detector's buffers)."""
+    cls: torch.Tensor        # u8  [B,H,W]  bit0 thresh, bit1 markers (bit2 internal)
+    mask: torch.Tensor       # u8  [B,H,W]  final mask {0,255}
+    labels: torch.Tensor     # i32 [B,H,W]  0 / 1 + raster index of the component's first pixel
+    det_count: torch.Tensor  # i32 [B]
+    det: torch.Tensor        # f32 [B,max_det,5]  cx, cy, w, h, angle
+    anchors: torch.Tensor    # i32 [B,max_det]
+    status: torch.Tensor     # i32 [B]  _lib.DET_* bits
+
+
+def _padded(n_bytes, device):
+    return torch.empty((n_bytes + 15) // 16 * 16, dtype=torch.uint8, device=device)
+
+
+class Detector:
+    """Owns the output/scratch buffers for a fixed (batch, H, W, max_det) geometry."""
+
+    def __init__(self, batch, height, width, max_det=2048, params: ThresholdParams | None = None,
+                 device="cuda:0", want_mask=True):
+        self.B, self.H, self.W, self.max_det = int(batch), int(height), int(width), int(max_det)
+        self.params = params or threshold_params(True, 5, 2.0)
+        self.device = torch.device(device)
+        L = _lib.lib()
+        n = self.B * self.H * self.W
+        ws = L.ysmr_detect_workspace_bytes(self.B, self.H, self.W, self.max_det)
+        if ws == 0:
+            raise ValueError("invalid detector geometry")
+        self._ws = torch.empty(ws, dtype=torch.uint8, device=self.device)
+        self._cls = _padded(n, self.device)
+        self._mask = _padded(n, self.device) if want_mask else None
+        self._labels = torch.empty((n + 3) // 4 * 4, dtype=torch.int32, device=self.device)
+        self.det_count = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.det = torch.zeros(self.B, self.max_det, 5, dtype=torch.float32, device=self.device)
+        self.anchors = torch.zeros(self.B, self.max_det, dtype=torch.int32, device=self.device)
+        self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+
+    def _view(self, buf, batch):
+        n = batch * self.H * self.W
+        return buf[:n].view(batch, self.H, self.W)
+
+    def _check_frames(self, frames):
+        if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous():
+            raise ValueError("frames must be a contiguous uint8 device tensor")
+        if frames.dim() not in (3, 4) or frames.shape[1] != self.H or frames.shape[2] != self.W:
+            raise ValueError(f"frames must be [b,{self.H},{self.W}] or [b,{self.H},{self.W},3]")
+        b = frames.shape[0]
+        if not 1 <= b <= self.B:
+            raise ValueError(f"batch {b} exceeds detector batch {self.B}")
+        ch = 1 if frames.dim() == 3 else frames.shape[3]
+        return b, ch
+
+    def threshold(self, frames: torch.Tensor) -> torch.Tensor:
+        """a1-a3 only: class map u8 [b,H,W] (bit0 thresh, bit1 markers)."""
+        b, ch = self._check_frames(frames)
+        p = self.params
+        rc = _lib.lib().ysmr_threshold_batch(_lib.stream_ptr(), frames.data_ptr(), b, self.H, self.W, ch,
+                                             p.inv, p.t_low, p.t_high, p.use_high, self._cls.data_ptr())
+        _lib.check(rc, "ysmr_threshold_batch")
+        return self._view(self._cls, b)
+
+    def detect(self, frames: torch.Tensor) -> DetectResult:
+        """a1-a6 for a batch of frames resident in HBM.  Asynchronous on the current stream."""
+        b, ch = self._check_frames(frames)
+        p = self.params
+        rc = _lib.lib().ysmr_detect_batch(
+            _lib.stream_ptr(), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.t_low, p.t_high, p.use_high,
+            self._ws.data_ptr(), self._ws.numel(), self._cls.data_ptr(),
+            self._mask.data_ptr() if self._mask is not None else None, self._labels.data_ptr(),
+            self.det_count.data_ptr(), self.det.data_ptr(), self.anchors.data_ptr(), self.max_det,
+            self.status.data_ptr())
+        _lib.check(rc, "ysmr_detect_batch")
+        return DetectResult(self._view(self._cls, b),
+                            self._view(self._mask, b) if self._mask is not None else None,
+                            self._view(self._labels, b), self.det_count[:b], self.det[:b], self.anchors[:b],
+                            self.status[:b])
