@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the YSMR detect+link hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the configuration `metric` is quoted on): one synthetic
+1228x922 video stream with ~500 blobs per GPU.  A *step* is one pass of the whole hot path over a
+clip of --frames distinct frames that are already resident in HBM: fused gray->blur->adaptive
+double threshold, hysteresis + component labelling + minAreaRect (batched over --batch frames per
+launch), then the strictly sequential link (nearest-detection claims, track lifecycle, GSFF, row
+emission) frame by frame from a freshly reset tracker.  Every output the path owes -- class map,
+final mask, label map, detections, rows -- is written inside the timed region.
+
+Independent streams shard one per GPU (weak scaling, no data-path collective; torch.distributed is
+used only for the barrier and the max-over-ranks time).
+
+One JSON line on rank 0: frames/s (whole job), the roofline of the threshold kernel measured live
+with HIP events on the launch stream, and the CPU oracle timed on this host's cores on a bounded
+sample of the same clip (a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=512, help="distinct frames per clip (512 x 1.13 MB > 256 MiB L3)")
+    ap.add_argument("--batch", type=int, default=64, help="frames per detection launch")
+    ap.add_argument("--height", type=int, default=922)
+    ap.add_argument("--width", type=int, default=1228)
+    ap.add_argument("--blobs", type=int, default=500)
+    ap.add_argument("--max-det", type=int, default=2048)
+    ap.add_argument("--capacity", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=48, help="frames of the clip timed on the CPU oracle (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames_np, sample, fps):
+    """Time the CPU oracle (single thread, like the reference's one process per video) on the
+    first `sample` frames of the clip."""
+    if sample <= 0:
+        return None
+    from oracle import ysmr_oracle as yo
+    yo.build()
+    sample = min(sample, len(frames_np))
+    t0 = time.perf_counter()
+    rows, _ = yo.track_frames(frames_np[:sample], fps=fps)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample} frames of the clip ({len(rows)} rows), oracle/ysmr_oracle.{{c,py}} "
+                      f"single process; host has {os.cpu_count()} cpus"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ysmr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+
+    F, B, H, W = args.frames, args.batch, args.height, args.width
+    fps_video = 30.0
+    video = SyntheticVideo(H, W, args.blobs, seed=rank, fps=fps_video)
+    frames_np = video.frames(F)                      # one independent stream per rank
+    frames = torch.from_numpy(frames_np).to(dev)     # resident in HBM before the timed region
+
+    det = Detector(B, H, W, max_det=args.max_det, params=threshold_params(True, 5, 2.0), device=dev)
+    trk = DeviceTracker(max_disappeared=fps_video, fps=fps_video, n_min=0, n_max=30, n_f=3, use_gsff=True,
+                        capacity=args.capacity, max_det=args.max_det, device=dev)
+    rows = torch.empty(F * args.capacity * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    row_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    thr_events = []
+
+    def step(timed):
+        trk.reset()
+        row_count.zero_()
+        for f0 in range(0, F, B):
+            clip = frames[f0:f0 + B]
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                det.threshold(clip)
+                e1.record()
+                thr_events.append((e0, e1, clip.shape[0]))
+            else:
+                det.threshold(clip)
+            res = det.components(clip.shape[0])
+            trk.run(res.det, res.det_count, f0, rows, row_count)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # the path must have produced sane output: no overflow/arena flags, no tracker errors, rows
+    n_tracks, next_id, err = trk.info()
+    n_rows = int(row_count.item())
+    status = int(det.status.max().item())
+    if err or status or n_rows <= 0:
+        raise SystemExit(f"hot path reported errors: tracker={err} detect_status={status} rows={n_rows}")
+
+    if rank == 0:
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in thr_events]
+        px = [b * H * W for _, _, b in thr_events]
+        # algorithmic bytes of the fused threshold kernel: 1 B/px read + 1 B/px class map written
+        # (SURVEY 8d), per launch of `batch` frames
+        alg_bytes = 2.0 * sum(px) / len(px)
+        avg_ms = sum(ms) / len(ms)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "threshold_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("batch") == B and rec.get("height") == H and rec.get("width") == W:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames/sec detect+link, 1228x922 ~500 blobs, 1/2/4/8 GPU; HBM GB/s %peak",
+            "value": world * F * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 image / f32 threshold+geometry / f64 link",
+            "data": "synthetic",
+            "config": {"workload": f"{W}x{H} stream, ~{args.blobs} blobs, detect+link end to end (BASELINE configs[2])",
+                       "frames_per_step": F, "detect_batch": B, "streams": world, "parallelism": f"1 stream/GPU x{world}",
+                       "rows_per_step": n_rows, "tracks_alive": n_tracks, "ids_issued": next_id},
+            "roofline": {"kernel": "k_threshold", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "launches_timed": len(ms)},
+        }
+        if world == 1:
+            out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_sample, fps_video)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

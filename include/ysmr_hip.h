@@ -10,9 +10,9 @@
  * Reference interfaces replaced (files under /root/reference):
  *   ysmr_threshold_batch  cv2.cvtColor + cv2.GaussianBlur + 2 x cv2.adaptiveThreshold
  *                         ysmr/track_eval.py:180-208
- *   ysmr_detect_batch     the above + scipy binary_propagation + cv2.findContours +
- *                         cv2.minAreaRect + reshape_result
- *                         ysmr/track_eval.py:180-303, ysmr/helper_file.py:1336-1347
+ *   ysmr_components_batch scipy binary_propagation + cv2.findContours + cv2.minAreaRect +
+ *                         reshape_result   ysmr/track_eval.py:211-303, ysmr/helper_file.py:1336-1347
+ *   ysmr_detect_batch     both of the above in one call
  *   ysmr_tracker_*        CentroidTracker.__init__/update   ysmr/tracker.py:37-71, 93-230
  *                         GaussianSumFIR.correct/predict    ysmr/gsff.py:204-347
  *                         row emission                      ysmr/track_eval.py:313-316
@@ -69,7 +69,15 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
                          int channels, int inv, int t_low, int t_high, int use_high,
                          uint8_t *cls_dev);
 
-/* a1-a6.  Outputs (all device):
+/* a4-a6 from a class map already in HBM (written by ysmr_threshold_batch or by the caller):
+ * hysteresis + labelling + RETR_EXTERNAL ordering + minAreaRect.  Same outputs as
+ * ysmr_detect_batch; cls_dev is read and its bit2 is written. */
+int ysmr_components_batch(void *stream, int batch, int height, int width, void *workspace_dev,
+                          size_t workspace_bytes, uint8_t *cls_dev, uint8_t *mask_dev,
+                          int32_t *labels_dev, int32_t *det_count_dev, float *det_dev,
+                          int32_t *anchors_dev, int max_det, int32_t *status_dev);
+
+/* a1-a6 = ysmr_threshold_batch followed by ysmr_components_batch.  Outputs (all device):
  *   cls_dev     u8  [batch][H][W]  class map as above (bit2 is used internally as a flag)
  *   mask_dev    u8  [batch][H][W]  final mask {0,255} == binary_propagation(markers, mask=thresh)
  *                                  (may be NULL)

@@ -869,13 +869,12 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
                             use_high, cls_dev);
 }
 
-int ysmr_detect_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels, int inv,
-                      int t_low, int t_high, int use_high, void *workspace_dev, size_t workspace_bytes,
-                      uint8_t *cls_dev, uint8_t *mask_dev, int32_t *labels_dev, int32_t *det_count_dev, float *det_dev,
-                      int32_t *anchors_dev, int max_det, int32_t *status_dev)
+int ysmr_components_batch(void *stream, int batch, int height, int width, void *workspace_dev, size_t workspace_bytes,
+                          uint8_t *cls_dev, uint8_t *mask_dev, int32_t *labels_dev, int32_t *det_count_dev,
+                          float *det_dev, int32_t *anchors_dev, int max_det, int32_t *status_dev)
 {
-    if (int rc = check_geometry(batch, height, width, channels, max_det)) return rc;
-    if (!frames_dev || !cls_dev || !labels_dev || !det_count_dev || !det_dev || !status_dev || !workspace_dev)
+    if (int rc = check_geometry(batch, height, width, 1, max_det)) return rc;
+    if (!cls_dev || !labels_dev || !det_count_dev || !det_dev || !status_dev || !workspace_dev)
         return ysmr::fail(YSMR_ERR_ARG, "a required device pointer is NULL");
     if (((uintptr_t)cls_dev & 15) || ((uintptr_t)labels_dev & 15) || (mask_dev && ((uintptr_t)mask_dev & 15)))
         return ysmr::fail(YSMR_ERR_ARG, "cls_dev, labels_dev and mask_dev must be 16-byte aligned");
@@ -890,8 +889,6 @@ int ysmr_detect_batch(void *stream, const uint8_t *frames_dev, int batch, int he
 
     YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch + 4), st));
     YSMR_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t) * batch, st));
-    if (int rc = launch_threshold(st, frames_dev, batch, height, width, channels, inv, t_low, t_high, use_high, cls_dev))
-        return rc;
     hipLaunchKernelGGL(k_init_labels, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
     hipLaunchKernelGGL(k_union4, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
     hipLaunchKernelGGL(k_flag, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
@@ -912,6 +909,18 @@ int ysmr_detect_batch(void *stream, const uint8_t *frames_dev, int batch, int he
     hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
+}
+
+int ysmr_detect_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels, int inv,
+                      int t_low, int t_high, int use_high, void *workspace_dev, size_t workspace_bytes,
+                      uint8_t *cls_dev, uint8_t *mask_dev, int32_t *labels_dev, int32_t *det_count_dev, float *det_dev,
+                      int32_t *anchors_dev, int max_det, int32_t *status_dev)
+{
+    if (int rc = ysmr_threshold_batch(stream, frames_dev, batch, height, width, channels, inv, t_low, t_high, use_high,
+                                      cls_dev))
+        return rc;
+    return ysmr_components_batch(stream, batch, height, width, workspace_dev, workspace_bytes, cls_dev, mask_dev,
+                                 labels_dev, det_count_dev, det_dev, anchors_dev, max_det, status_dev);
 }
 
 }  // extern "C"

@@ -106,6 +106,26 @@ class Detector:
         _lib.check(rc, "ysmr_threshold_batch")
         return self._view(self._cls, b)
 
+    def components(self, batch=None, cls: torch.Tensor | None = None) -> DetectResult:
+        """a4-a6 on the class map left by ``threshold`` (or on a caller-supplied u8 [b,H,W] map)."""
+        if cls is not None:
+            batch = cls.shape[0]
+            self._view(self._cls, batch).copy_(cls)
+        b = self.B if batch is None else int(batch)
+        rc = _lib.lib().ysmr_components_batch(
+            _lib.stream_ptr(), b, self.H, self.W, self._ws.data_ptr(), self._ws.numel(), self._cls.data_ptr(),
+            self._mask.data_ptr() if self._mask is not None else None, self._labels.data_ptr(),
+            self.det_count.data_ptr(), self.det.data_ptr(), self.anchors.data_ptr(), self.max_det,
+            self.status.data_ptr())
+        _lib.check(rc, "ysmr_components_batch")
+        return self._result(b)
+
+    def _result(self, b):
+        return DetectResult(self._view(self._cls, b),
+                            self._view(self._mask, b) if self._mask is not None else None,
+                            self._view(self._labels, b), self.det_count[:b], self.det[:b], self.anchors[:b],
+                            self.status[:b])
+
     def detect(self, frames: torch.Tensor) -> DetectResult:
         """a1-a6 for a batch of frames resident in HBM.  Asynchronous on the current stream."""
         b, ch = self._check_frames(frames)
@@ -117,7 +137,4 @@ class Detector:
             self.det_count.data_ptr(), self.det.data_ptr(), self.anchors.data_ptr(), self.max_det,
             self.status.data_ptr())
         _lib.check(rc, "ysmr_detect_batch")
-        return DetectResult(self._view(self._cls, b),
-                            self._view(self._mask, b) if self._mask is not None else None,
-                            self._view(self._labels, b), self.det_count[:b], self.det[:b], self.anchors[:b],
-                            self.status[:b])
+        return self._result(b)

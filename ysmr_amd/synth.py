@@ -65,7 +65,9 @@ class SyntheticVideo:
     def _render(self):
         rng = self.rng
         h, w, n = self.h, self.w, self.n
-        img = rng.normal(self.bg, self.sigma, size=(h, w)).astype(np.float32)
+        img = rng.standard_normal(size=(h, w), dtype=np.float32)
+        img *= np.float32(self.sigma)
+        img += np.float32(self.bg)
         if n:
             visible = rng.random(n) >= self.dropout
             idx = np.nonzero(visible)[0]
@@ -94,7 +96,9 @@ class SyntheticVideo:
             sy = rng.integers(0, h, k)
             sx = rng.integers(0, w, k)
             img[sy, sx] = rng.uniform(120.0, 220.0, k).astype(np.float32)
-        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        np.rint(img, out=img)
+        np.clip(img, 0, 255, out=img)
+        return img.astype(np.uint8)
 
     def next_frame(self):
         if self.frame_index:
