@@ -171,45 +171,87 @@ __device__ __forceinline__ uint32_t chunk_byte(const uint4 &v, int i)
     return (w >> (8 * (i & 3))) & 0xFFu;
 }
 
-// Pass A: every pixel with a class bit becomes its own root.
-__global__ __launch_bounds__(256) void k_init_labels(const uint8_t *__restrict__ cls,
-                                                     uint32_t *__restrict__ labels, Geo g, size_t nchunks)
+// The foreground is sparse (bacteria cover ~1 % of a frame), so every pass after this one walks a
+// compacted list of the 16-pixel chunks that contain class bits instead of the whole batch.
+struct ChunkList {
+    uint32_t *idx;     // chunk indices, unordered
+    uint32_t *count;   // number of entries
+};
+
+constexpr int SPARSE_BLOCKS = 2048;  // grid of the list-driven passes (grid-stride over the list)
+
+// 16 consecutive lanes share one listed chunk, one lane per pixel: the passes are bound by chains
+// of dependent L2 round trips (union-find), so they want many short threads, not few long ones.
+#define FOR_LISTED_PIXELS(cl, c, i)                                                                              \
+    for (size_t li_ = (size_t)blockIdx.x * 256 + threadIdx.x, ln_ = (size_t)(*(cl).count) * 16; li_ < ln_;      \
+         li_ += (size_t)gridDim.x * 256)                                                                         \
+        if (size_t c = (cl).idx[li_ >> 4]; true)                                                                 \
+            if (const int i = (int)(li_ & 15); true)
+
+// Pass A0 (dense, HBM-bound: 1 B/px read): compact the chunks that hold any class bit.  Each block
+// gathers its finds in LDS and publishes them with ONE global atomicAdd (a single hot counter
+// serves only ~90 atomics/us on this chip).
+constexpr int COLLECT_BLOCKS = 1024;
+constexpr int COLLECT_LDS = 8192;  // entries buffered per block before a flush
+
+__global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls, Geo g, size_t nchunks, ChunkList cl)
 {
+    __shared__ uint32_t s_buf[COLLECT_LDS];
+    __shared__ uint32_t s_n, s_base;
+    const int lane = threadIdx.x & 63;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t rounds = (nchunks + stride - 1) / stride;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nchunks) return;
-    uint4 v = load_chunk(cls, c, g.total);
-    size_t base = c * 16;
-    uint32_t out[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        uint32_t b = chunk_byte(v, i) & 3u;
-        size_t flat = base + i;
-        uint32_t f = (uint32_t)(flat / g.HW);
-        out[i] = b ? (uint32_t)(flat - (size_t)f * g.HW) + 1u : 0u;
+    for (size_t r = 0; r < rounds; ++r, c += stride) {
+        bool has = false;
+        if (c < nchunks) {
+            uint4 v = load_chunk(cls, c, g.total);
+            has = ((v.x | v.y | v.z | v.w) & 0x03030303u) != 0;
+        }
+        unsigned long long m = __ballot(has);
+        if (m) {
+            int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (has) s_buf[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)c;
+        }
+        // flush when the next round could overflow the buffer (block-uniform decision)
+        __syncthreads();
+        uint32_t n = s_n;
+        if (n + 256 > COLLECT_LDS || r + 1 == rounds) {
+            if (threadIdx.x == 0) { s_base = n ? atomicAdd(cl.count, n) : 0; }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += 256) cl.idx[s_base + i] = s_buf[i];
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+        }
     }
-    if (base + 16 <= g.total) {
-        uint4 *dst = reinterpret_cast<uint4 *>(labels + base);
-        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
-        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
-        dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
-        dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
-    } else {
-        for (int i = 0; i < 16 && base + i < g.total; ++i) labels[base + i] = out[i];
+}
+
+// Pass A (sparse): every pixel with a class bit becomes its own root (the label map itself was
+// cleared by a memset).
+__global__ __launch_bounds__(256) void k_init_labels(const uint8_t *__restrict__ cls,
+                                                     uint32_t *__restrict__ labels, Geo g, ChunkList cl)
+{
+    FOR_LISTED_PIXELS(cl, c, i) {
+        size_t flat = c * 16 + i;
+        if (flat >= g.total || !(cls[flat] & 3u)) continue;
+        uint32_t f = (uint32_t)(flat / g.HW);
+        labels[flat] = (uint32_t)(flat - (size_t)f * g.HW) + 1u;
     }
 }
 
 // Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
 __global__ __launch_bounds__(256) void k_union4(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
-                                                size_t nchunks)
+                                                ChunkList cl)
 {
-    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nchunks) return;
-    uint4 v = load_chunk(cls, c, g.total);
-    if (((v.x | v.y | v.z | v.w) & 0x01010101u) == 0) return;
-    size_t base = c * 16;
-    for (int i = 0; i < 16; ++i) {
-        if (!(chunk_byte(v, i) & 1u)) continue;
-        size_t flat = base + i;
+    FOR_LISTED_PIXELS(cl, c, i) {
+        size_t flat = c * 16 + i;
+        if (flat >= g.total || !(cls[flat] & 1u)) continue;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
         uint32_t *L = labels + (size_t)f * g.HW;
@@ -226,28 +268,26 @@ __device__ __forceinline__ void set_flag(uint8_t *cls, size_t flat)
 
 // Pass C: flag (bit2 on the root's class byte) every thresh-component that holds a marker pixel
 // or touches (4-neighbourhood) a marker pixel lying outside the mask.
-__global__ __launch_bounds__(256) void k_flag(uint8_t *cls, const uint32_t *labels, Geo g, size_t nchunks)
+__global__ __launch_bounds__(256) void k_flag(uint8_t *cls, const uint32_t *labels, Geo g, ChunkList cl)
 {
-    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nchunks) return;
-    uint4 v = load_chunk(cls, c, g.total);
-    if (((v.x | v.y | v.z | v.w) & 0x02020202u) == 0) return;
-    size_t base = c * 16;
-    for (int i = 0; i < 16; ++i) {
-        uint32_t b = chunk_byte(v, i);
-        if (!(b & 2u)) continue;
-        size_t flat = base + i;
-        uint32_t f, p; int y, x;
-        locate(g, flat, f, p, y, x);
-        const uint32_t *L = labels + (size_t)f * g.HW;
-        size_t fbase = (size_t)f * g.HW;
-        if (b & 1u) {
-            set_flag(cls, fbase + find_root(L, p));
-        } else {
-            if (x > 0 && (cls[flat - 1] & 1u)) set_flag(cls, fbase + find_root(L, p - 1));
-            if (x < g.W - 1 && (cls[flat + 1] & 1u)) set_flag(cls, fbase + find_root(L, p + 1));
-            if (y > 0 && (cls[flat - g.W] & 1u)) set_flag(cls, fbase + find_root(L, p - g.W));
-            if (y < g.H - 1 && (cls[flat + g.W] & 1u)) set_flag(cls, fbase + find_root(L, p + g.W));
+    FOR_LISTED_PIXELS(cl, c, i) {
+        {
+            size_t flat = c * 16 + i;
+            if (flat >= g.total) continue;
+            uint32_t b = cls[flat];
+            if (!(b & 2u)) continue;
+            uint32_t f, p; int y, x;
+            locate(g, flat, f, p, y, x);
+            const uint32_t *L = labels + (size_t)f * g.HW;
+            size_t fbase = (size_t)f * g.HW;
+            if (b & 1u) {
+                set_flag(cls, fbase + find_root(L, p));
+            } else {
+                if (x > 0 && (cls[flat - 1] & 1u)) set_flag(cls, fbase + find_root(L, p - 1));
+                if (x < g.W - 1 && (cls[flat + 1] & 1u)) set_flag(cls, fbase + find_root(L, p + 1));
+                if (y > 0 && (cls[flat - g.W] & 1u)) set_flag(cls, fbase + find_root(L, p - g.W));
+                if (y < g.H - 1 && (cls[flat + g.W] & 1u)) set_flag(cls, fbase + find_root(L, p + g.W));
+            }
         }
     }
 }
@@ -263,17 +303,14 @@ __device__ __forceinline__ bool in_result(const uint8_t *cls_frame, const uint32
 
 // Pass D: 8-connected components of R (what cv2.findContours traces).
 __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
-                                                size_t nchunks)
+                                                ChunkList cl)
 {
-    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nchunks) return;
-    uint4 v = load_chunk(cls, c, g.total);
-    if (((v.x | v.y | v.z | v.w) & 0x03030303u) == 0) return;
-    size_t base = c * 16;
-    for (int i = 0; i < 16; ++i) {
-        uint32_t b = chunk_byte(v, i);
+    FOR_LISTED_PIXELS(cl, c, i) {
+    {
+        size_t flat = c * 16 + i;
+        if (flat >= g.total) continue;
+        uint32_t b = cls[flat];
         if (!(b & 3u)) continue;
-        size_t flat = base + i;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
         uint32_t *L = labels + (size_t)f * g.HW;
@@ -289,44 +326,35 @@ __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls,
             if (x < W - 1) { q = p - W + 1; bq = cf[q]; if ((bq & 3u) && in_result(cf, L, q, bq)) unite(L, p, q); }
         }
     }
+    }
 }
 
-// Pass E: final labels (root + 1), final mask, list of roots per frame.
+// Pass E: final labels (root + 1), final mask (cleared by a memset beforehand), roots per frame.
 __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls, uint32_t *labels,
-                                                 uint8_t *__restrict__ mask, Geo g, size_t nchunks,
+                                                 uint8_t *__restrict__ mask, Geo g, ChunkList cl,
                                                  int32_t *nroots, int32_t *roots, int max_det)
 {
-    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nchunks) return;
-    uint4 v = load_chunk(cls, c, g.total);
-    size_t base = c * 16;
-    uint32_t mw[4] = {0, 0, 0, 0};
-    if (((v.x | v.y | v.z | v.w) & 0x03030303u) != 0) {
-        for (int i = 0; i < 16; ++i) {
-            uint32_t b = chunk_byte(v, i);
-            if (!(b & 3u)) continue;
-            size_t flat = base + i;
-            uint32_t f = (uint32_t)(flat / g.HW);
-            uint32_t p = (uint32_t)(flat - (size_t)f * g.HW);
-            uint32_t *L = labels + (size_t)f * g.HW;
-            const uint8_t *cf = cls + (size_t)f * g.HW;
-            uint32_t r = find_root(L, p);
-            bool inr = (r != DEAD) && ((b & 2u) || (cf[r] & 6u));
-            if (inr) {
-                if (r != p) __hip_atomic_store(&L[p], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mw[i >> 2] |= 0xFFu << (8 * (i & 3));
-                if (r == p) {
-                    int idx = atomicAdd(&nroots[f], 1);
-                    if (idx < max_det) roots[(size_t)f * max_det + idx] = (int32_t)p;
-                }
-            } else {
-                __hip_atomic_store(&L[p], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FOR_LISTED_PIXELS(cl, c, i) {
+        size_t flat = c * 16 + i;
+        if (flat >= g.total) continue;
+        uint32_t b = cls[flat];
+        if (!(b & 3u)) continue;
+        uint32_t f = (uint32_t)(flat / g.HW);
+        uint32_t p = (uint32_t)(flat - (size_t)f * g.HW);
+        uint32_t *L = labels + (size_t)f * g.HW;
+        const uint8_t *cf = cls + (size_t)f * g.HW;
+        uint32_t r = find_root(L, p);
+        bool inr = (r != DEAD) && ((b & 2u) || (cf[r] & 6u));
+        if (inr) {
+            if (r != p) __hip_atomic_store(&L[p], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mask) mask[flat] = 255;
+            if (r == p) {
+                int idx = atomicAdd(&nroots[f], 1);
+                if (idx < max_det) roots[(size_t)f * max_det + idx] = (int32_t)p;
             }
+        } else {
+            __hip_atomic_store(&L[p], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    }
-    if (mask) {
-        if (base + 16 <= g.total) *reinterpret_cast<uint4 *>(mask + base) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-        else for (int i = 0; i < 16 && base + i < g.total; ++i) mask[base + i] = (uint8_t)(mw[i >> 2] >> (8 * (i & 3)));
     }
 }
 
@@ -387,29 +415,20 @@ __device__ __forceinline__ int find_rank(const int32_t *order, int n, int32_t ro
 
 // Per final-mask pixel: bounding box of its component; bit-quad counts for the Euler number
 // (E8 = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows, each window counted by its first set pixel).
-__global__ __launch_bounds__(256) void k_bbox_euler(const uint32_t *__restrict__ labels, Geo g, size_t nchunks,
-                                                    CompTables t)
+__global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ cls, const uint32_t *__restrict__ labels,
+                                                    Geo g, ChunkList cl, CompTables t)
 {
-    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nchunks) return;
-    size_t base = c * 16;
-    uint32_t lab[16];
-    if (base + 16 <= g.total) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(labels + base);
-        uint4 a = src[0], b = src[1], cc = src[2], d = src[3];
-        if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | cc.x | cc.y | cc.z | cc.w | d.x | d.y | d.z | d.w) == 0) return;
-        lab[0] = a.x; lab[1] = a.y; lab[2] = a.z; lab[3] = a.w; lab[4] = b.x; lab[5] = b.y; lab[6] = b.z; lab[7] = b.w;
-        lab[8] = cc.x; lab[9] = cc.y; lab[10] = cc.z; lab[11] = cc.w; lab[12] = d.x; lab[13] = d.y; lab[14] = d.z; lab[15] = d.w;
-    } else {
-        for (int i = 0; i < 16; ++i) lab[i] = (base + i < g.total) ? labels[base + i] : 0u;
-    }
-    for (int i = 0; i < 16; ++i) {
-        if (!lab[i]) continue;
+    FOR_LISTED_PIXELS(cl, c, i) {
+    {
+        const size_t base = c * 16;
+        if (base + i >= g.total || !(cls[base + i] & 3u)) continue;
+        const uint32_t lab_i = labels[base + i];
+        if (!lab_i) continue;
         size_t flat = base + i;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
         int n = min(t.nroots[f], t.max_det);
-        int k = find_rank(t.order + (size_t)f * t.max_det, n, (int32_t)(lab[i] - 1));
+        int k = find_rank(t.order + (size_t)f * t.max_det, n, (int32_t)(lab_i - 1));
         if (k < 0) continue;  // component beyond max_det (overflow already flagged)
         size_t o = (size_t)f * t.max_det + k;
         const uint32_t *L = labels + (size_t)f * g.HW;
@@ -438,6 +457,7 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint32_t *__restrict__
         if (!nn && !ne) quad(nn, ne, 1, ee);        // BL: first iff TL, TR clear
         if (!nw && !nn && !ww) quad(nw, nn, ww, 1); // BR: first iff all others clear
         if (q) atomicAdd(&t.euler4[o], q);
+    }
     }
 }
 
@@ -793,6 +813,7 @@ Gauss11 make_gauss11()
 struct Workspace {
     int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed;
     int2 *holed;
+    ChunkList chunks;
     uint32_t *arena_used;
     float *det_tmp, *arena;
     uint32_t arena_floats;
@@ -809,6 +830,8 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     w.nroots = (int32_t *)take(sizeof(int32_t) * ((size_t)batch + 4));
     w.n_holed = w.nroots + batch;
     w.arena_used = (uint32_t *)(w.n_holed + 1);
+    w.chunks.count = (uint32_t *)(w.n_holed + 2);
+    w.chunks.idx = (uint32_t *)take(sizeof(uint32_t) * (((size_t)batch * H * W + 15) / 16));
     w.holed = (int2 *)take(sizeof(int2) * HOLED_CAP);
     w.roots = (int32_t *)take(sizeof(int32_t) * bm);
     w.order = (int32_t *)take(sizeof(int32_t) * bm);
@@ -889,16 +912,20 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
 
     YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch + 4), st));
     YSMR_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t) * batch, st));
-    hipLaunchKernelGGL(k_init_labels, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
-    hipLaunchKernelGGL(k_union4, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
-    hipLaunchKernelGGL(k_flag, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
-    hipLaunchKernelGGL(k_union8, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, g, nchunks);
-    hipLaunchKernelGGL(k_flatten, dim3(cgrid), dim3(256), 0, st, cls_dev, labels, mask_dev, g, nchunks, w.nroots,
-                       w.roots, max_det);
+    YSMR_HIP_CHECK(hipMemsetAsync(labels, 0, sizeof(uint32_t) * g.total, st));
+    if (mask_dev) YSMR_HIP_CHECK(hipMemsetAsync(mask_dev, 0, g.total, st));
+    const unsigned dense_grid = cgrid < (unsigned)COLLECT_BLOCKS ? cgrid : (unsigned)COLLECT_BLOCKS;
+    const dim3 sg(SPARSE_BLOCKS), tb(256);
+    hipLaunchKernelGGL(k_collect, dim3(dense_grid), tb, 0, st, cls_dev, g, nchunks, w.chunks);
+    hipLaunchKernelGGL(k_init_labels, sg, tb, 0, st, cls_dev, labels, g, w.chunks);
+    hipLaunchKernelGGL(k_union4, sg, tb, 0, st, cls_dev, labels, g, w.chunks);
+    hipLaunchKernelGGL(k_flag, sg, tb, 0, st, cls_dev, labels, g, w.chunks);
+    hipLaunchKernelGGL(k_union8, sg, tb, 0, st, cls_dev, labels, g, w.chunks);
+    hipLaunchKernelGGL(k_flatten, sg, tb, 0, st, cls_dev, labels, mask_dev, g, w.chunks, w.nroots, w.roots, max_det);
     YSMR_LAUNCH_CHECK();
     CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, max_det};
     hipLaunchKernelGGL(k_rank, dim3(batch), dim3(256), 0, st, t, width, height, status_dev);
-    hipLaunchKernelGGL(k_bbox_euler, dim3(cgrid), dim3(256), 0, st, labels, g, nchunks, t);
+    hipLaunchKernelGGL(k_bbox_euler, sg, tb, 0, st, cls_dev, labels, g, w.chunks, t);
     const unsigned comp_threads = (unsigned)((size_t)batch * max_det);
     hipLaunchKernelGGL(k_holes, dim3((comp_threads + 255) / 256), dim3(256), 0, st, t, batch, w.n_holed, w.holed, status_dev);
     hipLaunchKernelGGL(k_nested, dim3(HOLED_CAP), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,

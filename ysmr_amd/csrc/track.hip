@@ -3,11 +3,13 @@
 // (ysmr/track_eval.py:313-316), device-resident across frames.
 //
 // Per frame two launches, no host round trip:
-//   k_rowmin  (one wave per track)  nearest detection of every track: fused row-min / arg-min of
-//                                   the N x M float64 distance matrix, which is never stored
-//                                   (tracker.py:151-163 only ever reads D.min(1), D.argmin(1))
 //   k_link    (one workgroup)       claim resolution, ageing / deregistration, registration in
-//                                   CPython set order, GSFF correct+predict per track, rows
+//                                   CPython set order
+//   k_track   (one wave per track)  GSFF correct+predict, the frame's output row, and the nearest
+//                                   detection of the NEXT frame: fused row-min / arg-min of the
+//                                   N x M float64 distance matrix, which is never stored
+//                                   (tracker.py:151-163 only ever reads D.min(1), D.argmin(1))
+//   (k_rowmin does that last step stand-alone for the first frame of a batch.)
 //
 // Claim rule (tracker.py:158-189): proposals are visited in ascending (row minimum, row); a
 // proposal is accepted iff its column is still free.  Each row occurs once, so the winner of a
@@ -23,7 +25,7 @@
 #define YSMR_MAX_FILTERS 8
 
 struct TrackerDev {
-    int capacity, max_det, n_f, use_gsff, hist_cap, table_cap;
+    int capacity, max_det, n_f, use_gsff, hist_cap, table_cap, gain_total;
     double max_gone, lik_min;
     int n_i[YSMR_MAX_FILTERS];
     int gain_off[YSMR_MAX_FILTERS];  // filter i: row0 at gains[gain_off[i]], row1 at +2*n_i[i]
@@ -34,20 +36,18 @@ struct TrackerDev {
     int *id, *gone, *mode, *hist_len, *hist_head;
     double *pos;      // [2][cap]
     float *info;      // [3][cap]
-    double *hist;     // [hist_cap][2][cap]
+    double *hist;     // [cap][hist_cap][2]  (one contiguous ring per track slot)
     double *weights;  // [n_f][cap]
     double *liks;     // [n_f][cap]
     double *xhat;     // [2][n_f][cap]
     // per-frame scratch
-    unsigned long long *col_key;  // [max_det] smallest row-minimum (as ordered bits) proposing this column
-    int *col_row;                 // [max_det] winning row, INT_MAX = column unused
+    int *unused;                  // [max_det] unclaimed detection columns, ascending
     double *row_min;              // [cap]
     int *row_arg;                 // [cap]
-    int *claim_col;               // [cap]
     int *dead;                    // [cap]
     int *new_cols;                // [max_det]
     int *set_table;               // [2][table_cap] CPython set model
-    int *scalars;                 // n_before, n_new
+    long long *row_base;          // first output row of the current frame (k_link -> k_gsff)
 };
 
 struct ysmr_tracker {
@@ -71,46 +71,56 @@ __device__ __forceinline__ int det_count(int m_host, const int32_t *m_dev, int m
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rowmin: one wave per track row.
+// Nearest detection of one track, computed by one wave (64 lanes stride over the detections).
 // scipy cdist('euclidean') on 2-D points is sqrt(dx*dx + dy*dy) in float64; argmin
 // takes the lowest column among equal distances.  sqrt is monotone, so the row minimum is
-// sqrt(min s); two different s can round to the same sqrt, which is resolved exactly in merge().
+// sqrt(min s); two different s can round to the same sqrt -- merge() resolves that exactly, and
+// keeps the (expensive, almost never needed) float64 sqrt behind a wave-uniform branch.
 // ------------------------------------------------------------------------------------------
 struct Cand { double s; int j; };
 
 __device__ __forceinline__ Cand merge(Cand a, Cand b)
 {
     // each candidate = (min s of its subset, first index whose sqrt equals sqrt(min s))
-    if (a.j < 0) return b;
-    if (b.j < 0) return a;
-    double lo = fmin(a.s, b.s), hi = fmax(a.s, b.s);
-    bool same = (hi == lo);
-    if (!same && (hi - lo) <= lo * 0x1p-48) same = (sqrt(hi) == sqrt(lo));
+    const double lo = fmin(a.s, b.s), hi = fmax(a.s, b.s);
+    const bool valid = (a.j >= 0) && (b.j >= 0);
+    bool same = valid && (hi == lo);
+    const bool close = valid && !same && (hi - lo) <= lo * 0x1p-48;
+    if (__any(close)) {
+        if (close) same = (sqrt(hi) == sqrt(lo));
+    }
     Cand r;
-    if (same) { r.s = lo; r.j = min(a.j, b.j); }
+    if (a.j < 0) r = b;
+    else if (b.j < 0) r = a;
+    else if (same) { r.s = lo; r.j = min(a.j, b.j); }
     else if (a.s < b.s) r = a;
     else r = b;
     return r;
 }
 
 template <typename DetT>
-__global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__restrict__ det, int m_host,
-                                                const int32_t *m_dev)
+__device__ __forceinline__ void rowmin_wave(const TrackerDev &t, int row, double px, double py,
+                                            const DetT *__restrict__ det, int m, int lane)
 {
-    const int n = *t.n_tracks;
-    const int m = det_count(m_host, m_dev, t.max_det, nullptr);
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= n || m == 0) return;
-    const int slot = t.order[row];
-    const double px = t.pos[slot], py = t.pos[t.capacity + slot];
     Cand best{0.0, -1};
-    for (int j = lane; j < m; j += 64) {
-        double dx = px - (double)det[(size_t)j * 5 + 0];
-        double dy = py - (double)det[(size_t)j * 5 + 1];
-        double s = dx * dx;
-        s = s + dy * dy;
-        best = merge(best, Cand{s, j});
+    for (int j0 = 0; j0 < m; j0 += 256) {
+        double qx[4], qy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {   // four independent loads in flight per lane
+            int j = min(j0 + u * 64 + lane, m - 1);
+            qx[u] = (double)det[(size_t)j * 5 + 0];
+            qy[u] = (double)det[(size_t)j * 5 + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int j = j0 + u * 64 + lane;
+            double dx = px - qx[u];
+            double dy = py - qy[u];
+            double s = dx * dx;
+            s = s + dy * dy;
+            Cand c{s, j < m ? j : -1};
+            best = merge(best, c);
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -123,113 +133,225 @@ __global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__rest
         double d = sqrt(best.s);
         t.row_min[row] = d;
         t.row_arg[row] = best.j;
-        atomicMin(&t.col_key[best.j], (unsigned long long)__double_as_longlong(d));  // d >= 0: bits are ordered
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// GSFF (gsff.py).  History is a ring of hist_cap = n_i[-1] + 1 measurements per track slot.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fir(const TrackerDev &t, int slot, int i, int head, double &x0, double &x1)
+// Stand-alone row-min pass (first frame of a batch / single-frame updates); inside a batch the
+// row-min of frame f+1 rides on k_track of frame f.
+template <typename DetT>
+__global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__restrict__ det, int m_host,
+                                                const int32_t *m_dev)
 {
-    // lsff_calc (gsff.py:156-177): np.dot(gain, flatten(measurements[-N:])), rows 0 and 1
-    const int N = t.n_i[i];
-    const double *g0 = t.gains + t.gain_off[i];
-    const double *g1 = g0 + 2 * N;
-    int e = head - N;
-    if (e < 0) e += t.hist_cap;
-    double a0 = 0.0, a1 = 0.0;
-    for (int j = 0; j < N; ++j) {
-        double yx = t.hist[((size_t)e * 2 + 0) * t.capacity + slot];
-        double yy = t.hist[((size_t)e * 2 + 1) * t.capacity + slot];
-        a0 = a0 + g0[2 * j] * yx;
-        a0 = a0 + g0[2 * j + 1] * yy;
-        a1 = a1 + g1[2 * j] * yx;
-        a1 = a1 + g1[2 * j + 1] * yy;
-        if (++e == t.hist_cap) e = 0;
-    }
-    x0 = a0;
-    x1 = a1;
+    const int n = *t.n_tracks;
+    const int m = det_count(m_host, m_dev, t.max_det, nullptr);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n || m == 0) return;
+    const int slot = t.order[row];
+    rowmin_wave(t, row, t.pos[slot], t.pos[t.capacity + slot], det, m, threadIdx.x & 63);
 }
 
-__device__ void gsff_step(const TrackerDev &t, int slot, double z0, double z1, double &out0, double &out1,
-                          double &pred0, double &pred1)
+// ------------------------------------------------------------------------------------------
+// GSFF (gsff.py), one WAVE per track.  The track's history ring (hist_cap entries of (x, y),
+// contiguous in HBM) is spread over the lanes -- value k = 2*entry + component lives in lane
+// k % 64 -- so a FIR estimate sum_k G[k] * y[k] is one multiply per lane plus a butterfly
+// reduction instead of a 2N-long chain of dependent float64 adds, and the whole state arrives with
+// one coalesced load.
+// ------------------------------------------------------------------------------------------
+constexpr int TRACK_VALS = 2;  // values per lane: supports hist_cap <= 64 entries
+
+struct TrackRegs {
+    double v[TRACK_VALS];   // history values held by this lane
+};
+
+// FIR estimates of ALL active filters at once (rows 0 and 1 of gain f times the last n_f[f]
+// measurements: lsff_calc, gsff.py:156-177).  The 2*mode butterflies are interleaved so that the
+// cross-lane latency is paid once per level, not once per sum.
+__device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const TrackRegs &h, int lane, int mode, int head,
+                                             double *x0, double *x1)
 {
-    const int cap = t.capacity, nf = t.n_f;
-    int len = t.hist_len[slot], head = t.hist_head[slot], mode = t.mode[slot];
-    // ---- correct (gsff.py:251-347)
-    if (len == 0) {
-        for (int j = 0; j < t.n_i[0]; ++j) {
-            t.hist[((size_t)j * 2 + 0) * cap + slot] = z0;
-            t.hist[((size_t)j * 2 + 1) * cap + slot] = z1;
-        }
-        len = t.n_i[0];
-        head = len % t.hist_cap;
-    }
-    bool grew = false;
-    if (mode < nf) {
-        while (len >= t.n_i[mode]) {
-            ++mode;
-            grew = true;
-            if (mode >= nf) break;
-        }
-    }
-    if (grew) {
-        const double w0 = 1.0 / (double)mode;
-        for (int i = 0; i < mode; ++i) {
-            double a, b;
-            fir(t, slot, i, head, a, b);
-            t.xhat[((size_t)0 * nf + i) * cap + slot] = a;
-            t.xhat[((size_t)1 * nf + i) * cap + slot] = b;
-            t.weights[(size_t)i * cap + slot] = w0;
+    const int L = t.hist_cap;
+    double p0[YSMR_MAX_FILTERS], p1[YSMR_MAX_FILTERS];
+#pragma unroll
+    for (int f = 0; f < YSMR_MAX_FILTERS; ++f) { p0[f] = 0.0; p1[f] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < TRACK_VALS; ++q) {
+        int k = lane + 64 * q;
+        int e = k >> 1, comp = k & 1;
+        int age = head - 1 - e;          // 0 = newest
+        if (age < 0) age += L;
+        if (e < L) {
+#pragma unroll
+            for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
+                if (f < mode) {
+                    const int N = t.n_i[f];
+                    if (age < N) {
+                        const double *g0 = t.gains + t.gain_off[f];
+                        int col = 2 * (N - 1 - age) + comp;
+                        p0[f] = p0[f] + g0[col] * h.v[q];
+                        p1[f] = p1[f] + g0[2 * N + col] * h.v[q];
+                    }
+                }
+            }
         }
     }
-    double total = 0.0;
-    for (int i = 0; i < mode; ++i) {
-        double d0 = z0 - t.xhat[((size_t)0 * nf + i) * cap + slot];
-        double d1 = z1 - t.xhat[((size_t)1 * nf + i) * cap + slot];
-        double q = d0 * d0;
-        q = q + d1 * d1;
-        double lik = exp(-0.5 * q);
-        if (lik < t.lik_min) lik = t.lik_min;
-        t.liks[(size_t)i * cap + slot] = lik;
-        total = total + lik * t.weights[(size_t)i * cap + slot];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
+            if (f < mode) {
+                p0[f] = p0[f] + __shfl_xor(p0[f], off);
+                p1[f] = p1[f] + __shfl_xor(p1[f], off);
+            }
+        }
     }
-    t.hist[((size_t)head * 2 + 0) * cap + slot] = z0;
-    t.hist[((size_t)head * 2 + 1) * cap + slot] = z1;
-    if (++head == t.hist_cap) head = 0;
-    if (len < t.hist_cap) ++len;
-    // np.sum(x_hat * w, axis=1): NumPy seeds the reduction with element 0 and adds the running
-    // sum of the remaining ones, i.e. a0 + ((a1 + a2) + ...)
-    double f0 = 0.0, f1 = 0.0, r0 = 0.0, r1 = 0.0;
-    for (int i = 0; i < mode; ++i) {
-        double w = t.liks[(size_t)i * cap + slot] * t.weights[(size_t)i * cap + slot] / total;
-        t.weights[(size_t)i * cap + slot] = w;
-        double a = t.xhat[((size_t)0 * nf + i) * cap + slot] * w;
-        double b = t.xhat[((size_t)1 * nf + i) * cap + slot] * w;
-        if (i == 0) { f0 = a; f1 = b; }
-        else if (i == 1) { r0 = a; r1 = b; }
-        else { r0 = r0 + a; r1 = r1 + b; }
+#pragma unroll
+    for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+        if (f < mode) { x0[f] = p0[f]; x1[f] = p1[f]; }
+}
+
+template <typename DetT>
+__global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row *rows, long long rows_capacity,
+                                               const DetT *__restrict__ next_det, int next_m_host,
+                                               const int32_t *next_m_dev)
+{
+    const int n_live = *t.n_tracks;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_live) return;
+    const int lane = threadIdx.x & 63;
+    const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
+    const int slot = __builtin_amdgcn_readfirstlane(t.order[i]);
+    const double z0 = t.pos[slot], z1 = t.pos[cap + slot];
+    double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
+    if (t.use_gsff) {
+        double *hist = t.hist + (size_t)slot * 2 * L;
+        int len = t.hist_len[slot], head = t.hist_head[slot], mode = t.mode[slot];
+        TrackRegs h;
+#pragma unroll
+        for (int q = 0; q < TRACK_VALS; ++q) {
+            int k = lane + 64 * q;
+            h.v[q] = (k < 2 * L) ? hist[k] : 0.0;
+        }
+        double w[YSMR_MAX_FILTERS], xh0[YSMR_MAX_FILTERS], xh1[YSMR_MAX_FILTERS];
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
+            bool on = f < mode;
+            w[f] = on ? t.weights[(size_t)f * cap + slot] : 0.0;
+            xh0[f] = on ? t.xhat[((size_t)0 * nf + f) * cap + slot] : 0.0;
+            xh1[f] = on ? t.xhat[((size_t)1 * nf + f) * cap + slot] : 0.0;
+        }
+        // ---- correct (gsff.py:251-347)
+        bool fresh = (len == 0);
+        if (fresh) {   // history starts as n_i[0] copies of the first measurement
+#pragma unroll
+            for (int q = 0; q < TRACK_VALS; ++q) {
+                int k = lane + 64 * q;
+                if ((k >> 1) < t.n_i[0]) h.v[q] = (k & 1) ? z1 : z0;
+            }
+            len = t.n_i[0];
+            head = len % L;
+        }
+        bool grew = false;
+        if (mode < nf) {
+            while (len >= t.n_i[mode]) {
+                ++mode;
+                grew = true;
+                if (mode >= nf) break;
+            }
+        }
+        if (grew) {
+            const double w0 = 1.0 / (double)mode;
+            fir_wave_all(t, h, lane, mode, head, xh0, xh1);
+#pragma unroll
+            for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+                if (f < mode) w[f] = w0;
+        }
+        double lik[YSMR_MAX_FILTERS];
+        double total = 0.0;
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+            if (f < mode) {
+                double d0 = z0 - xh0[f], d1 = z1 - xh1[f];
+                double q = d0 * d0;
+                q = q + d1 * d1;
+                double l = exp(-0.5 * q);
+                if (l < t.lik_min) l = t.lik_min;
+                lik[f] = l;
+                total = total + l * w[f];
+            }
+        // append the measurement
+        const int at = head;
+#pragma unroll
+        for (int q = 0; q < TRACK_VALS; ++q) {
+            int k = lane + 64 * q;
+            if ((k >> 1) == at) h.v[q] = (k & 1) ? z1 : z0;
+        }
+        if (++head == L) head = 0;
+        if (len < L) ++len;
+        // new weights; output = np.sum(x_hat * w, axis=1) = a0 + ((a1 + a2) + ...)
+        double f0 = 0.0, f1 = 0.0, r0 = 0.0, r1 = 0.0;
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+            if (f < mode) {
+                w[f] = lik[f] * w[f] / total;
+                double a = xh0[f] * w[f], b = xh1[f] * w[f];
+                if (f == 0) { f0 = a; f1 = b; }
+                else if (f == 1) { r0 = a; r1 = b; }
+                else { r0 = r0 + a; r1 = r1 + b; }
+            }
+        o0 = mode > 1 ? f0 + r0 : f0;
+        o1 = mode > 1 ? f1 + r1 : f1;
+        // ---- predict (gsff.py:204-249)
+        f0 = f1 = r0 = r1 = 0.0;
+        fir_wave_all(t, h, lane, mode, head, xh0, xh1);
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+            if (f < mode) {
+                double a = xh0[f] * w[f], b = xh1[f] * w[f];
+                if (f == 0) { f0 = a; f1 = b; }
+                else if (f == 1) { r0 = a; r1 = b; }
+                else { r0 = r0 + a; r1 = r1 + b; }
+            }
+        p0 = mode > 1 ? f0 + r0 : f0;
+        p1 = mode > 1 ? f1 + r1 : f1;
+        // ---- write back
+#pragma unroll
+        for (int q = 0; q < TRACK_VALS; ++q) {
+            int k = lane + 64 * q;
+            if (k < 2 * L && (fresh || (k >> 1) == at)) hist[k] = h.v[q];
+        }
+        if (lane == 0) {
+            t.hist_len[slot] = len;
+            t.hist_head[slot] = head;
+            t.mode[slot] = mode;
+            t.pos[slot] = p0;
+            t.pos[cap + slot] = p1;
+        }
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+            if (f < mode && lane == f) {
+                t.weights[(size_t)f * cap + slot] = w[f];
+                t.liks[(size_t)f * cap + slot] = lik[f];
+                t.xhat[((size_t)0 * nf + f) * cap + slot] = xh0[f];
+                t.xhat[((size_t)1 * nf + f) * cap + slot] = xh1[f];
+            }
     }
-    out0 = mode > 1 ? f0 + r0 : f0;
-    out1 = mode > 1 ? f1 + r1 : f1;
-    // ---- predict (gsff.py:204-249)
-    f0 = f1 = r0 = r1 = 0.0;
-    for (int i = 0; i < mode; ++i) {
-        double a, b;
-        fir(t, slot, i, head, a, b);
-        t.xhat[((size_t)0 * nf + i) * cap + slot] = a;
-        t.xhat[((size_t)1 * nf + i) * cap + slot] = b;
-        double w = t.weights[(size_t)i * cap + slot];
-        if (i == 0) { f0 = a * w; f1 = b * w; }
-        else if (i == 1) { r0 = a * w; r1 = b * w; }
-        else { r0 = r0 + a * w; r1 = r1 + b * w; }
+    if (lane == 0) {
+        const long long base = t.row_base[0];
+        if (rows && base + i < rows_capacity) {
+            ysmr_row r;
+            r.frame = frame;
+            r.track_id = t.id[slot];
+            r.x = o0; r.y = o1;
+            r.w = t.info[slot]; r.h = t.info[cap + slot]; r.angle = t.info[2 * cap + slot];
+            r.disappeared = t.gone[slot];
+            rows[base + i] = r;
+        }
     }
-    pred0 = mode > 1 ? f0 + r0 : f0;
-    pred1 = mode > 1 ? f1 + r1 : f1;
-    t.hist_len[slot] = len;
-    t.hist_head[slot] = head;
-    t.mode[slot] = mode;
+    // ---- nearest detection of the NEXT frame for this track (tracker.py:151-163)
+    if (next_det) {
+        const int m = det_count(next_m_host, next_m_dev, t.max_det, nullptr);
+        if (m > 0) rowmin_wave(t, i, p0, p1, next_det, m, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -251,21 +373,19 @@ __device__ void set_insert_clean(int *table, unsigned mask, int key)
     }
 }
 
-__device__ int cpython_unused_order(const TrackerDev &t, int m, int n_used, int *out)
+__device__ int cpython_unused_order(const TrackerDev &t, int m, int n_used, int n_unused, int *out)
 {
-    int count = 0;
-    if ((m >> 2) > n_used) {  // set_copy_and_difference: a copy of set(range(m)) iterates ascending
-        for (int c = 0; c < m; ++c)
-            if (t.col_row[c] == 0x7FFFFFFF) out[count++] = c;
-        return count;
+    const int *unused = t.unused;  // ascending
+    if ((m >> 2) > n_used) {       // set_copy_and_difference: a copy of set(range(m)) iterates ascending
+        for (int k = 0; k < n_unused; ++k) out[k] = unused[k];
+        return n_unused;
     }
     int *table = t.set_table, *other = t.set_table + t.table_cap;
     unsigned mask = 7;
     int fill = 0;
     for (int i = 0; i < 8; ++i) table[i] = -1;
-    for (int c = 0; c < m; ++c) {
-        if (t.col_row[c] != 0x7FFFFFFF) continue;
-        set_insert_clean(table, mask, c);  // no equal keys, no dummies: add == insert_clean
+    for (int k = 0; k < n_unused; ++k) {
+        set_insert_clean(table, mask, unused[k]);  // no equal keys, no dummies: add == insert_clean
         ++fill;
         if ((unsigned long long)fill * 5ull >= (unsigned long long)mask * 3ull) {
             unsigned minused = fill > 50000 ? (unsigned)fill * 2u : (unsigned)fill * 4u;
@@ -279,6 +399,7 @@ __device__ int cpython_unused_order(const TrackerDev &t, int m, int n_used, int 
             mask = newsize - 1;
         }
     }
+    int count = 0;
     for (unsigned i = 0; i <= mask; ++i)
         if (table[i] >= 0) out[count++] = table[i];
     return count;
@@ -314,6 +435,12 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
                                                        int32_t *n_rows_out, int32_t *claim_out, int32_t *n_before_out,
                                                        int32_t *new_cols_out, int32_t *n_new_out)
 {
+    // dynamic LDS: per-column winner tables and per-row claims live on chip, so the claim
+    // resolution costs LDS atomics and barriers instead of global round trips
+    extern __shared__ unsigned long long s_dyn[];
+    unsigned long long *s_col_key = s_dyn;                                // [max_det]
+    int *s_col_row = reinterpret_cast<int *>(s_col_key + t.max_det);      // [max_det]
+    int *s_claim = s_col_row + t.max_det;                                 // [capacity]
     __shared__ int s_scan[LINK_THREADS];
     __shared__ int s_n_used, s_n_new, s_any_dead;
     const int tid = threadIdx.x;
@@ -321,21 +448,24 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     const int n = *t.n_tracks;
     const int m = det_count(m_host, m_dev, t.max_det, t.err);
     if (tid == 0) { s_n_used = 0; s_n_new = 0; s_any_dead = 0; }
+    for (int c = tid; c < m; c += LINK_THREADS) { s_col_key[c] = ~0ull; s_col_row[c] = 0x7FFFFFFF; }
     __syncthreads();
 
-    // ---- claims
+    // ---- claims: the winner of a column is the proposer with the smallest (distance, row)
     if (n > 0 && m > 0) {
+        for (int r = tid; r < n; r += LINK_THREADS)
+            atomicMin(&s_col_key[t.row_arg[r]], (unsigned long long)__double_as_longlong(t.row_min[r]));
+        __syncthreads();
         for (int r = tid; r < n; r += LINK_THREADS) {
             int c = t.row_arg[r];
-            if ((unsigned long long)__double_as_longlong(t.row_min[r]) == t.col_key[c]) atomicMin(&t.col_row[c], r);
+            if ((unsigned long long)__double_as_longlong(t.row_min[r]) == s_col_key[c]) atomicMin(&s_col_row[c], r);
         }
-        __threadfence_block();
         __syncthreads();
         int used = 0;
         for (int r = tid; r < n; r += LINK_THREADS) {
             int c = t.row_arg[r];
-            int mine = (__hip_atomic_load(&t.col_row[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == r) ? c : -1;
-            t.claim_col[r] = mine;
+            int mine = (s_col_row[c] == r) ? c : -1;
+            s_claim[r] = mine;
             if (mine >= 0) {
                 int slot = t.order[r];
                 t.pos[slot] = (double)det[(size_t)mine * 5 + 0];
@@ -349,22 +479,24 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         }
         if (used) atomicAdd(&s_n_used, used);
     } else {
-        for (int r = tid; r < n; r += LINK_THREADS) t.claim_col[r] = -1;
+        for (int r = tid; r < n; r += LINK_THREADS) s_claim[r] = -1;
     }
     __syncthreads();
 
     // ---- ageing (tracker.py:95-107, 198-211): only when there are no detections or N >= M
     const bool age = (m == 0) || (n > 0 && n >= m);
-    for (int r = tid; r < n; r += LINK_THREADS) {
-        int d = 0;
-        if (age && t.claim_col[r] < 0) {
-            int slot = t.order[r];
-            int g = t.gone[slot] + 1;
-            t.gone[slot] = g;
-            t.info[slot] = 0.f; t.info[cap + slot] = 0.f; t.info[2 * cap + slot] = 0.f;
-            if ((double)g > t.max_gone) { d = 1; s_any_dead = 1; }
+    if (age) {
+        for (int r = tid; r < n; r += LINK_THREADS) {
+            int d = 0;
+            if (s_claim[r] < 0) {
+                int slot = t.order[r];
+                int g = t.gone[slot] + 1;
+                t.gone[slot] = g;
+                t.info[slot] = 0.f; t.info[cap + slot] = 0.f; t.info[2 * cap + slot] = 0.f;
+                if ((double)g > t.max_gone) { d = 1; s_any_dead = 1; }
+            }
+            t.dead[r] = d;
         }
-        t.dead[r] = d;
     }
     __syncthreads();
 
@@ -396,10 +528,24 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         if (n == 0) {
             for (int c = tid; c < m; c += LINK_THREADS) t.new_cols[c] = c;
             if (tid == 0) s_n_new = m;
-        } else if (tid == 0) {
-            int cnt = cpython_unused_order(t, m, s_n_used, t.new_cols);
-            if (cnt < 0) { atomicOr(t.err, ERR_TRACK_CAPACITY); cnt = 0; }
-            s_n_new = cnt;
+        } else {
+            // unused columns in ascending order (parallel), then CPython's set order (one thread)
+            int base = 0;
+            for (int c0 = 0; c0 < m; c0 += LINK_THREADS) {
+                int c = c0 + tid;
+                int un = (c < m && s_col_row[c] == 0x7FFFFFFF) ? 1 : 0;
+                int total;
+                int ex = block_exclusive_scan(un, s_scan, &total);
+                if (un) t.unused[base + ex] = c;
+                base += total;
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (tid == 0) {
+                int cnt = cpython_unused_order(t, m, s_n_used, base, t.new_cols);
+                if (cnt < 0) { atomicOr(t.err, ERR_TRACK_CAPACITY); cnt = 0; }
+                s_n_new = cnt;
+            }
         }
         __threadfence_block();
         __syncthreads();
@@ -435,40 +581,14 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         __syncthreads();
         n_live += n_new;
     }
-    __threadfence_block();
-    __syncthreads();
 
-    // ---- GSFF + rows (tracker.py:219-230, track_eval.py:313-316)
-    long long base = row_count ? *row_count : 0;
-    for (int i = tid; i < n_live; i += LINK_THREADS) {
-        int slot = t.order[i];
-        double z0 = t.pos[slot], z1 = t.pos[cap + slot];
-        double o0 = z0, o1 = z1;
-        if (t.use_gsff) {
-            double p0, p1;
-            gsff_step(t, slot, z0, z1, o0, o1, p0, p1);
-            t.pos[slot] = p0;
-            t.pos[cap + slot] = p1;
-        }
-        if (rows && base + i < rows_capacity) {
-            ysmr_row r;
-            r.frame = frame;
-            r.track_id = t.id[slot];
-            r.x = o0; r.y = o1;
-            r.w = t.info[slot]; r.h = t.info[cap + slot]; r.angle = t.info[2 * cap + slot];
-            r.disappeared = t.gone[slot];
-            rows[base + i] = r;
-        }
-    }
-    // ---- bookkeeping, reset of the per-frame column tables
-    for (int c = tid; c < m; c += LINK_THREADS) {
-        t.col_key[c] = ~0ull;
-        t.col_row[c] = 0x7FFFFFFF;
-    }
-    for (int r = tid; r < n; r += LINK_THREADS)
-        if (claim_out) claim_out[r] = t.claim_col[r];
+    // ---- bookkeeping for k_track
+    if (claim_out)
+        for (int r = tid; r < n; r += LINK_THREADS) claim_out[r] = s_claim[r];
     if (tid == 0) {
+        long long base = row_count ? *row_count : 0;
         *t.n_tracks = n_live;
+        t.row_base[0] = base;
         if (rows && base + n_live > rows_capacity) atomicOr(t.err, ERR_ROWS_CAPACITY);
         if (row_count) *row_count = base + n_live;
         if (n_rows_out) *n_rows_out = n_live;
@@ -481,7 +601,6 @@ __global__ void k_tracker_reset(TrackerDev t)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < t.capacity) t.free_slots[i] = t.capacity - 1 - i;  // slot 0 is handed out first
-    if (i < t.max_det) { t.col_key[i] = ~0ull; t.col_row[i] = 0x7FFFFFFF; }
     if (i == 0) { *t.n_tracks = 0; *t.next_id = 0; *t.err = 0; *t.n_free = t.capacity; }
 }
 
@@ -519,12 +638,16 @@ void closed_form_gain(int N, double *g)
 template <typename DetT>
 int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, const int32_t *m_dev, int frame,
                     ysmr_row *rows, long long rows_capacity, long long *row_count, int32_t *n_rows, int32_t *claim,
-                    int32_t *n_before, int32_t *new_cols, int32_t *n_new)
+                    int32_t *n_before, int32_t *new_cols, int32_t *n_new, bool rowmin_done, const DetT *next_det,
+                    const int32_t *next_m_dev)
 {
     const TrackerDev &d = t->d;
-    hipLaunchKernelGGL(k_rowmin<DetT>, dim3((d.capacity + 3) / 4), dim3(256), 0, st, d, det, m, m_dev);
-    hipLaunchKernelGGL(k_link<DetT>, dim3(1), dim3(LINK_THREADS), 0, st, d, det, m, m_dev, frame, rows,
+    const dim3 wgrid((d.capacity + 3) / 4);
+    if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, d, det, m, m_dev);
+    const size_t link_lds = 12 * (size_t)d.max_det + 4 * (size_t)d.capacity;
+    hipLaunchKernelGGL(k_link<DetT>, dim3(1), dim3(LINK_THREADS), link_lds, st, d, det, m, m_dev, frame, rows,
                        rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
+    hipLaunchKernelGGL(k_track<DetT>, wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det, -1, next_m_dev);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }
@@ -564,8 +687,10 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
 {
     if (!out) return ysmr::fail(YSMR_ERR_ARG, "out must not be NULL");
     *out = nullptr;
-    if (capacity <= 0 || max_det <= 0 || capacity > (1 << 20) || max_det > (1 << 20))
-        return ysmr::fail(YSMR_ERR_ARG, "capacity and max_det must be in 1..2^20");
+    // k_link keeps 12 B per detection column and 4 B per track row in LDS (160 KiB per CU)
+    if (capacity <= 0 || max_det <= 0 || 12 * (size_t)max_det + 4 * (size_t)capacity > 140 * 1024)
+        return ysmr::fail(YSMR_ERR_ARG, "capacity/max_det out of range: need 12*max_det + 4*capacity <= 140 KiB "
+                                        "(e.g. 8192/8192), got %d/%d", capacity, max_det);
     ysmr_tracker *t = new ysmr_tracker();
     TrackerDev &d = t->d;
     std::memset(&d, 0, sizeof(d));
@@ -583,6 +708,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
         if (gains_host) std::memcpy(t->gains_host.data(), gains_host, sizeof(double) * gain_doubles);
         else for (int i = 0; i < n_f; ++i) closed_form_gain(d.n_i[i], t->gains_host.data() + d.gain_off[i]);
         d.hist_cap = d.n_i[n_f - 1] + 1;
+        if (d.hist_cap > 64) { delete t; return ysmr::fail(YSMR_ERR_ARG, "maximum horizon size %d exceeds the supported 63", d.n_i[n_f - 1]); }
     } else {
         d.n_i[0] = 1;
         d.hist_cap = 1;
@@ -590,6 +716,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     unsigned tc = 8;
     while (tc <= (unsigned)max_det * 4u) tc <<= 1;
     d.table_cap = (int)tc;
+    d.gain_total = (int)gain_doubles;
 
     const size_t cap = capacity, nf = d.n_f;
     size_t off = 0;
@@ -603,9 +730,9 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const size_t o_w = take(sizeof(double) * nf * cap), o_l = take(sizeof(double) * nf * cap);
     const size_t o_x = take(sizeof(double) * 2 * nf * cap);
     const size_t o_gain = take(sizeof(double) * (gain_doubles ? gain_doubles : 1));
-    const size_t o_ckey = take(sizeof(unsigned long long) * max_det), o_crow = take(sizeof(int) * max_det);
+    const size_t o_unused = take(sizeof(int) * max_det);
     const size_t o_rmin = take(sizeof(double) * cap), o_rarg = take(sizeof(int) * cap);
-    const size_t o_claim = take(sizeof(int) * cap), o_dead = take(sizeof(int) * cap);
+    const size_t o_dead = take(sizeof(int) * cap);
     const size_t o_new = take(sizeof(int) * max_det), o_table = take(sizeof(int) * 2 * (size_t)d.table_cap);
     t->block_bytes = off;
     hipError_t e = hipMalloc(&t->block, off);
@@ -615,16 +742,17 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     }
     char *b = (char *)t->block;
     int *scal = (int *)(b + o_scal);
-    d.n_tracks = scal; d.next_id = scal + 1; d.err = scal + 2; d.n_free = scal + 3; d.scalars = scal + 4;
+    d.n_tracks = scal; d.next_id = scal + 1; d.err = scal + 2; d.n_free = scal + 3;
+    d.row_base = (long long *)(scal + 8);
     d.order = (int *)(b + o_order); d.order_tmp = (int *)(b + o_order_tmp); d.free_slots = (int *)(b + o_free);
     d.id = (int *)(b + o_id); d.gone = (int *)(b + o_gone); d.mode = (int *)(b + o_mode);
     d.hist_len = (int *)(b + o_hlen); d.hist_head = (int *)(b + o_hhead);
     d.pos = (double *)(b + o_pos); d.info = (float *)(b + o_info); d.hist = (double *)(b + o_hist);
     d.weights = (double *)(b + o_w); d.liks = (double *)(b + o_l); d.xhat = (double *)(b + o_x);
     d.gains = (const double *)(b + o_gain);
-    d.col_key = (unsigned long long *)(b + o_ckey); d.col_row = (int *)(b + o_crow);
+    d.unused = (int *)(b + o_unused);
     d.row_min = (double *)(b + o_rmin); d.row_arg = (int *)(b + o_rarg);
-    d.claim_col = (int *)(b + o_claim); d.dead = (int *)(b + o_dead);
+    d.dead = (int *)(b + o_dead);
     d.new_cols = (int *)(b + o_new); d.set_table = (int *)(b + o_table);
     e = hipMemset(t->block, 0, off);
     if (e == hipSuccess && gain_doubles)
@@ -667,10 +795,10 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
     if (det_is_f64)
         return launch_update_t<double>(t, (hipStream_t)stream, (const double *)det_dev, m, m_dev, frame_index, rows_dev,
                                        t->d.capacity, nullptr, n_rows_dev, claim_col_dev, n_before_dev, new_cols_dev,
-                                       n_new_dev);
+                                       n_new_dev, false, nullptr, nullptr);
     return launch_update_t<float>(t, (hipStream_t)stream, (const float *)det_dev, m, m_dev, frame_index, rows_dev,
                                   t->d.capacity, nullptr, n_rows_dev, claim_col_dev, n_before_dev, new_cols_dev,
-                                  n_new_dev);
+                                  n_new_dev, false, nullptr, nullptr);
 }
 
 int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
@@ -680,9 +808,12 @@ int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const 
     if (!det_dev || !det_count_dev || !rows_dev || !row_count_dev || batch <= 0)
         return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev, rows_dev, row_count_dev must be set and batch > 0");
     for (int f = 0; f < batch; ++f) {
+        const bool has_next = f + 1 < batch;
         int rc = launch_update_t<float>(t, (hipStream_t)stream, det_dev + (size_t)f * t->d.max_det * 5, -1,
                                         det_count_dev + f, first_frame_index + f, rows_dev, (long long)rows_capacity,
-                                        (long long *)row_count_dev, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                        (long long *)row_count_dev, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                        f > 0, has_next ? det_dev + (size_t)(f + 1) * t->d.max_det * 5 : nullptr,
+                                        has_next ? det_count_dev + f + 1 : nullptr);
         if (rc) return rc;
     }
     return YSMR_OK;
