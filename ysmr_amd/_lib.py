@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libysmr_hip.so")
+LIB_PATH = os.environ.get("YSMR_HIP_LIB") or os.path.join(_HERE, "csrc", "libysmr_hip.so")  # env: tuning builds
 
 YSMR_OK = 0
 DET_OVERFLOW = 1

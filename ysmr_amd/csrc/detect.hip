@@ -12,6 +12,7 @@
 #include "common.h"
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -102,6 +103,299 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ f
         int lo = inv ? (d <= t_low) : (d > t_low);
         int hi = use_high ? (inv ? (d <= t_high) : (d > t_high)) : lo;
         cls[(size_t)blockIdx.z * frame_px + (size_t)y * W + x] = (uint8_t)(lo | (hi << 1));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_threshold_strip: a1-a3 for gray input, the HBM-facing kernel of the path.
+//
+// One WAVE owns a vertical strip: lane L holds the 4 pixels (one dword) at columns
+// xs - 12 + 4L .. +3 and marches down the rows.  Lanes 0-2 and 61-63 are halo (the 3x3 blur needs
+// 1 and the 11-tap row filter 5 more pixels on each side).  Per row:
+//   gray dword (HBM, read once, coalesced 256 B / wave)  -> horizontal 1-2-1 sums as SWAR on two
+//   16-bit fields -> vertical 1-2-1 with a 3-row sliding window -> blurred dword (exact u8)
+//   -> neighbour dwords by DPP, 14 x v_cvt_f32_ubyte -> 4 x 11-tap ascending FMA chains (row filter)
+//   -> 11-row ring of row-filtered values in REGISTERS (static slots, loop unrolled by 11)
+//   -> symmetric column filter, round-half-even, SWAR compare, 4 class bytes = one dword store.
+// Nothing but the input frame and the class map touches HBM: 1 B/px read + 1 B/px written.
+// ------------------------------------------------------------------------------------------
+#ifndef STRIP_LDS_EXCHANGE
+#define STRIP_LDS_EXCHANGE 1   // measured 3 % faster than 14 v_cvt_f32_ubyte + 4 DPP shifts per row
+#endif
+#ifndef STRIP_PF
+#define STRIP_PF 2   // gray rows kept in flight per lane
+#endif
+constexpr int STRIP_HALO_LANES = 3;
+constexpr int STRIP_MAX_OUT_LANES = 64 - 2 * STRIP_HALO_LANES;   // 58 lanes = 232 columns
+
+struct StripParams {
+    int H, W, batch;
+    int out_lanes;     // output lanes per strip (<= 58), strips_x * out_lanes * 4 >= W
+    int strips_x;
+    int seg_h;         // output rows per wave
+    int segs_y;
+    int inv, t_low, t_high;
+};
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+struct HSum { uint32_t a, b; };   // horizontal 1-2-1 sums of 4 pixels as 2 x (16-bit, 16-bit)
+
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v)   // value of lane-1 (0 into lane 0)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v)   // value of lane+1 (0 into lane 63)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ HSum hsum4(uint32_t g)
+{
+    const uint32_t gp = wave_shr1(g), gn = wave_shl1(g);
+    // v_perm_b32(S0, S1, sel): result bytes picked from {S1: 0-3, S0: 4-7}, 0x0c = zero
+    uint32_t p0 = __builtin_amdgcn_perm(gp, g, 0x0C000C07u);   // (b-1, b0)
+    uint32_t p1 = __builtin_amdgcn_perm(g, g, 0x0C010C00u);    // (b0, b1)
+    uint32_t p2 = __builtin_amdgcn_perm(g, g, 0x0C020C01u);    // (b1, b2)
+    uint32_t p3 = __builtin_amdgcn_perm(g, g, 0x0C030C02u);    // (b2, b3)
+    uint32_t p4 = __builtin_amdgcn_perm(gn, g, 0x0C040C03u);   // (b3, b4)
+    HSum h;
+    h.a = p0 + (p1 << 1) + p2;   // fields <= 1020: no carry between the 16-bit halves
+    h.b = p2 + (p3 << 1) + p4;
+    return h;
+}
+
+__device__ __forceinline__ uint32_t vblur4(const HSum &u, const HSum &c, const HSum &d)
+{
+    uint32_t ta = (u.a + (c.a << 1) + d.a + 0x00080008u) >> 4;
+    uint32_t tb = (u.b + (c.b << 1) + d.b + 0x00080008u) >> 4;
+    return __builtin_amdgcn_perm(tb, ta, 0x06040200u);   // bytes 0,2 of ta then bytes 0,2 of tb
+}
+
+// Per-wave constants of a strip
+struct StripCtx {
+    const uint8_t *src;   // frame base
+    uint8_t *dst;
+    int H, W, lane, c0, y0, y1;
+    uint32_t ld_col;      // column actually loaded by this lane (clamped into the row)
+    bool left_edge, right_edge;
+    int edge_lane;        // lane holding the last image column (W % 4 == 0: in its byte 3)
+    bool writes;
+    float sgn, k_lo, k_hi;   // class bit = clamp(sgn * (s - m) + k, 0, 1)
+    float *xrow;             // this wave's LDS exchange row (with 8 floats of slack on each side)
+};
+
+// gray dword of `row` for this lane (lanes outside the image load a clamped, valid address)
+__device__ __forceinline__ uint32_t load_row(const StripCtx &c, int row)
+{
+    return load_u32_unaligned(c.src + ((uint32_t)row * (uint32_t)c.W + c.ld_col));
+}
+
+// XEDGE: the single out-of-image byte that matters -- the REFLECT_101 neighbour of the first/last
+// image column -- is patched in from the neighbouring lane when the row is CONSUMED (patching at
+// load time would force a vmcnt(0) right behind every prefetch).
+template <bool XEDGE>
+__device__ __forceinline__ uint32_t patch_row(const StripCtx &c, uint32_t g)
+{
+    if (XEDGE) {
+        if (c.left_edge) {   // column -1 (byte 3 of lane 2) := column 1 (byte 1 of lane 3)
+            uint32_t g3 = (uint32_t)__builtin_amdgcn_readlane((int)g, STRIP_HALO_LANES);
+            if (c.lane == STRIP_HALO_LANES - 1) g = (g3 << 16) & 0xFF000000u;
+        }
+        if (c.right_edge) {  // column W (byte 0 of lane edge+1) := column W-2 (byte 2 of lane edge)
+            uint32_t ge = (uint32_t)__builtin_amdgcn_readlane((int)g, c.edge_lane);
+            if (c.lane == c.edge_lane + 1) g = (ge >> 16) & 0xFFu;
+        }
+    }
+    return g;
+}
+
+// One strip.  XEDGE: the strip touches the left/right image border.  YEDGE: the segment's halo
+// leaves the image at the top/bottom (rows are clamped/reflected and the 3-row window may have to
+// be reloaded); interior segments slide unconditionally.
+template <bool XEDGE, bool YEDGE>
+__device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
+{
+    const int H = c.H, W = c.W, lane = c.lane;
+    float ring[11][4];    // row-filtered values of the last 11 blurred rows
+    float fring[11][4];   // the blurred pixels themselves (only the last 6 rows are live)
+#pragma unroll
+    for (int s = 0; s < 11; ++s)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { ring[s][o] = 0.f; fring[s][o] = 0.f; }
+
+    const int rb_lo = c.y0 - 5, rb_hi = c.y1 - 1 + 5;
+    HSum hu, hc, hd;
+    int ic, id;
+    uint32_t gq[STRIP_PF];
+    {   // prologue: window for the first blurred row, and the rows in flight
+        const int rbc = YEDGE ? clampi(rb_lo, 0, H - 1) : rb_lo;
+        const int ru = YEDGE ? reflect101(rbc - 1, H) : rbc - 1;
+        hc = hsum4(patch_row<XEDGE>(c, load_row(c, ru)));      // becomes hu after the first slide
+        hd = hsum4(patch_row<XEDGE>(c, load_row(c, rbc)));     // becomes hc
+        hu = hc;
+        ic = ru; id = rbc;
+#pragma unroll
+        for (int d = 0; d < STRIP_PF; ++d) {
+            const int r = YEDGE ? reflect101(clampi(rb_lo + d, 0, H - 1) + 1, H) : rb_lo + d + 1;
+            gq[d] = load_row(c, r);
+        }
+    }
+    for (int rb0 = rb_lo; rb0 <= rb_hi; rb0 += 11) {
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const int rb = rb0 + s;
+            if (rb <= rb_hi) {   // (no break: the slot index s must stay a compile-time constant)
+            // ---- blurred row rbc = clamp(rb): REPLICATE for the Gaussian outside the image
+            if (YEDGE) {
+                const int rbc = clampi(rb, 0, H - 1);
+                const int ru = reflect101(rbc - 1, H), rd = reflect101(rbc + 1, H);
+                if (ic == ru && id == rbc) {          // steady state: slide down one row
+                    hu = hc; hc = hd; ic = id;
+                    hd = hsum4(patch_row<XEDGE>(c, gq[0]));
+                } else {                              // border rows: rebuild the window
+                    hu = hsum4(patch_row<XEDGE>(c, load_row(c, ru)));
+                    hc = hsum4(patch_row<XEDGE>(c, load_row(c, rbc)));
+                    hd = hsum4(patch_row<XEDGE>(c, load_row(c, rd)));
+                    ic = rbc;
+                }
+                id = rd;
+#pragma unroll
+                for (int d = 0; d + 1 < STRIP_PF; ++d) gq[d] = gq[d + 1];
+                gq[STRIP_PF - 1] = load_row(c, reflect101(clampi(rb + STRIP_PF, 0, H - 1) + 1, H));
+            } else {
+                hu = hc; hc = hd;
+                hd = hsum4(patch_row<XEDGE>(c, gq[0]));
+#pragma unroll
+                for (int d = 0; d + 1 < STRIP_PF; ++d) gq[d] = gq[d + 1];
+                gq[STRIP_PF - 1] = load_row(c, rb + STRIP_PF + 1);
+            }
+            uint32_t b = vblur4(hu, hc, hd);
+            if (XEDGE) {
+                if (c.left_edge) {
+                    uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)b, STRIP_HALO_LANES) & 0xFFu;
+                    if (lane < STRIP_HALO_LANES) b = e * 0x01010101u;
+                }
+                if (c.right_edge) {
+                    uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)b, c.edge_lane) >> 24;
+                    if (lane > c.edge_lane) b = e * 0x01010101u;
+                }
+            }
+#if STRIP_LDS_EXCHANGE
+            // ---- row filter: convert once, exchange floats with the neighbour lanes through one LDS row
+            // (a wave's LDS accesses complete in order; the fences only pin the compiler)
+            const float4 mine = make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu),
+                                            (float)(b >> 24));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            *reinterpret_cast<float4 *>(c.xrow + 4 * lane) = mine;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float4 l1 = *reinterpret_cast<const float4 *>(c.xrow + 4 * lane - 4);
+            const float4 r1 = *reinterpret_cast<const float4 *>(c.xrow + 4 * lane + 4);
+            const float l2 = c.xrow[4 * lane - 5];
+            const float r2 = c.xrow[4 * lane + 8];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float v[14] = {l2, l1.x, l1.y, l1.z, l1.w, mine.x, mine.y, mine.z, mine.w, r1.x, r1.y, r1.z, r1.w, r2};
+#else
+            // ---- row filter: neighbour pixels arrive as packed dwords through whole-wave DPP shifts
+            // (no LDS round trip, no wait counters), then one v_cvt_f32_ubyteN per tap
+            const uint32_t bm1 = wave_shr1(b), bm2 = wave_shr1(bm1), bp1 = wave_shl1(b), bp2 = wave_shl1(bp1);
+            const float v[14] = {(float)(bm2 >> 24),
+                                 (float)(bm1 & 0xFFu), (float)((bm1 >> 8) & 0xFFu), (float)((bm1 >> 16) & 0xFFu), (float)(bm1 >> 24),
+                                 (float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu), (float)(b >> 24),
+                                 (float)(bp1 & 0xFFu), (float)((bp1 >> 8) & 0xFFu), (float)((bp1 >> 16) & 0xFFu), (float)(bp1 >> 24),
+                                 (float)(bp2 & 0xFFu)};
+#endif
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc = fmaf(v[o + k], gk.k[k], acc);
+                ring[s][o] = acc;
+            }
+            fring[s][0] = v[5]; fring[s][1] = v[6]; fring[s][2] = v[7]; fring[s][3] = v[8];
+            // ---- column filter for output row y = rb - 5 (slot of row y+j is (s - 5 + j) mod 11)
+            const int y = rb - 5;
+            if (y >= c.y0) {
+                const int sc = (s + 6) % 11;   // slot of the centre row y
+                // Everything below stays in full-rate f32 ops (on gfx950 v_fma/v_add issue in 2 cycles,
+                // integer, conversion and rounding ops in 4): round-half-even by the 1.5*2^23 trick,
+                // the two comparisons as clamped adds (s - m is an integer, so
+                // clamp(s - m - t, 0, 1) == (s - m > t)), classes 0..3 packed by v_cvt_pk_u8_f32.
+                uint32_t out = 0;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float acc = fmaf(ring[sc][o], gk.k[5], 0.0f);
+#pragma unroll
+                    for (int j = 1; j <= 5; ++j)
+                        acc = fmaf(ring[(sc + j) % 11][o] + ring[(sc + 11 - j) % 11][o], gk.k[5 + j], acc);
+                    float m = (acc + 12582912.0f) - 12582912.0f;       // rintf for 0 <= acc < 2^22
+                    float d = fring[sc][o] - m;
+                    float lo = __builtin_amdgcn_fmed3f(fmaf(d, c.sgn, c.k_lo), 0.0f, 1.0f);
+                    float hi = __builtin_amdgcn_fmed3f(fmaf(d, c.sgn, c.k_hi), 0.0f, 1.0f);
+                    out = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(hi, 2.0f, lo), o, out);
+                }
+                if (c.writes)
+                    *reinterpret_cast<uint32_t *>(c.dst + ((uint32_t)y * (uint32_t)W + (uint32_t)c.c0)) = out;
+            }
+            }
+        }
+    }
+}
+
+// Requires W % 4 == 0 and W >= 16 (else the tile kernel above is used).
+__global__ __launch_bounds__(256, 4) void k_threshold_strip(const uint8_t *__restrict__ frames,
+                                                         uint8_t *__restrict__ cls, StripParams P, Gauss11 gk)
+{
+#if STRIP_LDS_EXCHANGE
+    __shared__ float s_x[4][64 * 4 + 16];
+#endif
+    // everything derived from the wave index is wave-uniform: say so (readfirstlane), or the compiler
+    // keeps row counters in VGPRs and turns every loop test into a divergent branch + vmcnt(0)
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + wave_in_block;
+    const int per_frame = P.strips_x * P.segs_y;
+    const int f = (int)(wave / per_frame);
+    if (f >= P.batch) return;
+    const int rem = (int)(wave - (long long)f * per_frame);
+    const int sx = rem % P.strips_x, sy = rem / P.strips_x;
+    StripCtx c;
+    c.H = P.H; c.W = P.W; c.lane = lane;
+#if STRIP_LDS_EXCHANGE
+    c.xrow = s_x[wave_in_block] + 8;
+#else
+    c.xrow = nullptr;
+#endif
+    const int xs = sx * P.out_lanes * 4;
+    c.c0 = xs - 4 * STRIP_HALO_LANES + 4 * lane;
+    c.y0 = sy * P.seg_h;
+    c.y1 = min(c.y0 + P.seg_h, P.H);
+    c.src = frames + (size_t)f * P.H * P.W;
+    c.dst = cls + (size_t)f * P.H * P.W;
+    c.ld_col = (uint32_t)clampi(c.c0, 0, P.W - 4);
+    c.left_edge = (xs == 0);
+    const int last_col_rel = (P.W - 1) - (xs - 4 * STRIP_HALO_LANES);
+    c.right_edge = last_col_rel < 252;           // column W falls inside this wave's lanes
+    c.edge_lane = min(last_col_rel >> 2, 63);
+    c.writes = lane >= STRIP_HALO_LANES && lane < STRIP_HALO_LANES + P.out_lanes && c.c0 < P.W;
+    // THRESH_BINARY: bit = (d > t) = clamp(d - t);  THRESH_BINARY_INV: bit = (d <= t) = clamp(t + 1 - d)
+    c.sgn = P.inv ? -1.0f : 1.0f;
+    c.k_lo = P.inv ? (float)(P.t_low + 1) : (float)(-P.t_low);
+    c.k_hi = P.inv ? (float)(P.t_high + 1) : (float)(-P.t_high);
+    const bool xedge = c.left_edge || c.right_edge;
+    const bool yedge = (c.y0 - 6 < 0) || (c.y1 + 5 + STRIP_PF + 1 >= P.H);
+    if (xedge) {
+        if (yedge) strip_body<true, true>(c, gk); else strip_body<true, false>(c, gk);
+    } else {
+        if (yedge) strip_body<false, true>(c, gk); else strip_body<false, false>(c, gk);
     }
 }
 
@@ -863,12 +1157,27 @@ int check_geometry(int batch, int H, int W, int channels, int max_det)
 int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, int W, int channels, int inv, int t_low,
                      int t_high, int use_high, uint8_t *cls)
 {
-    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, batch);
     Gauss11 gk = make_gauss11();
-    if (channels == 1)
-        hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high);
-    else
-        hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high);
+    if (channels == 1 && (W & 3) == 0 && W >= 16 && H >= 2 && t_low > -100000 && t_low < 100000 && t_high > -100000 &&
+        t_high < 100000) {
+        StripParams P;
+        P.H = H; P.W = W; P.batch = batch;
+        const int quads = (W + 3) / 4;
+        P.strips_x = (quads + STRIP_MAX_OUT_LANES - 1) / STRIP_MAX_OUT_LANES;
+        P.out_lanes = (quads + P.strips_x - 1) / P.strips_x;
+        P.seg_h = 45;   // 45 + 10 halo rows = 5 x 11 ring rotations (best of a 45..155 sweep)
+        if (const char *e = getenv("YSMR_SEG_H")) P.seg_h = atoi(e);   // tuning knob
+        P.segs_y = (H + P.seg_h - 1) / P.seg_h;
+        P.inv = inv; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
+        const long long waves = (long long)batch * P.strips_x * P.segs_y;
+        hipLaunchKernelGGL(k_threshold_strip, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, frames, cls, P, gk);
+    } else {
+        dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, batch);
+        if (channels == 1)
+            hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high);
+        else
+            hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high);
+    }
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }
