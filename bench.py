@@ -68,24 +68,22 @@ def main():
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from ysmr_amd import dist
+    info = dist.rank_info()
+    rank, local_rank, world = info.rank, info.local_rank, info.world
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    dist.init(info, backend="nccl", device=dev)   # barrier + max-over-ranks time only; no data-path collective
 
     from ysmr_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
-    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.helper_file import default_settings
     from ysmr_amd.synth import SyntheticVideo
-    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    from ysmr_amd.track_eval import TrackingPipeline
 
     F, B, H, W = args.frames, args.batch, args.height, args.width
     fps_video = 30.0
@@ -93,54 +91,41 @@ def main():
     frames_np = video.frames(F)                      # one independent stream per rank
     frames = torch.from_numpy(frames_np).to(dev)     # resident in HBM before the timed region
 
-    det = Detector(B, H, W, max_det=args.max_det, params=threshold_params(True, 5, 2.0), device=dev)
-    trk = DeviceTracker(max_disappeared=fps_video, fps=fps_video, n_min=0, n_max=30, n_f=3, use_gsff=True,
-                        capacity=args.capacity, max_det=args.max_det, device=dev)
-    rows = torch.empty(F * args.capacity * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    row_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    settings = default_settings()                    # tracking.ini defaults: offset 5, adt 2.0, GSFF 10/20/30
+    pipe = TrackingPipeline(H, W, fps_video, settings, batch=B, max_det=args.max_det, capacity=args.capacity,
+                            device=dev, rows_per_flush=F * args.capacity)
     thr_events = []
 
     def step(timed):
-        trk.reset()
-        row_count.zero_()
+        # one clip, fresh tracker; detection of batch b+1 (side stream) overlaps the link of batch b
+        pipe.reset()
+        pending, last = None, None
         for f0 in range(0, F, B):
-            clip = frames[f0:f0 + B]
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                det.threshold(clip)
-                e1.record()
-                thr_events.append((e0, e1, clip.shape[0]))
-            else:
-                det.threshold(clip)
-            res = det.components(clip.shape[0])
-            trk.run(res.det, res.det_count, f0, rows, row_count)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
+            nxt = (pipe.detect_async(frames[f0:f0 + B], thr_events if timed else None), f0)
+            if pending is not None:
+                (slot, res, ready), p0 = pending
+                last = pipe.link(slot, res, ready, p0)
+            pending = nxt
+        (slot, res, ready), p0 = pending
+        return pipe.link(slot, res, ready, p0)
 
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
-    barrier()
+    dist.barrier(info)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        last_res = step(True)
     torch.cuda.synchronize()
-    barrier()
+    dist.barrier(info)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, info, device=dev)
 
     # the path must have produced sane output: no overflow/arena flags, no tracker errors, rows
-    n_tracks, next_id, err = trk.info()
-    n_rows = int(row_count.item())
-    status = int(det.status.max().item())
+    n_tracks, next_id, err = pipe.trk.info()
+    n_rows = int(pipe.row_count.item())
+    status = max(int(d.status.max().item()) for d in pipe.det)
     if err or status or n_rows <= 0:
         raise SystemExit(f"hot path reported errors: tracker={err} detect_status={status} rows={n_rows}")
 
@@ -185,8 +170,7 @@ def main():
         if world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_sample, fps_video)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    dist.finish(info)
 
 
 if __name__ == "__main__":

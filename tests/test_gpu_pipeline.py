@@ -1,0 +1,83 @@
+"""GPU: the reference-shaped entry points (track_bacteria / analyse / ysmr) end to end vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import compare_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(**kw):
+    from ysmr_amd.helper_file import default_settings
+    s = default_settings(**{"user input": False, "select files": False, "display video analysis": False,
+                            "log to file": False, "minimal frame count": 40})
+    s.update(kw)
+    return s
+
+
+def _rows_from_df(df):
+    from ysmr_amd import _lib
+    df = df.sort_values(["POSITION_T", "TRACK_ID"]).reset_index(drop=True)
+    rows = np.zeros(len(df), _lib.ROW_DTYPE)
+    rows["frame"], rows["track_id"] = df["POSITION_T"], df["TRACK_ID"]
+    rows["x"], rows["y"] = df["POSITION_X"], df["POSITION_Y"]
+    rows["w"], rows["h"], rows["angle"] = df["WIDTH"], df["HEIGHT"], df["DEGREES_ANGLE"]
+    rows["disappeared"] = ((df["WIDTH"] == 0) & (df["HEIGHT"] == 0) & (df["DEGREES_ANGLE"] == 0)).astype(int)
+    return rows
+
+
+def test_track_bacteria_matches_oracle(tmp_path, oracle):
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(208, 272, 30, seed=21, dropout=0.04, speckle=0.04).frames(70)
+    path = tmp_path / "clip.npy"
+    np.save(path, frames)
+    res = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16, max_det=256, capacity=256)
+    assert res is not None
+    df, fps, h, w, csv_path = res
+    assert (fps, h, w) == (30.0, 208, 272) and os.path.basename(csv_path) == "clip_list.csv"
+    assert list(df.columns) == ["TRACK_ID", "POSITION_T", "POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE"]
+    assert df["TRACK_ID"].is_monotonic_increasing
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0)
+    got = _rows_from_df(df)
+    # a matched 1-pixel blob also has w = h = angle = 0; use the oracle's notion of "disappeared"
+    ref = np.array(ref_rows)
+    compare_rows(got, ref_rows)
+    assert open(csv_path).readline().strip() == "TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE"
+    assert len(ref) == len(df)
+
+
+def test_dark_on_bright_and_offset_sign_quirk(tmp_path, oracle):
+    """THRESH_BINARY_INV path + the reference's in-place sign flip of the offset (track_eval.py:132)."""
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = 255 - SyntheticVideo(160, 200, 15, seed=5).frames(48)
+    path = tmp_path / "dark.npy"
+    np.save(path, frames)
+    s = _settings(**{"white bacteria on dark background": False})
+    res = track_bacteria(str(path), settings=s, result_folder=str(tmp_path), batch=16, max_det=512, capacity=512)
+    assert res is not None and s["threshold offset for detection"] == -5     # mutated like upstream
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, white_on_dark=False, offset=5, adt=2.0)
+    compare_rows(_rows_from_df(res[0]), ref_rows)
+
+
+def test_analyse_and_ysmr(tmp_path):
+    import json
+    from ysmr_amd import analyse, ysmr
+    from ysmr_amd.synth import SyntheticVideo
+    paths = []
+    for i in range(2):
+        p = tmp_path / f"v{i}.npy"
+        np.save(p, SyntheticVideo(120, 160, 8, seed=i).frames(45))
+        paths.append(str(p))
+    out = tmp_path / "results"
+    df = analyse(paths[0], settings=_settings(), result_folder=str(out), return_df=True, note="x")
+    assert df is not None and len(df) > 0
+    meta = json.load(open(out / "v0_meta.json"))
+    assert meta["fps"] == 30.0 and meta["frame_height"] == 120 and meta["frame_width"] == 160 and meta["note"] == "x"
+    done = ysmr(paths + [str(tmp_path / "nope.npy")], settings=_settings(), result_folder=str(out))
+    assert [p for p, _ in done] == paths + [str(tmp_path / "nope.npy")]
+    assert done[0][1] is True and done[1][1] is True and done[2][1] is None
+    assert (out / "v1_list.csv").exists()

@@ -68,3 +68,4 @@ def test_tracker_matches_reference(oracle, name):
         assert [t.gone for t in tr.tracks] == list(g["disappeared"][sl])
         assert tr.next_id == g["next_id"][f]
         assert sorted(claims) == sorted(map(tuple, g["claims"][coff[f]:coff[f + 1]].tolist())), f"frame {f}"
+

@@ -1,0 +1,31 @@
+"""ysmr_amd -- MI355X-native implementation of YSMR's per-frame detect-and-link hot path.
+
+The public surface mirrors the reference package (``ysmr/__init__.py`` re-exports ``main``,
+``plot_functions``, ``track_eval``): ``ysmr()``, ``analyse()``, ``track_bacteria()``,
+``CentroidTracker``, ``GaussianSumFIR`` and the tracking.ini helpers.  Importing this package does
+not touch the GPU; the HIP library (``csrc/libysmr_hip.so``) is loaded on first use and there is no
+CPU fallback.
+"""
+__version__ = "0.1.0"
+
+__all__ = ["ysmr", "analyse", "track_bacteria", "CentroidTracker", "GaussianSumFIR", "get_configs",
+           "create_configs", "default_settings"]
+
+
+def __getattr__(name):   # lazy: keep `import ysmr_amd.synth` usable without torch
+    if name in ("ysmr", "analyse"):
+        from . import main
+        return getattr(main, name)
+    if name == "track_bacteria":
+        from .track_eval import track_bacteria
+        return track_bacteria
+    if name == "CentroidTracker":
+        from .tracker import CentroidTracker
+        return CentroidTracker
+    if name == "GaussianSumFIR":
+        from .gsff import GaussianSumFIR
+        return GaussianSumFIR
+    if name in ("get_configs", "create_configs", "default_settings"):
+        from . import helper_file
+        return getattr(helper_file, name)
+    raise AttributeError(name)

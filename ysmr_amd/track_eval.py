@@ -1,0 +1,238 @@
+"""``track_bacteria`` -- the per-frame detect-and-link loop of YSMR on the GPU.
+
+Same contract as ``ysmr.track_eval.track_bacteria`` (ysmr/track_eval.py:38-405): given a video
+path and the tracking.ini settings it writes ``<name>_list.csv`` and returns
+``(DataFrame, fps, frame_height, frame_width, csv_path)``, or ``None`` after logging the reason.
+The loop body (track_eval.py:156-366) is replaced by batched device work:
+
+    frames (host) --H2D--> ysmr_detect_batch  (threshold, hysteresis, components, minAreaRect)
+                           ysmr_tracker_run   (claims, lifecycle, GSFF, rows; state stays in HBM)
+                     <--D2H-- rows, every `list save length interval` rows
+
+Detection of batch b+1 is issued on a second HIP stream while batch b is being linked.
+"""
+from __future__ import annotations
+
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .detect import Detector, threshold_params
+from .frames import open_video
+from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_text,
+                          save_list, sort_list)
+from .tracker import DeviceTracker, rows_to_numpy
+
+__all__ = ["track_bacteria", "TrackingPipeline"]
+
+
+class TrackingPipeline:
+    """Device-resident detect+link over consecutive batches of one video stream."""
+
+    def __init__(self, height, width, fps, settings, batch=64, max_det=2048, capacity=2048, device="cuda:0",
+                 rows_per_flush=None):
+        self.device = torch.device(device)
+        self.B = int(batch)
+        offset = settings["threshold offset for detection"]
+        params = threshold_params(settings["white bacteria on dark background"], offset,
+                                  settings["adaptive double threshold"])
+        # two detectors: batch b+1 is detected (stream 1) while batch b is linked (stream 0)
+        self.det = [Detector(self.B, height, width, max_det=max_det, params=params, device=self.device)
+                    for _ in range(2)]
+        self.trk = DeviceTracker(max_disappeared=fps, fps=fps, n_min=settings["minimum horizon size"],
+                                 n_max=settings["maximum horizon size"], n_f=settings["number of LSFFs"],
+                                 use_gsff=not settings["disable gsff"], capacity=capacity, max_det=max_det,
+                                 device=self.device)
+        self.capacity = int(capacity)
+        n_rows = self.B * self.capacity if rows_per_flush is None else int(rows_per_flush)
+        self.rows = torch.empty(n_rows * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+        self.row_count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self._done = [None, None]   # event: detector i's outputs consumed by the tracker
+        self._k = 0
+
+    def detect_async(self, frames_dev, threshold_events=None):
+        """Issue detection of one batch on the side stream; returns (slot, result, ready_event).
+        ``threshold_events``: list that receives a (start, stop) HIP event pair bracketing the fused
+        threshold kernel on the stream it is launched on (bench.py's roofline measurement)."""
+        slot = self._k & 1
+        self._k += 1
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.side):
+            self.side.wait_stream(cur)          # the frames were produced/uploaded on the caller's stream
+            if self._done[slot] is not None:
+                self.side.wait_event(self._done[slot])
+            det = self.det[slot]
+            if threshold_events is None:
+                res = det.detect(frames_dev)
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
+                det.threshold(frames_dev)
+                e1.record(self.side)
+                threshold_events.append((e0, e1, frames_dev.shape[0]))
+                res = det.components(frames_dev.shape[0])
+            ready = torch.cuda.Event()
+            ready.record(self.side)
+        return slot, res, ready
+
+    def reset(self):
+        self.trk.reset()
+        self.row_count.zero_()
+
+    def link(self, slot, res, ready, first_frame):
+        """Link one detected batch on the current stream; rows accumulate in self.rows."""
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ready)
+        self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
+        done = torch.cuda.Event()
+        done.record(cur)
+        self._done[slot] = done
+        return res
+
+    def take_rows(self):
+        """Synchronise, download the accumulated rows and reset the row buffer."""
+        n = int(self.row_count.item())
+        cap = self.rows.numel() // _lib.ROW_DTYPE.itemsize
+        if n > cap:
+            raise _lib.YsmrLibraryError(f"row buffer overflow: {n} rows > capacity {cap}")
+        rows = rows_to_numpy(self.rows, n).copy()
+        self.row_count.zero_()
+        return rows
+
+    def check(self, res):
+        status = int(res.status.max().item())
+        _, _, err = self.trk.info()
+        if status or err:
+            raise _lib.YsmrLibraryError(f"device path reported errors: detection status {status}, tracker {err} "
+                                        "(raise max_det / capacity)")
+
+
+def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_det=2048, capacity=2048,
+                   device="cuda:0"):
+    """Detect and track bright (or dark) spots in a video; write ``<name>_list.csv``.
+
+    Returns ``(DataFrame, fps, frame_height, frame_width, csv_path)`` or ``None`` (errors are
+    logged on logger 'ysmr', never raised -- track_eval.py:50-77, 389-392, 402-404).
+    """
+    logger = logging.getLogger("ysmr").getChild(__name__)
+    settings = get_configs(settings)
+    if settings is None:
+        logger.critical("No settings provided / could not get settings for track_bacteria().")
+        return None
+    get_loggers(log_level=settings["log_level"], logfile_name=settings["log file path"],
+                short_stream_output=settings["shorten displayed logging output"],
+                short_file_output=settings["shorten logfile logging output"], log_to_file=settings["log to file"])
+    if not os.path.isfile(video_path):
+        logger.critical("File {} does not exist".format(video_path))
+        return None
+    for key, why in (("include luminosity in tracking calculation", "luminosity as a third tracking dimension"),
+                     ("display video analysis", "interactive display")):
+        if settings[key]:
+            logger.critical("'{}' = True ({}) is not supported by the HIP path".format(key, why))
+            return None
+    if settings["color filter"] != COLOR_BGR2GRAY:
+        logger.critical("Only 'color filter = COLOR_BGR2GRAY' is supported by the HIP path")
+        return None
+    if settings["adaptive double threshold"] < 0:
+        logger.critical("'adaptive double threshold' < 0 (mean-gray threshold) is not supported by the HIP path")
+        return None
+    try:
+        video = open_video(video_path, default_fps=settings["frames per second"])
+    except (OSError, ValueError) as exc:
+        logger.exception("Cannot open file {} due to error: {}".format(video_path, exc))
+        return None
+    frame_count = video.frame_count
+    if frame_count < settings["minimal frame count"]:
+        logger.warning("File {} too short; file was skipped. Limit for 'minimal frame count': {}".format(
+            video_path, settings["minimal frame count"]))
+        return None
+    fps_of_file = settings["frames per second"] if settings["force tracking.ini fps settings"] else video.fps
+    if fps_of_file <= 0:
+        logger.critical("User defined fps unacceptable: {}".format(fps_of_file))
+        return None
+    if not result_folder:
+        result_folder = create_results_folder(video_path)
+    logger.info("Starting with file {}".format(video_path))
+    old_list, list_name = save_list(path=video_path, result_folder=result_folder, first_call=True,
+                                    rename_old_list=settings["rename previous result .csv"])
+    # The reference flips the sign of the offset IN the caller's dict for dark-on-bright videos
+    # (track_eval.py:132), so a dict reused across files alternates; kept for drop-in parity.
+    # threshold_params() applies the same sign change internally, from the value seen on entry.
+    offset_on_entry = settings["threshold offset for detection"]
+    if not settings["white bacteria on dark background"]:
+        settings["threshold offset for detection"] = offset_on_entry * -1
+    local = dict(settings)
+    local["threshold offset for detection"] = offset_on_entry
+
+    frame_height, frame_width = video.height, video.width
+    error_during_read = False
+    n_rows_total, last_id, frames_done = 0, None, 0
+    try:
+        pipe = TrackingPipeline(frame_height, frame_width, fps_of_file, local, batch=batch, max_det=max_det,
+                                capacity=capacity, device=device)
+        flush_at = max(int(settings["list save length interval"]), 1)
+        pending = None
+        res = None
+        for f0 in range(0, frame_count, pipe.B):
+            host = video.read(f0, pipe.B)
+            if host.shape[0] == 0:
+                break
+            dev = torch.from_numpy(host).to(pipe.device, non_blocking=True)
+            nxt = (pipe.detect_async(dev), f0, host.shape[0])
+            if pending is not None:
+                (slot, r, ready), p0, cnt = pending
+                res = pipe.link(slot, r, ready, p0)
+                frames_done = p0 + cnt
+                if int(pipe.row_count.item()) >= flush_at or (pipe.rows.numel() // _lib.ROW_DTYPE.itemsize
+                                                              - int(pipe.row_count.item())) < pipe.B * pipe.capacity:
+                    pipe.check(res)
+                    rows = pipe.take_rows()
+                    n_rows_total += len(rows)
+                    if len(rows):
+                        last_id = int(rows["track_id"].max()) if last_id is None else max(last_id, int(rows["track_id"].max()))
+                    with open(list_name, "a", newline="") as fh:
+                        fh.write(rows_to_csv_text(rows))
+            pending = nxt
+        if pending is not None:
+            (slot, r, ready), p0, cnt = pending
+            res = pipe.link(slot, r, ready, p0)
+            frames_done = p0 + cnt
+        if res is not None:
+            torch.cuda.synchronize(pipe.device)
+            pipe.check(res)
+            rows = pipe.take_rows()
+            n_rows_total += len(rows)
+            if len(rows):
+                last_id = int(rows["track_id"].max()) if last_id is None else max(last_id, int(rows["track_id"].max()))
+            with open(list_name, "a", newline="") as fh:
+                fh.write(rows_to_csv_text(rows))
+        if frames_done < frame_count - 1:   # some containers over-report by one frame (track_eval.py:170-171)
+            logger.critical("Error during read with file {}".format(video_path))
+            error_during_read = settings["stop evaluation on error"]
+    except (_lib.YsmrLibraryError, RuntimeError, ValueError) as exc:
+        logger.critical("Device path failed for file {}: {}".format(video_path, exc))
+        error_during_read = True
+    finally:
+        video.close()
+
+    if old_list and error_during_read:
+        try:
+            os.remove(list_name)
+            os.rename(old_list, list_name)
+            logger.info("Restoring old list: {}".format(list_name))
+        except OSError as exc:
+            logger.error("Could not restore {}: {!r}".format(list_name, exc.args))
+    if last_id is None:
+        logger.warning("Did not track any objects. File: {}".format(video_path))
+        return None
+    df_for_eval = sort_list(file_path=list_name, save_file=not settings["delete .csv file after analysis"])
+    logger.info("objects: {}, frames: {} of {}, rows: {}, csv: {}".format(last_id + 1, frames_done, frame_count,
+                                                                          n_rows_total, list_name))
+    if error_during_read:
+        logger.critical("Error during read, stopping before evaluation. File: {}".format(video_path))
+        return None
+    return df_for_eval, fps_of_file, frame_height, frame_width, list_name
