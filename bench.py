@@ -123,6 +123,7 @@ def main():
     elapsed = dist.max_over_ranks(time.perf_counter() - t0, info, device=dev)
 
     # the path must have produced sane output: no overflow/arena flags, no tracker errors, rows
+    pipe.wait()
     n_tracks, next_id, err = pipe.trk.info()
     n_rows = int(pipe.row_count.item())
     status = max(int(d.status.max().item()) for d in pipe.det)

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round profile bundle (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats of
+# the same command, PMC passes (each in its own run, no tracing domains) for the threshold kernel
+# plus the FETCH/WRITE calibration copy.  Everything lands in gpurun_out/round/.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O
+python $R/bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python3 $R/bench.py --cpu-sample 0 > $O/ktrace.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_thr_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real > $O/pmc_thr_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_cal_$c -- $R/scripts/ubench/copy_calib > $O/pmc_cal_$c.log 2>&1
+done
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_thr_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real > $O/pmc_thr_SQ.log 2>&1
+python3 - <<PY
+import csv, glob, collections, json
+O = "$O"
+def mean(path, kernel):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(path + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    out["threshold_" + c] = mean(f"{O}/pmc_thr_{c}", "k_threshold").get(c)
+    out["calib_" + c] = mean(f"{O}/pmc_cal_{c}", "copy_dword").get(c)
+out.update({"threshold_" + k: v for k, v in mean(f"{O}/pmc_thr_SQ", "k_threshold").items()})
+json.dump(out, open(f"{O}/pmc_summary.json", "w"), indent=1)
+print(json.dumps(out))
+PY

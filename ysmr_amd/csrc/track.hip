@@ -98,24 +98,36 @@ __device__ __forceinline__ Cand merge(Cand a, Cand b)
     return r;
 }
 
+constexpr int ROWMIN_U = 8;   // detections per lane per chunk (all loads of a chunk in flight together)
+
+template <typename DetT>
+struct DetChunk { double qx[ROWMIN_U], qy[ROWMIN_U]; };
+
+template <typename DetT>
+__device__ __forceinline__ void load_chunk(DetChunk<DetT> &c, const DetT *__restrict__ det, int m, int j0, int lane)
+{
+#pragma unroll
+    for (int u = 0; u < ROWMIN_U; ++u) {
+        int j = min(j0 + u * 64 + lane, m - 1);
+        c.qx[u] = (double)det[(size_t)j * 5 + 0];
+        c.qy[u] = (double)det[(size_t)j * 5 + 1];
+    }
+}
+
+// `first` holds detections [0, 64*ROWMIN_U) already loaded by the caller (issued before the GSFF so
+// that their latency hides behind it).
 template <typename DetT>
 __device__ __forceinline__ void rowmin_wave(const TrackerDev &t, int row, double px, double py,
-                                            const DetT *__restrict__ det, int m, int lane)
+                                            const DetT *__restrict__ det, int m, int lane, DetChunk<DetT> &first)
 {
     Cand best{0.0, -1};
-    for (int j0 = 0; j0 < m; j0 += 256) {
-        double qx[4], qy[4];
+    for (int j0 = 0; j0 < m; j0 += 64 * ROWMIN_U) {
+        if (j0 > 0) load_chunk(first, det, m, j0, lane);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {   // four independent loads in flight per lane
-            int j = min(j0 + u * 64 + lane, m - 1);
-            qx[u] = (double)det[(size_t)j * 5 + 0];
-            qy[u] = (double)det[(size_t)j * 5 + 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < ROWMIN_U; ++u) {
             int j = j0 + u * 64 + lane;
-            double dx = px - qx[u];
-            double dy = py - qy[u];
+            double dx = px - first.qx[u];
+            double dy = py - first.qy[u];
             double s = dx * dx;
             s = s + dy * dy;
             Cand c{s, j < m ? j : -1};
@@ -147,7 +159,10 @@ __global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__rest
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n || m == 0) return;
     const int slot = t.order[row];
-    rowmin_wave(t, row, t.pos[slot], t.pos[t.capacity + slot], det, m, threadIdx.x & 63);
+    const int lane = threadIdx.x & 63;
+    DetChunk<DetT> first;
+    load_chunk(first, det, m, 0, lane);
+    rowmin_wave(t, row, t.pos[slot], t.pos[t.capacity + slot], det, m, lane, first);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -219,6 +234,10 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     if (i >= n_live) return;
     const int lane = threadIdx.x & 63;
     const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
+    // the next frame's detections do not depend on this frame's state: fetch them first
+    const int m_next = next_det ? det_count(next_m_host, next_m_dev, t.max_det, nullptr) : 0;
+    DetChunk<DetT> first;
+    if (m_next > 0) load_chunk(first, next_det, m_next, 0, lane);
     const int slot = __builtin_amdgcn_readfirstlane(t.order[i]);
     const double z0 = t.pos[slot], z1 = t.pos[cap + slot];
     double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
@@ -348,10 +367,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
         }
     }
     // ---- nearest detection of the NEXT frame for this track (tracker.py:151-163)
-    if (next_det) {
-        const int m = det_count(next_m_host, next_m_dev, t.max_det, nullptr);
-        if (m > 0) rowmin_wave(t, i, p0, p1, next_det, m, lane);
-    }
+    if (m_next > 0) rowmin_wave(t, i, p0, p1, next_det, m_next, lane, first);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -452,7 +468,38 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     __syncthreads();
 
     // ---- claims: the winner of a column is the proposer with the smallest (distance, row)
-    if (n > 0 && m > 0) {
+    if (n > 0 && m > 0 && n <= LINK_THREADS) {
+        // common case, one row per thread: everything a claim will need is fetched up front so the
+        // LDS rounds below overlap the loads instead of waiting behind them
+        const int r = tid;
+        int c = 0, slot = 0;
+        unsigned long long key = ~0ull;
+        DetT d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
+        if (r < n) {
+            c = t.row_arg[r];
+            key = (unsigned long long)__double_as_longlong(t.row_min[r]);
+            slot = t.order[r];
+            d0 = det[(size_t)c * 5 + 0]; d1 = det[(size_t)c * 5 + 1]; d2 = det[(size_t)c * 5 + 2];
+            d3 = det[(size_t)c * 5 + 3]; d4 = det[(size_t)c * 5 + 4];
+            atomicMin(&s_col_key[c], key);
+        }
+        __syncthreads();
+        if (r < n && key == s_col_key[c]) atomicMin(&s_col_row[c], r);
+        __syncthreads();
+        if (r < n) {
+            const bool mine = (s_col_row[c] == r);
+            s_claim[r] = mine ? c : -1;
+            if (mine) {
+                t.pos[slot] = (double)d0;
+                t.pos[cap + slot] = (double)d1;
+                t.info[slot] = (float)d2;
+                t.info[cap + slot] = (float)d3;
+                t.info[2 * cap + slot] = (float)d4;
+                t.gone[slot] = 0;
+                atomicAdd(&s_n_used, 1);
+            }
+        }
+    } else if (n > 0 && m > 0) {
         for (int r = tid; r < n; r += LINK_THREADS)
             atomicMin(&s_col_key[t.row_arg[r]], (unsigned long long)__double_as_longlong(t.row_min[r]));
         __syncthreads();
