@@ -404,6 +404,7 @@ __global__ __launch_bounds__(256, 4) void k_threshold_strip(const uint8_t *__res
 // The smaller raster index always becomes the root, so a component's root is its first pixel.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t DEAD = 0xFFFFFFFFu;
+constexpr int NR_STRIDE = 32;   // ints between per-frame counters
 
 __device__ __forceinline__ uint32_t ld_node(const uint32_t *L, uint32_t i)
 {
@@ -418,6 +419,19 @@ __device__ __forceinline__ uint32_t find_root(const uint32_t *L, uint32_t p)
         if (v - 1 == p) return p;
         p = v - 1;
         v = ld_node(L, p);
+    }
+}
+
+// Same walk with ordinary cached loads: for passes in which no union runs concurrently (parents
+// then only change by path compression towards the root, so a stale value is still an ancestor).
+__device__ __forceinline__ uint32_t find_root_cached(const uint32_t *L, uint32_t p)
+{
+    uint32_t v = L[p];
+    while (true) {
+        if (v == 0) return DEAD;
+        if (v - 1 == p) return p;
+        p = v - 1;
+        v = L[p];
     }
 }
 
@@ -472,7 +486,7 @@ struct ChunkList {
     uint32_t *count;   // number of entries
 };
 
-constexpr int SPARSE_BLOCKS = 2048;  // grid of the list-driven passes (grid-stride over the list)
+constexpr int SPARSE_BLOCKS = 8192;  // grid of the list-driven passes (grid-stride over the list)
 
 // 16 consecutive lanes share one listed chunk, one lane per pixel: the passes are bound by chains
 // of dependent L2 round trips (union-find), so they want many short threads, not few long ones.
@@ -637,17 +651,17 @@ __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls
         uint32_t p = (uint32_t)(flat - (size_t)f * g.HW);
         uint32_t *L = labels + (size_t)f * g.HW;
         const uint8_t *cf = cls + (size_t)f * g.HW;
-        uint32_t r = find_root(L, p);
+        uint32_t r = find_root_cached(L, p);
         bool inr = (r != DEAD) && ((b & 2u) || (cf[r] & 6u));
         if (inr) {
-            if (r != p) __hip_atomic_store(&L[p], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (r != p) L[p] = r + 1;   // plain store: write-through agent-scope stores cost a fabric write each
             if (mask) mask[flat] = 255;
             if (r == p) {
-                int idx = atomicAdd(&nroots[f], 1);
+                int idx = atomicAdd(&nroots[(size_t)f * NR_STRIDE], 1);
                 if (idx < max_det) roots[(size_t)f * max_det + idx] = (int32_t)p;
             }
         } else {
-            __hip_atomic_store(&L[p], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L[p] = 0u;
         }
     }
 }
@@ -656,7 +670,7 @@ __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls
 // Ordering (reverse raster order of first pixels), bounding boxes, Euler numbers
 // ------------------------------------------------------------------------------------------
 struct CompTables {
-    int32_t *nroots;   // [B]
+    int32_t *nroots;   // [B * NR_STRIDE]: one counter per 128-byte line (same-line atomics serialise)
     int32_t *roots;    // [B][max_det] unordered
     int32_t *order;    // [B][max_det] roots sorted descending (= findContours order)
     int32_t *bbox;     // [B][max_det][4] minx, maxx, miny, maxy
@@ -668,7 +682,7 @@ struct CompTables {
 __global__ __launch_bounds__(256) void k_rank(CompTables t, int W, int H, int32_t *status)
 {
     const int f = blockIdx.x;
-    int n = t.nroots[f];
+    int n = t.nroots[(size_t)f * NR_STRIDE];
     if (n > t.max_det) {
         if (threadIdx.x == 0) atomicOr(&status[f], YSMR_DET_OVERFLOW);
         n = t.max_det;
@@ -721,7 +735,7 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ 
         size_t flat = base + i;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
-        int n = min(t.nroots[f], t.max_det);
+        int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
         int k = find_rank(t.order + (size_t)f * t.max_det, n, (int32_t)(lab_i - 1));
         if (k < 0) continue;  // component beyond max_det (overflow already flagged)
         size_t o = (size_t)f * t.max_det + k;
@@ -764,7 +778,7 @@ __global__ __launch_bounds__(256) void k_holes(CompTables t, int batch, int32_t 
     int i = blockIdx.x * 256 + threadIdx.x;
     int f = i / t.max_det, k = i - f * t.max_det;
     if (f >= batch) return;
-    int n = min(t.nroots[f], t.max_det);
+    int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
     if (k < n && t.euler4[(size_t)f * t.max_det + k] != 4) {
         int idx = atomicAdd(n_holed, 1);
         if (idx < HOLED_CAP) holed[idx] = make_int2(f, k);
@@ -844,7 +858,7 @@ __global__ __launch_bounds__(256) void k_nested(const uint32_t *__restrict__ lab
         __syncthreads();
         if (!s_changed) break;
     }
-    const int n = min(t.nroots[f], t.max_det);
+    const int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
     for (int i = threadIdx.x; i < cells; i += 256) {
         int r = i / ww, c = i - r * ww;
         if (c == 0 || cell[i] != 0) continue;
@@ -859,8 +873,8 @@ __global__ __launch_bounds__(256) void k_nested(const uint32_t *__restrict__ lab
 // ------------------------------------------------------------------------------------------
 // k_geometry: a6, one thread per component
 // ------------------------------------------------------------------------------------------
-constexpr int GEO_THREADS = 64;
-constexpr int LDS_POINTS = 32;  // hull capacity of the in-LDS fast path
+constexpr int GEO_THREADS = 256;
+constexpr int LDS_POINTS = 2 * 16 + 3;  // hull capacity of the in-LDS fast path (components <= 16 columns wide)
 
 struct HullStore {
     float *base;
@@ -991,31 +1005,66 @@ __device__ void min_area_rect_hull(const HullStore &s, int n, float *rect)
 }
 
 // det slots are compacted afterwards (nested components dropped) by k_compact.
+// 16 lanes per component: lane `sub` scans column minx+sub of the bounding box for the top-most and
+// bottom-most pixel of the component (the only hull candidates of that column; all loads of a
+// column are independent), lane 0 then builds the chains from the 16 (top, bottom) pairs and runs
+// the calipers.  Components wider than 16 columns take the serial path with arena storage.
+constexpr int GEO_GROUP = 16;
+constexpr int GEO_COMPS = GEO_THREADS / GEO_GROUP;          // components per block
+constexpr int GEO_LDS_STRIDE = LDS_POINTS * 5 + 1;          // +1: keep the 4 active lanes of a wave off one bank
+
+__device__ __forceinline__ void column_extent(const uint32_t *L, int W, int x, int miny, int maxy, uint32_t want,
+                                              int &top, int &bot)
+{
+    top = -1; bot = -1;
+    for (int y0 = miny; y0 <= maxy; y0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = L[(size_t)min(y0 + u, maxy) * W + x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (y0 + u <= maxy && v[u] == want) { if (top < 0) top = y0 + u; bot = y0 + u; }
+    }
+}
+
 __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__restrict__ labels, Geo g, CompTables t,
                                                           int batch, float *det_tmp, float *arena,
                                                           uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
 {
-    __shared__ float lds[LDS_POINTS * 5 * GEO_THREADS];
-    int i = blockIdx.x * GEO_THREADS + threadIdx.x;
-    int f = i / t.max_det, k = i - f * t.max_det;
-    if (f >= batch) return;
-    int n = min(t.nroots[f], t.max_det);
-    if (k >= n) return;
-    size_t o = (size_t)f * t.max_det + k;
-    if (t.nested[o]) return;
-    const uint32_t want = (uint32_t)t.order[o] + 1u;
-    const int minx = t.bbox[o * 4 + 0], maxx = t.bbox[o * 4 + 1], miny = t.bbox[o * 4 + 2], maxy = t.bbox[o * 4 + 3];
+    __shared__ float lds[GEO_COMPS * GEO_LDS_STRIDE];
+    __shared__ int s_top[GEO_COMPS][GEO_GROUP], s_bot[GEO_COMPS][GEO_GROUP];
+    const int grp = threadIdx.x / GEO_GROUP, sub = threadIdx.x % GEO_GROUP;
+    const long long gi = (long long)blockIdx.x * GEO_COMPS + grp;
+    const int f = (int)(gi / t.max_det), k = (int)(gi - (long long)f * t.max_det);
+    bool live = f < batch;
+    if (live) live = k < min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
+    const size_t o = live ? (size_t)f * t.max_det + k : 0;
+    if (live) live = !t.nested[o];
+    uint32_t want = 0;
+    int minx = 0, maxx = -1, miny = 0, maxy = -1;
+    if (live) {
+        want = (uint32_t)t.order[o] + 1u;
+        minx = t.bbox[o * 4 + 0]; maxx = t.bbox[o * 4 + 1]; miny = t.bbox[o * 4 + 2]; maxy = t.bbox[o * 4 + 3];
+    }
     const int bwid = maxx - minx + 1;
-    const uint32_t *L = labels + (size_t)f * g.HW;
+    const uint32_t *L = labels + (size_t)(live ? f : 0) * g.HW;
     const int W = g.W;
+    const bool narrow = live && bwid <= GEO_GROUP;
+    if (narrow && sub < bwid) {
+        int top, bot;
+        column_extent(L, W, minx + sub, miny, maxy, want, top, bot);
+        s_top[grp][sub] = top;
+        s_bot[grp][sub] = bot;
+    }
+    __syncthreads();
+    if (!live || sub != 0) return;
 
     HullStore s;
-    const int need_pts = 2 * bwid + 3;
-    if (need_pts <= LDS_POINTS) {
-        s.base = lds + threadIdx.x;
-        s.stride = GEO_THREADS;
+    if (narrow) {
+        s.base = lds + grp * GEO_LDS_STRIDE;
+        s.stride = 1;
     } else {
-        uint32_t need = (uint32_t)need_pts * 5u;
+        uint32_t need = (uint32_t)(2 * bwid + 3) * 5u;
         uint32_t off = atomicAdd(arena_used, need);
         if (off + need > arena_floats) {
             atomicOr(&status[f], YSMR_DET_ARENA);
@@ -1029,9 +1078,9 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
     // max-y side: columns right -> left, within a column bottom first then top
     int nh = 0;
     for (int x = maxx; x >= minx; --x) {
-        int top = -1, bot = -1;
-        for (int y = miny; y <= maxy; ++y)
-            if (L[(size_t)y * W + x] == want) { if (top < 0) top = y; bot = y; }
+        int top, bot;
+        if (narrow) { top = s_top[grp][x - minx]; bot = s_bot[grp][x - minx]; }
+        else column_extent(L, W, x, miny, maxy, want, top, bot);
         if (top < 0) continue;
         chain_push(s, 0, nh, x, bot);
         chain_push(s, 0, nh, x, top);
@@ -1040,9 +1089,9 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
     int start = nh - 1;
     int nl = start;
     for (int x = minx; x <= maxx; ++x) {
-        int top = -1, bot = -1;
-        for (int y = miny; y <= maxy; ++y)
-            if (L[(size_t)y * W + x] == want) { if (top < 0) top = y; bot = y; }
+        int top, bot;
+        if (narrow) { top = s_top[grp][x - minx]; bot = s_bot[grp][x - minx]; }
+        else column_extent(L, W, x, miny, maxy, want, top, bot);
         if (top < 0) continue;
         chain_push(s, start, nl, x, top);
         chain_push(s, start, nl, x, bot);
@@ -1058,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__re
                                                  int32_t *det_count, int32_t *anchors)
 {
     const int f = blockIdx.x;
-    int n = min(t.nroots[f], t.max_det);
+    int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
     __shared__ int s_scan[256];
     __shared__ int s_base;
     if (threadIdx.x == 0) s_base = 0;
@@ -1121,8 +1170,8 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return (char *)base + o; };
     size_t bm = (size_t)batch * max_det;
     // counters first: one memset clears nroots, n_holed, arena_used
-    w.nroots = (int32_t *)take(sizeof(int32_t) * ((size_t)batch + 4));
-    w.n_holed = w.nroots + batch;
+    w.nroots = (int32_t *)take(sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 4));
+    w.n_holed = w.nroots + (size_t)batch * NR_STRIDE;
     w.arena_used = (uint32_t *)(w.n_holed + 1);
     w.chunks.count = (uint32_t *)(w.n_holed + 2);
     w.chunks.idx = (uint32_t *)take(sizeof(uint32_t) * (((size_t)batch * H * W + 15) / 16));
@@ -1219,7 +1268,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     const unsigned cgrid = (unsigned)((nchunks + 255) / 256);
     uint32_t *labels = reinterpret_cast<uint32_t *>(labels_dev);
 
-    YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch + 4), st));
+    YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 4), st));
     YSMR_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t) * batch, st));
     YSMR_HIP_CHECK(hipMemsetAsync(labels, 0, sizeof(uint32_t) * g.total, st));
     if (mask_dev) YSMR_HIP_CHECK(hipMemsetAsync(mask_dev, 0, g.total, st));
@@ -1240,7 +1289,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     hipLaunchKernelGGL(k_nested, dim3(HOLED_CAP), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
                        w.arena_floats, w.arena_used, status_dev);
     YSMR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_geometry, dim3((comp_threads + GEO_THREADS - 1) / GEO_THREADS), dim3(GEO_THREADS), 0, st,
+    hipLaunchKernelGGL(k_geometry, dim3((comp_threads + GEO_COMPS - 1) / GEO_COMPS), dim3(GEO_THREADS), 0, st,
                        labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
     hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev);
     YSMR_LAUNCH_CHECK();
