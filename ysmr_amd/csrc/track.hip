@@ -19,13 +19,14 @@
 // All arithmetic is float64 like the reference; -ffp-contract=off keeps mul/add unfused.
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #define YSMR_MAX_FILTERS 8
 
 struct TrackerDev {
-    int capacity, max_det, n_f, use_gsff, hist_cap, table_cap, gain_total;
+    int capacity, max_det, n_f, use_gsff, hist_cap, table_cap, gain_total, gone_by_row;
     double max_gone, lik_min;
     int n_i[YSMR_MAX_FILTERS];
     int gain_off[YSMR_MAX_FILTERS];  // filter i: row0 at gains[gain_off[i]], row1 at +2*n_i[i]
@@ -51,11 +52,25 @@ struct TrackerDev {
 };
 
 struct ysmr_tracker {
-    TrackerDev d;
+    TrackerDev d;      // view of parity 0
+    TrackerDev d1;     // view of parity 1 (fused path: small per-frame arrays are double-buffered)
+    int par;           // parity of the current state
+    bool fused;        // one k_frame launch per frame instead of k_link + k_track
+    size_t frame_lds;
     void *block;       // the single device allocation
     size_t block_bytes;
     std::vector<double> gains_host;
+    const TrackerDev &cur() const { return par ? d1 : d; }
+    const TrackerDev &nxt() const { return par ? d : d1; }
 };
+
+#ifdef YSMR_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define GSTAMP(k) do { if (blockIdx.x == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_stamps[k] = t_; } } while (0)
+extern "C" int ysmr_debug_read_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32); }
+#else
+#define GSTAMP(k) do {} while (0)
+#endif
 
 namespace {
 
@@ -178,11 +193,36 @@ struct TrackRegs {
     double v[TRACK_VALS];   // history values held by this lane
 };
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    // lanes outside ROW_MASK / without a source get +0.0 (old = 0, bound_ctrl off writes old)
+    return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// sum over the 64 lanes, returned to every lane; a fixed (deterministic) association order
+__device__ __forceinline__ double wave_total(double v)
+{
+    v = dpp_add<0x111, 0xF>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);   // row_shr:8  -> lane 15 of each row holds the row sum
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), 63);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // FIR estimates of ALL active filters at once (rows 0 and 1 of gain f times the last n_f[f]
 // measurements: lsff_calc, gsff.py:156-177).  The 2*mode butterflies are interleaved so that the
 // cross-lane latency is paid once per level, not once per sum.
-__device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const TrackRegs &h, int lane, int mode, int head,
-                                             double *x0, double *x1)
+__device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const double *gains, const TrackRegs &h, int lane,
+                                             int mode, int head, double *x0, double *x1)
 {
     const int L = t.hist_cap;
     double p0[YSMR_MAX_FILTERS], p1[YSMR_MAX_FILTERS];
@@ -194,34 +234,187 @@ __device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const TrackReg
         int e = k >> 1, comp = k & 1;
         int age = head - 1 - e;          // 0 = newest
         if (age < 0) age += L;
-        if (e < L) {
-#pragma unroll
-            for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
-                if (f < mode) {
-                    const int N = t.n_i[f];
-                    if (age < N) {
-                        const double *g0 = t.gains + t.gain_off[f];
-                        int col = 2 * (N - 1 - age) + comp;
-                        p0[f] = p0[f] + g0[col] * h.v[q];
-                        p1[f] = p1[f] + g0[2 * N + col] * h.v[q];
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+        // unconditional gathers (clamped index, masked product): all 2*mode loads of a lane are in
+        // flight together instead of one dependent round trip per divergent branch
+        double ga[YSMR_MAX_FILTERS], gb[YSMR_MAX_FILTERS];
+        bool in[YSMR_MAX_FILTERS];
 #pragma unroll
         for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
             if (f < mode) {
-                p0[f] = p0[f] + __shfl_xor(p0[f], off);
-                p1[f] = p1[f] + __shfl_xor(p1[f], off);
+                const int N = t.n_i[f];
+                in[f] = (e < L) && (age < N);
+                const int col = in[f] ? 2 * (N - 1 - age) + comp : 0;
+                const double *g0 = gains + t.gain_off[f];
+                ga[f] = g0[col];
+                gb[f] = g0[2 * N + col];
             }
+        }
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
+            if (f < mode && in[f]) {
+                p0[f] = p0[f] + ga[f] * h.v[q];
+                p1[f] = p1[f] + gb[f] * h.v[q];
+            }
+        }
+    }
+    // wave sums by DPP (no LDS round trips): row_shr 1,2,4,8 leave each 16-lane row's sum in its
+    // last lane, row_bcast15 / row_bcast31 carry it across rows, lane 63 ends with the total
+#pragma unroll
+    for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
+        if (f < mode) {
+            p0[f] = wave_total(p0[f]);
+            p1[f] = wave_total(p1[f]);
         }
     }
 #pragma unroll
     for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
         if (f < mode) { x0[f] = p0[f]; x1[f] = p1[f]; }
+}
+
+// GSFF correct + predict of one track by one wave (gsff.py:204-347).  z = measurement; returns the
+// filtered position (o) and the prediction (p), and leaves the prediction in t.pos[slot].
+// fresh_track: the slot was just (re)assigned -- ignore whatever filter state it still holds.
+__device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gains, int slot, int lane, double z0,
+                                          double z1, bool fresh_track, double &o0, double &o1, double &p0, double &p1)
+{
+    const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
+    GSTAMP(0);
+    double *hist = t.hist + (size_t)slot * 2 * L;
+    int len = t.hist_len[slot], head = t.hist_head[slot], mode = t.mode[slot];
+    TrackRegs h;
+#pragma unroll
+    for (int q = 0; q < TRACK_VALS; ++q) {
+        int k = lane + 64 * q;
+        h.v[q] = (k < 2 * L) ? hist[k] : 0.0;
+    }
+    double w[YSMR_MAX_FILTERS], xh0[YSMR_MAX_FILTERS], xh1[YSMR_MAX_FILTERS];
+#pragma unroll
+    for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
+        bool on = f < mode;
+        w[f] = on ? t.weights[(size_t)f * cap + slot] : 0.0;
+        xh0[f] = on ? t.xhat[((size_t)0 * nf + f) * cap + slot] : 0.0;
+        xh1[f] = on ? t.xhat[((size_t)1 * nf + f) * cap + slot] : 0.0;
+    }
+    GSTAMP(1);
+    // ---- correct (gsff.py:251-347)
+    bool fresh = (len == 0) || fresh_track;
+    if (fresh_track) { len = 0; mode = 0; }
+    if (fresh) {   // history starts as n_i[0] copies of the first measurement
+#pragma unroll
+        for (int q = 0; q < TRACK_VALS; ++q) {
+            int k = lane + 64 * q;
+            if ((k >> 1) < t.n_i[0]) h.v[q] = (k & 1) ? z1 : z0;
+        }
+        len = t.n_i[0];
+        head = len % L;
+    }
+    bool grew = false;
+    if (mode < nf) {
+        while (len >= t.n_i[mode]) {
+            ++mode;
+            grew = true;
+            if (mode >= nf) break;
+        }
+    }
+    if (grew) {
+        const double w0 = 1.0 / (double)mode;
+        fir_wave_all(t, gains, h, lane, mode, head, xh0, xh1);
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+            if (f < mode) w[f] = w0;
+    }
+    GSTAMP(2);
+    // likelihoods (gsff.py:179-202): lane f evaluates filter f's exp(), the results are broadcast
+    // (the float64 exp is ~150 instructions; doing the n_f of them one after the other on every
+    // lane was a third of this function)
+    double lik[YSMR_MAX_FILTERS];
+    double total = 0.0;
+    {
+        double xa = 0.0, xb = 0.0;
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+            if (lane == f) { xa = xh0[f]; xb = xh1[f]; }
+        double d0 = z0 - xa, d1 = z1 - xb;
+        double q = d0 * d0;
+        q = q + d1 * d1;
+        double l = exp(-0.5 * q);
+        if (l < t.lik_min) l = t.lik_min;
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+            if (f < mode) {
+                lik[f] = __shfl(l, f);
+                total = total + lik[f] * w[f];
+            }
+    }
+    GSTAMP(3);
+    // append the measurement
+    const int at = head;
+#pragma unroll
+    for (int q = 0; q < TRACK_VALS; ++q) {
+        int k = lane + 64 * q;
+        if ((k >> 1) == at) h.v[q] = (k & 1) ? z1 : z0;
+    }
+    if (++head == L) head = 0;
+    if (len < L) ++len;
+    // new weights; output = np.sum(x_hat * w, axis=1) = a0 + ((a1 + a2) + ...)
+    double f0 = 0.0, f1 = 0.0, r0 = 0.0, r1 = 0.0;
+    {   // new weights w_i = lik_i * w_i / total: one division per lane instead of n_f per lane
+        double lw = 0.0;
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+            if (lane == f && f < mode) lw = lik[f] * w[f];
+        const double wn = lw / total;
+#pragma unroll
+        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+            if (f < mode) w[f] = __shfl(wn, f);
+    }
+#pragma unroll
+    for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+        if (f < mode) {
+            double a = xh0[f] * w[f], b = xh1[f] * w[f];
+            if (f == 0) { f0 = a; f1 = b; }
+            else if (f == 1) { r0 = a; r1 = b; }
+            else { r0 = r0 + a; r1 = r1 + b; }
+        }
+    o0 = mode > 1 ? f0 + r0 : f0;
+    o1 = mode > 1 ? f1 + r1 : f1;
+    GSTAMP(4);
+    // ---- predict (gsff.py:204-249)
+    f0 = f1 = r0 = r1 = 0.0;
+    fir_wave_all(t, gains, h, lane, mode, head, xh0, xh1);
+#pragma unroll
+    for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+        if (f < mode) {
+            double a = xh0[f] * w[f], b = xh1[f] * w[f];
+            if (f == 0) { f0 = a; f1 = b; }
+            else if (f == 1) { r0 = a; r1 = b; }
+            else { r0 = r0 + a; r1 = r1 + b; }
+        }
+    p0 = mode > 1 ? f0 + r0 : f0;
+    p1 = mode > 1 ? f1 + r1 : f1;
+    GSTAMP(5);
+    // ---- write back
+#pragma unroll
+    for (int q = 0; q < TRACK_VALS; ++q) {
+        int k = lane + 64 * q;
+        if (k < 2 * L && (fresh || (k >> 1) == at)) hist[k] = h.v[q];
+    }
+    if (lane == 0) {
+        t.hist_len[slot] = len;
+        t.hist_head[slot] = head;
+        t.mode[slot] = mode;
+        t.pos[slot] = p0;
+        t.pos[cap + slot] = p1;
+    }
+#pragma unroll
+    for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+        if (f < mode && lane == f) {
+            t.weights[(size_t)f * cap + slot] = w[f];
+            t.liks[(size_t)f * cap + slot] = lik[f];
+            t.xhat[((size_t)0 * nf + f) * cap + slot] = xh0[f];
+            t.xhat[((size_t)1 * nf + f) * cap + slot] = xh1[f];
+        }
+    GSTAMP(6);
 }
 
 template <typename DetT>
@@ -233,7 +426,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_live) return;
     const int lane = threadIdx.x & 63;
-    const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
+    const int cap = t.capacity;
     // the next frame's detections do not depend on this frame's state: fetch them first
     const int m_next = next_det ? det_count(next_m_host, next_m_dev, t.max_det, nullptr) : 0;
     DetChunk<DetT> first;
@@ -241,119 +434,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     const int slot = __builtin_amdgcn_readfirstlane(t.order[i]);
     const double z0 = t.pos[slot], z1 = t.pos[cap + slot];
     double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
-    if (t.use_gsff) {
-        double *hist = t.hist + (size_t)slot * 2 * L;
-        int len = t.hist_len[slot], head = t.hist_head[slot], mode = t.mode[slot];
-        TrackRegs h;
-#pragma unroll
-        for (int q = 0; q < TRACK_VALS; ++q) {
-            int k = lane + 64 * q;
-            h.v[q] = (k < 2 * L) ? hist[k] : 0.0;
-        }
-        double w[YSMR_MAX_FILTERS], xh0[YSMR_MAX_FILTERS], xh1[YSMR_MAX_FILTERS];
-#pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
-            bool on = f < mode;
-            w[f] = on ? t.weights[(size_t)f * cap + slot] : 0.0;
-            xh0[f] = on ? t.xhat[((size_t)0 * nf + f) * cap + slot] : 0.0;
-            xh1[f] = on ? t.xhat[((size_t)1 * nf + f) * cap + slot] : 0.0;
-        }
-        // ---- correct (gsff.py:251-347)
-        bool fresh = (len == 0);
-        if (fresh) {   // history starts as n_i[0] copies of the first measurement
-#pragma unroll
-            for (int q = 0; q < TRACK_VALS; ++q) {
-                int k = lane + 64 * q;
-                if ((k >> 1) < t.n_i[0]) h.v[q] = (k & 1) ? z1 : z0;
-            }
-            len = t.n_i[0];
-            head = len % L;
-        }
-        bool grew = false;
-        if (mode < nf) {
-            while (len >= t.n_i[mode]) {
-                ++mode;
-                grew = true;
-                if (mode >= nf) break;
-            }
-        }
-        if (grew) {
-            const double w0 = 1.0 / (double)mode;
-            fir_wave_all(t, h, lane, mode, head, xh0, xh1);
-#pragma unroll
-            for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
-                if (f < mode) w[f] = w0;
-        }
-        double lik[YSMR_MAX_FILTERS];
-        double total = 0.0;
-#pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
-            if (f < mode) {
-                double d0 = z0 - xh0[f], d1 = z1 - xh1[f];
-                double q = d0 * d0;
-                q = q + d1 * d1;
-                double l = exp(-0.5 * q);
-                if (l < t.lik_min) l = t.lik_min;
-                lik[f] = l;
-                total = total + l * w[f];
-            }
-        // append the measurement
-        const int at = head;
-#pragma unroll
-        for (int q = 0; q < TRACK_VALS; ++q) {
-            int k = lane + 64 * q;
-            if ((k >> 1) == at) h.v[q] = (k & 1) ? z1 : z0;
-        }
-        if (++head == L) head = 0;
-        if (len < L) ++len;
-        // new weights; output = np.sum(x_hat * w, axis=1) = a0 + ((a1 + a2) + ...)
-        double f0 = 0.0, f1 = 0.0, r0 = 0.0, r1 = 0.0;
-#pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
-            if (f < mode) {
-                w[f] = lik[f] * w[f] / total;
-                double a = xh0[f] * w[f], b = xh1[f] * w[f];
-                if (f == 0) { f0 = a; f1 = b; }
-                else if (f == 1) { r0 = a; r1 = b; }
-                else { r0 = r0 + a; r1 = r1 + b; }
-            }
-        o0 = mode > 1 ? f0 + r0 : f0;
-        o1 = mode > 1 ? f1 + r1 : f1;
-        // ---- predict (gsff.py:204-249)
-        f0 = f1 = r0 = r1 = 0.0;
-        fir_wave_all(t, h, lane, mode, head, xh0, xh1);
-#pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
-            if (f < mode) {
-                double a = xh0[f] * w[f], b = xh1[f] * w[f];
-                if (f == 0) { f0 = a; f1 = b; }
-                else if (f == 1) { r0 = a; r1 = b; }
-                else { r0 = r0 + a; r1 = r1 + b; }
-            }
-        p0 = mode > 1 ? f0 + r0 : f0;
-        p1 = mode > 1 ? f1 + r1 : f1;
-        // ---- write back
-#pragma unroll
-        for (int q = 0; q < TRACK_VALS; ++q) {
-            int k = lane + 64 * q;
-            if (k < 2 * L && (fresh || (k >> 1) == at)) hist[k] = h.v[q];
-        }
-        if (lane == 0) {
-            t.hist_len[slot] = len;
-            t.hist_head[slot] = head;
-            t.mode[slot] = mode;
-            t.pos[slot] = p0;
-            t.pos[cap + slot] = p1;
-        }
-#pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
-            if (f < mode && lane == f) {
-                t.weights[(size_t)f * cap + slot] = w[f];
-                t.liks[(size_t)f * cap + slot] = lik[f];
-                t.xhat[((size_t)0 * nf + f) * cap + slot] = xh0[f];
-                t.xhat[((size_t)1 * nf + f) * cap + slot] = xh1[f];
-            }
-    }
+    if (t.use_gsff) gsff_wave(t, t.gains, slot, lane, z0, z1, false, o0, o1, p0, p1);
     if (lane == 0) {
         const long long base = t.row_base[0];
         if (rows && base + i < rows_capacity) {
@@ -644,6 +725,308 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_frame: the whole CentroidTracker.update of one frame in ONE launch (fused path).
+//
+// Every block redundantly resolves the frame's bookkeeping in LDS from the same inputs -- claims,
+// ageing, which tracks die, the compacted id-ordered table, which detections become new tracks and
+// in which (CPython set) order -- so no inter-block synchronisation is needed; then each WAVE
+// processes one track of the NEW table: applies its claim, runs the GSFF, writes its row, and
+// computes its nearest detection of the next frame.  Small per-frame arrays that one block would
+// write while another still reads them (order, gone, row_min/row_arg, the counters) are
+// double-buffered by frame parity: `a` is the state before this frame, `b` the state after it.
+// ------------------------------------------------------------------------------------------
+constexpr int FRAME_THREADS = 256;
+constexpr int FRAME_TABLE = 4096;   // CPython set model table (entries) in LDS: up to 2457 unused columns
+
+struct FrameLds {
+    unsigned long long *col_key, *key;
+    int *col_row, *arg, *slot, *newgone, *claim, *inv, *unused, *newcols, *table, *scan;
+    double *gains;   // LDS copy of the gain rows
+};
+
+__host__ __device__ inline size_t frame_lds_bytes(int cap, int max_det, int gain_total)
+{
+    return 8 * ((size_t)max_det + cap + gain_total) + 4 * ((size_t)max_det * 3 + (size_t)cap * 5 + 2 * FRAME_TABLE + FRAME_THREADS) + 64;
+}
+
+__device__ int block_scan256(int v, int *s_scan, int *total)
+{
+    const int tid = threadIdx.x;
+    s_scan[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < FRAME_THREADS; d <<= 1) {
+        int add = tid >= d ? s_scan[tid - d] : 0;
+        __syncthreads();
+        s_scan[tid] += add;
+        __syncthreads();
+    }
+    int incl = s_scan[tid];
+    *total = s_scan[FRAME_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+// CPython order of the ascending list `unused` (see cpython_unused_order), tables in LDS
+__device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_used, int *out, int *tables)
+{
+    if ((m >> 2) > n_used) {
+        for (int k = 0; k < n_unused; ++k) out[k] = unused[k];
+        return n_unused;
+    }
+    int *table = tables, *other = tables + FRAME_TABLE;
+    unsigned mask = 7;
+    int fill = 0;
+    for (int i = 0; i < 8; ++i) table[i] = -1;
+    for (int k = 0; k < n_unused; ++k) {
+        set_insert_clean(table, mask, unused[k]);
+        ++fill;
+        if ((unsigned long long)fill * 5ull >= (unsigned long long)mask * 3ull) {
+            unsigned minused = fill > 50000 ? (unsigned)fill * 2u : (unsigned)fill * 4u;
+            unsigned newsize = 8;
+            while (newsize <= minused) newsize <<= 1;
+            if ((int)newsize > FRAME_TABLE) return -1;
+            for (unsigned i = 0; i < newsize; ++i) other[i] = -1;
+            for (unsigned i = 0; i <= mask; ++i)
+                if (table[i] >= 0) set_insert_clean(other, newsize - 1, table[i]);
+            int *tmp = table; table = other; other = tmp;
+            mask = newsize - 1;
+        }
+    }
+    int count = 0;
+    for (unsigned i = 0; i <= mask; ++i)
+        if (table[i] >= 0) out[count++] = table[i];
+    return count;
+}
+
+#ifdef YSMR_STAMPS
+#define STAMP(k) do { if (blockIdx.x == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((unsigned long long *)(rows + rows_capacity - 4))[k] = t_; } } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
+template <typename DetT>
+__global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDev b, const DetT *__restrict__ det,
+                                                         int m_host, const int32_t *m_dev, int frame, ysmr_row *rows,
+                                                         long long rows_capacity, long long *row_count_ext,
+                                                         int32_t *n_rows_out, int32_t *claim_out, int32_t *n_before_out,
+                                                         int32_t *new_cols_out, int32_t *n_new_out,
+                                                         const DetT *__restrict__ next_det, const int32_t *next_m_dev)
+{
+    extern __shared__ unsigned long long s_raw[];
+    __shared__ int s_n_used, s_n_new, s_n_dead, s_any_dead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cap = a.capacity, md = a.max_det;
+    STAMP(0);
+    const int n = *a.n_tracks;
+    const int nfree = *a.n_free, id0 = *a.next_id;      // (all counters in one round trip)
+    const long long row_base = a.row_base[0];
+    const int m = det_count(m_host, m_dev, md, blockIdx.x == 0 ? a.err : nullptr);
+    if ((long long)blockIdx.x * 4 >= (long long)n + m && blockIdx.x != 0) return;   // cannot own a live track
+    STAMP(1);
+
+    // the next frame's detections do not depend on this frame's state: fetch them first
+    const int m_next = next_det ? det_count(-1, next_m_dev, md, nullptr) : 0;
+    DetChunk<DetT> first;
+    if (m_next > 0) load_chunk(first, next_det, m_next, 0, lane);
+
+    FrameLds L;
+    L.gains = reinterpret_cast<double *>(s_raw);
+    L.col_key = s_raw + a.gain_total;
+    L.key = L.col_key + md;
+    L.col_row = reinterpret_cast<int *>(L.key + cap);
+    L.unused = L.col_row + md;
+    L.newcols = L.unused + md;
+    L.arg = L.newcols + md;
+    L.slot = L.arg + cap;
+    L.newgone = L.slot + cap;
+    L.claim = L.newgone + cap;
+    L.inv = L.claim + cap;
+    L.table = L.inv + cap;
+    L.scan = L.table + 2 * FRAME_TABLE;
+
+    // ---- phase A (redundant in every block): the frame's bookkeeping
+    if (tid == 0) { s_n_used = 0; s_n_new = 0; s_n_dead = 0; s_any_dead = 0; }
+    for (int c = tid; c < m; c += FRAME_THREADS) { L.col_key[c] = ~0ull; L.col_row[c] = 0x7FFFFFFF; }
+    for (int k = tid; k < a.gain_total; k += FRAME_THREADS) L.gains[k] = a.gains[k];
+    for (int r = tid; r < n; r += FRAME_THREADS) {
+        L.slot[r] = a.order[r];
+        L.newgone[r] = a.gone[r];          // fused path: `gone` is indexed by table row, not by slot
+        L.arg[r] = (m > 0) ? a.row_arg[r] : 0;
+        L.key[r] = (m > 0) ? (unsigned long long)__double_as_longlong(a.row_min[r]) : ~0ull;
+    }
+    __syncthreads();
+    STAMP(2);
+    if (n > 0 && m > 0) {   // winner of a column = proposer with the smallest (distance, row)
+        for (int r = tid; r < n; r += FRAME_THREADS) atomicMin(&L.col_key[L.arg[r]], L.key[r]);
+        __syncthreads();
+        for (int r = tid; r < n; r += FRAME_THREADS)
+            if (L.key[r] == L.col_key[L.arg[r]]) atomicMin(&L.col_row[L.arg[r]], r);
+        __syncthreads();
+    }
+    STAMP(3);
+    const bool age = (m == 0) || (n > 0 && n >= m);   // tracker.py:95-107, 198-211
+    int used = 0;
+    for (int r = tid; r < n; r += FRAME_THREADS) {
+        const int c = L.arg[r];
+        const bool mine = (n > 0 && m > 0) && (L.col_row[c] == r);
+        L.claim[r] = mine ? c : -1;
+        int g = L.newgone[r];
+        int dead = 0;
+        if (mine) { g = 0; ++used; }
+        else if (age) { ++g; dead = ((double)g > a.max_gone) ? 1 : 0; }
+        L.newgone[r] = dead ? -1 : g;     // -1 marks a track that is deregistered this frame
+        if (dead) s_any_dead = 1;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) used += __shfl_xor(used, off);
+    if (lane == 0 && used) atomicAdd(&s_n_used, used);   // one LDS atomic per wave, not per thread
+    __syncthreads();
+    int n_keep = n;
+    if (s_any_dead) {   // stable compaction of the id-ordered table
+        int base = 0;
+        for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
+            const int r = r0 + tid;
+            const int keep = (r < n && L.newgone[r] >= 0) ? 1 : 0;
+            int total;
+            const int ex = block_scan256(keep, L.scan, &total);
+            if (keep) L.inv[base + ex] = r;
+            if (r < n && !keep && blockIdx.x == 0) {
+                const int k = atomicAdd(&s_n_dead, 1);
+                a.free_slots[nfree + k] = L.slot[r];   // entries above n_free are read by nobody this frame
+            }
+            base += total;
+        }
+        n_keep = base;
+    } else {
+        for (int r = tid; r < n; r += FRAME_THREADS) L.inv[r] = r;
+    }
+    __syncthreads();
+    int n_new = 0;
+    if (m > 0 && (n == 0 || n < m)) {   // registration (tracker.py:135-137, 212-217)
+        if (n == 0) {
+            for (int c = tid; c < m; c += FRAME_THREADS) L.newcols[c] = c;
+            n_new = m;
+        } else {
+            int base = 0;
+            for (int c0 = 0; c0 < m; c0 += FRAME_THREADS) {
+                const int c = c0 + tid;
+                const int un = (c < m && L.col_row[c] == 0x7FFFFFFF) ? 1 : 0;
+                int total;
+                const int ex = block_scan256(un, L.scan, &total);
+                if (un) L.unused[base + ex] = c;
+                base += total;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cnt = cpython_order_lds(L.unused, base, m, s_n_used, L.newcols, L.table);
+                if (cnt < 0) { if (blockIdx.x == 0) atomicOr(a.err, ERR_TRACK_CAPACITY); cnt = 0; }
+                s_n_new = cnt;
+            }
+            __syncthreads();
+            n_new = s_n_new;
+        }
+        __syncthreads();
+    }
+    const int n_new_all = n_new;
+    if (n_keep + n_new > cap) {
+        if (blockIdx.x == 0 && tid == 0) atomicOr(a.err, ERR_TRACK_CAPACITY);
+        n_new = cap - n_keep;
+    }
+    const int n_live = n_keep + n_new;
+
+    STAMP(4);
+    // ---- phase B: one wave per track of the new table
+    const int i = blockIdx.x * 4 + wave;
+    if (i < n_live) {
+        int slot, gone;
+        double z0, z1;
+        bool fresh_track = false;
+        if (i < n_keep) {
+            const int r = L.inv[i];
+            slot = L.slot[r];
+            gone = L.newgone[r];
+            const int c = L.claim[r];
+            if (c >= 0) {
+                z0 = (double)det[(size_t)c * 5 + 0];
+                z1 = (double)det[(size_t)c * 5 + 1];
+                if (lane < 3) a.info[lane * cap + slot] = (float)det[(size_t)c * 5 + 2 + lane];
+            } else {
+                z0 = a.pos[slot];
+                z1 = a.pos[cap + slot];
+                if (age && lane < 3) a.info[lane * cap + slot] = 0.f;
+            }
+        } else {
+            const int j = i - n_keep;
+            const int c = L.newcols[j];
+            slot = a.free_slots[nfree - 1 - j];
+            gone = 0;
+            fresh_track = true;
+            z0 = (double)det[(size_t)c * 5 + 0];
+            z1 = (double)det[(size_t)c * 5 + 1];
+            if (lane < 3) a.info[lane * cap + slot] = (float)det[(size_t)c * 5 + 2 + lane];
+            if (lane == 0) a.id[slot] = id0 + j;
+        }
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
+        STAMP(5);
+        if (a.use_gsff) gsff_wave(a, L.gains, slot, lane, z0, z1, fresh_track, o0, o1, p0, p1);
+        else if (lane == 0) { a.pos[slot] = z0; a.pos[cap + slot] = z1; }
+        STAMP(6);
+        if (lane == 0) {
+            b.order[i] = slot;
+            b.gone[i] = gone;
+            if (rows && row_base + i < rows_capacity) {
+                ysmr_row rr;
+                rr.frame = frame;
+                rr.track_id = fresh_track ? id0 + (i - n_keep) : a.id[slot];
+                rr.x = o0; rr.y = o1;
+                const int r = i < n_keep ? L.inv[i] : -1;
+                const int c = r >= 0 ? L.claim[r] : L.newcols[i - n_keep];
+                const bool zero = (c < 0 && age);
+                if (c >= 0) {
+                    rr.w = (float)det[(size_t)c * 5 + 2]; rr.h = (float)det[(size_t)c * 5 + 3];
+                    rr.angle = (float)det[(size_t)c * 5 + 4];
+                } else if (zero) {
+                    rr.w = rr.h = rr.angle = 0.f;
+                } else {
+                    rr.w = a.info[slot]; rr.h = a.info[cap + slot]; rr.angle = a.info[2 * cap + slot];
+                }
+                rr.disappeared = gone;
+                rows[row_base + i] = rr;
+            }
+        }
+        STAMP(7);
+        if (m_next > 0) rowmin_wave(b, i, p0, p1, next_det, m_next, lane, first);
+        STAMP(8);
+    }
+    // ---- block 0 publishes the counters of the new state
+    if (blockIdx.x == 0) {
+        if (claim_out)
+            for (int r = tid; r < n; r += FRAME_THREADS) claim_out[r] = L.claim[r];
+        if (new_cols_out)
+            for (int j = tid; j < n_new; j += FRAME_THREADS) new_cols_out[j] = L.newcols[j];
+        __syncthreads();
+        if (tid == 0) {
+            *b.n_tracks = n_live;
+            *b.next_id = id0 + n_new_all;   // ids are consumed even for registrations dropped on overflow
+            *b.n_free = nfree - n_new + s_n_dead;
+            b.row_base[0] = row_base + n_live;
+            if (rows && row_base + n_live > rows_capacity) atomicOr(a.err, ERR_ROWS_CAPACITY);
+            if (row_count_ext) *row_count_ext = row_base + n_live;
+            if (n_rows_out) *n_rows_out = n_live;
+            if (n_before_out) *n_before_out = n;
+            if (n_new_out) *n_new_out = n_new;
+        }
+    }
+}
+
+// row_base of the current state := the caller's running row count (start of ysmr_tracker_run)
+__global__ void k_set_row_base(TrackerDev t, const long long *row_count_ext)
+{
+    t.row_base[0] = row_count_ext ? *row_count_ext : 0;
+}
+
 __global__ void k_tracker_reset(TrackerDev t)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -688,13 +1071,21 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
                     int32_t *n_before, int32_t *new_cols, int32_t *n_new, bool rowmin_done, const DetT *next_det,
                     const int32_t *next_m_dev)
 {
-    const TrackerDev &d = t->d;
-    const dim3 wgrid((d.capacity + 3) / 4);
-    if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, d, det, m, m_dev);
-    const size_t link_lds = 12 * (size_t)d.max_det + 4 * (size_t)d.capacity;
-    hipLaunchKernelGGL(k_link<DetT>, dim3(1), dim3(LINK_THREADS), link_lds, st, d, det, m, m_dev, frame, rows,
-                       rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
-    hipLaunchKernelGGL(k_track<DetT>, wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det, -1, next_m_dev);
+    const dim3 wgrid((t->d.capacity + 3) / 4);
+    if (t->fused) {
+        const TrackerDev &a = t->cur(), &b = t->nxt();
+        if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, a, det, m, m_dev);
+        hipLaunchKernelGGL(k_frame<DetT>, wgrid, dim3(FRAME_THREADS), t->frame_lds, st, a, b, det, m, m_dev, frame, rows,
+                           rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new, next_det, next_m_dev);
+        t->par ^= 1;
+    } else {
+        const TrackerDev &d = t->d;
+        if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, d, det, m, m_dev);
+        const size_t link_lds = 12 * (size_t)d.max_det + 4 * (size_t)d.capacity;
+        hipLaunchKernelGGL(k_link<DetT>, dim3(1), dim3(LINK_THREADS), link_lds, st, d, det, m, m_dev, frame, rows,
+                           rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
+        hipLaunchKernelGGL(k_track<DetT>, wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det, -1, next_m_dev);
+    }
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }
@@ -708,7 +1099,7 @@ __global__ void k_peek(TrackerDev t, int32_t *ids, double *xy, int32_t *gone, in
     int slot = t.order[i];
     if (ids) ids[i] = t.id[slot];
     if (xy) { xy[2 * i] = t.pos[slot]; xy[2 * i + 1] = t.pos[t.capacity + slot]; }
-    if (gone) gone[i] = t.gone[slot];
+    if (gone) gone[i] = t.gone[t.gone_by_row ? i : slot];
 }
 
 }  // namespace
@@ -781,6 +1172,9 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const size_t o_rmin = take(sizeof(double) * cap), o_rarg = take(sizeof(int) * cap);
     const size_t o_dead = take(sizeof(int) * cap);
     const size_t o_new = take(sizeof(int) * max_det), o_table = take(sizeof(int) * 2 * (size_t)d.table_cap);
+    // parity-1 copies of the arrays k_frame double-buffers
+    const size_t o_scal1 = take(sizeof(int) * 16), o_order1 = take(sizeof(int) * cap), o_gone1 = take(sizeof(int) * cap);
+    const size_t o_rmin1 = take(sizeof(double) * cap), o_rarg1 = take(sizeof(int) * cap);
     t->block_bytes = off;
     hipError_t e = hipMalloc(&t->block, off);
     if (e != hipSuccess) {
@@ -801,6 +1195,25 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     d.row_min = (double *)(b + o_rmin); d.row_arg = (int *)(b + o_rarg);
     d.dead = (int *)(b + o_dead);
     d.new_cols = (int *)(b + o_new); d.set_table = (int *)(b + o_table);
+    t->d1 = d;
+    {
+        TrackerDev &q = t->d1;
+        int *scal1 = (int *)(b + o_scal1);
+        q.n_tracks = scal1; q.next_id = scal1 + 1; q.n_free = scal1 + 3;   // err stays shared (sticky)
+        q.row_base = (long long *)(scal1 + 8);
+        q.order = (int *)(b + o_order1); q.gone = (int *)(b + o_gone1);
+        q.row_min = (double *)(b + o_rmin1); q.row_arg = (int *)(b + o_rarg1);
+    }
+    t->par = 0;
+    t->frame_lds = frame_lds_bytes(capacity, max_det, (int)gain_doubles);
+    const char *mode_env = getenv("YSMR_LINK_MODE");   // "split" forces the two-kernel path (tests)
+    t->fused = t->frame_lds <= 150 * 1024 && !(mode_env && !strcmp(mode_env, "split"));
+    if (t->fused) {
+        hipError_t ea = hipFuncSetAttribute((const void *)k_frame<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->frame_lds);
+        hipError_t eb = hipFuncSetAttribute((const void *)k_frame<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->frame_lds);
+        if (ea != hipSuccess || eb != hipSuccess) t->fused = false;
+    }
+    t->d.gone_by_row = t->d1.gone_by_row = t->fused ? 1 : 0;
     e = hipMemset(t->block, 0, off);
     if (e == hipSuccess && gain_doubles)
         e = hipMemcpy(b + o_gain, t->gains_host.data(), sizeof(double) * gain_doubles, hipMemcpyHostToDevice);
@@ -817,6 +1230,7 @@ int ysmr_tracker_reset(ysmr_tracker *t, void *stream)
 {
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
     int n = t->d.capacity > t->d.max_det ? t->d.capacity : t->d.max_det;
+    t->par = 0;
     hipLaunchKernelGGL(k_tracker_reset, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
@@ -839,6 +1253,7 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
     if (m < 0 && !m_dev) return ysmr::fail(YSMR_ERR_ARG, "m < 0 requires m_dev");
     if (m > t->d.max_det) return ysmr::fail(YSMR_ERR_CAPACITY, "m = %d exceeds max_det = %d", m, t->d.max_det);
     if (!det_dev && m != 0) return ysmr::fail(YSMR_ERR_ARG, "det_dev is NULL");
+    if (t->fused) hipLaunchKernelGGL(k_set_row_base, dim3(1), dim3(1), 0, (hipStream_t)stream, t->cur(), nullptr);
     if (det_is_f64)
         return launch_update_t<double>(t, (hipStream_t)stream, (const double *)det_dev, m, m_dev, frame_index, rows_dev,
                                        t->d.capacity, nullptr, n_rows_dev, claim_col_dev, n_before_dev, new_cols_dev,
@@ -854,6 +1269,9 @@ int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const 
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
     if (!det_dev || !det_count_dev || !rows_dev || !row_count_dev || batch <= 0)
         return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev, rows_dev, row_count_dev must be set and batch > 0");
+    if (t->fused)
+        hipLaunchKernelGGL(k_set_row_base, dim3(1), dim3(1), 0, (hipStream_t)stream, t->cur(),
+                           (const long long *)row_count_dev);
     for (int f = 0; f < batch; ++f) {
         const bool has_next = f + 1 < batch;
         int rc = launch_update_t<float>(t, (hipStream_t)stream, det_dev + (size_t)f * t->d.max_det * 5, -1,
@@ -870,7 +1288,7 @@ int ysmr_tracker_peek(ysmr_tracker *t, void *stream, int32_t *ids_dev, double *x
                       int32_t *n_dev)
 {
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
-    hipLaunchKernelGGL(k_peek, dim3((t->d.capacity + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d, ids_dev,
+    hipLaunchKernelGGL(k_peek, dim3((t->d.capacity + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->cur(), ids_dev,
                        xy_dev, disappeared_dev, n_dev);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
@@ -879,12 +1297,13 @@ int ysmr_tracker_peek(ysmr_tracker *t, void *stream, int32_t *ids_dev, double *x
 int ysmr_tracker_info(ysmr_tracker *t, void *stream, int32_t *n_tracks, int32_t *next_id, int32_t *error_bits)
 {
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
-    int host[4];
-    YSMR_HIP_CHECK(hipMemcpyAsync(host, t->d.n_tracks, sizeof(int) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    int host[4], err = 0;
+    YSMR_HIP_CHECK(hipMemcpyAsync(host, t->cur().n_tracks, sizeof(int) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    YSMR_HIP_CHECK(hipMemcpyAsync(&err, t->d.err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     YSMR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     if (n_tracks) *n_tracks = host[0];
     if (next_id) *next_id = host[1];
-    if (error_bits) *error_bits = host[2];
+    if (error_bits) *error_bits = err;
     return YSMR_OK;
 }
 

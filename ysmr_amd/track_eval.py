@@ -93,6 +93,11 @@ class TrackingPipeline:
         self._done[slot] = done
         return res
 
+    def wait(self):
+        """Detection runs on the side stream, linking on the caller's stream: nothing to join here
+        (kept so that callers need not know which streams the pipeline uses)."""
+        return None
+
     def take_rows(self):
         """Synchronise, download the accumulated rows and reset the row buffer."""
         n = int(self.row_count.item())
