@@ -81,3 +81,31 @@ def test_analyse_and_ysmr(tmp_path):
     assert [p for p, _ in done] == paths + [str(tmp_path / "nope.npy")]
     assert done[0][1] is True and done[1][1] is True and done[2][1] is None
     assert (out / "v1_list.csv").exists()
+
+
+def test_4k_dense_field_config(oracle):
+    """BASELINE configs[4]: 3840x2160, ~5000 blobs.  Exercises large frames, max_det/capacity 8192
+    (the two-kernel link path: the fused one needs its tables in LDS) and large-N assignment."""
+    import torch
+    from ysmr_amd import _lib
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import S4K
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    frames = S4K(seed=1).frames(3)
+    p = threshold_params(True, 5, 2.0)
+    det = Detector(3, 2160, 3840, max_det=8192, params=p)
+    trk = DeviceTracker(max_disappeared=30.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=8192, max_det=8192)
+    rows = torch.empty(3 * 8192 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    res = det.detect(torch.from_numpy(frames).cuda())
+    trk.run(res.det, res.det_count, 0, rows, count)
+    torch.cuda.synchronize()
+    assert int(res.status.max().item()) == 0 and trk.info()[2] == 0
+    fd = oracle.detect_frame(frames[0], p.inv, p.t_low, p.t_high, p.use_high, 8192)
+    assert 4500 < fd.count < 5200
+    np.testing.assert_array_equal(res.labels[0].cpu().numpy(), fd.labels)
+    np.testing.assert_array_equal(res.mask[0].cpu().numpy(), fd.mask)
+    assert int(res.det_count[0].item()) == fd.count
+    np.testing.assert_array_equal(res.det[0, :fd.count, :4].cpu().numpy(), fd.det[:, :4])
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, max_det=8192)
+    compare_rows(rows_to_numpy(rows, int(count.item())), ref_rows)
