@@ -149,3 +149,31 @@ def test_large_component_uses_arena(torch_cuda, oracle):
     img[95:99, 55:62] = 220                                            # nested blob
     frames = img[None]
     _compare(oracle, frames, _detect_gpu(torch_cuda, frames, p), p)
+
+
+def test_components_on_arbitrary_class_maps(torch_cuda, oracle):
+    """ysmr_components_batch on caller-supplied class maps with ANY combination of the two bits
+    (markers inside, outside and next to the mask): hysteresis = scipy's binary_propagation rule,
+    then labels / nesting / rectangles as for thresholded frames."""
+    import torch
+    from scipy import ndimage
+    from ysmr_amd.detect import Detector
+    rng = np.random.default_rng(17)
+    for (h, w, p_mask, p_mark) in [(61, 83, 0.45, 0.03), (40, 56, 0.6, 0.01), (97, 131, 0.3, 0.1), (33, 47, 0.15, 0.3)]:
+        b = 3
+        mask = rng.random((b, h, w)) < p_mask
+        mark = rng.random((b, h, w)) < p_mark           # independent of the mask: all 4 byte values occur
+        cls = (mask.astype(np.uint8) | (mark.astype(np.uint8) << 1))
+        det = Detector(b, h, w, max_det=4096)
+        res = det.components(cls=torch.from_numpy(cls).cuda())
+        torch.cuda.synchronize()
+        for f in range(b):
+            ref_mask = ndimage.binary_propagation(mark[f], mask=mask[f])
+            np.testing.assert_array_equal(res.mask[f].cpu().numpy() > 0, ref_mask, err_msg=f"{h}x{w} frame {f}")
+            labels, rects, anchors, n = oracle.components(ref_mask.astype(np.uint8), max_det=4096)
+            assert int(res.status[f].item()) == 0
+            np.testing.assert_array_equal(res.labels[f].cpu().numpy(), labels)
+            assert int(res.det_count[f].item()) == n
+            np.testing.assert_array_equal(res.anchors[f, :n].cpu().numpy(), anchors)
+            np.testing.assert_array_equal(res.det[f, :n, :4].cpu().numpy(), rects[:, :4])
+            _assert_angle_close(res.det[f, :n, 4].cpu().numpy(), rects[:, 4])

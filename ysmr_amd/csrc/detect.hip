@@ -886,20 +886,30 @@ struct HullStore {
     __device__ __forceinline__ float &il(int i) const { return base[(size_t)(i * 5 + 4) * stride]; }
 };
 
-// monotone-chain push with strict turns (collinear points are dropped); coordinates are small
-// integers, so the cross product is exact in int64
-__device__ __forceinline__ void chain_push(const HullStore &s, int start, int &n, int x, int y)
+// Monotone-chain stack with strict turns (collinear points are dropped).  The two topmost points
+// live in registers, so a push costs one LDS write and no dependent LDS reads; a pop reloads one
+// point.  Coordinates are pixel indices < 16384 (check_geometry), so the cross product is exact in
+// 32-bit integers.
+struct Chain {
+    int start, n;       // stack occupies store slots [start, n)
+    int x1, y1, x2, y2; // top and second-from-top (valid when n - start >= 1 / >= 2)
+};
+
+__device__ __forceinline__ void chain_push(const HullStore &s, Chain &c, int x, int y)
 {
-    if (n > start && (int)s.px(n - 1) == x && (int)s.py(n - 1) == y) return;
-    while (n - start >= 2) {
-        long long ox = (long long)s.px(n - 2), oy = (long long)s.py(n - 2);
-        long long ax = (long long)s.px(n - 1), ay = (long long)s.py(n - 1);
-        long long cr = (ax - ox) * ((long long)y - oy) - (ay - oy) * ((long long)x - ox);
-        if (cr <= 0) --n; else break;
+    if (c.n > c.start && c.x1 == x && c.y1 == y) return;
+    while (c.n - c.start >= 2) {
+        int cr = (c.x1 - c.x2) * (y - c.y2) - (c.y1 - c.y2) * (x - c.x2);
+        if (cr > 0) break;
+        --c.n;                      // pop: the second becomes the top, reload the new second
+        c.x1 = c.x2; c.y1 = c.y2;
+        if (c.n - c.start >= 2) { c.x2 = (int)s.px(c.n - 2); c.y2 = (int)s.py(c.n - 2); }
     }
-    s.px(n) = (float)x;
-    s.py(n) = (float)y;
-    ++n;
+    s.px(c.n) = (float)x;
+    s.py(c.n) = (float)y;
+    c.x2 = c.x1; c.y2 = c.y1;
+    c.x1 = x; c.y1 = y;
+    ++c.n;
 }
 
 #define YSMR_PI 3.1415926535897932384626433832795
@@ -1005,6 +1015,14 @@ __device__ void min_area_rect_hull(const HullStore &s, int n, float *rect)
 }
 
 // det slots are compacted afterwards (nested components dropped) by k_compact.
+#ifdef YSMR_STAMPS
+__device__ unsigned long long g_geo_stamps[16];
+#define GEOSTAMP(k) do { if (blockIdx.x == 3 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_geo_stamps[k] = t_; } } while (0)
+extern "C" int ysmr_debug_read_geo_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_geo_stamps), sizeof(unsigned long long) * 16); }
+#else
+#define GEOSTAMP(k) do {} while (0)
+#endif
+
 // 16 lanes per component: lane `sub` scans column minx+sub of the bounding box for the top-most and
 // bottom-most pixel of the component (the only hull candidates of that column; all loads of a
 // column are independent), lane 0 then builds the chains from the 16 (top, bottom) pairs and runs
@@ -1033,6 +1051,7 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
 {
     __shared__ float lds[GEO_COMPS * GEO_LDS_STRIDE];
     __shared__ int s_top[GEO_COMPS][GEO_GROUP], s_bot[GEO_COMPS][GEO_GROUP];
+    GEOSTAMP(0);
     const int grp = threadIdx.x / GEO_GROUP, sub = threadIdx.x % GEO_GROUP;
     const long long gi = (long long)blockIdx.x * GEO_COMPS + grp;
     const int f = (int)(gi / t.max_det), k = (int)(gi - (long long)f * t.max_det);
@@ -1050,6 +1069,7 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
     const uint32_t *L = labels + (size_t)(live ? f : 0) * g.HW;
     const int W = g.W;
     const bool narrow = live && bwid <= GEO_GROUP;
+    GEOSTAMP(1);
     if (narrow && sub < bwid) {
         int top, bot;
         column_extent(L, W, minx + sub, miny, maxy, want, top, bot);
@@ -1057,6 +1077,7 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
         s_bot[grp][sub] = bot;
     }
     __syncthreads();
+    GEOSTAMP(2);
     if (!live || sub != 0) return;
 
     HullStore s;
@@ -1076,30 +1097,31 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
         s.stride = 1;
     }
     // max-y side: columns right -> left, within a column bottom first then top
-    int nh = 0;
+    Chain up{0, 0, 0, 0, 0, 0};
     for (int x = maxx; x >= minx; --x) {
         int top, bot;
         if (narrow) { top = s_top[grp][x - minx]; bot = s_bot[grp][x - minx]; }
         else column_extent(L, W, x, miny, maxy, want, top, bot);
         if (top < 0) continue;
-        chain_push(s, 0, nh, x, bot);
-        chain_push(s, 0, nh, x, top);
+        chain_push(s, up, x, bot);
+        chain_push(s, up, x, top);
     }
-    // nh >= 1; the last point is the lexicographically first pixel, where the min-y side starts
-    int start = nh - 1;
-    int nl = start;
+    // up.n >= 1; its last point is the lexicographically first pixel, where the min-y side starts
+    Chain lo{up.n - 1, up.n - 1, 0, 0, 0, 0};
     for (int x = minx; x <= maxx; ++x) {
         int top, bot;
         if (narrow) { top = s_top[grp][x - minx]; bot = s_bot[grp][x - minx]; }
         else column_extent(L, W, x, miny, maxy, want, top, bot);
         if (top < 0) continue;
-        chain_push(s, start, nl, x, top);
-        chain_push(s, start, nl, x, bot);
+        chain_push(s, lo, x, top);
+        chain_push(s, lo, x, bot);
     }
     // drop the closing point (== point 0) unless the hull is a single point
-    int hn = nl - 1;
+    int hn = lo.n - 1;
     if (hn < 1) hn = 1;
+    GEOSTAMP(3);
     min_area_rect_hull(s, hn, det_tmp + o * 5);
+    GEOSTAMP(4);
 }
 
 // Drop nested components, write final detection list / count / anchors.
@@ -1198,8 +1220,8 @@ int check_geometry(int batch, int H, int W, int channels, int max_det)
         return ysmr::fail(YSMR_ERR_ARG, "batch, height, width, max_det must be positive (got %d, %d, %d, %d)", batch, H, W, max_det);
     if (channels != 1 && channels != 3)
         return ysmr::fail(YSMR_ERR_ARG, "channels must be 1 (gray) or 3 (BGR), got %d", channels);
-    if ((size_t)H * W >= 0x7FFFFFF0ull || (size_t)batch * H * W >= (1ull << 40))
-        return ysmr::fail(YSMR_ERR_ARG, "frame too large");
+    if (H > 16384 || W > 16384 || (size_t)batch * H * W >= (1ull << 40))
+        return ysmr::fail(YSMR_ERR_ARG, "frame too large (height and width are limited to 16384)");
     return YSMR_OK;
 }
 
