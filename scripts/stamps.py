@@ -13,6 +13,8 @@ for rep in range(5):
     pipe.trk.run(res.det, res.det_count, 0, pipe.rows, pipe.row_count); torch.cuda.synchronize()
     tail = pipe.rows[-160:].cpu().numpy().view(np.uint64)
     acc.append(np.diff(tail[:9].astype(np.int64)))
+    sub = tail[[3, 10, 11, 12, 13, 4]].astype(np.int64)
+    print("   bookkeeping split: claims+age %d | compaction %d | unused scan %d | set order %d | rest %d" % tuple(np.diff(sub)))
 d = np.median(np.array(acc), axis=0)
 names = ["n/m loads+exit test", "prefetch issue + phase A loads (order, gone, row_arg/min)", "claim atomics (LDS)", "claims/age/compaction/registration",
          "phase B: claim data", "GSFF", "order/gone/row write", "rowmin next frame"]
@@ -29,6 +31,8 @@ for rep in range(5):
     pipe.reset(); pipe.trk.run(res.det, res.det_count, 0, pipe.rows, pipe.row_count); torch.cuda.synchronize()
     L.ysmr_debug_read_stamps(buf)
     acc.append(np.diff(np.array(buf[:7], dtype=np.int64)))
+    fir = np.array(buf[8:11], dtype=np.int64)
+    print("   fir: products %d  wave sums %d" % (fir[1] - fir[0], fir[2] - fir[1]))
 d = np.median(np.array(acc), axis=0)
 for n, v in zip(["state loads", "fresh/grew", "likelihood exp + broadcast", "append + weights + output", "predict FIR", "write back"], d):
     print(f"  gsff: {n:40s} {v:8.0f} ticks")

@@ -67,9 +67,13 @@ struct ysmr_tracker {
 #ifdef YSMR_STAMPS
 __device__ unsigned long long g_stamps[32];
 #define GSTAMP(k) do { if (blockIdx.x == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_stamps[k] = t_; } } while (0)
+__device__ unsigned long long g_block_stamps[2 * 2048 * 8];
+#define BSTAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_block_stamps[((frame & 1) * 2048 + blockIdx.x) * 8 + (k)] = t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_block_stamps[((frame & 1) * 2048 + blockIdx.x) * 8 + 4 + (k)] = t_; } } while (0)
+extern "C" int ysmr_debug_read_block_stamps(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_stamps), sizeof(unsigned long long) * n); }
 extern "C" int ysmr_debug_read_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32); }
 #else
 #define GSTAMP(k) do {} while (0)
+#define BSTAMP(k) do {} while (0)
 #endif
 
 namespace {
@@ -89,34 +93,51 @@ __device__ __forceinline__ int det_count(int m_host, const int32_t *m_dev, int m
 // Nearest detection of one track, computed by one wave (64 lanes stride over the detections).
 // scipy cdist('euclidean') on 2-D points is sqrt(dx*dx + dy*dy) in float64; argmin
 // takes the lowest column among equal distances.  sqrt is monotone, so the row minimum is
-// sqrt(min s); two different s can round to the same sqrt -- merge() resolves that exactly, and
-// keeps the (expensive, almost never needed) float64 sqrt behind a wave-uniform branch.
+// sqrt(min s) -- but two different s can round to the same sqrt, and then the lower column wins.
+// Pass 1 finds min s; pass 2 takes the lowest column whose s is within 2^-48 (relative) of it.
+// Only if one of those differs from min s at all (practically never) a third pass compares the
+// float64 square roots themselves; that pass sits behind a wave-uniform branch.
 // ------------------------------------------------------------------------------------------
-struct Cand { double s; int j; };
-
-__device__ __forceinline__ Cand merge(Cand a, Cand b)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_min(double v)
 {
-    // each candidate = (min s of its subset, first index whose sqrt equals sqrt(min s))
-    const double lo = fmin(a.s, b.s), hi = fmax(a.s, b.s);
-    const bool valid = (a.j >= 0) && (b.j >= 0);
-    bool same = valid && (hi == lo);
-    const bool close = valid && !same && (hi - lo) <= lo * 0x1p-48;
-    if (__any(close)) {
-        if (close) same = (sqrt(hi) == sqrt(lo));
-    }
-    Cand r;
-    if (a.j < 0) r = b;
-    else if (b.j < 0) r = a;
-    else if (same) { r.s = lo; r.j = min(a.j, b.j); }
-    else if (a.s < b.s) r = a;
-    else r = b;
-    return r;
+    long long b = __double_as_longlong(v);
+    // lanes outside ROW_MASK / without a source read +inf (old = +inf bits, bound_ctrl off keeps old)
+    int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0x7FF00000, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    const double o = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    return o < v ? o : v;
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min(int v)
+{
+    const int o = __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, CTRL, ROW_MASK, 0xF, false);
+    return min(o, v);
+}
+template <typename T>
+__device__ __forceinline__ T wave_min_lane63(T v)
+{
+    v = dpp_min<0x111, 0xF>(v);   // row_shr:1
+    v = dpp_min<0x112, 0xF>(v);   // row_shr:2
+    v = dpp_min<0x114, 0xF>(v);   // row_shr:4
+    v = dpp_min<0x118, 0xF>(v);   // row_shr:8  -> lane 15 of each row holds the row minimum
+    v = dpp_min<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_min<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the minimum
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+    long long b = __double_as_longlong(wave_min_lane63(v));
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), 63);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ int wave_min(int v) { return __builtin_amdgcn_readlane(wave_min_lane63(v), 63); }
 
 constexpr int ROWMIN_U = 8;   // detections per lane per chunk (all loads of a chunk in flight together)
 
 template <typename DetT>
-struct DetChunk { double qx[ROWMIN_U], qy[ROWMIN_U]; };
+struct DetChunk { DetT qx[ROWMIN_U], qy[ROWMIN_U]; };   // raw: converting here would wait for the loads here
 
 template <typename DetT>
 __device__ __forceinline__ void load_chunk(DetChunk<DetT> &c, const DetT *__restrict__ det, int m, int j0, int lane)
@@ -124,42 +145,67 @@ __device__ __forceinline__ void load_chunk(DetChunk<DetT> &c, const DetT *__rest
 #pragma unroll
     for (int u = 0; u < ROWMIN_U; ++u) {
         int j = min(j0 + u * 64 + lane, m - 1);
-        c.qx[u] = (double)det[(size_t)j * 5 + 0];
-        c.qy[u] = (double)det[(size_t)j * 5 + 1];
+        c.qx[u] = det[(size_t)j * 5 + 0];
+        c.qy[u] = det[(size_t)j * 5 + 1];
     }
 }
 
 // `first` holds detections [0, 64*ROWMIN_U) already loaded by the caller (issued before the GSFF so
-// that their latency hides behind it).
+// that their latency hides behind it).  With m <= 64*ROWMIN_U every pass runs out of registers.
 template <typename DetT>
 __device__ __forceinline__ void rowmin_wave(const TrackerDev &t, int row, double px, double py,
                                             const DetT *__restrict__ det, int m, int lane, DetChunk<DetT> &first)
 {
-    Cand best{0.0, -1};
-    for (int j0 = 0; j0 < m; j0 += 64 * ROWMIN_U) {
+    constexpr int CHUNK = 64 * ROWMIN_U;
+    const bool multi = m > CHUNK;
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double lane_min = inf;
+    for (int j0 = 0; j0 < m; j0 += CHUNK) {
         if (j0 > 0) load_chunk(first, det, m, j0, lane);
 #pragma unroll
         for (int u = 0; u < ROWMIN_U; ++u) {
-            int j = j0 + u * 64 + lane;
-            double dx = px - first.qx[u];
-            double dy = py - first.qy[u];
+            const int j = j0 + u * 64 + lane;
+            const double dx = px - (double)first.qx[u];
+            const double dy = py - (double)first.qy[u];
             double s = dx * dx;
             s = s + dy * dy;
-            Cand c{s, j < m ? j : -1};
-            best = merge(best, c);
+            s = j < m ? s : inf;
+            lane_min = s < lane_min ? s : lane_min;
         }
     }
+    const double s_min = wave_min(lane_min);
+    const double near_limit = s_min + s_min * 0x1p-48;
+    int cand = 0x7FFFFFFF;
+    bool inexact = false;
+    for (int j0 = 0; j0 < m; j0 += CHUNK) {
+        if (multi) load_chunk(first, det, m, j0, lane);
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        Cand o;
-        o.s = __shfl_xor(best.s, off);
-        o.j = __shfl_xor(best.j, off);
-        best = merge(best, o);
+        for (int u = 0; u < ROWMIN_U; ++u) {
+            const int j = j0 + u * 64 + lane;
+            const double dx = px - (double)first.qx[u];
+            const double dy = py - (double)first.qy[u];
+            double s = dx * dx;
+            s = s + dy * dy;
+            const bool near = (j < m) && (s <= near_limit);
+            cand = near ? min(cand, j) : cand;
+            inexact = inexact || (near && s != s_min);
+        }
     }
+    const double d_min = sqrt(s_min);
+    if (__any(inexact)) {   // some s differs from min s by a few ulps: compare the rounded roots
+        cand = 0x7FFFFFFF;
+        for (int j = lane; j < m; j += 64) {
+            const double dx = px - (double)det[(size_t)j * 5 + 0];
+            const double dy = py - (double)det[(size_t)j * 5 + 1];
+            double s = dx * dx;
+            s = s + dy * dy;
+            if (s <= near_limit && sqrt(s) == d_min) cand = min(cand, j);
+        }
+    }
+    const int best = wave_min(cand);
     if (lane == 0) {
-        double d = sqrt(best.s);
-        t.row_min[row] = d;
-        t.row_arg[row] = best.j;
+        t.row_min[row] = d_min;
+        t.row_arg[row] = best;
     }
 }
 
@@ -221,13 +267,15 @@ __device__ __forceinline__ double wave_total(double v)
 // FIR estimates of ALL active filters at once (rows 0 and 1 of gain f times the last n_f[f]
 // measurements: lsff_calc, gsff.py:156-177).  The 2*mode butterflies are interleaved so that the
 // cross-lane latency is paid once per level, not once per sum.
+template <int NF>
 __device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const double *gains, const TrackRegs &h, int lane,
                                              int mode, int head, double *x0, double *x1)
 {
     const int L = t.hist_cap;
-    double p0[YSMR_MAX_FILTERS], p1[YSMR_MAX_FILTERS];
+    GSTAMP(8);
+    double p0[NF], p1[NF];
 #pragma unroll
-    for (int f = 0; f < YSMR_MAX_FILTERS; ++f) { p0[f] = 0.0; p1[f] = 0.0; }
+    for (int f = 0; f < NF; ++f) { p0[f] = 0.0; p1[f] = 0.0; }
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) {
         int k = lane + 64 * q;
@@ -236,10 +284,10 @@ __device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const double *
         if (age < 0) age += L;
         // unconditional gathers (clamped index, masked product): all 2*mode loads of a lane are in
         // flight together instead of one dependent round trip per divergent branch
-        double ga[YSMR_MAX_FILTERS], gb[YSMR_MAX_FILTERS];
-        bool in[YSMR_MAX_FILTERS];
+        double ga[NF], gb[NF];
+        bool in[NF];
 #pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
+        for (int f = 0; f < NF; ++f) {
             if (f < mode) {
                 const int N = t.n_i[f];
                 in[f] = (e < L) && (age < N);
@@ -250,51 +298,81 @@ __device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const double *
             }
         }
 #pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
+        for (int f = 0; f < NF; ++f) {
             if (f < mode && in[f]) {
                 p0[f] = p0[f] + ga[f] * h.v[q];
                 p1[f] = p1[f] + gb[f] * h.v[q];
             }
         }
     }
+    GSTAMP(9);
     // wave sums by DPP (no LDS round trips): row_shr 1,2,4,8 leave each 16-lane row's sum in its
     // last lane, row_bcast15 / row_bcast31 carry it across rows, lane 63 ends with the total
 #pragma unroll
-    for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
+    for (int f = 0; f < NF; ++f) {
         if (f < mode) {
             p0[f] = wave_total(p0[f]);
             p1[f] = wave_total(p1[f]);
         }
     }
 #pragma unroll
-    for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+    for (int f = 0; f < NF; ++f)
         if (f < mode) { x0[f] = p0[f]; x1[f] = p1[f]; }
+    GSTAMP(10);
 }
 
 // GSFF correct + predict of one track by one wave (gsff.py:204-347).  z = measurement; returns the
 // filtered position (o) and the prediction (p), and leaves the prediction in t.pos[slot].
 // fresh_track: the slot was just (re)assigned -- ignore whatever filter state it still holds.
+// filter state of one track, spread over the wave (history) or replicated (the rest)
+template <int NF>
+struct GsffState {
+    TrackRegs h;
+    double w[NF], xh0[NF], xh1[NF];
+    int len, head, mode;
+};
+// Issue every load of a track's filter state; no load depends on another, so one round trip.
+template <int NF>
+__device__ __forceinline__ void gsff_fetch(const TrackerDev &t, int slot, int lane, GsffState<NF> &s)
+{
+    const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
+    const double *hist = t.hist + (size_t)slot * 2 * L;
+    s.len = t.hist_len[slot]; s.head = t.hist_head[slot]; s.mode = t.mode[slot];
+#pragma unroll
+    for (int q = 0; q < TRACK_VALS; ++q) {
+        int k = lane + 64 * q;
+        s.h.v[q] = (k < 2 * L) ? hist[k] : 0.0;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const bool on = f < nf;   // entries >= mode hold stale values that nothing reads
+        s.w[f] = on ? t.weights[(size_t)f * cap + slot] : 0.0;
+        s.xh0[f] = on ? t.xhat[((size_t)0 * nf + f) * cap + slot] : 0.0;
+        s.xh1[f] = on ? t.xhat[((size_t)1 * nf + f) * cap + slot] : 0.0;
+    }
+}
+template <int NF>
+__device__ __forceinline__ void gsff_blank(GsffState<NF> &s)
+{
+    s.len = s.head = s.mode = 0;
+#pragma unroll
+    for (int q = 0; q < TRACK_VALS; ++q) s.h.v[q] = 0.0;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) s.w[f] = s.xh0[f] = s.xh1[f] = 0.0;
+}
+template <int NF>
 __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gains, int slot, int lane, double z0,
-                                          double z1, bool fresh_track, double &o0, double &o1, double &p0, double &p1)
+                                          double z1, bool fresh_track, GsffState<NF> &st, double &o0, double &o1,
+                                          double &p0, double &p1)
 {
     const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
     GSTAMP(0);
     double *hist = t.hist + (size_t)slot * 2 * L;
-    int len = t.hist_len[slot], head = t.hist_head[slot], mode = t.mode[slot];
-    TrackRegs h;
-#pragma unroll
-    for (int q = 0; q < TRACK_VALS; ++q) {
-        int k = lane + 64 * q;
-        h.v[q] = (k < 2 * L) ? hist[k] : 0.0;
-    }
-    double w[YSMR_MAX_FILTERS], xh0[YSMR_MAX_FILTERS], xh1[YSMR_MAX_FILTERS];
-#pragma unroll
-    for (int f = 0; f < YSMR_MAX_FILTERS; ++f) {
-        bool on = f < mode;
-        w[f] = on ? t.weights[(size_t)f * cap + slot] : 0.0;
-        xh0[f] = on ? t.xhat[((size_t)0 * nf + f) * cap + slot] : 0.0;
-        xh1[f] = on ? t.xhat[((size_t)1 * nf + f) * cap + slot] : 0.0;
-    }
+    int len = st.len, head = st.head, mode = st.mode;
+    TrackRegs &h = st.h;
+    double (&w)[NF] = st.w;
+    double (&xh0)[NF] = st.xh0;
+    double (&xh1)[NF] = st.xh1;
     GSTAMP(1);
     // ---- correct (gsff.py:251-347)
     bool fresh = (len == 0) || fresh_track;
@@ -318,21 +396,21 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     }
     if (grew) {
         const double w0 = 1.0 / (double)mode;
-        fir_wave_all(t, gains, h, lane, mode, head, xh0, xh1);
+        fir_wave_all<NF>(t, gains, h, lane, mode, head, xh0, xh1);
 #pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+        for (int f = 0; f < NF; ++f)
             if (f < mode) w[f] = w0;
     }
     GSTAMP(2);
     // likelihoods (gsff.py:179-202): lane f evaluates filter f's exp(), the results are broadcast
     // (the float64 exp is ~150 instructions; doing the n_f of them one after the other on every
     // lane was a third of this function)
-    double lik[YSMR_MAX_FILTERS];
+    double lik[NF];
     double total = 0.0;
     {
         double xa = 0.0, xb = 0.0;
 #pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+        for (int f = 0; f < NF; ++f)
             if (lane == f) { xa = xh0[f]; xb = xh1[f]; }
         double d0 = z0 - xa, d1 = z1 - xb;
         double q = d0 * d0;
@@ -340,7 +418,7 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
         double l = exp(-0.5 * q);
         if (l < t.lik_min) l = t.lik_min;
 #pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+        for (int f = 0; f < NF; ++f)
             if (f < mode) {
                 lik[f] = __shfl(l, f);
                 total = total + lik[f] * w[f];
@@ -361,15 +439,15 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     {   // new weights w_i = lik_i * w_i / total: one division per lane instead of n_f per lane
         double lw = 0.0;
 #pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+        for (int f = 0; f < NF; ++f)
             if (lane == f && f < mode) lw = lik[f] * w[f];
         const double wn = lw / total;
 #pragma unroll
-        for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+        for (int f = 0; f < NF; ++f)
             if (f < mode) w[f] = __shfl(wn, f);
     }
 #pragma unroll
-    for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+    for (int f = 0; f < NF; ++f)
         if (f < mode) {
             double a = xh0[f] * w[f], b = xh1[f] * w[f];
             if (f == 0) { f0 = a; f1 = b; }
@@ -381,9 +459,9 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     GSTAMP(4);
     // ---- predict (gsff.py:204-249)
     f0 = f1 = r0 = r1 = 0.0;
-    fir_wave_all(t, gains, h, lane, mode, head, xh0, xh1);
+    fir_wave_all<NF>(t, gains, h, lane, mode, head, xh0, xh1);
 #pragma unroll
-    for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+    for (int f = 0; f < NF; ++f)
         if (f < mode) {
             double a = xh0[f] * w[f], b = xh1[f] * w[f];
             if (f == 0) { f0 = a; f1 = b; }
@@ -407,7 +485,7 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
         t.pos[cap + slot] = p1;
     }
 #pragma unroll
-    for (int f = 0; f < YSMR_MAX_FILTERS; ++f)
+    for (int f = 0; f < NF; ++f)
         if (f < mode && lane == f) {
             t.weights[(size_t)f * cap + slot] = w[f];
             t.liks[(size_t)f * cap + slot] = lik[f];
@@ -417,7 +495,7 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     GSTAMP(6);
 }
 
-template <typename DetT>
+template <typename DetT, int NF>
 __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row *rows, long long rows_capacity,
                                                const DetT *__restrict__ next_det, int next_m_host,
                                                const int32_t *next_m_dev)
@@ -434,7 +512,11 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     const int slot = __builtin_amdgcn_readfirstlane(t.order[i]);
     const double z0 = t.pos[slot], z1 = t.pos[cap + slot];
     double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
-    if (t.use_gsff) gsff_wave(t, t.gains, slot, lane, z0, z1, false, o0, o1, p0, p1);
+    if (t.use_gsff) {
+        GsffState<NF> st;
+        gsff_fetch(t, slot, lane, st);
+        gsff_wave(t, t.gains, slot, lane, z0, z1, false, st, o0, o1, p0, p1);
+    }
     if (lane == 0) {
         const long long base = t.row_base[0];
         if (rows && base + i < rows_capacity) {
@@ -750,21 +832,19 @@ __host__ __device__ inline size_t frame_lds_bytes(int cap, int max_det, int gain
     return 8 * ((size_t)max_det + cap + gain_total) + 4 * ((size_t)max_det * 3 + (size_t)cap * 5 + 2 * FRAME_TABLE + FRAME_THREADS) + 64;
 }
 
-__device__ int block_scan256(int v, int *s_scan, int *total)
+// Exclusive rank of this thread's flag among the block's flags (thread order) and their count:
+// a ballot per wave, four wave counts through LDS, ONE barrier.  Consecutive calls must alternate
+// between two 4-int buffers (a wave may still be reading the previous call's counts).
+__device__ __forceinline__ int block_flag_rank(bool f, int *s_cnt, int *total)
 {
-    const int tid = threadIdx.x;
-    s_scan[tid] = v;
+    const unsigned long long bal = __ballot(f);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[w] = __popcll(bal);
     __syncthreads();
-    for (int d = 1; d < FRAME_THREADS; d <<= 1) {
-        int add = tid >= d ? s_scan[tid - d] : 0;
-        __syncthreads();
-        s_scan[tid] += add;
-        __syncthreads();
-    }
-    int incl = s_scan[tid];
-    *total = s_scan[FRAME_THREADS - 1];
-    __syncthreads();
-    return incl - v;
+    const int c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
+    *total = c0 + c1 + c2 + c3;
+    const int before = (w > 0 ? c0 : 0) + (w > 1 ? c1 : 0) + (w > 2 ? c2 : 0);
+    return before + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
 // CPython order of the ascending list `unused` (see cpython_unused_order), tables in LDS
@@ -800,12 +880,12 @@ __device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_u
 }
 
 #ifdef YSMR_STAMPS
-#define STAMP(k) do { if (blockIdx.x == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((unsigned long long *)(rows + rows_capacity - 4))[k] = t_; } } while (0)
+#define STAMP(k) do { if (blockIdx.x == 1 && threadIdx.x == 0 && (frame & 63) == 40) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((unsigned long long *)(rows + rows_capacity - 4))[k] = t_; } } while (0)
 #else
 #define STAMP(k) do {} while (0)
 #endif
 
-template <typename DetT>
+template <typename DetT, int NF>
 __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDev b, const DetT *__restrict__ det,
                                                          int m_host, const int32_t *m_dev, int frame, ysmr_row *rows,
                                                          long long rows_capacity, long long *row_count_ext,
@@ -815,20 +895,38 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
 {
     extern __shared__ unsigned long long s_raw[];
     __shared__ int s_n_used, s_n_new, s_n_dead, s_any_dead;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cap = a.capacity, md = a.max_det;
-    STAMP(0);
+    STAMP(0); BSTAMP(0);
+    // ---- round trip 1: everything that can be addressed without knowing n or m is requested
+    // together with the counters (entries past n / m are stale and never used)
+    constexpr int SPEC_ROWS = 3;       // table rows tid + 256k, k < 3, are fetched before n is known
+    const int i = blockIdx.x * 4 + wave;
+    int so[SPEC_ROWS], sg[SPEC_ROWS], sa[SPEC_ROWS];
+    unsigned long long sk[SPEC_ROWS];
+#pragma unroll
+    for (int k = 0; k < SPEC_ROWS; ++k) {
+        const int r = min(tid + k * FRAME_THREADS, cap - 1);
+        so[k] = a.order[r];
+        sg[k] = a.gone[r];          // fused path: `gone` is indexed by table row, not by slot
+        sa[k] = a.row_arg[r];
+        sk[k] = (unsigned long long)__double_as_longlong(a.row_min[r]);
+    }
+    // Speculation for phase B: unless a track ahead of row i is deregistered this frame, row i of
+    // the new table is row i of the old one, keeps its slot and can only claim row_arg[i].
+    int slot_s = a.order[min(i, cap - 1)], c_s = a.row_arg[min(i, cap - 1)];
+    const double gain0 = a.gain_total > 0 ? a.gains[min(tid, a.gain_total - 1)] : 0.0;
+    // the next frame's detections do not depend on this frame's state either (rows past m_next
+    // of the [max_det][5] frame slice are stale; rowmin_wave masks them)
+    DetChunk<DetT> first;
+    if (next_det) load_chunk(first, next_det, md, 0, lane);
     const int n = *a.n_tracks;
     const int nfree = *a.n_free, id0 = *a.next_id;      // (all counters in one round trip)
     const long long row_base = a.row_base[0];
     const int m = det_count(m_host, m_dev, md, blockIdx.x == 0 ? a.err : nullptr);
+    const int m_next = next_det ? det_count(-1, next_m_dev, md, nullptr) : 0;
     if ((long long)blockIdx.x * 4 >= (long long)n + m && blockIdx.x != 0) return;   // cannot own a live track
     STAMP(1);
-
-    // the next frame's detections do not depend on this frame's state: fetch them first
-    const int m_next = next_det ? det_count(-1, next_m_dev, md, nullptr) : 0;
-    DetChunk<DetT> first;
-    if (m_next > 0) load_chunk(first, next_det, m_next, 0, lane);
 
     FrameLds L;
     L.gains = reinterpret_cast<double *>(s_raw);
@@ -848,10 +946,39 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     // ---- phase A (redundant in every block): the frame's bookkeeping
     if (tid == 0) { s_n_used = 0; s_n_new = 0; s_n_dead = 0; s_any_dead = 0; }
     for (int c = tid; c < m; c += FRAME_THREADS) { L.col_key[c] = ~0ull; L.col_row[c] = 0x7FFFFFFF; }
-    for (int k = tid; k < a.gain_total; k += FRAME_THREADS) L.gains[k] = a.gains[k];
-    for (int r = tid; r < n; r += FRAME_THREADS) {
+    slot_s = __builtin_amdgcn_readfirstlane(i < n ? slot_s : -1);
+    c_s = __builtin_amdgcn_readfirstlane((i < n && m > 0) ? c_s : -1);
+    GsffState<NF> S;
+    double zs0 = 0.0, zs1 = 0.0;
+    int id_s = 0;
+    float in_s[3] = {0.f, 0.f, 0.f};
+    DetT dd[5] = {0, 0, 0, 0, 0};
+    if (slot_s >= 0) {
+        if (a.use_gsff) gsff_fetch(a, slot_s, lane, S);
+        zs0 = a.pos[slot_s]; zs1 = a.pos[cap + slot_s];
+        id_s = a.id[slot_s];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in_s[k] = a.info[k * cap + slot_s];
+        if (c_s >= 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) dd[k] = det[(size_t)c_s * 5 + k];
+        }
+    }
+    if (tid < a.gain_total) L.gains[tid] = gain0;
+    for (int k = tid + FRAME_THREADS; k < a.gain_total; k += FRAME_THREADS) L.gains[k] = a.gains[k];
+#pragma unroll
+    for (int k = 0; k < SPEC_ROWS; ++k) {
+        const int r = tid + k * FRAME_THREADS;
+        if (r < n) {
+            L.slot[r] = so[k];
+            L.newgone[r] = sg[k];
+            L.arg[r] = (m > 0) ? sa[k] : 0;
+            L.key[r] = (m > 0) ? sk[k] : ~0ull;
+        }
+    }
+    for (int r = tid + SPEC_ROWS * FRAME_THREADS; r < n; r += FRAME_THREADS) {
         L.slot[r] = a.order[r];
-        L.newgone[r] = a.gone[r];          // fused path: `gone` is indexed by table row, not by slot
+        L.newgone[r] = a.gone[r];
         L.arg[r] = (m > 0) ? a.row_arg[r] : 0;
         L.key[r] = (m > 0) ? (unsigned long long)__double_as_longlong(a.row_min[r]) : ~0ull;
     }
@@ -866,30 +993,34 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     }
     STAMP(3);
     const bool age = (m == 0) || (n > 0 && n >= m);   // tracker.py:95-107, 198-211
-    int used = 0;
-    for (int r = tid; r < n; r += FRAME_THREADS) {
-        const int c = L.arg[r];
-        const bool mine = (n > 0 && m > 0) && (L.col_row[c] == r);
-        L.claim[r] = mine ? c : -1;
-        int g = L.newgone[r];
-        int dead = 0;
-        if (mine) { g = 0; ++used; }
-        else if (age) { ++g; dead = ((double)g > a.max_gone) ? 1 : 0; }
-        L.newgone[r] = dead ? -1 : g;     // -1 marks a track that is deregistered this frame
-        if (dead) s_any_dead = 1;
+    int used = 0;   // claims made by this wave's rows (wave-uniform)
+    for (int r0 = wave * 64; r0 < n; r0 += FRAME_THREADS) {
+        const int r = r0 + lane;
+        bool mine = false;
+        if (r < n) {
+            const int c = L.arg[r];
+            mine = (m > 0) && (L.col_row[c] == r);
+            L.claim[r] = mine ? c : -1;
+            int g = L.newgone[r];
+            int dead = 0;
+            if (mine) g = 0;
+            else if (age) { ++g; dead = ((double)g > a.max_gone) ? 1 : 0; }
+            L.newgone[r] = dead ? -1 : g;     // -1 marks a track that is deregistered this frame
+            if (dead) s_any_dead = 1;
+        }
+        used += __popcll(__ballot(mine));
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) used += __shfl_xor(used, off);
     if (lane == 0 && used) atomicAdd(&s_n_used, used);   // one LDS atomic per wave, not per thread
     __syncthreads();
+    STAMP(10);
     int n_keep = n;
     if (s_any_dead) {   // stable compaction of the id-ordered table
         int base = 0;
         for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
             const int r = r0 + tid;
-            const int keep = (r < n && L.newgone[r] >= 0) ? 1 : 0;
+            const bool keep = (r < n && L.newgone[r] >= 0);
             int total;
-            const int ex = block_scan256(keep, L.scan, &total);
+            const int ex = block_flag_rank(keep, L.scan + ((r0 / FRAME_THREADS) & 1) * 4, &total);
             if (keep) L.inv[base + ex] = r;
             if (r < n && !keep && blockIdx.x == 0) {
                 const int k = atomicAdd(&s_n_dead, 1);
@@ -902,6 +1033,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
         for (int r = tid; r < n; r += FRAME_THREADS) L.inv[r] = r;
     }
     __syncthreads();
+    STAMP(11);
     int n_new = 0;
     if (m > 0 && (n == 0 || n < m)) {   // registration (tracker.py:135-137, 212-217)
         if (n == 0) {
@@ -911,19 +1043,21 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
             int base = 0;
             for (int c0 = 0; c0 < m; c0 += FRAME_THREADS) {
                 const int c = c0 + tid;
-                const int un = (c < m && L.col_row[c] == 0x7FFFFFFF) ? 1 : 0;
+                const bool un = (c < m && L.col_row[c] == 0x7FFFFFFF);
                 int total;
-                const int ex = block_scan256(un, L.scan, &total);
+                const int ex = block_flag_rank(un, L.scan + 8 + ((c0 / FRAME_THREADS) & 1) * 4, &total);
                 if (un) L.unused[base + ex] = c;
                 base += total;
             }
             __syncthreads();
+            STAMP(12);
             if (tid == 0) {
                 int cnt = cpython_order_lds(L.unused, base, m, s_n_used, L.newcols, L.table);
                 if (cnt < 0) { if (blockIdx.x == 0) atomicOr(a.err, ERR_TRACK_CAPACITY); cnt = 0; }
                 s_n_new = cnt;
             }
             __syncthreads();
+            STAMP(13);
             n_new = s_n_new;
         }
         __syncthreads();
@@ -935,42 +1069,52 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     }
     const int n_live = n_keep + n_new;
 
-    STAMP(4);
+    STAMP(4); BSTAMP(1);
     // ---- phase B: one wave per track of the new table
-    const int i = blockIdx.x * 4 + wave;
     if (i < n_live) {
-        int slot, gone;
-        double z0, z1;
+        int slot, gone, c;
         bool fresh_track = false;
         if (i < n_keep) {
-            const int r = L.inv[i];
-            slot = L.slot[r];
+            const int r = __builtin_amdgcn_readfirstlane(L.inv[i]);
+            slot = __builtin_amdgcn_readfirstlane(L.slot[r]);
             gone = L.newgone[r];
-            const int c = L.claim[r];
-            if (c >= 0) {
-                z0 = (double)det[(size_t)c * 5 + 0];
-                z1 = (double)det[(size_t)c * 5 + 1];
-                if (lane < 3) a.info[lane * cap + slot] = (float)det[(size_t)c * 5 + 2 + lane];
-            } else {
-                z0 = a.pos[slot];
-                z1 = a.pos[cap + slot];
+            c = __builtin_amdgcn_readfirstlane(L.claim[r]);
+            if (r != i || slot_s < 0) {   // a deregistration ahead of this row moved it: fetch for real
+                if (a.use_gsff) gsff_fetch(a, slot, lane, S);
+                zs0 = a.pos[slot]; zs1 = a.pos[cap + slot];
+                id_s = a.id[slot];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) in_s[k] = a.info[k * cap + slot];
+                if (c >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) dd[k] = det[(size_t)c * 5 + k];
+                }
+            }
+            if (c < 0) {
                 if (age && lane < 3) a.info[lane * cap + slot] = 0.f;
             }
         } else {
             const int j = i - n_keep;
-            const int c = L.newcols[j];
-            slot = a.free_slots[nfree - 1 - j];
+            c = __builtin_amdgcn_readfirstlane(L.newcols[j]);
+            slot = __builtin_amdgcn_readfirstlane(a.free_slots[nfree - 1 - j]);
             gone = 0;
             fresh_track = true;
-            z0 = (double)det[(size_t)c * 5 + 0];
-            z1 = (double)det[(size_t)c * 5 + 1];
-            if (lane < 3) a.info[lane * cap + slot] = (float)det[(size_t)c * 5 + 2 + lane];
-            if (lane == 0) a.id[slot] = id0 + j;
+            id_s = id0 + j;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) dd[k] = det[(size_t)c * 5 + k];
+            gsff_blank(S);    // nothing of the slot's previous owner is read
+            if (lane == 0) a.id[slot] = id_s;
         }
-        slot = __builtin_amdgcn_readfirstlane(slot);
+        double z0 = zs0, z1 = zs1;
+        if (c >= 0) {
+            z0 = (double)dd[0];
+            z1 = (double)dd[1];
+            const DetT v = lane == 0 ? dd[2] : lane == 1 ? dd[3] : dd[4];
+            if (lane < 3) a.info[lane * cap + slot] = (float)v;
+        }
         double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
         STAMP(5);
-        if (a.use_gsff) gsff_wave(a, L.gains, slot, lane, z0, z1, fresh_track, o0, o1, p0, p1);
+        if (a.use_gsff) gsff_wave(a, L.gains, slot, lane, z0, z1, fresh_track, S, o0, o1, p0, p1);
         else if (lane == 0) { a.pos[slot] = z0; a.pos[cap + slot] = z1; }
         STAMP(6);
         if (lane == 0) {
@@ -979,18 +1123,14 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
             if (rows && row_base + i < rows_capacity) {
                 ysmr_row rr;
                 rr.frame = frame;
-                rr.track_id = fresh_track ? id0 + (i - n_keep) : a.id[slot];
+                rr.track_id = id_s;
                 rr.x = o0; rr.y = o1;
-                const int r = i < n_keep ? L.inv[i] : -1;
-                const int c = r >= 0 ? L.claim[r] : L.newcols[i - n_keep];
-                const bool zero = (c < 0 && age);
                 if (c >= 0) {
-                    rr.w = (float)det[(size_t)c * 5 + 2]; rr.h = (float)det[(size_t)c * 5 + 3];
-                    rr.angle = (float)det[(size_t)c * 5 + 4];
-                } else if (zero) {
+                    rr.w = (float)dd[2]; rr.h = (float)dd[3]; rr.angle = (float)dd[4];
+                } else if (age) {
                     rr.w = rr.h = rr.angle = 0.f;
                 } else {
-                    rr.w = a.info[slot]; rr.h = a.info[cap + slot]; rr.angle = a.info[2 * cap + slot];
+                    rr.w = in_s[0]; rr.h = in_s[1]; rr.angle = in_s[2];
                 }
                 rr.disappeared = gone;
                 rows[row_base + i] = rr;
@@ -1000,6 +1140,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
         if (m_next > 0) rowmin_wave(b, i, p0, p1, next_det, m_next, lane, first);
         STAMP(8);
     }
+    BSTAMP(2);
     // ---- block 0 publishes the counters of the new state
     if (blockIdx.x == 0) {
         if (claim_out)
@@ -1075,8 +1216,14 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
     if (t->fused) {
         const TrackerDev &a = t->cur(), &b = t->nxt();
         if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, a, det, m, m_dev);
-        hipLaunchKernelGGL(k_frame<DetT>, wgrid, dim3(FRAME_THREADS), t->frame_lds, st, a, b, det, m, m_dev, frame, rows,
-                           rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new, next_det, next_m_dev);
+        // the filter bank is unrolled at compile time: 3 covers tracking.ini's default (and 1, 2), 8 the rest
+        if (a.n_f <= 3)
+            hipLaunchKernelGGL((k_frame<DetT, 3>), wgrid, dim3(FRAME_THREADS), t->frame_lds, st, a, b, det, m, m_dev, frame,
+                               rows, rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new, next_det, next_m_dev);
+        else
+            hipLaunchKernelGGL((k_frame<DetT, YSMR_MAX_FILTERS>), wgrid, dim3(FRAME_THREADS), t->frame_lds, st, a, b, det, m,
+                               m_dev, frame, rows, rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new,
+                               next_det, next_m_dev);
         t->par ^= 1;
     } else {
         const TrackerDev &d = t->d;
@@ -1084,7 +1231,11 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
         const size_t link_lds = 12 * (size_t)d.max_det + 4 * (size_t)d.capacity;
         hipLaunchKernelGGL(k_link<DetT>, dim3(1), dim3(LINK_THREADS), link_lds, st, d, det, m, m_dev, frame, rows,
                            rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
-        hipLaunchKernelGGL(k_track<DetT>, wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det, -1, next_m_dev);
+        if (d.n_f <= 3)
+            hipLaunchKernelGGL((k_track<DetT, 3>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det, -1, next_m_dev);
+        else
+            hipLaunchKernelGGL((k_track<DetT, YSMR_MAX_FILTERS>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det,
+                               -1, next_m_dev);
     }
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
@@ -1209,9 +1360,10 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const char *mode_env = getenv("YSMR_LINK_MODE");   // "split" forces the two-kernel path (tests)
     t->fused = t->frame_lds <= 150 * 1024 && !(mode_env && !strcmp(mode_env, "split"));
     if (t->fused) {
-        hipError_t ea = hipFuncSetAttribute((const void *)k_frame<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->frame_lds);
-        hipError_t eb = hipFuncSetAttribute((const void *)k_frame<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->frame_lds);
-        if (ea != hipSuccess || eb != hipSuccess) t->fused = false;
+        const void *variants[4] = {(const void *)k_frame<float, 3>, (const void *)k_frame<double, 3>,
+                                   (const void *)k_frame<float, YSMR_MAX_FILTERS>, (const void *)k_frame<double, YSMR_MAX_FILTERS>};
+        for (const void *fn : variants)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->frame_lds) != hipSuccess) t->fused = false;
     }
     t->d.gone_by_row = t->d1.gone_by_row = t->fused ? 1 : 0;
     e = hipMemset(t->block, 0, off);
