@@ -27,6 +27,7 @@
 
 struct TrackerDev {
     int capacity, max_det, n_f, use_gsff, hist_cap, table_cap, gain_total, gone_by_row;
+    int gains_decoupled;             // x-hat reads only x columns, y-hat only y columns (every closed-form gain)
     double max_gone, lik_min;
     int n_i[YSMR_MAX_FILTERS];
     int gain_off[YSMR_MAX_FILTERS];  // filter i: row0 at gains[gain_off[i]], row1 at +2*n_i[i]
@@ -264,61 +265,104 @@ __device__ __forceinline__ double wave_total(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// History layout inside the wave: lane l, register q holds coordinate (l >> 5) of history entry
+// (l & 31) + 32 q -- x in lanes 0..31, y in lanes 32..63 -- so that for a decoupled gain (x-hat
+// from x only, y-hat from y only: every constant-velocity LSF gain) one 5-step half-wave reduction
+// yields both sums.  In memory the history stays [entry][coordinate].
+__device__ __forceinline__ int hist_entry(int lane, int q) { return (lane & 31) + 32 * q; }
+__device__ __forceinline__ int hist_comp(int lane) { return lane >> 5; }
+
+__device__ __forceinline__ double lane_value(double v, int src_lane)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), src_lane);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// lanes 0..31 and lanes 32..63 summed separately: lane 31 and lane 63 hold the two totals
+__device__ __forceinline__ double half_wave_totals(double v)
+{
+    v = dpp_add<0x111, 0xF>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);   // row_shr:8  -> lane 15 of each row holds the row sum
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
 // FIR estimates of ALL active filters at once (rows 0 and 1 of gain f times the last n_f[f]
-// measurements: lsff_calc, gsff.py:156-177).  The 2*mode butterflies are interleaved so that the
-// cross-lane latency is paid once per level, not once per sum.
+// measurements: lsff_calc, gsff.py:156-177).  Branch-free over the filter bank so that the
+// independent reductions interleave; filters >= mode are computed on masked zeros and discarded.
 template <int NF>
 __device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const double *gains, const TrackRegs &h, int lane,
                                              int mode, int head, double *x0, double *x1)
 {
     const int L = t.hist_cap;
+    const int comp = hist_comp(lane);
     GSTAMP(8);
+    if (t.gains_decoupled) {
+        double p[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) p[f] = 0.0;
+#pragma unroll
+        for (int q = 0; q < TRACK_VALS; ++q) {
+            const int e = hist_entry(lane, q);
+            int age = head - 1 - e;          // 0 = newest
+            if (age < 0) age += L;
+            double g[NF];
+            bool in[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {   // unconditional gathers (clamped index, masked product)
+                const int N = t.n_i[f];
+                in[f] = (f < mode) && (e < L) && (age < N);
+                const int idx = in[f] ? comp * (2 * N + 1) + 2 * (N - 1 - age) : 0;
+                g[f] = gains[t.gain_off[f] + idx];
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) p[f] = in[f] ? p[f] + g[f] * h.v[q] : p[f];
+        }
+        GSTAMP(9);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) p[f] = half_wave_totals(p[f]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const double sx = lane_value(p[f], 31), sy = lane_value(p[f], 63);
+            if (f < mode) { x0[f] = sx; x1[f] = sy; }
+        }
+        GSTAMP(10);
+        return;
+    }
     double p0[NF], p1[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) { p0[f] = 0.0; p1[f] = 0.0; }
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) {
-        int k = lane + 64 * q;
-        int e = k >> 1, comp = k & 1;
+        const int e = hist_entry(lane, q);
         int age = head - 1 - e;          // 0 = newest
         if (age < 0) age += L;
-        // unconditional gathers (clamped index, masked product): all 2*mode loads of a lane are in
-        // flight together instead of one dependent round trip per divergent branch
         double ga[NF], gb[NF];
         bool in[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            if (f < mode) {
-                const int N = t.n_i[f];
-                in[f] = (e < L) && (age < N);
-                const int col = in[f] ? 2 * (N - 1 - age) + comp : 0;
-                const double *g0 = gains + t.gain_off[f];
-                ga[f] = g0[col];
-                gb[f] = g0[2 * N + col];
-            }
+            const int N = t.n_i[f];
+            in[f] = (f < mode) && (e < L) && (age < N);
+            const int col = in[f] ? 2 * (N - 1 - age) + comp : 0;
+            ga[f] = gains[t.gain_off[f] + col];
+            gb[f] = gains[t.gain_off[f] + 2 * N + col];
         }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            if (f < mode && in[f]) {
-                p0[f] = p0[f] + ga[f] * h.v[q];
-                p1[f] = p1[f] + gb[f] * h.v[q];
-            }
+            p0[f] = in[f] ? p0[f] + ga[f] * h.v[q] : p0[f];
+            p1[f] = in[f] ? p1[f] + gb[f] * h.v[q] : p1[f];
         }
     }
-    GSTAMP(9);
     // wave sums by DPP (no LDS round trips): row_shr 1,2,4,8 leave each 16-lane row's sum in its
     // last lane, row_bcast15 / row_bcast31 carry it across rows, lane 63 ends with the total
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        if (f < mode) {
-            p0[f] = wave_total(p0[f]);
-            p1[f] = wave_total(p1[f]);
-        }
+        const double sx = wave_total(p0[f]), sy = wave_total(p1[f]);
+        if (f < mode) { x0[f] = sx; x1[f] = sy; }
     }
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-        if (f < mode) { x0[f] = p0[f]; x1[f] = p1[f]; }
-    GSTAMP(10);
 }
 
 // GSFF correct + predict of one track by one wave (gsff.py:204-347).  z = measurement; returns the
@@ -337,11 +381,15 @@ __device__ __forceinline__ void gsff_fetch(const TrackerDev &t, int slot, int la
 {
     const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
     const double *hist = t.hist + (size_t)slot * 2 * L;
-    s.len = t.hist_len[slot]; s.head = t.hist_head[slot]; s.mode = t.mode[slot];
+    // (an opaque per-lane zero keeps these three loads in vector registers: as uniform loads the
+    // compiler moves them to scalar registers on the spot, which waits for them on the spot)
+    int lane0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
+    s.len = t.hist_len[slot + lane0]; s.head = t.hist_head[slot + lane0]; s.mode = t.mode[slot + lane0];
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) {
-        int k = lane + 64 * q;
-        s.h.v[q] = (k < 2 * L) ? hist[k] : 0.0;
+        const int e = hist_entry(lane, q);
+        s.h.v[q] = (e < L) ? hist[2 * e + hist_comp(lane)] : 0.0;
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -368,7 +416,8 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
     GSTAMP(0);
     double *hist = t.hist + (size_t)slot * 2 * L;
-    int len = st.len, head = st.head, mode = st.mode;
+    int len = __builtin_amdgcn_readfirstlane(st.len), head = __builtin_amdgcn_readfirstlane(st.head);
+    int mode = __builtin_amdgcn_readfirstlane(st.mode);
     TrackRegs &h = st.h;
     double (&w)[NF] = st.w;
     double (&xh0)[NF] = st.xh0;
@@ -379,10 +428,8 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     if (fresh_track) { len = 0; mode = 0; }
     if (fresh) {   // history starts as n_i[0] copies of the first measurement
 #pragma unroll
-        for (int q = 0; q < TRACK_VALS; ++q) {
-            int k = lane + 64 * q;
-            if ((k >> 1) < t.n_i[0]) h.v[q] = (k & 1) ? z1 : z0;
-        }
+        for (int q = 0; q < TRACK_VALS; ++q)
+            if (hist_entry(lane, q) < t.n_i[0]) h.v[q] = hist_comp(lane) ? z1 : z0;
         len = t.n_i[0];
         head = len % L;
     }
@@ -402,6 +449,19 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
             if (f < mode) w[f] = w0;
     }
     GSTAMP(2);
+    // append the measurement and start the predict-step FIR (gsff.py:204-249) right away: it reads
+    // only the history, so its reductions overlap the likelihood arithmetic below
+    const int at = head;
+#pragma unroll
+    for (int q = 0; q < TRACK_VALS; ++q)
+        if (hist_entry(lane, q) == at) h.v[q] = hist_comp(lane) ? z1 : z0;
+    if (++head == L) head = 0;
+    if (len < L) ++len;
+    double nx0[NF], nx1[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { nx0[f] = 0.0; nx1[f] = 0.0; }
+    fir_wave_all<NF>(t, gains, h, lane, mode, head, nx0, nx1);
+    GSTAMP(3);
     // likelihoods (gsff.py:179-202): lane f evaluates filter f's exp(), the results are broadcast
     // (the float64 exp is ~150 instructions; doing the n_f of them one after the other on every
     // lane was a third of this function)
@@ -410,41 +470,30 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     {
         double xa = 0.0, xb = 0.0;
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
-            if (lane == f) { xa = xh0[f]; xb = xh1[f]; }
+        for (int f = 0; f < NF; ++f) { xa = (lane == f) ? xh0[f] : xa; xb = (lane == f) ? xh1[f] : xb; }
         double d0 = z0 - xa, d1 = z1 - xb;
         double q = d0 * d0;
         q = q + d1 * d1;
         double l = exp(-0.5 * q);
         if (l < t.lik_min) l = t.lik_min;
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
-            if (f < mode) {
-                lik[f] = __shfl(l, f);
-                total = total + lik[f] * w[f];
-            }
+        for (int f = 0; f < NF; ++f) {
+            lik[f] = lane_value(l, f);
+            total = (f < mode) ? total + lik[f] * w[f] : total;
+        }
     }
-    GSTAMP(3);
-    // append the measurement
-    const int at = head;
-#pragma unroll
-    for (int q = 0; q < TRACK_VALS; ++q) {
-        int k = lane + 64 * q;
-        if ((k >> 1) == at) h.v[q] = (k & 1) ? z1 : z0;
-    }
-    if (++head == L) head = 0;
-    if (len < L) ++len;
     // new weights; output = np.sum(x_hat * w, axis=1) = a0 + ((a1 + a2) + ...)
     double f0 = 0.0, f1 = 0.0, r0 = 0.0, r1 = 0.0;
     {   // new weights w_i = lik_i * w_i / total: one division per lane instead of n_f per lane
-        double lw = 0.0;
+        double lw = 1.0;
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
-            if (lane == f && f < mode) lw = lik[f] * w[f];
+        for (int f = 0; f < NF; ++f) lw = (lane == f) ? lik[f] * w[f] : lw;
         const double wn = lw / total;
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
-            if (f < mode) w[f] = __shfl(wn, f);
+        for (int f = 0; f < NF; ++f) {
+            const double v = lane_value(wn, f);
+            w[f] = (f < mode) ? v : w[f];
+        }
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -457,12 +506,12 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     o0 = mode > 1 ? f0 + r0 : f0;
     o1 = mode > 1 ? f1 + r1 : f1;
     GSTAMP(4);
-    // ---- predict (gsff.py:204-249)
+    // ---- predict: the new estimates, weighted
     f0 = f1 = r0 = r1 = 0.0;
-    fir_wave_all<NF>(t, gains, h, lane, mode, head, xh0, xh1);
 #pragma unroll
     for (int f = 0; f < NF; ++f)
         if (f < mode) {
+            xh0[f] = nx0[f]; xh1[f] = nx1[f];
             double a = xh0[f] * w[f], b = xh1[f] * w[f];
             if (f == 0) { f0 = a; f1 = b; }
             else if (f == 1) { r0 = a; r1 = b; }
@@ -474,8 +523,8 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     // ---- write back
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) {
-        int k = lane + 64 * q;
-        if (k < 2 * L && (fresh || (k >> 1) == at)) hist[k] = h.v[q];
+        const int e = hist_entry(lane, q);
+        if (e < L && (fresh || e == at)) hist[2 * e + hist_comp(lane)] = h.v[q];
     }
     if (lane == 0) {
         t.hist_len[slot] = len;
@@ -894,7 +943,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
                                                          const DetT *__restrict__ next_det, const int32_t *next_m_dev)
 {
     extern __shared__ unsigned long long s_raw[];
-    __shared__ int s_n_used, s_n_new, s_n_dead, s_any_dead;
+    __shared__ int s_n_used, s_n_new, s_n_dead;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cap = a.capacity, md = a.max_det;
     STAMP(0); BSTAMP(0);
@@ -920,11 +969,20 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     // of the [max_det][5] frame slice are stale; rowmin_wave masks them)
     DetChunk<DetT> first;
     if (next_det) load_chunk(first, next_det, md, 0, lane);
-    const int n = *a.n_tracks;
-    const int nfree = *a.n_free, id0 = *a.next_id;      // (all counters in one round trip)
+    // all counters in the same round trip: the two detection counts are read through pointers that
+    // are always valid (a dummy when the count comes from the host / there is no next frame), so
+    // that no load hides behind a branch and a wait
+    const int32_t *m_ptr = m_host < 0 ? m_dev : a.n_tracks;
+    const int32_t *mn_ptr = next_det ? next_m_dev : a.n_tracks;
+    const int n_raw = *a.n_tracks, nfree_raw = *a.n_free, id0_raw = *a.next_id;
+    const int m_raw = *m_ptr, mn_raw = *mn_ptr;
     const long long row_base = a.row_base[0];
-    const int m = det_count(m_host, m_dev, md, blockIdx.x == 0 ? a.err : nullptr);
-    const int m_next = next_det ? det_count(-1, next_m_dev, md, nullptr) : 0;
+    const int n = __builtin_amdgcn_readfirstlane(n_raw);
+    const int nfree = __builtin_amdgcn_readfirstlane(nfree_raw), id0 = __builtin_amdgcn_readfirstlane(id0_raw);
+    int m = __builtin_amdgcn_readfirstlane(m_host < 0 ? m_raw : m_host);
+    if (m > md) { m = md; if (blockIdx.x == 0) atomicOr(a.err, ERR_DET_CLAMPED); }
+    m = max(m, 0);
+    const int m_next = next_det ? max(min(__builtin_amdgcn_readfirstlane(mn_raw), md), 0) : 0;
     if ((long long)blockIdx.x * 4 >= (long long)n + m && blockIdx.x != 0) return;   // cannot own a live track
     STAMP(1);
 
@@ -944,7 +1002,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     L.scan = L.table + 2 * FRAME_TABLE;
 
     // ---- phase A (redundant in every block): the frame's bookkeeping
-    if (tid == 0) { s_n_used = 0; s_n_new = 0; s_n_dead = 0; s_any_dead = 0; }
+    if (tid == 0) { s_n_used = 0; s_n_new = 0; s_n_dead = 0; }
     for (int c = tid; c < m; c += FRAME_THREADS) { L.col_key[c] = ~0ull; L.col_row[c] = 0x7FFFFFFF; }
     slot_s = __builtin_amdgcn_readfirstlane(i < n ? slot_s : -1);
     c_s = __builtin_amdgcn_readfirstlane((i < n && m > 0) ? c_s : -1);
@@ -993,46 +1051,36 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     }
     STAMP(3);
     const bool age = (m == 0) || (n > 0 && n >= m);   // tracker.py:95-107, 198-211
+    // claims, ageing and the stable compaction of the id-ordered table in one sweep: a row's fate is
+    // known to the thread that ranks it, so nothing goes through LDS in between
     int used = 0;   // claims made by this wave's rows (wave-uniform)
-    for (int r0 = wave * 64; r0 < n; r0 += FRAME_THREADS) {
-        const int r = r0 + lane;
-        bool mine = false;
+    int n_keep = 0;
+    for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
+        const int r = r0 + tid;
+        bool mine = false, keep = false;
         if (r < n) {
             const int c = L.arg[r];
             mine = (m > 0) && (L.col_row[c] == r);
             L.claim[r] = mine ? c : -1;
             int g = L.newgone[r];
-            int dead = 0;
             if (mine) g = 0;
-            else if (age) { ++g; dead = ((double)g > a.max_gone) ? 1 : 0; }
-            L.newgone[r] = dead ? -1 : g;     // -1 marks a track that is deregistered this frame
-            if (dead) s_any_dead = 1;
+            else if (age) ++g;
+            keep = mine || !age || !((double)g > a.max_gone);
+            L.newgone[r] = g;
         }
         used += __popcll(__ballot(mine));
+        int total;
+        const int ex = block_flag_rank(keep, L.scan + ((r0 / FRAME_THREADS) & 1) * 4, &total);
+        if (keep) L.inv[n_keep + ex] = r;
+        if (r < n && !keep && blockIdx.x == 0) {
+            const int k = atomicAdd(&s_n_dead, 1);
+            a.free_slots[nfree + k] = L.slot[r];   // entries above n_free are read by nobody this frame
+        }
+        n_keep += total;
     }
     if (lane == 0 && used) atomicAdd(&s_n_used, used);   // one LDS atomic per wave, not per thread
     __syncthreads();
     STAMP(10);
-    int n_keep = n;
-    if (s_any_dead) {   // stable compaction of the id-ordered table
-        int base = 0;
-        for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
-            const int r = r0 + tid;
-            const bool keep = (r < n && L.newgone[r] >= 0);
-            int total;
-            const int ex = block_flag_rank(keep, L.scan + ((r0 / FRAME_THREADS) & 1) * 4, &total);
-            if (keep) L.inv[base + ex] = r;
-            if (r < n && !keep && blockIdx.x == 0) {
-                const int k = atomicAdd(&s_n_dead, 1);
-                a.free_slots[nfree + k] = L.slot[r];   // entries above n_free are read by nobody this frame
-            }
-            base += total;
-        }
-        n_keep = base;
-    } else {
-        for (int r = tid; r < n; r += FRAME_THREADS) L.inv[r] = r;
-    }
-    __syncthreads();
     STAMP(11);
     int n_new = 0;
     if (m > 0 && (n == 0 || n < m)) {   // registration (tracker.py:135-137, 212-217)
@@ -1296,6 +1344,12 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
         t->gains_host.resize(gain_doubles);
         if (gains_host) std::memcpy(t->gains_host.data(), gains_host, sizeof(double) * gain_doubles);
         else for (int i = 0; i < n_f; ++i) closed_form_gain(d.n_i[i], t->gains_host.data() + d.gain_off[i]);
+        d.gains_decoupled = 1;   // row 0 must vanish on the y columns, row 1 on the x columns
+        for (int i = 0; i < n_f && d.gains_decoupled; ++i) {
+            const double *g = t->gains_host.data() + d.gain_off[i];
+            for (int j = 0; j < d.n_i[i]; ++j)
+                if (g[2 * j + 1] != 0.0 || g[2 * d.n_i[i] + 2 * j] != 0.0) { d.gains_decoupled = 0; break; }
+        }
         d.hist_cap = d.n_i[n_f - 1] + 1;
         if (d.hist_cap > 64) { delete t; return ysmr::fail(YSMR_ERR_ARG, "maximum horizon size %d exceeds the supported 63", d.n_i[n_f - 1]); }
     } else {
