@@ -479,60 +479,92 @@ __device__ __forceinline__ uint32_t chunk_byte(const uint4 &v, int i)
     return (w >> (8 * (i & 3))) & 0xFFu;
 }
 
-// The foreground is sparse (bacteria cover ~1 % of a frame), so every pass after this one walks a
-// compacted list of the 16-pixel chunks that contain class bits instead of the whole batch.
-struct ChunkList {
-    uint32_t *idx;     // chunk indices, unordered
-    uint32_t *count;   // number of entries
+// The foreground is sparse (bacteria cover ~1 % of a frame), so every pass after the dense collect
+// walks a compacted list of the pixels that carry class bits, one lane per listed pixel.  (A list
+// of 16-pixel chunks was tried first: on the benchmark clip only 19 % of its lane slots held a
+// foreground pixel.)  The list has room for 1/8 of the batch; a denser batch makes the passes fall
+// back to walking every pixel (`count` keeps counting past `cap`, which is how they know).
+struct PixelList {
+    uint32_t *idx;     // flat pixel indices (frame * H * W + y * W + x); chunk-local order, chunks unordered
+    uint32_t *count;   // number of foreground pixels found (may exceed cap)
+    uint32_t cap;      // entries idx can hold
 };
 
-constexpr int SPARSE_BLOCKS = 8192;  // grid of the list-driven passes (grid-stride over the list)
+constexpr int SPARSE_BLOCKS = 4096;  // upper bound of the list-driven grids (grid-stride over the list)
 
-// 16 consecutive lanes share one listed chunk, one lane per pixel: the passes are bound by chains
-// of dependent L2 round trips (union-find), so they want many short threads, not few long ones.
-#define FOR_LISTED_PIXELS(cl, c, i)                                                                              \
-    for (size_t li_ = (size_t)blockIdx.x * 256 + threadIdx.x, ln_ = (size_t)(*(cl).count) * 16; li_ < ln_;      \
-         li_ += (size_t)gridDim.x * 256)                                                                         \
-        if (size_t c = (cl).idx[li_ >> 4]; true)                                                                 \
-            if (const int i = (int)(li_ & 15); true)
+// The passes are bound by chains of dependent L2 round trips (union-find), so they want many
+// short threads: one lane per pixel, grid-stride.
+#define FOR_LISTED_PIXELS(pl, g, flat)                                                                           \
+    for (size_t cnt_ = *(pl).count, dense_ = cnt_ > (pl).cap, ln_ = dense_ ? (g).total : cnt_,                  \
+                li_ = (size_t)blockIdx.x * 256 + threadIdx.x;                                                    \
+         li_ < ln_; li_ += (size_t)gridDim.x * 256)                                                              \
+        if (const size_t flat = dense_ ? li_ : (size_t)(pl).idx[li_]; true)
 
-// Pass A0 (dense, HBM-bound: 1 B/px read): compact the chunks that hold any class bit.  Each block
+// Pass A0 (dense, HBM-bound: 1 B/px read): list the pixels that hold any class bit.  Each block
 // gathers its finds in LDS and publishes them with ONE global atomicAdd (a single hot counter
 // serves only ~90 atomics/us on this chip).
 constexpr int COLLECT_BLOCKS = 1024;
-constexpr int COLLECT_LDS = 8192;  // entries buffered per block before a flush
+constexpr int COLLECT_LDS = 8192;  // entries buffered per block before a flush (a round adds <= 4096)
 
-__global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls, Geo g, size_t nchunks, ChunkList cl)
+__global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls, uint32_t *__restrict__ labels, Geo g,
+                                                 size_t nchunks, PixelList pl)
 {
     __shared__ uint32_t s_buf[COLLECT_LDS];
     __shared__ uint32_t s_n, s_base;
     const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
     const size_t stride = (size_t)gridDim.x * 256;
     const size_t rounds = (nchunks + stride - 1) / stride;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
     for (size_t r = 0; r < rounds; ++r, c += stride) {
-        bool has = false;
+        uint32_t bits = 0;   // bit i: pixel i of this lane's chunk carries a class bit
         if (c < nchunks) {
-            uint4 v = load_chunk(cls, c, g.total);
-            has = ((v.x | v.y | v.z | v.w) & 0x03030303u) != 0;
+            const uint4 v = load_chunk(cls, c, g.total);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t t = w[k] & 0x03030303u;
+                t = (t | (t >> 1)) & 0x01010101u;                      // one flag bit per byte
+                bits |= ((t * 0x00204081u >> 21) & 0xFu) << (4 * k);  // gather bits 0, 8, 16, 24 -> a nibble
+            }
         }
-        unsigned long long m = __ballot(has);
-        if (m) {
-            int leader = __ffsll((long long)m) - 1;
+        const uint32_t cnt = __popc(bits);
+        if (__ballot(cnt != 0)) {
+            // exclusive prefix of cnt (<= 16) over the lanes from five ballots, one per bit of cnt
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const unsigned long long m = __ballot((cnt >> b) & 1u);
+                before += (uint32_t)__popcll(m & below) << b;
+                total += (uint32_t)__popcll(m) << b;
+            }
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (has) s_buf[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)c;
+            if (lane == 0) base = atomicAdd(&s_n, total);
+            base = __builtin_amdgcn_readfirstlane(base) + before;
+            uint32_t rest = bits;
+            const uint32_t first = (uint32_t)(c * 16);
+            const uint32_t frame_start = rest ? first / g.HW * g.HW : 0;   // (a chunk may straddle two frames)
+            while (rest) {   // a chunk's pixels stay adjacent in the list: adjacent lanes, adjacent pixels later
+                const int i = __ffs(rest) - 1;
+                rest &= rest - 1;
+                const uint32_t flat = first + i;
+                s_buf[base++] = flat;
+                // every listed pixel starts as its own root (the label map was cleared by a memset)
+                uint32_t p = flat - frame_start;
+                if (p >= g.HW) p -= g.HW;
+                labels[flat] = p + 1u;
+            }
         }
         // flush when the next round could overflow the buffer (block-uniform decision)
         __syncthreads();
-        uint32_t n = s_n;
-        if (n + 256 > COLLECT_LDS || r + 1 == rounds) {
-            if (threadIdx.x == 0) { s_base = n ? atomicAdd(cl.count, n) : 0; }
+        const uint32_t n = s_n;
+        if (n + 4096 > COLLECT_LDS || r + 1 == rounds) {
+            if (threadIdx.x == 0) { s_base = n ? atomicAdd(pl.count, n) : 0; }
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += 256) cl.idx[s_base + i] = s_buf[i];
+            for (uint32_t i = threadIdx.x; i < n; i += 256)
+                if ((size_t)s_base + i < pl.cap) pl.idx[s_base + i] = s_buf[i];
             __syncthreads();
             if (threadIdx.x == 0) s_n = 0;
             __syncthreads();
@@ -540,47 +572,35 @@ __global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls
     }
 }
 
-// Pass A (sparse): every pixel with a class bit becomes its own root (the label map itself was
-// cleared by a memset).
-__global__ __launch_bounds__(256) void k_init_labels(const uint8_t *__restrict__ cls,
-                                                     uint32_t *__restrict__ labels, Geo g, ChunkList cl)
-{
-    FOR_LISTED_PIXELS(cl, c, i) {
-        size_t flat = c * 16 + i;
-        if (flat >= g.total || !(cls[flat] & 3u)) continue;
-        uint32_t f = (uint32_t)(flat / g.HW);
-        labels[flat] = (uint32_t)(flat - (size_t)f * g.HW) + 1u;
-    }
-}
-
 // Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
 __global__ __launch_bounds__(256) void k_union4(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
-                                                ChunkList cl)
+                                                PixelList pl)
 {
-    FOR_LISTED_PIXELS(cl, c, i) {
-        size_t flat = c * 16 + i;
+    FOR_LISTED_PIXELS(pl, g, flat) {
         if (flat >= g.total || !(cls[flat] & 1u)) continue;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
         uint32_t *L = labels + (size_t)f * g.HW;
-        if (x > 0 && (cls[flat - 1] & 1u)) unite(L, p, p - 1);
-        if (y > 0 && (cls[flat - g.W] & 1u)) unite(L, p, p - (uint32_t)g.W);
+        const bool w = x > 0 && (cls[flat - 1] & 1u), n = y > 0 && (cls[flat - g.W] & 1u);
+        if (w) unite(L, p, p - 1);
+        // with W, NW and N all set, W-NW and NW-N are united by W's and N's own threads
+        if (n && !(w && (cls[flat - g.W - 1] & 1u))) unite(L, p, p - (uint32_t)g.W);
     }
 }
 
 __device__ __forceinline__ void set_flag(uint8_t *cls, size_t flat)
 {
+    if (cls[flat] & 4u) return;   // (a stale 0 only costs a redundant atomic)
     uint32_t *w = reinterpret_cast<uint32_t *>(cls) + (flat >> 2);
     atomicOr(w, 4u << (8 * (flat & 3)));
 }
 
 // Pass C: flag (bit2 on the root's class byte) every thresh-component that holds a marker pixel
 // or touches (4-neighbourhood) a marker pixel lying outside the mask.
-__global__ __launch_bounds__(256) void k_flag(uint8_t *cls, const uint32_t *labels, Geo g, ChunkList cl)
+__global__ __launch_bounds__(256) void k_flag(uint8_t *cls, const uint32_t *labels, Geo g, PixelList pl)
 {
-    FOR_LISTED_PIXELS(cl, c, i) {
+    FOR_LISTED_PIXELS(pl, g, flat) {
         {
-            size_t flat = c * 16 + i;
             if (flat >= g.total) continue;
             uint32_t b = cls[flat];
             if (!(b & 2u)) continue;
@@ -589,12 +609,12 @@ __global__ __launch_bounds__(256) void k_flag(uint8_t *cls, const uint32_t *labe
             const uint32_t *L = labels + (size_t)f * g.HW;
             size_t fbase = (size_t)f * g.HW;
             if (b & 1u) {
-                set_flag(cls, fbase + find_root(L, p));
+                set_flag(cls, fbase + find_root_cached(L, p));
             } else {
-                if (x > 0 && (cls[flat - 1] & 1u)) set_flag(cls, fbase + find_root(L, p - 1));
-                if (x < g.W - 1 && (cls[flat + 1] & 1u)) set_flag(cls, fbase + find_root(L, p + 1));
-                if (y > 0 && (cls[flat - g.W] & 1u)) set_flag(cls, fbase + find_root(L, p - g.W));
-                if (y < g.H - 1 && (cls[flat + g.W] & 1u)) set_flag(cls, fbase + find_root(L, p + g.W));
+                if (x > 0 && (cls[flat - 1] & 1u)) set_flag(cls, fbase + find_root_cached(L, p - 1));
+                if (x < g.W - 1 && (cls[flat + 1] & 1u)) set_flag(cls, fbase + find_root_cached(L, p + 1));
+                if (y > 0 && (cls[flat - g.W] & 1u)) set_flag(cls, fbase + find_root_cached(L, p - g.W));
+                if (y < g.H - 1 && (cls[flat + g.W] & 1u)) set_flag(cls, fbase + find_root_cached(L, p + g.W));
             }
         }
     }
@@ -611,11 +631,10 @@ __device__ __forceinline__ bool in_result(const uint8_t *cls_frame, const uint32
 
 // Pass D: 8-connected components of R (what cv2.findContours traces).
 __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
-                                                ChunkList cl)
+                                                PixelList pl)
 {
-    FOR_LISTED_PIXELS(cl, c, i) {
+    FOR_LISTED_PIXELS(pl, g, flat) {
     {
-        size_t flat = c * 16 + i;
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
         if (!(b & 3u)) continue;
@@ -630,8 +649,17 @@ __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls,
         if (y > 0) {
             uint32_t q = p - W, bq = cf[q];
             if ((bq & 3u) && !((b & bq) & 1u) && in_result(cf, L, q, bq)) unite(L, p, q);
-            if (x > 0) { q = p - W - 1; bq = cf[q]; if ((bq & 3u) && in_result(cf, L, q, bq)) unite(L, p, q); }
-            if (x < W - 1) { q = p - W + 1; bq = cf[q]; if ((bq & 3u) && in_result(cf, L, q, bq)) unite(L, p, q); }
+            // a diagonal pair of thresh pixels with a thresh pixel on a shared side is already one
+            // 4-component of pass B: nothing to unite (the usual case inside a blob)
+            const uint32_t bn = bq;
+            if (x > 0) {
+                q = p - W - 1; bq = cf[q];
+                if ((bq & 3u) && !((b & bq & 1u) && ((bn | cf[p - 1]) & 1u)) && in_result(cf, L, q, bq)) unite(L, p, q);
+            }
+            if (x < W - 1) {
+                q = p - W + 1; bq = cf[q];
+                if ((bq & 3u) && !((b & bq & 1u) && ((bn | cf[p + 1]) & 1u)) && in_result(cf, L, q, bq)) unite(L, p, q);
+            }
         }
     }
     }
@@ -639,11 +667,10 @@ __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls,
 
 // Pass E: final labels (root + 1), final mask (cleared by a memset beforehand), roots per frame.
 __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls, uint32_t *labels,
-                                                 uint8_t *__restrict__ mask, Geo g, ChunkList cl,
+                                                 uint8_t *__restrict__ mask, Geo g, PixelList pl,
                                                  int32_t *nroots, int32_t *roots, int max_det)
 {
-    FOR_LISTED_PIXELS(cl, c, i) {
-        size_t flat = c * 16 + i;
+    FOR_LISTED_PIXELS(pl, g, flat) {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
         if (!(b & 3u)) continue;
@@ -679,7 +706,15 @@ struct CompTables {
     int max_det;
 };
 
-__global__ __launch_bounds__(256) void k_rank(CompTables t, int W, int H, int32_t *status)
+// Rank of every root among its frame's roots (descending pixel index = findContours order); four
+// lanes share a root and split the comparisons.  While k_bbox_euler runs, a ranked root's own label
+// holds RANK_TAG | rank instead of root + 1, so that every pixel finds its component's table row
+// with one dependent load; k_holes puts root + 1 back.
+constexpr uint32_t RANK_TAG = 0x80000000u;
+constexpr int RANK_THREADS = 1024;
+
+__global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *labels, uint32_t HW, int W, int H,
+                                                       int32_t *status)
 {
     const int f = blockIdx.x;
     int n = t.nroots[(size_t)f * NR_STRIDE];
@@ -689,23 +724,27 @@ __global__ __launch_bounds__(256) void k_rank(CompTables t, int W, int H, int32_
     }
     const int32_t *roots = t.roots + (size_t)f * t.max_det;
     __shared__ int32_t tile[1024];
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        int i = i0 + threadIdx.x;
-        int32_t mine = i < n ? roots[i] : -1;
+    const int sub = threadIdx.x & 3;
+    for (int i0 = 0; i0 < n; i0 += RANK_THREADS / 4) {
+        const int i = i0 + (threadIdx.x >> 2);
+        const int32_t mine = i < n ? roots[i] : -1;
         int rank = 0;
         for (int j0 = 0; j0 < n; j0 += 1024) {
             __syncthreads();
-            for (int j = threadIdx.x; j < 1024 && j0 + j < n; j += 256) tile[j] = roots[j0 + j];
+            for (int j = threadIdx.x; j < 1024 && j0 + j < n; j += RANK_THREADS) tile[j] = roots[j0 + j];
             __syncthreads();
-            int m = min(1024, n - j0);
-            for (int j = 0; j < m; ++j) rank += tile[j] > mine;
+            const int m = min(1024, n - j0);
+            for (int j = sub; j < m; j += 4) rank += tile[j] > mine;
         }
-        if (i < n) {
+        rank += __shfl_xor(rank, 1);
+        rank += __shfl_xor(rank, 2);
+        if (i < n && sub == 0) {
             size_t o = (size_t)f * t.max_det + rank;
             t.order[o] = mine;
             t.bbox[o * 4 + 0] = W; t.bbox[o * 4 + 1] = -1; t.bbox[o * 4 + 2] = H; t.bbox[o * 4 + 3] = -1;
             t.euler4[o] = 0;
             t.nested[o] = 0;
+            labels[(size_t)f * HW + (uint32_t)mine] = RANK_TAG | (uint32_t)rank;
         }
     }
 }
@@ -724,48 +763,73 @@ __device__ __forceinline__ int find_rank(const int32_t *order, int n, int32_t ro
 // Per final-mask pixel: bounding box of its component; bit-quad counts for the Euler number
 // (E8 = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows, each window counted by its first set pixel).
 __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ cls, const uint32_t *__restrict__ labels,
-                                                    Geo g, ChunkList cl, CompTables t)
+                                                    Geo g, PixelList pl, CompTables t)
 {
-    FOR_LISTED_PIXELS(cl, c, i) {
-    {
-        const size_t base = c * 16;
-        if (base + i >= g.total || !(cls[base + i] & 3u)) continue;
-        const uint32_t lab_i = labels[base + i];
-        if (!lab_i) continue;
-        size_t flat = base + i;
-        uint32_t f, p; int y, x;
-        locate(g, flat, f, p, y, x);
-        int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
-        int k = find_rank(t.order + (size_t)f * t.max_det, n, (int32_t)(lab_i - 1));
-        if (k < 0) continue;  // component beyond max_det (overflow already flagged)
-        size_t o = (size_t)f * t.max_det + k;
+    // The list keeps the pixels of a 16-pixel chunk on adjacent lanes, so a horizontal run of a
+    // component sits on consecutive lanes: its lanes pool their y-extent candidates and quad counts
+    // with ballots, and only the run's first lane issues those atomics.  (The loop is kept
+    // wave-uniform for the ballots: lanes past the end of the list carry valid = false.)
+    const size_t cnt = *pl.count;
+    const bool dense = cnt > pl.cap;
+    const size_t ln = dense ? g.total : cnt;
+    const int lane = threadIdx.x & 63;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t base = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63); base < ln; base += stride) {
+        const size_t li = base + lane;
+        bool valid = li < ln;
+        size_t flat = 0;
+        if (valid) flat = dense ? li : (size_t)pl.idx[li];
+        uint32_t lab_i = 0;
+        if (valid) valid = (cls[flat] & 3u) != 0;
+        if (valid) { lab_i = labels[flat]; valid = lab_i != 0; }
+        uint32_t f = 0, p = 0; int y = 0, x = 0;
+        if (valid) locate(g, flat, f, p, y, x);
         const uint32_t *L = labels + (size_t)f * g.HW;
+        if (valid && !(lab_i & RANK_TAG)) lab_i = L[lab_i - 1];   // the root's label carries the rank (k_rank)
+        valid = valid && (lab_i & RANK_TAG);   // else: component beyond max_det (overflow already flagged)
+        const uint32_t o = valid ? f * (uint32_t)t.max_det + (lab_i & ~RANK_TAG) : 0xFFFFFFFFu;
         const int W = g.W, H = g.H;
         auto at = [&](int yy, int xx) -> int {
-            return (yy >= 0 && yy < H && xx >= 0 && xx < W && L[(size_t)yy * W + xx] != 0) ? 1 : 0;
+            return (valid && yy >= 0 && yy < H && xx >= 0 && xx < W && L[(size_t)yy * W + xx] != 0) ? 1 : 0;
         };
-        int nw = at(y - 1, x - 1), nn = at(y - 1, x), ne = at(y - 1, x + 1);
-        int ww = at(y, x - 1), ee = at(y, x + 1);
-        int sw = at(y + 1, x - 1), ss = at(y + 1, x), se = at(y + 1, x + 1);
-        // bbox: only extreme candidates issue atomics
-        if (!ww) atomicMin(&t.bbox[o * 4 + 0], x);
-        if (!ee) atomicMax(&t.bbox[o * 4 + 1], x);
-        if (!nn) atomicMin(&t.bbox[o * 4 + 2], y);
-        if (!ss) atomicMax(&t.bbox[o * 4 + 3], y);
+        const int nw = at(y - 1, x - 1), nn = at(y - 1, x), ne = at(y - 1, x + 1);
+        const int ww = at(y, x - 1), ee = at(y, x + 1);
+        const int sw = at(y + 1, x - 1), ss = at(y + 1, x), se = at(y + 1, x + 1);
         // the four 2x2 windows containing (y,x); window order of pixels: TL, TR, BL, BR
         int q = 0;
         auto quad = [&](int tl, int tr, int bl, int br) {
-            int cnt = tl + tr + bl + br;
-            if (cnt == 1) q += 1;
-            else if (cnt == 3) q -= 1;
-            else if (cnt == 2 && ((tl && br) || (tr && bl))) q -= 2;
+            int c4 = tl + tr + bl + br;
+            if (c4 == 1) q += 1;
+            else if (c4 == 3) q -= 1;
+            else if (c4 == 2 && ((tl && br) || (tr && bl))) q -= 2;
         };
         quad(1, ee, ss, se);                        // (y,x) is TL: always first
         if (!ww) quad(ww, 1, sw, ss);               // TR: first iff TL clear
         if (!nn && !ne) quad(nn, ne, 1, ee);        // BL: first iff TL, TR clear
         if (!nw && !nn && !ww) quad(nw, nn, ww, 1); // BR: first iff all others clear
-        if (q) atomicAdd(&t.euler4[o], q);
-    }
+        // runs: lane l continues lane l-1's run if that lane holds the west neighbour of the same component
+        const uint32_t prev_flat = wave_shr1((uint32_t)flat), prev_o = wave_shr1(o);
+        const bool head = valid && !(lane > 0 && x > 0 && prev_o == o && prev_flat + 1u == (uint32_t)flat);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long upto = (2ull << lane) - 1ull;                  // lanes 0..lane
+        const unsigned long long later = heads & ~upto;
+        const int end = later ? __ffsll((long long)later) - 2 : 63;            // last lane before the next run
+        const unsigned long long run = ((2ull << end) - 1ull) & ~((1ull << lane) - 1ull);   // valid for head lanes
+        const unsigned long long top = __ballot(valid && !nn), bottom = __ballot(valid && !ss);
+        const uint32_t qb = valid ? (uint32_t)(q + 8) : 0u;                     // q in [-8, 4] -> 4 bit planes
+        const unsigned long long members = __ballot(valid);
+        int run_q = -8 * (int)__popcll(members & run);
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit) run_q += (int)__popcll(__ballot((qb >> bit) & 1u) & run) << bit;
+        if (valid) {   // bbox: only extreme candidates issue atomics
+            if (!ww) atomicMin(&t.bbox[(size_t)o * 4 + 0], x);
+            if (!ee) atomicMax(&t.bbox[(size_t)o * 4 + 1], x);
+        }
+        if (head) {
+            if (top & run) atomicMin(&t.bbox[(size_t)o * 4 + 2], y);
+            if (bottom & run) atomicMax(&t.bbox[(size_t)o * 4 + 3], y);
+            if (run_q) atomicAdd(&t.euler4[o], run_q);
+        }
     }
 }
 
@@ -773,12 +837,17 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ 
 // other components (RETR_EXTERNAL skips those); queue them for k_nested.
 constexpr int HOLED_CAP = 4096;
 
-__global__ __launch_bounds__(256) void k_holes(CompTables t, int batch, int32_t *n_holed, int2 *holed, int32_t *status)
+__global__ __launch_bounds__(256) void k_holes(CompTables t, int batch, uint32_t *labels, uint32_t HW, int32_t *n_holed,
+                                               int2 *holed, int32_t *status)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     int f = i / t.max_det, k = i - f * t.max_det;
     if (f >= batch) return;
     int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
+    if (k < n) {   // the root's label goes back from RANK_TAG | rank to root + 1
+        const uint32_t root = (uint32_t)t.order[(size_t)f * t.max_det + k];
+        labels[(size_t)f * HW + root] = root + 1u;
+    }
     if (k < n && t.euler4[(size_t)f * t.max_det + k] != 4) {
         int idx = atomicAdd(n_holed, 1);
         if (idx < HOLED_CAP) holed[idx] = make_int2(f, k);
@@ -1178,7 +1247,7 @@ Gauss11 make_gauss11()
 struct Workspace {
     int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed;
     int2 *holed;
-    ChunkList chunks;
+    PixelList pixels;
     uint32_t *arena_used;
     float *det_tmp, *arena;
     uint32_t arena_floats;
@@ -1195,8 +1264,9 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     w.nroots = (int32_t *)take(sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 4));
     w.n_holed = w.nroots + (size_t)batch * NR_STRIDE;
     w.arena_used = (uint32_t *)(w.n_holed + 1);
-    w.chunks.count = (uint32_t *)(w.n_holed + 2);
-    w.chunks.idx = (uint32_t *)take(sizeof(uint32_t) * (((size_t)batch * H * W + 15) / 16));
+    w.pixels.count = (uint32_t *)(w.n_holed + 2);
+    w.pixels.cap = (uint32_t)(((size_t)batch * H * W + 7) / 8);
+    w.pixels.idx = (uint32_t *)take(sizeof(uint32_t) * w.pixels.cap);
     w.holed = (int2 *)take(sizeof(int2) * HOLED_CAP);
     w.roots = (int32_t *)take(sizeof(int32_t) * bm);
     w.order = (int32_t *)take(sizeof(int32_t) * bm);
@@ -1220,8 +1290,8 @@ int check_geometry(int batch, int H, int W, int channels, int max_det)
         return ysmr::fail(YSMR_ERR_ARG, "batch, height, width, max_det must be positive (got %d, %d, %d, %d)", batch, H, W, max_det);
     if (channels != 1 && channels != 3)
         return ysmr::fail(YSMR_ERR_ARG, "channels must be 1 (gray) or 3 (BGR), got %d", channels);
-    if (H > 16384 || W > 16384 || (size_t)batch * H * W >= (1ull << 40))
-        return ysmr::fail(YSMR_ERR_ARG, "frame too large (height and width are limited to 16384)");
+    if (H > 16384 || W > 16384 || (size_t)batch * H * W >= (1ull << 32))
+        return ysmr::fail(YSMR_ERR_ARG, "batch too large (height and width are limited to 16384, batch*height*width to 2^32 - 1)");
     return YSMR_OK;
 }
 
@@ -1296,18 +1366,18 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     if (mask_dev) YSMR_HIP_CHECK(hipMemsetAsync(mask_dev, 0, g.total, st));
     const unsigned dense_grid = cgrid < (unsigned)COLLECT_BLOCKS ? cgrid : (unsigned)COLLECT_BLOCKS;
     const dim3 sg(SPARSE_BLOCKS), tb(256);
-    hipLaunchKernelGGL(k_collect, dim3(dense_grid), tb, 0, st, cls_dev, g, nchunks, w.chunks);
-    hipLaunchKernelGGL(k_init_labels, sg, tb, 0, st, cls_dev, labels, g, w.chunks);
-    hipLaunchKernelGGL(k_union4, sg, tb, 0, st, cls_dev, labels, g, w.chunks);
-    hipLaunchKernelGGL(k_flag, sg, tb, 0, st, cls_dev, labels, g, w.chunks);
-    hipLaunchKernelGGL(k_union8, sg, tb, 0, st, cls_dev, labels, g, w.chunks);
-    hipLaunchKernelGGL(k_flatten, sg, tb, 0, st, cls_dev, labels, mask_dev, g, w.chunks, w.nroots, w.roots, max_det);
+    hipLaunchKernelGGL(k_collect, dim3(dense_grid), tb, 0, st, cls_dev, labels, g, nchunks, w.pixels);
+    hipLaunchKernelGGL(k_union4, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
+    hipLaunchKernelGGL(k_flag, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
+    hipLaunchKernelGGL(k_union8, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
+    hipLaunchKernelGGL(k_flatten, sg, tb, 0, st, cls_dev, labels, mask_dev, g, w.pixels, w.nroots, w.roots, max_det);
     YSMR_LAUNCH_CHECK();
     CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, max_det};
-    hipLaunchKernelGGL(k_rank, dim3(batch), dim3(256), 0, st, t, width, height, status_dev);
-    hipLaunchKernelGGL(k_bbox_euler, sg, tb, 0, st, cls_dev, labels, g, w.chunks, t);
+    hipLaunchKernelGGL(k_rank, dim3(batch), dim3(RANK_THREADS), 0, st, t, labels, g.HW, width, height, status_dev);
+    hipLaunchKernelGGL(k_bbox_euler, sg, tb, 0, st, cls_dev, labels, g, w.pixels, t);
     const unsigned comp_threads = (unsigned)((size_t)batch * max_det);
-    hipLaunchKernelGGL(k_holes, dim3((comp_threads + 255) / 256), dim3(256), 0, st, t, batch, w.n_holed, w.holed, status_dev);
+    hipLaunchKernelGGL(k_holes, dim3((comp_threads + 255) / 256), dim3(256), 0, st, t, batch, labels, g.HW, w.n_holed, w.holed,
+                       status_dev);
     hipLaunchKernelGGL(k_nested, dim3(HOLED_CAP), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
                        w.arena_floats, w.arena_used, status_dev);
     YSMR_LAUNCH_CHECK();
