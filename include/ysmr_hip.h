@@ -34,7 +34,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   1
+#define YSMR_ABI_VERSION   2
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -59,6 +59,13 @@ const char *ysmr_last_error(void);        /* message of the calling thread's las
 
 /* Bytes of scratch ysmr_detect_batch needs for this geometry. */
 size_t ysmr_detect_workspace_bytes(int batch, int height, int width, int max_det);
+
+/* Call once after allocating a workspace (and again if the output buffers used with it were
+ * written by anyone else).  The workspace remembers which pixels of labels_dev / mask_dev the
+ * previous ysmr_components_batch / ysmr_detect_batch call made non-zero; when the next call gets
+ * the same buffers and geometry it clears exactly those instead of the whole maps.  A workspace
+ * whose first 256 bytes are zero (this call) makes the next call clear everything. */
+int ysmr_detect_workspace_init(void *stream, void *workspace_dev, size_t workspace_bytes);
 
 /* a1-a3 fused.  frames_dev: u8 [batch][height][width][channels], channels 1 (gray) or 3 (BGR).
  * cls_dev: u8 [batch][height][width] (allocation rounded up to a multiple of 16 bytes):

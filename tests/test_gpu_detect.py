@@ -177,3 +177,36 @@ def test_components_on_arbitrary_class_maps(torch_cuda, oracle):
             np.testing.assert_array_equal(res.anchors[f, :n].cpu().numpy(), anchors)
             np.testing.assert_array_equal(res.det[f, :n, :4].cpu().numpy(), rects[:, :4])
             _assert_angle_close(res.det[f, :n, 4].cpu().numpy(), rects[:, 4])
+
+
+def test_detector_reuse_clears_what_the_previous_call_wrote(torch_cuda, oracle):
+    """The workspace clears labels/mask sparsely from the previous call's pixel list (ysmr_hip.h:
+    ysmr_detect_workspace_init).  Reusing one Detector for different clips, a shorter batch, a dense
+    batch (list overflow -> dense fallback) and again a sparse one must match the oracle each time,
+    and so must a call after someone else has scribbled over the label map (after re-init)."""
+    torch = torch_cuda
+    from ysmr_amd import _lib
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    p = threshold_params(True, 5, 2.0)
+    h, w = 200, 312
+    det = Detector(4, h, w, max_det=8192, params=p)
+    rng = np.random.default_rng(11)
+    clips = [SyntheticVideo(h, w, 60, seed=5).frames(4), SyntheticVideo(h, w, 25, seed=6).frames(4),
+             SyntheticVideo(h, w, 40, seed=7).frames(2),                          # shorter batch
+             rng.integers(0, 256, (4, h, w), dtype=np.uint8),                     # dense: > 1/8 foreground
+             SyntheticVideo(h, w, 30, seed=8).frames(4), SyntheticVideo(h, w, 30, seed=9).frames(4)]
+    for k, frames in enumerate(clips):
+        res = det.detect(torch.from_numpy(frames).cuda())
+        torch.cuda.synchronize()
+        got = {n: getattr(res, n).cpu().numpy() for n in ("cls", "mask", "labels", "det_count", "det", "anchors", "status")}
+        _compare(oracle, frames, got, p, max_det=8192)
+    # foreign writes into the outputs are only legal together with a re-init of the workspace
+    det._labels.fill_(7)
+    det._mask.fill_(9)
+    L = _lib.lib()
+    _lib.check(L.ysmr_detect_workspace_init(_lib.stream_ptr(), det._ws.data_ptr(), det._ws.numel()), "ysmr_detect_workspace_init")
+    res = det.detect(torch.from_numpy(clips[0]).cuda())
+    torch.cuda.synchronize()
+    got = {n: getattr(res, n).cpu().numpy() for n in ("cls", "mask", "labels", "det_count", "det", "anchors", "status")}
+    _compare(oracle, clips[0], got, p, max_det=8192)

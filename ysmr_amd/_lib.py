@@ -22,7 +22,8 @@ DET_ARENA = 2
 ROW_DTYPE = np.dtype([("frame", "<i4"), ("track_id", "<i4"), ("x", "<f8"), ("y", "<f8"),
                       ("w", "<f4"), ("h", "<f4"), ("angle", "<f4"), ("disappeared", "<i4")])
 
-EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_threshold_batch",
+EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_detect_workspace_init",
+           "ysmr_threshold_batch",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_peek",
            "ysmr_tracker_info")
@@ -53,6 +54,7 @@ def lib():
     L.ysmr_last_error.restype = ctypes.c_char_p
     L.ysmr_detect_workspace_bytes.argtypes = [ci, ci, ci, ci]
     L.ysmr_detect_workspace_bytes.restype = ctypes.c_size_t
+    L.ysmr_detect_workspace_init.argtypes = [vp, vp, ctypes.c_size_t]
     L.ysmr_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.ysmr_components_batch.argtypes = [vp, ci, ci, ci, vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, ci, vp]
     L.ysmr_detect_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, vp, vp,

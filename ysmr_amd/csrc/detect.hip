@@ -361,10 +361,12 @@ __global__ __launch_bounds__(256, 4) void k_threshold_strip(const uint8_t *__res
     // everything derived from the wave index is wave-uniform: say so (readfirstlane), or the compiler
     // keeps row counters in VGPRs and turns every loop test into a divergent branch + vmcnt(0)
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * 4 + wave_in_block;
     const int per_frame = P.strips_x * P.segs_y;
+    const long long n_items = (long long)P.batch * per_frame;
+    // resident grid, strided over the (frame, strip, segment) items: a grid larger than the chip
+    // can hold keeps the dispatcher busy and starves every other stream until it has drained
+    for (long long wave = (long long)blockIdx.x * 4 + wave_in_block; wave < n_items; wave += (long long)gridDim.x * 4) {
     const int f = (int)(wave / per_frame);
-    if (f >= P.batch) return;
     const int rem = (int)(wave - (long long)f * per_frame);
     const int sx = rem % P.strips_x, sy = rem / P.strips_x;
     StripCtx c;
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(256, 4) void k_threshold_strip(const uint8_t *__res
         if (yedge) strip_body<true, true>(c, gk); else strip_body<true, false>(c, gk);
     } else {
         if (yedge) strip_body<false, true>(c, gk); else strip_body<false, false>(c, gk);
+    }
     }
 }
 
@@ -484,26 +487,98 @@ __device__ __forceinline__ uint32_t chunk_byte(const uint4 &v, int i)
 // of 16-pixel chunks was tried first: on the benchmark clip only 19 % of its lane slots held a
 // foreground pixel.)  The list has room for 1/8 of the batch; a denser batch makes the passes fall
 // back to walking every pixel (`count` keeps counting past `cap`, which is how they know).
+// The workspace remembers, across calls, which pixels of the caller's label map / final mask the
+// previous call made non-zero: if the next call gets the same buffers and geometry, clearing those
+// pixels replaces a dense memset (362 MB per 64-frame batch at 1228x922 -- more HBM traffic than the
+// threshold kernel itself).  Hence two lists, used alternately, and a header that says which one is
+// current and for which buffers it is valid.
+constexpr unsigned long long WS_MAGIC = 0x59534D5248495031ull;   // "YSMRHIP1"
+struct WsHeader {
+    unsigned long long magic;    // WS_MAGIC while the fields below describe a completed call
+    unsigned long long labels;   // label map / final mask the current list refers to
+    unsigned long long mask;
+    unsigned long long total;    // batch * H * W of that call
+    uint32_t cur;                // index of the current list
+    uint32_t count[2];           // foreground pixels found (may exceed cap: list incomplete)
+    uint32_t pad;
+};
 struct PixelList {
-    uint32_t *idx;     // flat pixel indices (frame * H * W + y * W + x); chunk-local order, chunks unordered
-    uint32_t *count;   // number of foreground pixels found (may exceed cap)
-    uint32_t cap;      // entries idx can hold
+    uint32_t *idx[2];  // flat pixel indices (frame * H * W + y * W + x); chunk-local order, chunks unordered
+    WsHeader *hdr;
+    uint32_t cap;      // entries each list can hold
 };
 
-constexpr int SPARSE_BLOCKS = 4096;  // upper bound of the list-driven grids (grid-stride over the list)
+constexpr int SPARSE_BLOCKS = 1536;  // resident grid of the list-driven passes (grid-stride over the list)
 
 // The passes are bound by chains of dependent L2 round trips (union-find), so they want many
 // short threads: one lane per pixel, grid-stride.
 #define FOR_LISTED_PIXELS(pl, g, flat)                                                                           \
-    for (size_t cnt_ = *(pl).count, dense_ = cnt_ > (pl).cap, ln_ = dense_ ? (g).total : cnt_,                  \
-                li_ = (size_t)blockIdx.x * 256 + threadIdx.x;                                                    \
-         li_ < ln_; li_ += (size_t)gridDim.x * 256)                                                              \
-        if (const size_t flat = dense_ ? li_ : (size_t)(pl).idx[li_]; true)
+    if (const uint32_t cur_ = (pl).hdr->cur & 1u; true)                                                          \
+        if (const uint32_t *idx_ = (pl).idx[cur_]; true)                                                         \
+            for (size_t cnt_ = (pl).hdr->count[cur_], dense_ = cnt_ > (pl).cap, ln_ = dense_ ? (g).total : cnt_, \
+                        li_ = (size_t)blockIdx.x * 256 + threadIdx.x;                                            \
+                 li_ < ln_; li_ += (size_t)gridDim.x * 256)                                                      \
+                if (const size_t flat = dense_ ? li_ : (size_t)idx_[li_]; true)
+
+// Clears the label map and the final mask (both are written sparsely afterwards): only the pixels
+// the previous call listed if the header vouches for these buffers, everything otherwise.  A resident
+// grid instead of hipMemsetAsync: the runtime's fill kernels use grids far larger than the chip
+// holds, and such a grid starves every other stream (the link) until it has drained.
+constexpr int CLEAR_BLOCKS = 512;
+__global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, uint8_t *mask, size_t total)
+{
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    const WsHeader h = *pl.hdr;
+    const uint32_t prev = h.cur & 1u;
+    if (h.magic == WS_MAGIC && h.labels == (unsigned long long)labels && h.mask == (unsigned long long)mask &&
+        h.total == total && h.count[prev] <= pl.cap) {
+        const uint32_t *idx = pl.idx[prev];
+        uint32_t *lab = reinterpret_cast<uint32_t *>(labels);
+        for (size_t i = tid; i < h.count[prev]; i += stride) {
+            const uint32_t flat = idx[i];
+            lab[flat] = 0u;
+            if (mask) mask[flat] = 0;
+        }
+        return;
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int which = 0; which < 2; ++which) {
+        uint8_t *p = which ? mask : labels;
+        const size_t bytes = which ? total : total * sizeof(uint32_t);
+        if (!p) continue;
+        uint4 *q = reinterpret_cast<uint4 *>(p);       // (16-byte aligned: checked by the caller)
+        const size_t n16 = bytes / 16;
+        for (size_t i = tid; i < n16; i += stride) q[i] = z;
+        for (size_t i = n16 * 16 + tid; i < bytes; i += stride) p[i] = 0;
+    }
+}
+
+// After the last kernel of a call: the current list now describes these buffers.
+__global__ void k_list_end(PixelList pl, const uint8_t *labels, const uint8_t *mask, size_t total)
+{
+    WsHeader *h = pl.hdr;
+    h->labels = (unsigned long long)labels;
+    h->mask = (unsigned long long)mask;
+    h->total = total;
+    __threadfence();
+    h->magic = WS_MAGIC;
+}
+
+// Between k_clear and k_collect: switch to the other list, empty it, and mark the header invalid
+// until k_compact (the last kernel of the call) has run.
+__global__ void k_list_begin(PixelList pl)
+{
+    WsHeader *h = pl.hdr;
+    const uint32_t cur = (h->magic == WS_MAGIC) ? ((h->cur & 1u) ^ 1u) : 0u;
+    h->magic = 0;
+    h->cur = cur;
+    h->count[cur] = 0;
+}
 
 // Pass A0 (dense, HBM-bound: 1 B/px read): list the pixels that hold any class bit.  Each block
 // gathers its finds in LDS and publishes them with ONE global atomicAdd (a single hot counter
 // serves only ~90 atomics/us on this chip).
-constexpr int COLLECT_BLOCKS = 1024;
+constexpr int COLLECT_BLOCKS = 512;
 constexpr int COLLECT_LDS = 8192;  // entries buffered per block before a flush (a round adds <= 4096)
 
 __global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls, uint32_t *__restrict__ labels, Geo g,
@@ -561,10 +636,10 @@ __global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls
         __syncthreads();
         const uint32_t n = s_n;
         if (n + 4096 > COLLECT_LDS || r + 1 == rounds) {
-            if (threadIdx.x == 0) { s_base = n ? atomicAdd(pl.count, n) : 0; }
+            if (threadIdx.x == 0) { s_base = n ? atomicAdd(&pl.hdr->count[pl.hdr->cur & 1u], n) : 0; }
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n; i += 256)
-                if ((size_t)s_base + i < pl.cap) pl.idx[s_base + i] = s_buf[i];
+                if ((size_t)s_base + i < pl.cap) pl.idx[pl.hdr->cur & 1u][s_base + i] = s_buf[i];
             __syncthreads();
             if (threadIdx.x == 0) s_n = 0;
             __syncthreads();
@@ -703,6 +778,7 @@ struct CompTables {
     int32_t *bbox;     // [B][max_det][4] minx, maxx, miny, maxy
     int32_t *euler4;   // [B][max_det] 4 * Euler number (8-connectivity)
     int32_t *nested;   // [B][max_det] component lies in a hole of another one
+    int32_t *max_roots; // largest per-frame component count of the batch (k_rank)
     int max_det;
 };
 
@@ -722,6 +798,7 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *l
         if (threadIdx.x == 0) atomicOr(&status[f], YSMR_DET_OVERFLOW);
         n = t.max_det;
     }
+    if (threadIdx.x == 0) atomicMax(t.max_roots, n);
     const int32_t *roots = t.roots + (size_t)f * t.max_det;
     __shared__ int32_t tile[1024];
     const int sub = threadIdx.x & 3;
@@ -769,7 +846,9 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ 
     // component sits on consecutive lanes: its lanes pool their y-extent candidates and quad counts
     // with ballots, and only the run's first lane issues those atomics.  (The loop is kept
     // wave-uniform for the ballots: lanes past the end of the list carry valid = false.)
-    const size_t cnt = *pl.count;
+    const uint32_t cur = pl.hdr->cur & 1u;
+    const uint32_t *idx = pl.idx[cur];
+    const size_t cnt = pl.hdr->count[cur];
     const bool dense = cnt > pl.cap;
     const size_t ln = dense ? g.total : cnt;
     const int lane = threadIdx.x & 63;
@@ -778,7 +857,7 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ 
         const size_t li = base + lane;
         bool valid = li < ln;
         size_t flat = 0;
-        if (valid) flat = dense ? li : (size_t)pl.idx[li];
+        if (valid) flat = dense ? li : (size_t)idx[li];
         uint32_t lab_i = 0;
         if (valid) valid = (cls[flat] & 3u) != 0;
         if (valid) { lab_i = labels[flat]; valid = lab_i != 0; }
@@ -864,15 +943,13 @@ __global__ __launch_bounds__(256) void k_holes(CompTables t, int batch, uint32_t
 // ------------------------------------------------------------------------------------------
 constexpr int NEST_LDS_CELLS = 48 * 1024;
 
-__global__ __launch_bounds__(256) void k_nested(const uint32_t *__restrict__ labels, Geo g, CompTables t,
-                                                const int32_t *n_holed, const int2 *holed, float *arena,
-                                                uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
+__device__ void nested_component(const uint32_t *__restrict__ labels, const Geo &g, const CompTables &t, int idx,
+                                 const int2 *holed, float *arena, uint32_t arena_floats, uint32_t *arena_used,
+                                 int32_t *status)
 {
     __shared__ uint8_t s_cell[NEST_LDS_CELLS];
     __shared__ int s_changed;
     __shared__ uint32_t s_off;
-    const int idx = blockIdx.x;
-    if (idx >= min(*n_holed, HOLED_CAP)) return;
     const int f = holed[idx].x, k = holed[idx].y;
     const size_t o = (size_t)f * t.max_det + k;
     const int wx0 = t.bbox[o * 4 + 0] - 1, wy0 = t.bbox[o * 4 + 2] - 1;
@@ -936,6 +1013,20 @@ __global__ __launch_bounds__(256) void k_nested(const uint32_t *__restrict__ lab
         if (L[p] != p + 1u || cell[i - 1] != 2) continue;
         int kk = find_rank(t.order + (size_t)f * t.max_det, n, (int32_t)p);
         if (kk >= 0) t.nested[(size_t)f * t.max_det + kk] = 1;
+    }
+}
+
+// Resident grid over the queued components (usually a handful; see k_clear for why not one block
+// per queue slot).
+constexpr int NEST_BLOCKS = 128;
+__global__ __launch_bounds__(256) void k_nested(const uint32_t *__restrict__ labels, Geo g, CompTables t,
+                                                const int32_t *n_holed, const int2 *holed, float *arena,
+                                                uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
+{
+    const int nh = min(*n_holed, HOLED_CAP);
+    for (int idx = blockIdx.x; idx < nh; idx += gridDim.x) {
+        nested_component(labels, g, t, idx, holed, arena, arena_floats, arena_used, status);
+        __syncthreads();
     }
 }
 
@@ -1114,18 +1205,15 @@ __device__ __forceinline__ void column_extent(const uint32_t *L, int W, int x, i
     }
 }
 
-__global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__restrict__ labels, Geo g, CompTables t,
-                                                          int batch, float *det_tmp, float *arena,
-                                                          uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
+__device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g, const CompTables &t, int f, int k,
+                               float *det_tmp, float *arena, uint32_t arena_floats, uint32_t *arena_used,
+                               int32_t *status)
 {
     __shared__ float lds[GEO_COMPS * GEO_LDS_STRIDE];
     __shared__ int s_top[GEO_COMPS][GEO_GROUP], s_bot[GEO_COMPS][GEO_GROUP];
     GEOSTAMP(0);
     const int grp = threadIdx.x / GEO_GROUP, sub = threadIdx.x % GEO_GROUP;
-    const long long gi = (long long)blockIdx.x * GEO_COMPS + grp;
-    const int f = (int)(gi / t.max_det), k = (int)(gi - (long long)f * t.max_det);
-    bool live = f < batch;
-    if (live) live = k < min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
+    bool live = k < min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
     const size_t o = live ? (size_t)f * t.max_det + k : 0;
     if (live) live = !t.nested[o];
     uint32_t want = 0;
@@ -1193,6 +1281,24 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
     GEOSTAMP(4);
 }
 
+// Resident grid.  Work items are (block of GEO_COMPS ranks, frame), frame fastest: the populated
+// ranks come first in every frame, so the live items are spread evenly over the blocks and the
+// loop stops at the largest component count of the batch (t.max_roots, from k_rank).
+constexpr int GEO_BLOCKS = 512;
+__global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__restrict__ labels, Geo g, CompTables t,
+                                                          int batch, float *det_tmp, float *arena,
+                                                          uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
+{
+    const int most = min(*t.max_roots, t.max_det);
+    const long long items = (long long)((most + GEO_COMPS - 1) / GEO_COMPS) * batch;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int kb = (int)(it / batch), f = (int)(it - (long long)kb * batch);
+        geometry_group(labels, g, t, f, kb * GEO_COMPS + threadIdx.x / GEO_GROUP, det_tmp, arena, arena_floats,
+                       arena_used, status);
+        __syncthreads();
+    }
+}
+
 // Drop nested components, write final detection list / count / anchors.
 __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__restrict__ det_tmp, float *det,
                                                  int32_t *det_count, int32_t *anchors)
@@ -1245,7 +1351,7 @@ Gauss11 make_gauss11()
 }
 
 struct Workspace {
-    int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed;
+    int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed, *max_roots;
     int2 *holed;
     PixelList pixels;
     uint32_t *arena_used;
@@ -1260,13 +1366,15 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return (char *)base + o; };
     size_t bm = (size_t)batch * max_det;
+    w.pixels.hdr = (WsHeader *)take(256);   // persists across calls (ysmr_detect_workspace_init zeroes it)
     // counters first: one memset clears nroots, n_holed, arena_used
-    w.nroots = (int32_t *)take(sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 4));
+    w.nroots = (int32_t *)take(sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 8));
     w.n_holed = w.nroots + (size_t)batch * NR_STRIDE;
     w.arena_used = (uint32_t *)(w.n_holed + 1);
-    w.pixels.count = (uint32_t *)(w.n_holed + 2);
+    w.max_roots = w.n_holed + 3;
     w.pixels.cap = (uint32_t)(((size_t)batch * H * W + 7) / 8);
-    w.pixels.idx = (uint32_t *)take(sizeof(uint32_t) * w.pixels.cap);
+    w.pixels.idx[0] = (uint32_t *)take(sizeof(uint32_t) * w.pixels.cap);
+    w.pixels.idx[1] = (uint32_t *)take(sizeof(uint32_t) * w.pixels.cap);
     w.holed = (int2 *)take(sizeof(int2) * HOLED_CAP);
     w.roots = (int32_t *)take(sizeof(int32_t) * bm);
     w.order = (int32_t *)take(sizeof(int32_t) * bm);
@@ -1311,7 +1419,11 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
         P.segs_y = (H + P.seg_h - 1) / P.seg_h;
         P.inv = inv; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
         const long long waves = (long long)batch * P.strips_x * P.segs_y;
-        hipLaunchKernelGGL(k_threshold_strip, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, frames, cls, P, gk);
+        long long blocks = (waves + 3) / 4;
+        int resident = 768;   // 3 blocks per CU: leaves a wave slot and 128 VGPRs per SIMD to other streams
+        if (const char *e = getenv("YSMR_THR_BLOCKS")) resident = atoi(e);
+        if (resident > 0 && blocks > resident) blocks = resident;
+        hipLaunchKernelGGL(k_threshold_strip, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
     } else {
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, batch);
         if (channels == 1)
@@ -1331,6 +1443,13 @@ size_t ysmr_detect_workspace_bytes(int batch, int height, int width, int max_det
 {
     if (batch <= 0 || height <= 0 || width <= 0 || max_det <= 0) return 0;
     return carve(nullptr, batch, height, width, max_det).bytes;
+}
+
+int ysmr_detect_workspace_init(void *stream, void *workspace_dev, size_t workspace_bytes)
+{
+    if (!workspace_dev || workspace_bytes < 256) return ysmr::fail(YSMR_ERR_ARG, "workspace_dev is NULL or smaller than its header");
+    YSMR_HIP_CHECK(hipMemsetAsync(workspace_dev, 0, 256, (hipStream_t)stream));
+    return YSMR_OK;
 }
 
 int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels,
@@ -1360,10 +1479,11 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     const unsigned cgrid = (unsigned)((nchunks + 255) / 256);
     uint32_t *labels = reinterpret_cast<uint32_t *>(labels_dev);
 
-    YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 4), st));
+    YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 8), st));
     YSMR_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t) * batch, st));
-    YSMR_HIP_CHECK(hipMemsetAsync(labels, 0, sizeof(uint32_t) * g.total, st));
-    if (mask_dev) YSMR_HIP_CHECK(hipMemsetAsync(mask_dev, 0, g.total, st));
+    hipLaunchKernelGGL(k_clear, dim3(CLEAR_BLOCKS), dim3(256), 0, st, w.pixels, reinterpret_cast<uint8_t *>(labels), mask_dev,
+                       g.total);
+    hipLaunchKernelGGL(k_list_begin, dim3(1), dim3(1), 0, st, w.pixels);
     const unsigned dense_grid = cgrid < (unsigned)COLLECT_BLOCKS ? cgrid : (unsigned)COLLECT_BLOCKS;
     const dim3 sg(SPARSE_BLOCKS), tb(256);
     hipLaunchKernelGGL(k_collect, dim3(dense_grid), tb, 0, st, cls_dev, labels, g, nchunks, w.pixels);
@@ -1372,18 +1492,19 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     hipLaunchKernelGGL(k_union8, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
     hipLaunchKernelGGL(k_flatten, sg, tb, 0, st, cls_dev, labels, mask_dev, g, w.pixels, w.nroots, w.roots, max_det);
     YSMR_LAUNCH_CHECK();
-    CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, max_det};
+    CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, w.max_roots, max_det};
     hipLaunchKernelGGL(k_rank, dim3(batch), dim3(RANK_THREADS), 0, st, t, labels, g.HW, width, height, status_dev);
     hipLaunchKernelGGL(k_bbox_euler, sg, tb, 0, st, cls_dev, labels, g, w.pixels, t);
     const unsigned comp_threads = (unsigned)((size_t)batch * max_det);
     hipLaunchKernelGGL(k_holes, dim3((comp_threads + 255) / 256), dim3(256), 0, st, t, batch, labels, g.HW, w.n_holed, w.holed,
                        status_dev);
-    hipLaunchKernelGGL(k_nested, dim3(HOLED_CAP), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
+    hipLaunchKernelGGL(k_nested, dim3(NEST_BLOCKS), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
                        w.arena_floats, w.arena_used, status_dev);
     YSMR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_geometry, dim3((comp_threads + GEO_COMPS - 1) / GEO_COMPS), dim3(GEO_THREADS), 0, st,
+    hipLaunchKernelGGL(k_geometry, dim3(GEO_BLOCKS), dim3(GEO_THREADS), 0, st,
                        labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
     hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev);
+    hipLaunchKernelGGL(k_list_end, dim3(1), dim3(1), 0, st, w.pixels, reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }

@@ -71,10 +71,15 @@ __device__ unsigned long long g_stamps[32];
 __device__ unsigned long long g_block_stamps[2 * 2048 * 8];
 #define BSTAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_block_stamps[((frame & 1) * 2048 + blockIdx.x) * 8 + (k)] = t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_block_stamps[((frame & 1) * 2048 + blockIdx.x) * 8 + 4 + (k)] = t_; } } while (0)
 extern "C" int ysmr_debug_read_block_stamps(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_stamps), sizeof(unsigned long long) * n); }
+__device__ unsigned long long g_ring[4096 * 2];
+__device__ unsigned int g_ring_n;
+#define RING(tag) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); unsigned int i_ = atomicAdd(&g_ring_n, 1u) & 4095u; g_ring[2 * i_] = (unsigned long long)(tag); g_ring[2 * i_ + 1] = t_; } while (0)
+extern "C" int ysmr_debug_read_ring(unsigned long long *out, unsigned int *n) { hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring), sizeof(unsigned long long) * 8192); if (e == hipSuccess) e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_ring_n), 4); return (int)e; }
 extern "C" int ysmr_debug_read_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32); }
 #else
 #define GSTAMP(k) do {} while (0)
 #define BSTAMP(k) do {} while (0)
+#define RING(tag) do {} while (0)
 #endif
 
 namespace {
@@ -870,15 +875,24 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
 constexpr int FRAME_THREADS = 256;
 constexpr int FRAME_TABLE = 4096;   // CPython set model table (entries) in LDS: up to 2457 unused columns
 
+// LDS of k_frame.  Kept small on purpose (59 KB at capacity = max_det = 2048): a block that wants
+// most of a CU's 160 KB cannot be placed while kernels of another stream hold LDS there, and the
+// link waited tens of microseconds per frame for that.  Per-row inputs (slot, gone, row_arg,
+// row_min) stay in the registers of the thread that owns the row instead.
 struct FrameLds {
-    unsigned long long *col_key, *key;
-    int *col_row, *arg, *slot, *newgone, *claim, *inv, *unused, *newcols, *table, *scan;
-    double *gains;   // LDS copy of the gain rows
+    double *gains;                 // [gain_total] LDS copy of the gain rows
+    unsigned long long *col_key;   // [max_det] smallest proposing distance per column ...
+    int *unused, *newcols;         //   ... reused after the claims: unused columns, registration order
+    int *col_row;                  // [max_det] winning row per column
+    int *cg;                       // [capacity] (claimed column + 1) | new `gone` << 16, per old row
+    int *inv;                      // [capacity] new row -> old row
+    int *scan;                     // [16]
+    short *table;                  // [2 * FRAME_TABLE]
 };
 
 __host__ __device__ inline size_t frame_lds_bytes(int cap, int max_det, int gain_total)
 {
-    return 8 * ((size_t)max_det + cap + gain_total) + 4 * ((size_t)max_det * 3 + (size_t)cap * 5 + 2 * FRAME_TABLE + FRAME_THREADS) + 64;
+    return 8 * ((size_t)gain_total + max_det) + 4 * ((size_t)max_det + 2 * (size_t)cap + 16) + 2 * 2 * FRAME_TABLE + 64;
 }
 
 // Exclusive rank of this thread's flag among the block's flags (thread order) and their count:
@@ -896,19 +910,31 @@ __device__ __forceinline__ int block_flag_rank(bool f, int *s_cnt, int *total)
     return before + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
-// CPython order of the ascending list `unused` (see cpython_unused_order), tables in LDS
-__device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_used, int *out, int *tables)
+// CPython order of the ascending list `unused` (see cpython_unused_order), 16-bit tables in LDS
+__device__ void set_insert_clean16(short *table, unsigned mask, int key)
+{
+    unsigned long long perturb = (unsigned long long)key;
+    unsigned i = (unsigned)key & mask;
+    while (true) {
+        int probes = (i + 9u <= mask) ? 9 : 0;
+        for (int j = 0; j <= probes; ++j)
+            if (table[i + j] < 0) { table[i + j] = (short)key; return; }
+        perturb >>= 5;
+        i = (unsigned)(((unsigned long long)i * 5ull + 1ull + perturb) & mask);
+    }
+}
+__device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_used, int *out, short *tables)
 {
     if ((m >> 2) > n_used) {
         for (int k = 0; k < n_unused; ++k) out[k] = unused[k];
         return n_unused;
     }
-    int *table = tables, *other = tables + FRAME_TABLE;
+    short *table = tables, *other = tables + FRAME_TABLE;
     unsigned mask = 7;
     int fill = 0;
     for (int i = 0; i < 8; ++i) table[i] = -1;
     for (int k = 0; k < n_unused; ++k) {
-        set_insert_clean(table, mask, unused[k]);
+        set_insert_clean16(table, mask, unused[k]);
         ++fill;
         if ((unsigned long long)fill * 5ull >= (unsigned long long)mask * 3ull) {
             unsigned minused = fill > 50000 ? (unsigned)fill * 2u : (unsigned)fill * 4u;
@@ -917,8 +943,8 @@ __device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_u
             if ((int)newsize > FRAME_TABLE) return -1;
             for (unsigned i = 0; i < newsize; ++i) other[i] = -1;
             for (unsigned i = 0; i <= mask; ++i)
-                if (table[i] >= 0) set_insert_clean(other, newsize - 1, table[i]);
-            int *tmp = table; table = other; other = tmp;
+                if (table[i] >= 0) set_insert_clean16(other, newsize - 1, table[i]);
+            short *tmp = table; table = other; other = tmp;
             mask = newsize - 1;
         }
     }
@@ -947,6 +973,9 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cap = a.capacity, md = a.max_det;
     STAMP(0); BSTAMP(0);
+#ifdef YSMR_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) RING((2ull << 40) | (unsigned)frame);
+#endif
     // ---- round trip 1: everything that can be addressed without knowing n or m is requested
     // together with the counters (entries past n / m are stale and never used)
     constexpr int SPEC_ROWS = 3;       // table rows tid + 256k, k < 3, are fetched before n is known
@@ -989,17 +1018,13 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     FrameLds L;
     L.gains = reinterpret_cast<double *>(s_raw);
     L.col_key = s_raw + a.gain_total;
-    L.key = L.col_key + md;
-    L.col_row = reinterpret_cast<int *>(L.key + cap);
-    L.unused = L.col_row + md;
+    L.unused = reinterpret_cast<int *>(L.col_key);
     L.newcols = L.unused + md;
-    L.arg = L.newcols + md;
-    L.slot = L.arg + cap;
-    L.newgone = L.slot + cap;
-    L.claim = L.newgone + cap;
-    L.inv = L.claim + cap;
-    L.table = L.inv + cap;
-    L.scan = L.table + 2 * FRAME_TABLE;
+    L.col_row = reinterpret_cast<int *>(L.col_key + md);
+    L.cg = L.col_row + md;
+    L.inv = L.cg + cap;
+    L.scan = L.inv + cap;
+    L.table = reinterpret_cast<short *>(L.scan + 16);
 
     // ---- phase A (redundant in every block): the frame's bookkeeping
     if (tid == 0) { s_n_used = 0; s_n_new = 0; s_n_dead = 0; }
@@ -1024,29 +1049,34 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     }
     if (tid < a.gain_total) L.gains[tid] = gain0;
     for (int k = tid + FRAME_THREADS; k < a.gain_total; k += FRAME_THREADS) L.gains[k] = a.gains[k];
-#pragma unroll
-    for (int k = 0; k < SPEC_ROWS; ++k) {
-        const int r = tid + k * FRAME_THREADS;
-        if (r < n) {
-            L.slot[r] = so[k];
-            L.newgone[r] = sg[k];
-            L.arg[r] = (m > 0) ? sa[k] : 0;
-            L.key[r] = (m > 0) ? sk[k] : ~0ull;
+    // row r = tid + 256 k of the old table: from the registers above for k < SPEC_ROWS, from HBM beyond
+    auto row_inputs = [&](int k, int r, int &o_, int &g_, int &a_, unsigned long long &key_) {
+        if (k < SPEC_ROWS) {
+            o_ = k == 0 ? so[0] : k == 1 ? so[1] : so[2];
+            g_ = k == 0 ? sg[0] : k == 1 ? sg[1] : sg[2];
+            a_ = k == 0 ? sa[0] : k == 1 ? sa[1] : sa[2];
+            key_ = k == 0 ? sk[0] : k == 1 ? sk[1] : sk[2];
+        } else if (r < n) {
+            o_ = a.order[r]; g_ = a.gone[r]; a_ = a.row_arg[r];
+            key_ = (unsigned long long)__double_as_longlong(a.row_min[r]);
         }
-    }
-    for (int r = tid + SPEC_ROWS * FRAME_THREADS; r < n; r += FRAME_THREADS) {
-        L.slot[r] = a.order[r];
-        L.newgone[r] = a.gone[r];
-        L.arg[r] = (m > 0) ? a.row_arg[r] : 0;
-        L.key[r] = (m > 0) ? (unsigned long long)__double_as_longlong(a.row_min[r]) : ~0ull;
-    }
+    };
     __syncthreads();
     STAMP(2);
     if (n > 0 && m > 0) {   // winner of a column = proposer with the smallest (distance, row)
-        for (int r = tid; r < n; r += FRAME_THREADS) atomicMin(&L.col_key[L.arg[r]], L.key[r]);
+        for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
+            const int r = r0 + tid;
+            int o_ = 0, g_ = 0, a_ = 0; unsigned long long key_ = 0;
+            row_inputs(r0 / FRAME_THREADS, r, o_, g_, a_, key_);
+            if (r < n) atomicMin(&L.col_key[a_], key_);
+        }
         __syncthreads();
-        for (int r = tid; r < n; r += FRAME_THREADS)
-            if (L.key[r] == L.col_key[L.arg[r]]) atomicMin(&L.col_row[L.arg[r]], r);
+        for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
+            const int r = r0 + tid;
+            int o_ = 0, g_ = 0, a_ = 0; unsigned long long key_ = 0;
+            row_inputs(r0 / FRAME_THREADS, r, o_, g_, a_, key_);
+            if (r < n && key_ == L.col_key[a_]) atomicMin(&L.col_row[a_], r);
+        }
         __syncthreads();
     }
     STAMP(3);
@@ -1057,16 +1087,15 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     int n_keep = 0;
     for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
         const int r = r0 + tid;
+        int o_ = 0, g = 0, c = 0; unsigned long long key_ = 0;
+        row_inputs(r0 / FRAME_THREADS, r, o_, g, c, key_);
         bool mine = false, keep = false;
         if (r < n) {
-            const int c = L.arg[r];
             mine = (m > 0) && (L.col_row[c] == r);
-            L.claim[r] = mine ? c : -1;
-            int g = L.newgone[r];
             if (mine) g = 0;
             else if (age) ++g;
             keep = mine || !age || !((double)g > a.max_gone);
-            L.newgone[r] = g;
+            L.cg[r] = (mine ? c + 1 : 0) | (g << 16);
         }
         used += __popcll(__ballot(mine));
         int total;
@@ -1074,7 +1103,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
         if (keep) L.inv[n_keep + ex] = r;
         if (r < n && !keep && blockIdx.x == 0) {
             const int k = atomicAdd(&s_n_dead, 1);
-            a.free_slots[nfree + k] = L.slot[r];   // entries above n_free are read by nobody this frame
+            a.free_slots[nfree + k] = o_;   // entries above n_free are read by nobody this frame
         }
         n_keep += total;
     }
@@ -1084,6 +1113,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     STAMP(11);
     int n_new = 0;
     if (m > 0 && (n == 0 || n < m)) {   // registration (tracker.py:135-137, 212-217)
+        // (col_key is dead from here on: its space holds `unused` and `newcols`)
         if (n == 0) {
             for (int c = tid; c < m; c += FRAME_THREADS) L.newcols[c] = c;
             n_new = m;
@@ -1124,10 +1154,12 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
         bool fresh_track = false;
         if (i < n_keep) {
             const int r = __builtin_amdgcn_readfirstlane(L.inv[i]);
-            slot = __builtin_amdgcn_readfirstlane(L.slot[r]);
-            gone = L.newgone[r];
-            c = __builtin_amdgcn_readfirstlane(L.claim[r]);
+            const int cg = __builtin_amdgcn_readfirstlane(L.cg[r]);
+            gone = cg >> 16;
+            c = (cg & 0xFFFF) - 1;
+            slot = slot_s;
             if (r != i || slot_s < 0) {   // a deregistration ahead of this row moved it: fetch for real
+                slot = __builtin_amdgcn_readfirstlane(a.order[r]);
                 if (a.use_gsff) gsff_fetch(a, slot, lane, S);
                 zs0 = a.pos[slot]; zs1 = a.pos[cap + slot];
                 id_s = a.id[slot];
@@ -1189,10 +1221,13 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
         STAMP(8);
     }
     BSTAMP(2);
+#ifdef YSMR_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) RING((3ull << 40) | (unsigned)frame);
+#endif
     // ---- block 0 publishes the counters of the new state
     if (blockIdx.x == 0) {
         if (claim_out)
-            for (int r = tid; r < n; r += FRAME_THREADS) claim_out[r] = L.claim[r];
+            for (int r = tid; r < n; r += FRAME_THREADS) claim_out[r] = (L.cg[r] & 0xFFFF) - 1;
         if (new_cols_out)
             for (int j = tid; j < n_new; j += FRAME_THREADS) new_cols_out[j] = L.newcols[j];
         __syncthreads();
@@ -1213,6 +1248,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
 // row_base of the current state := the caller's running row count (start of ysmr_tracker_run)
 __global__ void k_set_row_base(TrackerDev t, const long long *row_count_ext)
 {
+    RING(1ull << 40);
     t.row_base[0] = row_count_ext ? *row_count_ext : 0;
 }
 
@@ -1412,7 +1448,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     t->par = 0;
     t->frame_lds = frame_lds_bytes(capacity, max_det, (int)gain_doubles);
     const char *mode_env = getenv("YSMR_LINK_MODE");   // "split" forces the two-kernel path (tests)
-    t->fused = t->frame_lds <= 150 * 1024 && !(mode_env && !strcmp(mode_env, "split"));
+    t->fused = t->frame_lds <= 150 * 1024 && max_det < 65535 && !(mode_env && !strcmp(mode_env, "split"));
     if (t->fused) {
         const void *variants[4] = {(const void *)k_frame<float, 3>, (const void *)k_frame<double, 3>,
                                    (const void *)k_frame<float, YSMR_MAX_FILTERS>, (const void *)k_frame<double, YSMR_MAX_FILTERS>};

@@ -74,6 +74,8 @@ class Detector:
         if ws == 0:
             raise ValueError("invalid detector geometry")
         self._ws = torch.empty(ws, dtype=torch.uint8, device=self.device)
+        # the workspace remembers what the previous call wrote into labels/mask: start it blank
+        _lib.check(L.ysmr_detect_workspace_init(_lib.stream_ptr(), self._ws.data_ptr(), ws), "ysmr_detect_workspace_init")
         self._cls = _padded(n, self.device)
         self._mask = _padded(n, self.device) if want_mask else None
         self._labels = torch.empty((n + 3) // 4 * 4, dtype=torch.int32, device=self.device)
