@@ -578,73 +578,94 @@ __global__ void k_list_begin(PixelList pl)
 // Pass A0 (dense, HBM-bound: 1 B/px read): list the pixels that hold any class bit.  Each block
 // gathers its finds in LDS and publishes them with ONE global atomicAdd (a single hot counter
 // serves only ~90 atomics/us on this chip).
-constexpr int COLLECT_BLOCKS = 512;
-constexpr int COLLECT_LDS = 8192;  // entries buffered per block before a flush (a round adds <= 4096)
+constexpr int COLLECT_BLOCKS = 1024;
+constexpr int COLLECT_WAVE_BUF = 1280;  // entries buffered per wave before a flush (a round adds <= 1024)
 
 __global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls, uint32_t *__restrict__ labels, Geo g,
                                                  size_t nchunks, PixelList pl)
 {
-    __shared__ uint32_t s_buf[COLLECT_LDS];
-    __shared__ uint32_t s_n, s_base;
+    // one buffer per wave: nothing in this kernel needs a block barrier
+    __shared__ uint32_t s_buf[4][COLLECT_WAVE_BUF];
     const int lane = threadIdx.x & 63;
+    uint32_t *buf = s_buf[threadIdx.x >> 6];
     const unsigned long long below = (1ull << lane) - 1ull;
     const size_t stride = (size_t)gridDim.x * 256;
-    const size_t rounds = (nchunks + stride - 1) / stride;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (size_t r = 0; r < rounds; ++r, c += stride) {
-        uint32_t bits = 0;   // bit i: pixel i of this lane's chunk carries a class bit
-        if (c < nchunks) {
-            const uint4 v = load_chunk(cls, c, g.total);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    constexpr int U = 4;   // chunks in flight per lane: the pass is a pure HBM stream, it needs the bytes in flight
+    const size_t rounds = (nchunks + stride * U - 1) / (stride * U);
+    const uint32_t cur = pl.hdr->cur & 1u;
+    uint32_t n = 0;   // entries in this wave's buffer (wave-uniform)
+    size_t c0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t r = 0; r < rounds; ++r, c0 += stride * U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t c = c0 + (size_t)u * stride;
+            v[u] = c < nchunks ? load_chunk(cls, c, g.total) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t c = c0 + (size_t)u * stride;
+            uint32_t bits = 0;   // bit i: pixel i of this lane's chunk carries a class bit
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 uint32_t t = w[k] & 0x03030303u;
                 t = (t | (t >> 1)) & 0x01010101u;                      // one flag bit per byte
                 bits |= ((t * 0x00204081u >> 21) & 0xFu) << (4 * k);  // gather bits 0, 8, 16, 24 -> a nibble
             }
-        }
-        const uint32_t cnt = __popc(bits);
-        if (__ballot(cnt != 0)) {
-            // exclusive prefix of cnt (<= 16) over the lanes from five ballots, one per bit of cnt
-            uint32_t before = 0, total = 0;
+            const uint32_t cnt = __popc(bits);
+            if (__ballot(cnt != 0)) {
+                // exclusive prefix of cnt (<= 16) over the lanes from five ballots, one per bit of cnt
+                uint32_t before = 0, total = 0;
 #pragma unroll
-            for (int b = 0; b < 5; ++b) {
-                const unsigned long long m = __ballot((cnt >> b) & 1u);
-                before += (uint32_t)__popcll(m & below) << b;
-                total += (uint32_t)__popcll(m) << b;
+                for (int b = 0; b < 5; ++b) {
+                    const unsigned long long m = __ballot((cnt >> b) & 1u);
+                    before += (uint32_t)__popcll(m & below) << b;
+                    total += (uint32_t)__popcll(m) << b;
+                }
+                uint32_t at = n + before;
+                n += total;
+                uint32_t rest = bits;
+                const uint32_t first = (uint32_t)(c * 16);
+                const uint32_t frame_start = rest ? first / g.HW * g.HW : 0;   // (a chunk may straddle two frames)
+                while (rest) {   // a chunk's pixels stay adjacent in the list: adjacent lanes, adjacent pixels later
+                    const int i = __ffs(rest) - 1;
+                    rest &= rest - 1;
+                    const uint32_t flat = first + i;
+                    buf[at++] = flat;
+                    // every listed pixel starts as its own root (the label map was cleared beforehand)
+                    uint32_t p = flat - frame_start;
+                    if (p >= g.HW) p -= g.HW;
+                    labels[flat] = p + 1u;
+                }
             }
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_n, total);
-            base = __builtin_amdgcn_readfirstlane(base) + before;
-            uint32_t rest = bits;
-            const uint32_t first = (uint32_t)(c * 16);
-            const uint32_t frame_start = rest ? first / g.HW * g.HW : 0;   // (a chunk may straddle two frames)
-            while (rest) {   // a chunk's pixels stay adjacent in the list: adjacent lanes, adjacent pixels later
-                const int i = __ffs(rest) - 1;
-                rest &= rest - 1;
-                const uint32_t flat = first + i;
-                s_buf[base++] = flat;
-                // every listed pixel starts as its own root (the label map was cleared by a memset)
-                uint32_t p = flat - frame_start;
-                if (p >= g.HW) p -= g.HW;
-                labels[flat] = p + 1u;
+            // mid-stream flush when the next chunk could overflow the buffer (wave-uniform; rare: the
+            // foreground would have to exceed a quarter of this wave's share of the batch)
+            if (n + 1024 > COLLECT_WAVE_BUF) {
+                __threadfence_block();   // this wave's LDS writes before its LDS reads
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&pl.hdr->count[cur], n);
+                base = __builtin_amdgcn_readfirstlane(base);
+                for (uint32_t i = lane; i < n; i += 64)
+                    if ((size_t)base + i < pl.cap) pl.idx[cur][base + i] = buf[i];
+                __threadfence_block();
+                n = 0;
             }
-        }
-        // flush when the next round could overflow the buffer (block-uniform decision)
-        __syncthreads();
-        const uint32_t n = s_n;
-        if (n + 4096 > COLLECT_LDS || r + 1 == rounds) {
-            if (threadIdx.x == 0) { s_base = n ? atomicAdd(&pl.hdr->count[pl.hdr->cur & 1u], n) : 0; }
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += 256)
-                if ((size_t)s_base + i < pl.cap) pl.idx[pl.hdr->cur & 1u][s_base + i] = s_buf[i];
-            __syncthreads();
-            if (threadIdx.x == 0) s_n = 0;
-            __syncthreads();
         }
     }
+    // final flush: ONE global atomic per block (a single hot counter serves only ~90 atomics/us)
+    __shared__ uint32_t s_cnt[4], s_base;
+    if (lane == 0) s_cnt[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t all = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = all ? atomicAdd(&pl.hdr->count[cur], all) : 0;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_cnt[w];
+    for (uint32_t i = lane; i < n; i += 64)
+        if ((size_t)base + i < pl.cap) pl.idx[cur][base + i] = buf[i];
 }
 
 // Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
@@ -1284,7 +1305,7 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
 // Resident grid.  Work items are (block of GEO_COMPS ranks, frame), frame fastest: the populated
 // ranks come first in every frame, so the live items are spread evenly over the blocks and the
 // loop stops at the largest component count of the batch (t.max_roots, from k_rank).
-constexpr int GEO_BLOCKS = 512;
+constexpr int GEO_BLOCKS = 1536;
 __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__restrict__ labels, Geo g, CompTables t,
                                                           int batch, float *det_tmp, float *arena,
                                                           uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
