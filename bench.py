@@ -147,6 +147,9 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        which = {(1228, 922, 500): "BASELINE configs[2], the configuration the metric is quoted on",
+                 (1228, 922, 50): "BASELINE configs[0] geometry", (3840, 2160, 5000): "BASELINE configs[4]"}.get(
+                     (W, H, args.blobs), "custom geometry")
         out = {
             "metric": "frames/sec detect+link, 1228x922 ~500 blobs, 1/2/4/8 GPU; HBM GB/s %peak",
             "value": world * F * args.steps / elapsed,
@@ -160,7 +163,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8 image / f32 threshold+geometry / f64 link",
             "data": "synthetic",
-            "config": {"workload": f"{W}x{H} stream, ~{args.blobs} blobs, detect+link end to end (BASELINE configs[2])",
+            "config": {"workload": f"{W}x{H} stream, ~{args.blobs} blobs, detect+link end to end ({which})",
                        "frames_per_step": F, "detect_batch": B, "streams": world, "parallelism": f"1 stream/GPU x{world}",
                        "rows_per_step": n_rows, "tracks_alive": n_tracks, "ids_issued": next_id},
             "roofline": {"kernel": "k_threshold", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
