@@ -508,7 +508,7 @@ struct PixelList {
     uint32_t cap;      // entries each list can hold
 };
 
-constexpr int SPARSE_BLOCKS = 1536;  // resident grid of the list-driven passes (grid-stride over the list)
+constexpr int SPARSE_BLOCKS = 768;  // resident grid of the list-driven passes (grid-stride over the list)
 
 // The passes are bound by chains of dependent L2 round trips (union-find), so they want many
 // short threads: one lane per pixel, grid-stride.
@@ -1500,13 +1500,17 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     const unsigned cgrid = (unsigned)((nchunks + 255) / 256);
     uint32_t *labels = reinterpret_cast<uint32_t *>(labels_dev);
 
+    unsigned collect_blocks = COLLECT_BLOCKS, sparse_blocks = SPARSE_BLOCKS, clear_blocks = CLEAR_BLOCKS;
+    if (const char *e = getenv("YSMR_COLLECT_BLOCKS")) collect_blocks = (unsigned)atoi(e);   // tuning knobs
+    if (const char *e = getenv("YSMR_SPARSE_BLOCKS")) sparse_blocks = (unsigned)atoi(e);
+    if (const char *e = getenv("YSMR_CLEAR_BLOCKS")) clear_blocks = (unsigned)atoi(e);
     YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 8), st));
     YSMR_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t) * batch, st));
-    hipLaunchKernelGGL(k_clear, dim3(CLEAR_BLOCKS), dim3(256), 0, st, w.pixels, reinterpret_cast<uint8_t *>(labels), mask_dev,
+    hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, st, w.pixels, reinterpret_cast<uint8_t *>(labels), mask_dev,
                        g.total);
     hipLaunchKernelGGL(k_list_begin, dim3(1), dim3(1), 0, st, w.pixels);
-    const unsigned dense_grid = cgrid < (unsigned)COLLECT_BLOCKS ? cgrid : (unsigned)COLLECT_BLOCKS;
-    const dim3 sg(SPARSE_BLOCKS), tb(256);
+    const unsigned dense_grid = cgrid < collect_blocks ? cgrid : collect_blocks;
+    const dim3 sg(sparse_blocks), tb(256);
     hipLaunchKernelGGL(k_collect, dim3(dense_grid), tb, 0, st, cls_dev, labels, g, nchunks, w.pixels);
     hipLaunchKernelGGL(k_union4, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
     hipLaunchKernelGGL(k_flag, sg, tb, 0, st, cls_dev, labels, g, w.pixels);

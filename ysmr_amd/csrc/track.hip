@@ -970,6 +970,9 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
 {
     extern __shared__ unsigned long long s_raw[];
     __shared__ int s_n_used, s_n_new, s_n_dead;
+    // the link is a chain of short latency-bound kernels sharing SIMDs with throughput kernels of the
+    // detection stream: let its waves win the issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cap = a.capacity, md = a.max_det;
     STAMP(0); BSTAMP(0);
