@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--blobs", type=int, default=500)
     ap.add_argument("--max-det", type=int, default=2048)
     ap.add_argument("--capacity", type=int, default=2048)
+    ap.add_argument("--channels", type=int, default=1, choices=(1, 3),
+                    help="1: gray frames (the metric's configuration); 3: the same frames as BGR (B=G=R), which adds a1")
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames of the clip timed on the CPU oracle (0 = skip)")
     return ap.parse_args()
 
@@ -90,6 +92,8 @@ def main():
     video = SyntheticVideo(H, W, args.blobs, seed=rank, fps=fps_video)
     frames_np = video.frames(F)                      # one independent stream per rank
     frames = torch.from_numpy(frames_np).to(dev)     # resident in HBM before the timed region
+    if args.channels == 3:
+        frames = frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
 
     settings = default_settings()                    # tracking.ini defaults: offset 5, adt 2.0, GSFF 10/20/30
     pipe = TrackingPipeline(H, W, fps_video, settings, batch=B, max_det=args.max_det, capacity=args.capacity,
@@ -134,8 +138,8 @@ def main():
         ms = [e0.elapsed_time(e1) for e0, e1, _ in thr_events]
         px = [b * H * W for _, _, b in thr_events]
         # algorithmic bytes of the fused threshold kernel: 1 B/px read + 1 B/px class map written
-        # (SURVEY 8d), per launch of `batch` frames
-        alg_bytes = 2.0 * sum(px) / len(px)
+        # (3 B/px read for BGR input), per launch of `batch` frames
+        alg_bytes = (1.0 + args.channels) * sum(px) / len(px)
         avg_ms = sum(ms) / len(ms)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -164,7 +168,7 @@ def main():
             "dtype": "u8 image / f32 threshold+geometry / f64 link",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} stream, ~{args.blobs} blobs, detect+link end to end ({which})",
-                       "frames_per_step": F, "detect_batch": B, "streams": world, "parallelism": f"1 stream/GPU x{world}",
+                       "frames_per_step": F, "detect_batch": B, "channels": args.channels, "streams": world, "parallelism": f"1 stream/GPU x{world}",
                        "rows_per_step": n_rows, "tracks_alive": n_tracks, "ids_issued": next_id},
             "roofline": {"kernel": "k_threshold", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -7,6 +7,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=512); ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--height", type=int, default=922); ap.add_argument("--width", type=int, default=1228)
 ap.add_argument("--reps", type=int, default=3); ap.add_argument("--real", action="store_true")
+ap.add_argument("--bgr", action="store_true", help="3-channel input (gray replicated)")
 a = ap.parse_args()
 H, W, B, F = a.height, a.width, a.batch, a.frames
 if a.real:
@@ -15,6 +16,8 @@ if a.real:
 else:  # background-like noise (40 +- 2), enough for timing
     g = torch.Generator(device="cuda").manual_seed(0)
     frames = (torch.randn(F, H, W, device="cuda", generator=g) * 2 + 40).round().clamp(0, 255).to(torch.uint8)
+if a.bgr:
+    frames = frames[:F // 2].unsqueeze(-1).expand(-1, -1, -1, 3).contiguous(); F = F // 2
 det = Detector(B, H, W, max_det=2048)
 for f0 in range(0, F, B): det.threshold(frames[f0:f0 + B])
 torch.cuda.synchronize()
@@ -25,6 +28,6 @@ for _ in range(a.reps):
         e0.record(); det.threshold(frames[f0:f0 + B]); e1.record(); ts.append((e0, e1))
 torch.cuda.synchronize()
 ms = np.array([x.elapsed_time(y) for x, y in ts])
-alg = 2.0 * B * H * W
+alg = (4.0 if a.bgr else 2.0) * B * H * W
 print(f"threshold {W}x{H} batch {B}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
       f"{alg/np.median(ms)/1e6:.0f} GB/s algorithmic = {alg/np.median(ms)/1e6/8000:.3f} of 8 TB/s")

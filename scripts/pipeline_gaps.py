@@ -1,5 +1,5 @@
 """Batch-boundary gaps and k_frame duration histogram from a rocprofv3 kernel trace of bench.py."""
-import csv, glob, sys, statistics as st, collections
+import csv, glob, re, sys, statistics as st, collections
 f = sorted(glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 kf = [(int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows if 'k_frame' in r['Kernel_Name']]
@@ -13,11 +13,11 @@ print("timed span %.2f ms: k_frame %.2f ms, small gaps %.2f ms, %d big gaps %.2f
 h = collections.Counter(min(int(d/4000)*4, 60) for d in durs[k0:])
 print("dur histogram (us bucket: count):", sorted(h.items()))
 # what runs on the other queue during slow k_frames
-slow = [(s,e) for s,e in kf[k0:] if e-s > 16000]
+slow = [(s,e) for s,e in kf[k0:] if e-s > 20000]
 names = collections.Counter()
 for s,e in slow:
     for r in rows:
         if 'k_frame' in r['Kernel_Name']: continue
         rs, re_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-        if rs < e and re_ > s: names[r['Kernel_Name'].split('(')[0][-28:]] += 1
-print("kernels overlapping slow k_frames:", names.most_common(8))
+        if rs < e and re_ > s: m_ = re.search(r'(k_\w+|fillBuffer\w*|copyBuffer)', r['Kernel_Name']); names[m_.group(1) if m_ else r['Kernel_Name'][:30]] += 1
+print("kernels overlapping slow k_frames (> 20 us):", len(slow), names.most_common(12))

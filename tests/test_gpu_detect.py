@@ -66,12 +66,17 @@ def test_threshold_only_matches_oracle(torch_cuda, oracle):
                 np.testing.assert_array_equal(cls[f], ref, err_msg=f"{h}x{w} {args} frame {f}")
 
 
-def test_threshold_bgr(torch_cuda, oracle):
+@pytest.mark.parametrize("h,w", [(70, 90), (70, 92), (130, 1228), (61, 16)])
+def test_threshold_bgr(torch_cuda, oracle, h, w):
+    """a1: BGR input (what cv2.VideoCapture delivers).  W % 4 == 0 takes the strip kernel (several
+    strips at 1228), other widths the tile kernel; colours are random so the fixed-point weights matter."""
     from ysmr_amd.detect import Detector
     torch = torch_cuda
     rng = np.random.default_rng(1)
-    frames = rng.integers(0, 256, (2, 70, 90, 3), dtype=np.uint8)
-    d = Detector(2, 70, 90, max_det=64)
+    frames = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    frames[1, :, :, :] = (frames[1, :, :, :1] // 3 + 30)       # low-contrast gray-ish frame: thresholds bite
+    frames[1, ::7, ::5, 1] = 255
+    d = Detector(2, h, w, max_det=64)
     cls = d.threshold(torch.from_numpy(frames).cuda()).cpu().numpy()
     for f in range(2):
         blur = oracle.blur3(oracle.bgr2gray(frames[f]))

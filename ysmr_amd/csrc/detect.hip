@@ -192,10 +192,34 @@ struct StripCtx {
     float *xrow;             // this wave's LDS exchange row (with 8 floats of slack on each side)
 };
 
-// gray dword of `row` for this lane (lanes outside the image load a clamped, valid address)
-__device__ __forceinline__ uint32_t load_row(const StripCtx &c, int row)
+// The 4 pixels of `row` held by this lane, as loaded (lanes outside the image load a clamped, valid
+// address).  Gray input: one dword.  BGR input: three dwords, turned into the gray dword only when
+// the row is consumed (converting at load time would wait for the load right behind its issue).
+template <int CH> struct RawRow;
+template <> struct RawRow<1> { uint32_t w0; };
+template <> struct RawRow<3> { uint32_t w0, w1, w2; };
+
+template <int CH>
+__device__ __forceinline__ RawRow<CH> load_row(const StripCtx &c, int row)
 {
-    return load_u32_unaligned(c.src + ((uint32_t)row * (uint32_t)c.W + c.ld_col));
+    const uint8_t *p = c.src + ((size_t)((uint32_t)row * (uint32_t)c.W + c.ld_col)) * CH;
+    RawRow<CH> r;
+    r.w0 = load_u32_unaligned(p);
+    if constexpr (CH == 3) { r.w1 = load_u32_unaligned(p + 4); r.w2 = load_u32_unaligned(p + 8); }
+    return r;
+}
+__device__ __forceinline__ uint32_t bgr2gray15(uint32_t b, uint32_t g, uint32_t r)
+{
+    return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15;   // cv2 COLOR_BGR2GRAY, 15-bit fixed point (a1)
+}
+__device__ __forceinline__ uint32_t gray_of(const RawRow<1> &r) { return r.w0; }
+__device__ __forceinline__ uint32_t gray_of(const RawRow<3> &r)
+{
+    const uint32_t g0 = bgr2gray15(r.w0 & 0xFFu, (r.w0 >> 8) & 0xFFu, (r.w0 >> 16) & 0xFFu);
+    const uint32_t g1 = bgr2gray15(r.w0 >> 24, r.w1 & 0xFFu, (r.w1 >> 8) & 0xFFu);
+    const uint32_t g2 = bgr2gray15((r.w1 >> 16) & 0xFFu, r.w1 >> 24, r.w2 & 0xFFu);
+    const uint32_t g3 = bgr2gray15((r.w2 >> 8) & 0xFFu, (r.w2 >> 16) & 0xFFu, r.w2 >> 24);
+    return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
 }
 
 // XEDGE: the single out-of-image byte that matters -- the REFLECT_101 neighbour of the first/last
@@ -220,7 +244,7 @@ __device__ __forceinline__ uint32_t patch_row(const StripCtx &c, uint32_t g)
 // One strip.  XEDGE: the strip touches the left/right image border.  YEDGE: the segment's halo
 // leaves the image at the top/bottom (rows are clamped/reflected and the 3-row window may have to
 // be reloaded); interior segments slide unconditionally.
-template <bool XEDGE, bool YEDGE>
+template <int CH, bool XEDGE, bool YEDGE>
 __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
 {
     const int H = c.H, W = c.W, lane = c.lane;
@@ -234,18 +258,18 @@ __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
     const int rb_lo = c.y0 - 5, rb_hi = c.y1 - 1 + 5;
     HSum hu, hc, hd;
     int ic, id;
-    uint32_t gq[STRIP_PF];
+    RawRow<CH> gq[STRIP_PF];
     {   // prologue: window for the first blurred row, and the rows in flight
         const int rbc = YEDGE ? clampi(rb_lo, 0, H - 1) : rb_lo;
         const int ru = YEDGE ? reflect101(rbc - 1, H) : rbc - 1;
-        hc = hsum4(patch_row<XEDGE>(c, load_row(c, ru)));      // becomes hu after the first slide
-        hd = hsum4(patch_row<XEDGE>(c, load_row(c, rbc)));     // becomes hc
+        hc = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, ru))));      // becomes hu after the first slide
+        hd = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, rbc))));     // becomes hc
         hu = hc;
         ic = ru; id = rbc;
 #pragma unroll
         for (int d = 0; d < STRIP_PF; ++d) {
             const int r = YEDGE ? reflect101(clampi(rb_lo + d, 0, H - 1) + 1, H) : rb_lo + d + 1;
-            gq[d] = load_row(c, r);
+            gq[d] = load_row<CH>(c, r);
         }
     }
     for (int rb0 = rb_lo; rb0 <= rb_hi; rb0 += 11) {
@@ -259,23 +283,23 @@ __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
                 const int ru = reflect101(rbc - 1, H), rd = reflect101(rbc + 1, H);
                 if (ic == ru && id == rbc) {          // steady state: slide down one row
                     hu = hc; hc = hd; ic = id;
-                    hd = hsum4(patch_row<XEDGE>(c, gq[0]));
+                    hd = hsum4(patch_row<XEDGE>(c, gray_of(gq[0])));
                 } else {                              // border rows: rebuild the window
-                    hu = hsum4(patch_row<XEDGE>(c, load_row(c, ru)));
-                    hc = hsum4(patch_row<XEDGE>(c, load_row(c, rbc)));
-                    hd = hsum4(patch_row<XEDGE>(c, load_row(c, rd)));
+                    hu = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, ru))));
+                    hc = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, rbc))));
+                    hd = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, rd))));
                     ic = rbc;
                 }
                 id = rd;
 #pragma unroll
                 for (int d = 0; d + 1 < STRIP_PF; ++d) gq[d] = gq[d + 1];
-                gq[STRIP_PF - 1] = load_row(c, reflect101(clampi(rb + STRIP_PF, 0, H - 1) + 1, H));
+                gq[STRIP_PF - 1] = load_row<CH>(c, reflect101(clampi(rb + STRIP_PF, 0, H - 1) + 1, H));
             } else {
                 hu = hc; hc = hd;
-                hd = hsum4(patch_row<XEDGE>(c, gq[0]));
+                hd = hsum4(patch_row<XEDGE>(c, gray_of(gq[0])));
 #pragma unroll
                 for (int d = 0; d + 1 < STRIP_PF; ++d) gq[d] = gq[d + 1];
-                gq[STRIP_PF - 1] = load_row(c, rb + STRIP_PF + 1);
+                gq[STRIP_PF - 1] = load_row<CH>(c, rb + STRIP_PF + 1);
             }
             uint32_t b = vblur4(hu, hc, hd);
             if (XEDGE) {
@@ -352,7 +376,10 @@ __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
 }
 
 // Requires W % 4 == 0 and W >= 16 (else the tile kernel above is used).
-__global__ __launch_bounds__(256, 4) void k_threshold_strip(const uint8_t *__restrict__ frames,
+// (gray: 128 VGPRs, so that three resident blocks per CU leave a fourth of each SIMD's registers to
+// the link kernel's waves; the BGR variant needs ~150 and runs two blocks per CU for the same reason)
+template <int CH>
+__global__ __launch_bounds__(256, CH == 1 ? 4 : 3) void k_threshold_strip(const uint8_t *__restrict__ frames,
                                                          uint8_t *__restrict__ cls, StripParams P, Gauss11 gk)
 {
 #if STRIP_LDS_EXCHANGE
@@ -380,7 +407,7 @@ __global__ __launch_bounds__(256, 4) void k_threshold_strip(const uint8_t *__res
     c.c0 = xs - 4 * STRIP_HALO_LANES + 4 * lane;
     c.y0 = sy * P.seg_h;
     c.y1 = min(c.y0 + P.seg_h, P.H);
-    c.src = frames + (size_t)f * P.H * P.W;
+    c.src = frames + (size_t)f * P.H * P.W * CH;
     c.dst = cls + (size_t)f * P.H * P.W;
     c.ld_col = (uint32_t)clampi(c.c0, 0, P.W - 4);
     c.left_edge = (xs == 0);
@@ -395,9 +422,9 @@ __global__ __launch_bounds__(256, 4) void k_threshold_strip(const uint8_t *__res
     const bool xedge = c.left_edge || c.right_edge;
     const bool yedge = (c.y0 - 6 < 0) || (c.y1 + 5 + STRIP_PF + 1 >= P.H);
     if (xedge) {
-        if (yedge) strip_body<true, true>(c, gk); else strip_body<true, false>(c, gk);
+        if (yedge) strip_body<CH, true, true>(c, gk); else strip_body<CH, true, false>(c, gk);
     } else {
-        if (yedge) strip_body<false, true>(c, gk); else strip_body<false, false>(c, gk);
+        if (yedge) strip_body<CH, false, true>(c, gk); else strip_body<CH, false, false>(c, gk);
     }
     }
 }
@@ -1428,8 +1455,7 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
                      int t_high, int use_high, uint8_t *cls)
 {
     Gauss11 gk = make_gauss11();
-    if (channels == 1 && (W & 3) == 0 && W >= 16 && H >= 2 && t_low > -100000 && t_low < 100000 && t_high > -100000 &&
-        t_high < 100000) {
+    if ((W & 3) == 0 && W >= 16 && H >= 2 && t_low > -100000 && t_low < 100000 && t_high > -100000 && t_high < 100000) {
         StripParams P;
         P.H = H; P.W = W; P.batch = batch;
         const int quads = (W + 3) / 4;
@@ -1441,10 +1467,11 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
         P.inv = inv; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
         const long long waves = (long long)batch * P.strips_x * P.segs_y;
         long long blocks = (waves + 3) / 4;
-        int resident = 768;   // 3 blocks per CU: leaves a wave slot and 128 VGPRs per SIMD to other streams
+        int resident = channels == 1 ? 768 : 512;   // 3 (gray) / 2 (BGR) blocks per CU: leaves a wave slot and >= 128 VGPRs per SIMD to other streams
         if (const char *e = getenv("YSMR_THR_BLOCKS")) resident = atoi(e);
         if (resident > 0 && blocks > resident) blocks = resident;
-        hipLaunchKernelGGL(k_threshold_strip, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
+        if (channels == 1) hipLaunchKernelGGL(k_threshold_strip<1>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
+        else hipLaunchKernelGGL(k_threshold_strip<3>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
     } else {
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, batch);
         if (channels == 1)
@@ -1504,6 +1531,8 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     if (const char *e = getenv("YSMR_COLLECT_BLOCKS")) collect_blocks = (unsigned)atoi(e);   // tuning knobs
     if (const char *e = getenv("YSMR_SPARSE_BLOCKS")) sparse_blocks = (unsigned)atoi(e);
     if (const char *e = getenv("YSMR_CLEAR_BLOCKS")) clear_blocks = (unsigned)atoi(e);
+    unsigned geo_blocks = GEO_BLOCKS;
+    if (const char *e = getenv("YSMR_GEO_BLOCKS")) geo_blocks = (unsigned)atoi(e);
     YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 8), st));
     YSMR_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t) * batch, st));
     hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, st, w.pixels, reinterpret_cast<uint8_t *>(labels), mask_dev,
@@ -1526,7 +1555,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     hipLaunchKernelGGL(k_nested, dim3(NEST_BLOCKS), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
                        w.arena_floats, w.arena_used, status_dev);
     YSMR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_geometry, dim3(GEO_BLOCKS), dim3(GEO_THREADS), 0, st,
+    hipLaunchKernelGGL(k_geometry, dim3(geo_blocks), dim3(GEO_THREADS), 0, st,
                        labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
     hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev);
     hipLaunchKernelGGL(k_list_end, dim3(1), dim3(1), 0, st, w.pixels, reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total);
