@@ -159,6 +159,34 @@ int ysmr_tracker_peek(ysmr_tracker *t, void *stream, int32_t *ids_dev, double *x
 int ysmr_tracker_info(ysmr_tracker *t, void *stream, int32_t *n_tracks, int32_t *next_id,
                       int32_t *error_bits);
 
+/* ---- output: a19, f2 --------------------------------------------------------------------- */
+
+/* Order rows by (TRACK_ID, POSITION_T): what sort_list does to the csv after tracking
+ * (helper_file.py:1538-1574, called at track_eval.py:393).  rows_dev and sorted_dev are distinct
+ * device arrays of n_rows rows; (track_id, frame) pairs are unique, so the order is total. */
+size_t ysmr_rows_sort_workspace_bytes(long long n_rows);
+int    ysmr_rows_sort(void *stream, const ysmr_row *rows_dev, long long n_rows, void *workspace_dev,
+                      size_t workspace_bytes, ysmr_row *sorted_dev);
+
+/* HOST function (no GPU involved): the csv text of `rows_host` exactly as the reference's final
+ * file has it -- header of save_list (helper_file.py:1451), one line per row, numbers printed the
+ * way DataFrame.to_csv prints uint32 / float64 columns (shortest repr; WIDTH, HEIGHT and
+ * DEGREES_ANGLE are the float32 values widened to float64, 0.0 for disappeared tracks;
+ * helper_file.py:1366-1400, 881-889).  out_capacity >= ysmr_rows_csv_bound(n_rows, with_header);
+ * threads <= 0: one per hardware thread. */
+size_t ysmr_rows_csv_bound(long long n_rows, int with_header);
+int    ysmr_rows_format_csv(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas,
+                            int threads, char *out, size_t out_capacity, size_t *out_length);
+
+/* HOST function: the seven DataFrame columns (dtypes of helper_file.py:881-889).
+ * via_pandas (here and above): the reference does not keep the tracker's float64 values, it prints
+ * them and reads the text back with pandas.read_csv (helper_file.py:860-905), whose default float
+ * converter returns about one value in five 1 ulp off.  via_pandas = 1 applies that same text ->
+ * double conversion (restated from pandas' precise_xstrtod), so that the DataFrame and the csv equal
+ * the reference's; via_pandas = 0 keeps the exact values. */
+int    ysmr_rows_columns(const ysmr_row *rows_host, long long n_rows, int via_pandas, uint32_t *track_id,
+                         uint32_t *t, double *x, double *y, double *w, double *h, double *angle);
+
 #ifdef __cplusplus
 }
 #endif

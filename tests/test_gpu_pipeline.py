@@ -109,3 +109,52 @@ def test_4k_dense_field_config(oracle):
     np.testing.assert_array_equal(res.det[0, :fd.count, :4].cpu().numpy(), fd.det[:, :4])
     ref_rows, _ = oracle.track_frames(frames, fps=30.0, max_det=8192)
     compare_rows(rows_to_numpy(rows, int(count.item())), ref_rows)
+
+
+def test_rows_sort_on_device():
+    """ysmr_rows_sort: (TRACK_ID, POSITION_T) order, the key of sort_list (helper_file.py:1538-1574)."""
+    import torch
+    from ysmr_amd import _lib
+    from ysmr_amd.tracker import rows_to_numpy, sort_rows
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 5000, 300001):
+        rows = np.zeros(n, _lib.ROW_DTYPE)
+        perm = rng.permutation(n)
+        rows["track_id"], rows["frame"] = perm % 977, perm // 977          # unique pairs
+        rows["x"] = rng.uniform(0, 1000, n)
+        rows["w"] = rng.uniform(0, 10, n).astype(np.float32)
+        dev = torch.from_numpy(rows.view(np.uint8)).cuda()
+        got = rows_to_numpy(sort_rows(dev, n), n)
+        ref = rows[np.lexsort((rows["frame"], rows["track_id"]))]
+        assert got.tobytes() == ref.tobytes()
+
+
+def test_track_bacteria_output_equals_the_reference_detour(tmp_path):
+    """a19 + f2: the csv and the DataFrame of track_bacteria against what the reference's own
+    sequence -- append Python-formatted rows, pandas.read_csv, sort_values, to_csv
+    (track_eval.py:313-316, 340-346, 393; helper_file.py:1538-1574) -- makes of the same rows."""
+    import pandas as pd
+    import torch
+    from ysmr_amd.helper_file import rows_to_csv_text, sort_list
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import TrackingPipeline, track_bacteria
+    frames = SyntheticVideo(208, 272, 30, seed=23, dropout=0.05, speckle=0.05).frames(64)
+    path = tmp_path / "clip.npy"
+    np.save(path, frames)
+    res = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16, max_det=256, capacity=256)
+    assert res is not None
+    df, _, _, _, csv_path = res
+    # the same rows in emission order, then the reference's detour on the host
+    pipe = TrackingPipeline(208, 272, 30.0, _settings(), batch=16, max_det=256, capacity=256, rows_per_flush=64 * 256)
+    dev = torch.from_numpy(frames).cuda()
+    for f0 in range(0, 64, 16):
+        slot, r, ready = pipe.detect_async(dev[f0:f0 + 16])
+        pipe.link(slot, r, ready, f0)
+    rows = pipe.take_rows()
+    ref_path = tmp_path / "ref_list.csv"
+    with open(ref_path, "w", newline="") as fh:
+        fh.write("TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE\n")
+        fh.write(rows_to_csv_text(rows))
+    df_ref = sort_list(file_path=str(ref_path), save_file=True)
+    pd.testing.assert_frame_equal(df, df_ref, check_exact=True)
+    assert open(csv_path, "rb").read() == ref_path.read_bytes()

@@ -136,3 +136,108 @@ def test_stream_sharding_world_size_2_gloo(tmp_path):
     r1 = (tmp_path / "r1.txt").read_text().split(";")
     assert r0[0] == "video0,video2,video4" and r1[0] == "video1,video3"
     assert float(r0[1]) == float(r1[1]) == 2.0
+
+
+# ---- a19 / f2: the csv the reference ends up with ------------------------------------------------------
+
+def _random_rows(n, seed):
+    from ysmr_amd import _lib
+    rng = np.random.default_rng(seed)
+    rows = np.zeros(n, dtype=_lib.ROW_DTYPE)
+    rows["frame"] = rng.integers(0, 100000, n)
+    rows["track_id"] = rng.integers(0, 5000, n)
+    rows["x"] = rng.uniform(-5, 1300, n)
+    rows["y"] = rng.uniform(-5, 1000, n)
+    rows["w"] = rng.uniform(0, 40, n).astype(np.float32)
+    rows["h"] = rng.uniform(0, 40, n).astype(np.float32)
+    rows["angle"] = rng.uniform(-90, 0, n).astype(np.float32)
+    gone = rng.random(n) < 0.2
+    rows["disappeared"] = gone * rng.integers(1, 30, n)
+    for k in ("w", "h", "angle"):
+        rows[k][gone] = 0
+    return rows
+
+
+def _pandas_csv(rows, tmp_path):
+    """DataFrame.to_csv exactly as save_df_to_csv calls it (helper_file.py:1392-1394), on the exact values."""
+    from ysmr_amd.helper_file import rows_to_dataframe
+    path = tmp_path / "ref.csv"
+    with open(path, "w+", newline="\n") as fh:
+        rows_to_dataframe(rows, via_pandas=False).to_csv(fh, index=False, encoding="utf-8")
+    return path.read_bytes()
+
+
+_SPECIAL = [0.0, -0.0, 1.0, 100000.0, 1e15, 9999999999999998.0, 1e16, 1.5e16, 1e22, 1e-4, 0.00012345, 9.999e-5, 1e-5,
+            1.5e-7, 123456.789, 0.1, 1 / 3, 2 / 3, 5e-324, 1.7976931348623157e308, 922.0000000000001, 613.5,
+            float(np.float32(3.6)), float(np.float32(-89.98)), -1234.5678, 1e100, 1.2345678901234567e-100,
+            0.00012345678901234567, 1234567890123456.7, 4.35e-320]
+
+
+def _with_special_values(rows):
+    # values that exercise every branch of the float layout: exponent form on both sides, integral
+    # values, leading zeros, 17 significant digits, negative zero, subnormals, float32 widened to float64
+    k = len(_SPECIAL)
+    rows["x"][:k] = _SPECIAL
+    rows["y"][:k] = _SPECIAL[::-1]
+    rows["w"][:6] = np.float32([0.1, 1e-8, 3.4e38, 16777216.0, 1e10, 2.5])
+    rows["disappeared"][:6] = 0      # (a disappeared track always carries zeros: tracker.py:101, 205)
+    return rows
+
+
+def test_native_csv_matches_pandas_bytes(tmp_path):
+    """ysmr_rows_format_csv (a host function of the library) against DataFrame.to_csv, byte for byte."""
+    from ysmr_amd.helper_file import rows_to_csv_bytes
+    rows = _with_special_values(_random_rows(20000, 3))
+    for threads in (1, 4):
+        got = rows_to_csv_bytes(rows, header=True, via_pandas=False, threads=threads)
+        assert got == _pandas_csv(rows, tmp_path)
+    assert rows_to_csv_bytes(rows[:0]) == b"TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE\n"
+    assert rows_to_csv_bytes(rows[:3], header=False, via_pandas=False) == \
+        b"".join(_pandas_csv(rows[:3], tmp_path).split(b"\n", 1)[1:])
+
+
+def test_output_equals_the_reference_text_pandas_detour(tmp_path):
+    """a19 end to end.  The reference appends Python-formatted rows (track_eval.py:313-316, 340-346;
+    integer zeros for disappeared tracks, tracker.py:101, 205), re-reads the file with
+    pandas.read_csv, sorts by (TRACK_ID, POSITION_T) and rewrites it with to_csv (sort_list,
+    helper_file.py:1538-1574).  pandas' float parser is not correctly rounded, so that detour is not
+    the identity; the native path restates it.  DataFrame and file must come out identical."""
+    import pandas as pd
+    from ysmr_amd.helper_file import get_data, rows_to_csv_bytes, rows_to_csv_text, rows_to_dataframe, sort_list
+    rows = _with_special_values(_random_rows(30000, 5))
+    rows["x"][40:] = np.random.default_rng(6).uniform(0, 1300, len(rows) - 40)
+    rows["frame"] = np.arange(len(rows)) // 50          # (track_id, frame) must be unique
+    rows["track_id"] = np.arange(len(rows)) % 50 * 7
+    # --- the reference's way
+    ref_path = tmp_path / "ref_list.csv"
+    with open(ref_path, "w", newline="") as fh:
+        fh.write("TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE\n")
+        fh.write(rows_to_csv_text(rows))
+    df_ref = sort_list(file_path=str(ref_path), save_file=True)
+    # --- the native way
+    order = np.lexsort((rows["frame"], rows["track_id"]))
+    srt = rows[order]
+    df = rows_to_dataframe(srt)
+    assert (df_ref["POSITION_X"].to_numpy() != srt["x"]).any(), "expected pandas' parser to perturb some values"
+    pd.testing.assert_frame_equal(df, df_ref, check_exact=True)
+    assert rows_to_csv_bytes(srt) == ref_path.read_bytes()
+
+
+def test_native_csv_round_trips_through_get_data(tmp_path):
+    """The file written natively reads back (get_data, helper_file.py:860-905) to the frame handed over."""
+    from ysmr_amd.helper_file import get_data, rows_to_csv_bytes, rows_to_dataframe
+    rows = _random_rows(5000, 4)
+    order = np.lexsort((rows["frame"], rows["track_id"]))
+    rows = rows[order]
+    path = tmp_path / "x_list.csv"
+    path.write_bytes(rows_to_csv_bytes(rows))
+    df = get_data(str(path), check_sorted=False)
+    ref = rows_to_dataframe(rows)
+    assert list(df.columns) == list(ref.columns)
+    for c in ref.columns:
+        assert df[c].dtype == ref[c].dtype
+    # reading the final file once more goes through the inexact parser again: equal to 1 ulp
+    for c in ("POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE"):
+        np.testing.assert_allclose(df[c].to_numpy(), ref[c].to_numpy(), rtol=4e-16, atol=0)
+    for c in ("TRACK_ID", "POSITION_T"):
+        np.testing.assert_array_equal(df[c].to_numpy(), ref[c].to_numpy())

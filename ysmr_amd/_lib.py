@@ -26,7 +26,8 @@ EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes",
            "ysmr_threshold_batch",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_peek",
-           "ysmr_tracker_info")
+           "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
+           "ysmr_rows_format_csv", "ysmr_rows_columns")
 
 
 class YsmrLibraryError(RuntimeError):
@@ -68,8 +69,16 @@ def lib():
     L.ysmr_tracker_run.argtypes = [vp, vp, vp, vp, ci, ctypes.c_int32, vp, ctypes.c_int64, vp]
     L.ysmr_tracker_info.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
                                     ctypes.POINTER(ctypes.c_int32)]
+    L.ysmr_rows_sort_workspace_bytes.argtypes = [ctypes.c_longlong]
+    L.ysmr_rows_sort_workspace_bytes.restype = ctypes.c_size_t
+    L.ysmr_rows_sort.argtypes = [vp, vp, ctypes.c_longlong, vp, ctypes.c_size_t, vp]
+    L.ysmr_rows_csv_bound.argtypes = [ctypes.c_longlong, ci]
+    L.ysmr_rows_csv_bound.restype = ctypes.c_size_t
+    L.ysmr_rows_format_csv.argtypes = [vp, ctypes.c_longlong, ci, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.ysmr_rows_columns.argtypes = [vp, ctypes.c_longlong, ci, vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
-        if name not in ("ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_abi_version"):
+        if name not in ("ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_abi_version",
+                        "ysmr_rows_sort_workspace_bytes", "ysmr_rows_csv_bound"):
             getattr(L, name).restype = ci
     _lib = L
     return L

@@ -1,0 +1,322 @@
+// libysmr_hip -- the output side of the path: the rows the link emits frame by frame
+// are ordered by (TRACK_ID, POSITION_T) on the device and written as the csv the reference ends up
+// with.  The reference appends Python-formatted text per frame (track_eval.py:313-316, 340-346,
+// helper_file.py:1403-1478), then re-reads the file with pandas, sorts it and rewrites it with
+// DataFrame.to_csv (helper_file.py:1538-1574, 1366-1400).  The final file and DataFrame are a pure
+// function of the row values -- shortest-repr text, pandas' float parser (not correctly rounded, see
+// pandas_parse below), shortest-repr text again -- so they are produced here directly, without the
+// Python string formatting (0.5 s per 250 k rows) and the two pandas passes.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_row_keys(const ysmr_row *__restrict__ rows, long long n,
+                                                  unsigned long long *__restrict__ keys, uint32_t *__restrict__ idx)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        // TRACK_ID and POSITION_T are uint32 columns in the reference (helper_file.py:881-889)
+        keys[i] = ((unsigned long long)(uint32_t)rows[i].track_id << 32) | (uint32_t)rows[i].frame;
+        idx[i] = (uint32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_row_gather(const ysmr_row *__restrict__ rows, const uint32_t *__restrict__ idx,
+                                                    long long n, ysmr_row *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = rows[idx[i]];
+}
+
+struct SortLayout {
+    size_t keys_in, keys_out, idx_in, idx_out, temp, temp_bytes, total;
+};
+
+SortLayout sort_layout(long long n)
+{
+    SortLayout L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return o; };
+    L.keys_in = take(sizeof(unsigned long long) * (size_t)n);
+    L.keys_out = take(sizeof(unsigned long long) * (size_t)n);
+    L.idx_in = take(sizeof(uint32_t) * (size_t)n);
+    L.idx_out = take(sizeof(uint32_t) * (size_t)n);
+    size_t tb = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 64, (hipStream_t)0);
+    L.temp_bytes = tb;
+    L.temp = take(tb);
+    L.total = off;
+    return L;
+}
+
+// ---- float formatting: what str(numpy.float64) / repr(float) print --------------------------------------
+// shortest digits that round-trip (std::to_chars), laid out by CPython's rules (format_float_short, 'r'):
+// exponent form iff the decimal exponent is < -4 or >= 16, otherwise positional with at least ".0".
+char *put_float(char *p, double v)
+{
+    if (std::isnan(v)) return p;                                   // pandas writes NaN as an empty field
+    if (std::isinf(v)) { const char *s = v < 0 ? "-inf" : "inf"; size_t k = std::strlen(s); std::memcpy(p, s, k); return p + k; }
+    if (std::signbit(v)) { *p++ = '-'; v = -v; }
+    if (v == 0.0) { std::memcpy(p, "0.0", 3); return p + 3; }
+    char buf[40];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::scientific);   // d[.ddd]e[+-]XX
+    char *e = buf;
+    while (*e != 'e') ++e;
+    char digits[24];
+    int nd = 0;
+    for (char *q = buf; q < e; ++q)
+        if (*q != '.') digits[nd++] = *q;
+    int exp10 = 0;
+    {
+        const char *q = e + 1;
+        const bool neg = (*q == '-');
+        ++q;
+        for (; q < r.ptr; ++q) exp10 = exp10 * 10 + (*q - '0');
+        if (neg) exp10 = -exp10;
+    }
+    if (exp10 < -4 || exp10 >= 16) {
+        *p++ = digits[0];
+        if (nd > 1) { *p++ = '.'; std::memcpy(p, digits + 1, (size_t)nd - 1); p += nd - 1; }
+        *p++ = 'e';
+        *p++ = exp10 < 0 ? '-' : '+';
+        int a = exp10 < 0 ? -exp10 : exp10;
+        if (a >= 100) { *p++ = (char)('0' + a / 100); a %= 100; *p++ = (char)('0' + a / 10); *p++ = (char)('0' + a % 10); }
+        else { *p++ = (char)('0' + a / 10); *p++ = (char)('0' + a % 10); }
+        return p;
+    }
+    const int decpt = exp10 + 1;   // digits before the decimal point
+    if (decpt <= 0) {
+        *p++ = '0'; *p++ = '.';
+        for (int k = 0; k < -decpt; ++k) *p++ = '0';
+        std::memcpy(p, digits, (size_t)nd); p += nd;
+    } else if (decpt >= nd) {
+        std::memcpy(p, digits, (size_t)nd); p += nd;
+        for (int k = nd; k < decpt; ++k) *p++ = '0';
+        *p++ = '.'; *p++ = '0';
+    } else {
+        std::memcpy(p, digits, (size_t)decpt); p += decpt;
+        *p++ = '.';
+        std::memcpy(p, digits + decpt, (size_t)(nd - decpt)); p += nd - decpt;
+    }
+    return p;
+}
+
+// The reference never keeps the tracker's float64 values: it writes them as text and reads the file
+// back with pandas.read_csv (helper_file.py:860-905, called from sort_list), whose default float
+// converter (pandas >= 1.2: "high" = precise_xstrtod in pandas/_libs/src/parser/tokenizer.c) is not
+// correctly rounded -- about one value in five comes back 1 ulp off.  To hand over the SAME DataFrame
+// and the same final csv, that converter is restated here: at most 17 digits (leading zeros included)
+// are accumulated in a double, the rest only shifts the exponent, and the result is scaled by one
+// multiplication or division with a table power of ten.  Checked against the installed pandas in
+// tests/test_host.py on several hundred thousand values.
+double pandas_parse(const char *p, const char *end)
+{
+    static const double e[] = {
+        1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21,
+        1e22, 1e23, 1e24, 1e25, 1e26, 1e27, 1e28, 1e29, 1e30, 1e31, 1e32, 1e33, 1e34, 1e35, 1e36, 1e37, 1e38, 1e39, 1e40, 1e41,
+        1e42, 1e43, 1e44, 1e45, 1e46, 1e47, 1e48, 1e49, 1e50, 1e51, 1e52, 1e53, 1e54, 1e55, 1e56, 1e57, 1e58, 1e59, 1e60, 1e61,
+        1e62, 1e63, 1e64, 1e65, 1e66, 1e67, 1e68, 1e69, 1e70, 1e71, 1e72, 1e73, 1e74, 1e75, 1e76, 1e77, 1e78, 1e79, 1e80, 1e81,
+        1e82, 1e83, 1e84, 1e85, 1e86, 1e87, 1e88, 1e89, 1e90, 1e91, 1e92, 1e93, 1e94, 1e95, 1e96, 1e97, 1e98, 1e99, 1e100, 1e101,
+        1e102, 1e103, 1e104, 1e105, 1e106, 1e107, 1e108, 1e109, 1e110, 1e111, 1e112, 1e113, 1e114, 1e115, 1e116, 1e117, 1e118,
+        1e119, 1e120, 1e121, 1e122, 1e123, 1e124, 1e125, 1e126, 1e127, 1e128, 1e129, 1e130, 1e131, 1e132, 1e133, 1e134, 1e135,
+        1e136, 1e137, 1e138, 1e139, 1e140, 1e141, 1e142, 1e143, 1e144, 1e145, 1e146, 1e147, 1e148, 1e149, 1e150, 1e151, 1e152,
+        1e153, 1e154, 1e155, 1e156, 1e157, 1e158, 1e159, 1e160, 1e161, 1e162, 1e163, 1e164, 1e165, 1e166, 1e167, 1e168, 1e169,
+        1e170, 1e171, 1e172, 1e173, 1e174, 1e175, 1e176, 1e177, 1e178, 1e179, 1e180, 1e181, 1e182, 1e183, 1e184, 1e185, 1e186,
+        1e187, 1e188, 1e189, 1e190, 1e191, 1e192, 1e193, 1e194, 1e195, 1e196, 1e197, 1e198, 1e199, 1e200, 1e201, 1e202, 1e203,
+        1e204, 1e205, 1e206, 1e207, 1e208, 1e209, 1e210, 1e211, 1e212, 1e213, 1e214, 1e215, 1e216, 1e217, 1e218, 1e219, 1e220,
+        1e221, 1e222, 1e223, 1e224, 1e225, 1e226, 1e227, 1e228, 1e229, 1e230, 1e231, 1e232, 1e233, 1e234, 1e235, 1e236, 1e237,
+        1e238, 1e239, 1e240, 1e241, 1e242, 1e243, 1e244, 1e245, 1e246, 1e247, 1e248, 1e249, 1e250, 1e251, 1e252, 1e253, 1e254,
+        1e255, 1e256, 1e257, 1e258, 1e259, 1e260, 1e261, 1e262, 1e263, 1e264, 1e265, 1e266, 1e267, 1e268, 1e269, 1e270, 1e271,
+        1e272, 1e273, 1e274, 1e275, 1e276, 1e277, 1e278, 1e279, 1e280, 1e281, 1e282, 1e283, 1e284, 1e285, 1e286, 1e287, 1e288,
+        1e289, 1e290, 1e291, 1e292, 1e293, 1e294, 1e295, 1e296, 1e297, 1e298, 1e299, 1e300, 1e301, 1e302, 1e303, 1e304, 1e305,
+        1e306, 1e307, 1e308};
+    bool neg = false;
+    if (p < end && *p == '-') { neg = true; ++p; }
+    double number = 0.0;
+    int exponent = 0, nd = 0, ndec = 0;
+    const int max_digits = 17;
+    auto digit = [&](const char *q) { return q < end && *q >= '0' && *q <= '9'; };
+    while (digit(p)) {
+        if (nd < max_digits) { number = number * 10.0 + (*p - '0'); ++nd; }
+        else ++exponent;
+        ++p;
+    }
+    if (p < end && *p == '.') {
+        ++p;
+        while (nd < max_digits && digit(p)) { number = number * 10.0 + (*p - '0'); ++p; ++nd; ++ndec; }
+        if (nd >= max_digits)
+            while (digit(p)) ++p;
+        exponent -= ndec;
+    }
+    if (neg) number = -number;
+    if (p < end && (*p == 'e' || *p == 'E')) {
+        ++p;
+        bool eneg = false;
+        if (p < end && *p == '-') { eneg = true; ++p; }
+        else if (p < end && *p == '+') ++p;
+        int n = 0;
+        while (digit(p)) { n = n * 10 + (*p - '0'); ++p; }
+        exponent += eneg ? -n : n;
+    }
+    if (exponent > 308) return neg ? -HUGE_VAL : HUGE_VAL;
+    if (exponent > 0) number *= e[exponent];
+    else if (exponent < -308) {
+        if (exponent < -616) number = 0.0;
+        else { number /= e[-308 - exponent]; number /= e[308]; }
+    } else number /= e[-exponent];
+    return number;
+}
+
+// value -> text -> pandas -> value
+double pandas_roundtrip(double v)
+{
+    if (!std::isfinite(v)) return v;
+    char buf[48];
+    char *end = put_float(buf, v);
+    return pandas_parse(buf, end);
+}
+
+char *put_u32(char *p, uint32_t v)
+{
+    auto r = std::to_chars(p, p + 12, v);
+    return r.ptr;
+}
+
+constexpr size_t ROW_TEXT_MAX = 2 * 11 + 5 * 26 + 8;   // two uint32, five floats, separators
+const char CSV_HEADER[] = "TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE\n";   // helper_file.py:1451
+
+size_t format_range(const ysmr_row *rows, long long lo, long long hi, bool via_pandas, char *out)
+{
+    char *p = out;
+    for (long long i = lo; i < hi; ++i) {
+        const ysmr_row &r = rows[i];
+        double v[5] = {r.x, r.y, (double)r.w, (double)r.h, (double)r.angle};
+        if (via_pandas)
+            for (double &x : v) x = pandas_roundtrip(x);
+        p = put_u32(p, (uint32_t)r.track_id); *p++ = ',';
+        p = put_u32(p, (uint32_t)r.frame); *p++ = ',';
+        for (int k = 0; k < 5; ++k) { p = put_float(p, v[k]); *p++ = k == 4 ? '\n' : ','; }
+    }
+    return (size_t)(p - out);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ysmr_rows_sort_workspace_bytes(long long n_rows)
+{
+    if (n_rows <= 0 || n_rows > 0x7FFFFFFFll) return 0;
+    return sort_layout(n_rows).total;
+}
+
+int ysmr_rows_sort(void *stream, const ysmr_row *rows_dev, long long n_rows, void *workspace_dev, size_t workspace_bytes,
+                   ysmr_row *sorted_dev)
+{
+    if (n_rows == 0) return YSMR_OK;
+    if (n_rows < 0 || n_rows > 0x7FFFFFFFll) return ysmr::fail(YSMR_ERR_ARG, "n_rows must be in 0..2^31-1, got %lld", n_rows);
+    if (!rows_dev || !sorted_dev || !workspace_dev || rows_dev == sorted_dev)
+        return ysmr::fail(YSMR_ERR_ARG, "rows_dev, sorted_dev (distinct) and workspace_dev must be set");
+    const SortLayout L = sort_layout(n_rows);
+    if (workspace_bytes < L.total)
+        return ysmr::fail(YSMR_ERR_CAPACITY, "sort workspace too small: %zu < %zu bytes", workspace_bytes, L.total);
+    char *w = (char *)workspace_dev;
+    auto *keys_in = (unsigned long long *)(w + L.keys_in), *keys_out = (unsigned long long *)(w + L.keys_out);
+    auto *idx_in = (uint32_t *)(w + L.idx_in), *idx_out = (uint32_t *)(w + L.idx_out);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)std::min<long long>((n_rows + 255) / 256, 1024);   // resident grid (see detect.hip)
+    hipLaunchKernelGGL(k_row_keys, dim3(grid), dim3(256), 0, st, rows_dev, n_rows, keys_in, idx_in);
+    size_t tb = L.temp_bytes;
+    YSMR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(w + L.temp, tb, keys_in, keys_out, idx_in, idx_out, (int)n_rows, 0, 64, st));
+    hipLaunchKernelGGL(k_row_gather, dim3(grid), dim3(256), 0, st, rows_dev, idx_out, n_rows, sorted_dev);
+    YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+size_t ysmr_rows_csv_bound(long long n_rows, int with_header)
+{
+    if (n_rows < 0) return 0;
+    return (size_t)n_rows * ROW_TEXT_MAX + (with_header ? sizeof(CSV_HEADER) - 1 : 0) + 1;
+}
+
+int ysmr_rows_format_csv(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas, int threads,
+                         char *out, size_t out_capacity, size_t *out_length)
+{
+    if (n_rows < 0 || (!rows_host && n_rows) || !out || !out_length)
+        return ysmr::fail(YSMR_ERR_ARG, "rows_host, out and out_length must be set");
+    if (out_capacity < ysmr_rows_csv_bound(n_rows, with_header))
+        return ysmr::fail(YSMR_ERR_CAPACITY, "csv buffer too small: %zu < %zu bytes", out_capacity,
+                          ysmr_rows_csv_bound(n_rows, with_header));
+    size_t len = 0;
+    if (with_header) { std::memcpy(out, CSV_HEADER, sizeof(CSV_HEADER) - 1); len = sizeof(CSV_HEADER) - 1; }
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, 64));
+    if (n_rows < 4096) nt = 1;
+    if (nt == 1) {
+        len += format_range(rows_host, 0, n_rows, via_pandas != 0, out + len);
+    } else {
+        // each thread formats a contiguous range into the slot reserved for it, then the pieces are packed
+        std::vector<size_t> used((size_t)nt, 0);
+        std::vector<std::thread> pool;
+        const long long per = (n_rows + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) {
+            const long long lo = std::min<long long>((long long)t * per, n_rows), hi = std::min<long long>(lo + per, n_rows);
+            char *dst = out + len + (size_t)lo * ROW_TEXT_MAX;
+            pool.emplace_back([=, &used] { used[(size_t)t] = format_range(rows_host, lo, hi, via_pandas != 0, dst); });
+        }
+        for (auto &th : pool) th.join();
+        char *w = out + len;
+        for (int t = 0; t < nt; ++t) {
+            const long long lo = std::min<long long>((long long)t * per, n_rows);
+            const char *src = out + len + (size_t)lo * ROW_TEXT_MAX;
+            if (w != src) std::memmove(w, src, used[(size_t)t]);
+            w += used[(size_t)t];
+        }
+        len = (size_t)(w - out);
+    }
+    *out_length = len;
+    return YSMR_OK;
+}
+
+int ysmr_rows_columns(const ysmr_row *rows_host, long long n_rows, int via_pandas, uint32_t *track_id, uint32_t *t,
+                      double *x, double *y, double *w, double *h, double *angle)
+{
+    if (n_rows < 0 || (n_rows && (!rows_host || !track_id || !t || !x || !y || !w || !h || !angle)))
+        return ysmr::fail(YSMR_ERR_ARG, "rows_host and all seven column pointers must be set");
+    int nt = (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, 64));
+    if (n_rows < 4096 || !via_pandas) nt = 1;
+    auto work = [=](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i) {
+            const ysmr_row &r = rows_host[i];
+            track_id[i] = (uint32_t)r.track_id;
+            t[i] = (uint32_t)r.frame;
+            double v[5] = {r.x, r.y, (double)r.w, (double)r.h, (double)r.angle};
+            if (via_pandas)
+                for (double &q : v) q = pandas_roundtrip(q);
+            x[i] = v[0]; y[i] = v[1]; w[i] = v[2]; h[i] = v[3]; angle[i] = v[4];
+        }
+    };
+    if (nt == 1) { work(0, n_rows); return YSMR_OK; }
+    std::vector<std::thread> pool;
+    const long long per = (n_rows + nt - 1) / nt;
+    for (int k = 0; k < nt; ++k) {
+        const long long lo = std::min<long long>((long long)k * per, n_rows), hi = std::min<long long>(lo + per, n_rows);
+        pool.emplace_back(work, lo, hi);
+    }
+    for (auto &th : pool) th.join();
+    return YSMR_OK;
+}
+
+}  // extern "C"

@@ -339,6 +339,41 @@ def rows_to_csv_text(rows):
     return "".join(out)
 
 
+def rows_to_csv_bytes(rows, header=True, via_pandas=True, threads=0):
+    """The csv the reference ends up with for these rows, as bytes: header of save_list
+    (helper_file.py:1451) and one line per row formatted the way ``DataFrame.to_csv`` prints the
+    uint32 / float64 columns (helper_file.py:1366-1400) -- produced by the library's native
+    formatter (``ysmr_rows_format_csv``, a host function) instead of Python string formatting and
+    a pandas round trip.  ``rows``: structured ``ysmr_row`` array, already in file order.
+    ``via_pandas``: reproduce the 1-ulp noise of the reference's text -> read_csv detour
+    (include/ysmr_hip.h); False prints the exact values."""
+    import ctypes
+    from . import _lib
+    rows = np.ascontiguousarray(rows, dtype=_lib.ROW_DTYPE)
+    L = _lib.lib()
+    cap = L.ysmr_rows_csv_bound(len(rows), int(bool(header)))
+    out = np.empty(cap, dtype=np.uint8)
+    n = ctypes.c_size_t(0)
+    _lib.check(L.ysmr_rows_format_csv(rows.ctypes.data, len(rows), int(bool(header)), int(bool(via_pandas)), int(threads),
+                                      out.ctypes.data, cap, ctypes.byref(n)), "ysmr_rows_format_csv")
+    return out[:n.value].tobytes()
+
+
+def rows_to_dataframe(rows, via_pandas=True):
+    """Rows (already sorted) -> the DataFrame ``get_data`` would have read back from the csv
+    (dtypes of helper_file.py:881-889; ``via_pandas`` as in :func:`rows_to_csv_bytes`)."""
+    import pandas as pd
+    from . import _lib
+    rows = np.ascontiguousarray(rows, dtype=_lib.ROW_DTYPE)
+    n = len(rows)
+    ids, t = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    cols = [np.empty(n, np.float64) for _ in range(5)]
+    _lib.check(_lib.lib().ysmr_rows_columns(rows.ctypes.data, n, int(bool(via_pandas)), ids.ctypes.data, t.ctypes.data,
+                                            *[c.ctypes.data for c in cols]), "ysmr_rows_columns")
+    return pd.DataFrame({"TRACK_ID": ids, "POSITION_T": t, "POSITION_X": cols[0], "POSITION_Y": cols[1],
+                         "WIDTH": cols[2], "HEIGHT": cols[3], "DEGREES_ANGLE": cols[4]})
+
+
 _DTYPES = {"TRACK_ID": np.uint32, "POSITION_T": np.uint32, "POSITION_X": np.float64, "POSITION_Y": np.float64,
            "WIDTH": np.float64, "HEIGHT": np.float64, "DEGREES_ANGLE": np.float64}
 

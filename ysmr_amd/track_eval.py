@@ -22,9 +22,9 @@ import torch
 from . import _lib
 from .detect import Detector, threshold_params
 from .frames import open_video
-from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_text,
-                          save_list, sort_list)
-from .tracker import DeviceTracker, rows_to_numpy
+from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes,
+                          rows_to_dataframe, save_list)
+from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
 __all__ = ["track_bacteria", "TrackingPipeline"]
 
@@ -98,13 +98,14 @@ class TrackingPipeline:
         (kept so that callers need not know which streams the pipeline uses)."""
         return None
 
-    def take_rows(self):
-        """Synchronise, download the accumulated rows and reset the row buffer."""
+    def take_rows(self, sort=False):
+        """Synchronise, download the accumulated rows and reset the row buffer.  ``sort``: order them
+        by (TRACK_ID, POSITION_T) on the device first (``sort_list``, helper_file.py:1538-1574)."""
         n = int(self.row_count.item())
         cap = self.rows.numel() // _lib.ROW_DTYPE.itemsize
         if n > cap:
             raise _lib.YsmrLibraryError(f"row buffer overflow: {n} rows > capacity {cap}")
-        rows = rows_to_numpy(self.rows, n).copy()
+        rows = rows_to_numpy(sort_rows(self.rows, n) if sort else self.rows, n).copy()
         self.row_count.zero_()
         return rows
 
@@ -175,13 +176,22 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
 
     frame_height, frame_width = video.height, video.width
     error_during_read = False
-    n_rows_total, last_id, frames_done = 0, None, 0
+    frames_done = 0
+    sorted_rows = None
     try:
+        # Rows stay on the device for the whole video when they fit (capacity rows per frame is the
+        # worst case; 32 M rows = 1.3 GB) and are ordered there at the end; otherwise full buffers are
+        # moved to the host in between.  ('list save length interval' bounded the reference's Python
+        # list, helper_file.py:171; here it only sets the smallest buffer.)
+        row_budget = min(max(frame_count, 1) * capacity, 32 << 20)
+        row_budget = max(row_budget, 2 * batch * capacity, int(settings["list save length interval"]))
         pipe = TrackingPipeline(frame_height, frame_width, fps_of_file, local, batch=batch, max_det=max_det,
-                                capacity=capacity, device=device)
-        flush_at = max(int(settings["list save length interval"]), 1)
+                                capacity=capacity, device=device, rows_per_flush=row_budget)
+        chunks = []
         pending = None
         res = None
+        row_capacity = pipe.rows.numel() // _lib.ROW_DTYPE.itemsize
+        rows_upper = 0     # host-side bound on the rows in the device buffer (no sync per batch)
         for f0 in range(0, frame_count, pipe.B):
             host = video.read(f0, pipe.B)
             if host.shape[0] == 0:
@@ -190,31 +200,33 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
             nxt = (pipe.detect_async(dev), f0, host.shape[0])
             if pending is not None:
                 (slot, r, ready), p0, cnt = pending
+                if rows_upper + cnt * pipe.capacity > row_capacity:
+                    if res is not None:
+                        pipe.check(res)
+                    chunks.append(pipe.take_rows())
+                    rows_upper = 0
                 res = pipe.link(slot, r, ready, p0)
+                rows_upper += cnt * pipe.capacity
                 frames_done = p0 + cnt
-                if int(pipe.row_count.item()) >= flush_at or (pipe.rows.numel() // _lib.ROW_DTYPE.itemsize
-                                                              - int(pipe.row_count.item())) < pipe.B * pipe.capacity:
-                    pipe.check(res)
-                    rows = pipe.take_rows()
-                    n_rows_total += len(rows)
-                    if len(rows):
-                        last_id = int(rows["track_id"].max()) if last_id is None else max(last_id, int(rows["track_id"].max()))
-                    with open(list_name, "a", newline="") as fh:
-                        fh.write(rows_to_csv_text(rows))
             pending = nxt
         if pending is not None:
             (slot, r, ready), p0, cnt = pending
+            if rows_upper + cnt * pipe.capacity > row_capacity:
+                if res is not None:
+                    pipe.check(res)
+                chunks.append(pipe.take_rows())
             res = pipe.link(slot, r, ready, p0)
             frames_done = p0 + cnt
         if res is not None:
             torch.cuda.synchronize(pipe.device)
             pipe.check(res)
-            rows = pipe.take_rows()
-            n_rows_total += len(rows)
-            if len(rows):
-                last_id = int(rows["track_id"].max()) if last_id is None else max(last_id, int(rows["track_id"].max()))
-            with open(list_name, "a", newline="") as fh:
-                fh.write(rows_to_csv_text(rows))
+            if chunks:      # did not fit: gather on the host, order on the device in one go
+                chunks.append(pipe.take_rows())
+                everything = np.concatenate(chunks)
+                on_dev = torch.from_numpy(everything.view(np.uint8)).to(pipe.device)
+                sorted_rows = rows_to_numpy(sort_rows(on_dev, len(everything)), len(everything)).copy()
+            else:
+                sorted_rows = pipe.take_rows(sort=True)
         if frames_done < frame_count - 1:   # some containers over-report by one frame (track_eval.py:170-171)
             logger.critical("Error during read with file {}".format(video_path))
             error_during_read = settings["stop evaluation on error"]
@@ -231,10 +243,20 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
             logger.info("Restoring old list: {}".format(list_name))
         except OSError as exc:
             logger.error("Could not restore {}: {!r}".format(list_name, exc.args))
-    if last_id is None:
+    if sorted_rows is None or len(sorted_rows) == 0:
         logger.warning("Did not track any objects. File: {}".format(video_path))
         return None
-    df_for_eval = sort_list(file_path=list_name, save_file=not settings["delete .csv file after analysis"])
+    # track_eval.py:393: sort_list(file_path=list_name, save_file=not settings['delete .csv ...']) re-reads
+    # the csv with pandas, sorts it and rewrites it; the same DataFrame and the same bytes come
+    # straight from the rows here (helper_file.rows_to_dataframe / rows_to_csv_bytes).
+    n_rows_total, last_id = len(sorted_rows), int(sorted_rows["track_id"][-1])
+    df_for_eval = rows_to_dataframe(sorted_rows)
+    if not settings["delete .csv file after analysis"]:   # (else analyse() removes the file anyway, main.py:156)
+        try:
+            with open(list_name, "wb") as fh:
+                fh.write(rows_to_csv_bytes(sorted_rows))
+        except OSError as exc:
+            logger.exception("Could not write {}: {}".format(list_name, exc))
     logger.info("objects: {}, frames: {} of {}, rows: {}, csv: {}".format(last_id + 1, frames_done, frame_count,
                                                                           n_rows_total, list_name))
     if error_during_read:

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from .gsff import horizon_sizes, lsf_gain_rows
 
-__all__ = ["DeviceTracker", "CentroidTracker"]
+__all__ = ["sort_rows", "DeviceTracker", "CentroidTracker"]
 
 
 class DeviceTracker:
@@ -139,6 +139,22 @@ def rows_to_numpy(rows_u8: torch.Tensor, count: int) -> np.ndarray:
     size = _lib.ROW_DTYPE.itemsize
     host = rows_u8[: count * size].cpu().numpy()
     return host.view(_lib.ROW_DTYPE)
+
+
+def sort_rows(rows_u8: torch.Tensor, count: int) -> torch.Tensor:
+    """Order `count` device rows by (TRACK_ID, POSITION_T) on the device -- what ``sort_list`` does to
+    the csv after tracking (helper_file.py:1538-1574).  Returns a new device uint8 buffer."""
+    size = _lib.ROW_DTYPE.itemsize
+    out = torch.empty(max(count, 1) * size, dtype=torch.uint8, device=rows_u8.device)
+    if count == 0:
+        return out[:0]
+    L = _lib.lib()
+    ws_bytes = L.ysmr_rows_sort_workspace_bytes(count)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=rows_u8.device)
+    with torch.cuda.device(rows_u8.device):
+        _lib.check(L.ysmr_rows_sort(_lib.stream_ptr(), rows_u8.data_ptr(), count, ws.data_ptr(), ws_bytes, out.data_ptr()),
+                   "ysmr_rows_sort")
+    return out[: count * size]
 
 
 class CentroidTracker:
