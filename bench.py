@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--blobs", type=int, default=500)
     ap.add_argument("--max-det", type=int, default=2048)
     ap.add_argument("--capacity", type=int, default=2048)
+    ap.add_argument("--streams-per-gpu", type=int, default=1,
+                    help="independent video streams processed concurrently on each GPU (the metric's configuration is 1)")
     ap.add_argument("--channels", type=int, default=1, choices=(1, 3),
                     help="1: gray frames (the metric's configuration); 3: the same frames as BGR (B=G=R), which adds a1")
     ap.add_argument("--cpu-sample", type=int, default=48, help="frames of the clip timed on the CPU oracle (0 = skip)")
@@ -87,31 +89,41 @@ def main():
     from ysmr_amd.synth import SyntheticVideo
     from ysmr_amd.track_eval import TrackingPipeline
 
-    F, B, H, W = args.frames, args.batch, args.height, args.width
+    F, B, H, W, S = args.frames, args.batch, args.height, args.width, max(1, args.streams_per_gpu)
     fps_video = 30.0
-    video = SyntheticVideo(H, W, args.blobs, seed=rank, fps=fps_video)
-    frames_np = video.frames(F)                      # one independent stream per rank
-    frames = torch.from_numpy(frames_np).to(dev)     # resident in HBM before the timed region
-    if args.channels == 3:
-        frames = frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
-
     settings = default_settings()                    # tracking.ini defaults: offset 5, adt 2.0, GSFF 10/20/30
-    pipe = TrackingPipeline(H, W, fps_video, settings, batch=B, max_det=args.max_det, capacity=args.capacity,
-                            device=dev, rows_per_flush=F * args.capacity)
+    clips_np, clips, pipes, link_streams = [], [], [], []
+    for k in range(S):                               # one independent stream per (rank, k)
+        video = SyntheticVideo(H, W, args.blobs, seed=rank * S + k, fps=fps_video)
+        frames_np = video.frames(F)
+        frames = torch.from_numpy(frames_np).to(dev)  # resident in HBM before the timed region
+        if args.channels == 3:
+            frames = frames.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+        clips_np.append(frames_np)
+        clips.append(frames)
+        pipes.append(TrackingPipeline(H, W, fps_video, settings, batch=B, max_det=args.max_det, capacity=args.capacity,
+                                      device=dev, rows_per_flush=F * args.capacity))
+        link_streams.append(torch.cuda.current_stream(dev) if S == 1 else torch.cuda.Stream(device=dev))
+    frames_np, pipe = clips_np[0], pipes[0]
     thr_events = []
 
     def step(timed):
-        # one clip, fresh tracker; detection of batch b+1 (side stream) overlaps the link of batch b
-        pipe.reset()
-        pending, last = None, None
-        for f0 in range(0, F, B):
-            nxt = (pipe.detect_async(frames[f0:f0 + B], thr_events if timed else None), f0)
-            if pending is not None:
-                (slot, res, ready), p0 = pending
-                last = pipe.link(slot, res, ready, p0)
-            pending = nxt
-        (slot, res, ready), p0 = pending
-        return pipe.link(slot, res, ready, p0)
+        # one clip per stream, fresh trackers; detection of batch b+1 (side stream) overlaps the link of
+        # batch b; with several streams per GPU their (serial) link chains interleave as well
+        pending = [None] * S
+        for k in range(S):
+            with torch.cuda.stream(link_streams[k]):
+                pipes[k].reset()
+        for f0 in list(range(0, F, B)) + [None]:
+            for k in range(S):
+                with torch.cuda.stream(link_streams[k]):
+                    nxt = None
+                    if f0 is not None:
+                        nxt = (pipes[k].detect_async(clips[k][f0:f0 + B], thr_events if (timed and k == 0) else None), f0)
+                    if pending[k] is not None:
+                        (slot, res, ready), p0 = pending[k]
+                        pipes[k].link(slot, res, ready, p0)
+                    pending[k] = nxt
 
     for _ in range(args.warmup):
         step(False)
@@ -120,19 +132,22 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        last_res = step(True)
+        step(True)
     torch.cuda.synchronize()
     dist.barrier(info)
     torch.cuda.synchronize()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0, info, device=dev)
 
     # the path must have produced sane output: no overflow/arena flags, no tracker errors, rows
-    pipe.wait()
-    n_tracks, next_id, err = pipe.trk.info()
-    n_rows = int(pipe.row_count.item())
-    status = max(int(d.status.max().item()) for d in pipe.det)
-    if err or status or n_rows <= 0:
-        raise SystemExit(f"hot path reported errors: tracker={err} detect_status={status} rows={n_rows}")
+    n_rows = 0
+    for p in pipes:
+        p.wait()
+        n_tracks, next_id, err = p.trk.info()
+        rows_k = int(p.row_count.item())
+        status = max(int(d.status.max().item()) for d in p.det)
+        if err or status or rows_k <= 0:
+            raise SystemExit(f"hot path reported errors: tracker={err} detect_status={status} rows={rows_k}")
+        n_rows += rows_k
 
     if rank == 0:
         ms = [e0.elapsed_time(e1) for e0, e1, _ in thr_events]
@@ -156,7 +171,7 @@ def main():
                      (W, H, args.blobs), "custom geometry")
         out = {
             "metric": "frames/sec detect+link, 1228x922 ~500 blobs, 1/2/4/8 GPU; HBM GB/s %peak",
-            "value": world * F * args.steps / elapsed,
+            "value": world * S * F * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -168,7 +183,7 @@ def main():
             "dtype": "u8 image / f32 threshold+geometry / f64 link",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} stream, ~{args.blobs} blobs, detect+link end to end ({which})",
-                       "frames_per_step": F, "detect_batch": B, "channels": args.channels, "streams": world, "parallelism": f"1 stream/GPU x{world}",
+                       "frames_per_step": F, "detect_batch": B, "channels": args.channels, "streams": world * S, "parallelism": f"{S} stream{'s' if S > 1 else ''}/GPU x{world}",
                        "rows_per_step": n_rows, "tracks_alive": n_tracks, "ids_issued": next_id},
             "roofline": {"kernel": "k_threshold", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
