@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ f
 #define STRIP_LDS_EXCHANGE 1   // measured 3 % faster than 14 v_cvt_f32_ubyte + 4 DPP shifts per row
 #endif
 #ifndef STRIP_PF
-#define STRIP_PF 2   // gray rows kept in flight per lane
+#define STRIP_PF 3   // gray rows kept in flight per lane
 #endif
 constexpr int STRIP_HALO_LANES = 3;
 constexpr int STRIP_MAX_OUT_LANES = 64 - 2 * STRIP_HALO_LANES;   // 58 lanes = 232 columns
@@ -183,7 +183,7 @@ __device__ __forceinline__ uint32_t vblur4(const HSum &u, const HSum &c, const H
 struct StripCtx {
     const uint8_t *src;   // frame base
     uint8_t *dst;
-    int H, W, lane, c0, y0, y1;
+    int H, W, lane, c0, c0_base, y0, y1;   // c0 = c0_base + 4 * lane
     uint32_t ld_col;      // column actually loaded by this lane (clamped into the row)
     bool left_edge, right_edge;
     int edge_lane;        // lane holding the last image column (W % 4 == 0: in its byte 3)
@@ -367,8 +367,14 @@ __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
                     float hi = __builtin_amdgcn_fmed3f(fmaf(d, c.sgn, c.k_hi), 0.0f, 1.0f);
                     out = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(hi, 2.0f, lo), o, out);
                 }
-                if (c.writes)
-                    *reinterpret_cast<uint32_t *>(c.dst + ((uint32_t)y * (uint32_t)W + (uint32_t)c.c0)) = out;
+                if (c.writes) {
+                    // the lane's column is rebuilt from a fresh lane id: kept live across the loop it is
+                    // the one value that got spilled, and its reload came with an s_waitcnt vmcnt(0) that
+                    // also waited for the row prefetches in flight
+                    uint32_t l;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+                    *reinterpret_cast<uint32_t *>(c.dst + ((uint32_t)y * (uint32_t)W + (uint32_t)c.c0_base + 4u * l)) = out;
+                }
             }
             }
         }
@@ -376,8 +382,9 @@ __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
 }
 
 // Requires W % 4 == 0 and W >= 16 (else the tile kernel above is used).
-// (gray: 128 VGPRs, so that three resident blocks per CU leave a fourth of each SIMD's registers to
-// the link kernel's waves; the BGR variant needs ~150 and runs two blocks per CU for the same reason)
+// (resident grid: gray 3 blocks per CU at 128 VGPRs -- with 4 blocks and 58-row items the kernel alone is
+// 15 % faster (101 us), but the link kernel's waves then find no registers while it runs and the
+// end-to-end rate is no better; the BGR variant needs ~140 VGPRs and runs 2 blocks per CU)
 template <int CH>
 __global__ __launch_bounds__(256, CH == 1 ? 4 : 3) void k_threshold_strip(const uint8_t *__restrict__ frames,
                                                          uint8_t *__restrict__ cls, StripParams P, Gauss11 gk)
@@ -404,7 +411,8 @@ __global__ __launch_bounds__(256, CH == 1 ? 4 : 3) void k_threshold_strip(const 
     c.xrow = nullptr;
 #endif
     const int xs = sx * P.out_lanes * 4;
-    c.c0 = xs - 4 * STRIP_HALO_LANES + 4 * lane;
+    c.c0_base = xs - 4 * STRIP_HALO_LANES;
+    c.c0 = c.c0_base + 4 * lane;
     c.y0 = sy * P.seg_h;
     c.y1 = min(c.y0 + P.seg_h, P.H);
     c.src = frames + (size_t)f * P.H * P.W * CH;
@@ -1461,13 +1469,14 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
         const int quads = (W + 3) / 4;
         P.strips_x = (quads + STRIP_MAX_OUT_LANES - 1) / STRIP_MAX_OUT_LANES;
         P.out_lanes = (quads + P.strips_x - 1) / P.strips_x;
-        P.seg_h = 45;   // 45 + 10 halo rows = 5 x 11 ring rotations (best of a 45..155 sweep)
+        P.seg_h = 45;   // rows per work item (+10 halo rows = 5 x 11 ring rotations; 2.6 items per resident wave)
         if (const char *e = getenv("YSMR_SEG_H")) P.seg_h = atoi(e);   // tuning knob
         P.segs_y = (H + P.seg_h - 1) / P.seg_h;
         P.inv = inv; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
         const long long waves = (long long)batch * P.strips_x * P.segs_y;
         long long blocks = (waves + 3) / 4;
-        int resident = channels == 1 ? 768 : 512;   // 3 (gray) / 2 (BGR) blocks per CU: leaves a wave slot and >= 128 VGPRs per SIMD to other streams
+        int resident = channels == 1 ? 768 : 512;   // 3 (gray, 128 VGPRs) / 2 (BGR, ~140 VGPRs) blocks per CU: a wave slot and
+                                                     // >= 128 VGPRs per SIMD stay free for the link kernel's waves
         if (const char *e = getenv("YSMR_THR_BLOCKS")) resident = atoi(e);
         if (resident > 0 && blocks > resident) blocks = resident;
         if (channels == 1) hipLaunchKernelGGL(k_threshold_strip<1>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
