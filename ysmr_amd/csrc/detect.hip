@@ -588,26 +588,20 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, ui
     }
 }
 
-// After the last kernel of a call: the current list now describes these buffers.
-__global__ void k_list_end(PixelList pl, const uint8_t *labels, const uint8_t *mask, size_t total)
-{
-    WsHeader *h = pl.hdr;
-    h->labels = (unsigned long long)labels;
-    h->mask = (unsigned long long)mask;
-    h->total = total;
-    __threadfence();
-    h->magic = WS_MAGIC;
-}
-
 // Between k_clear and k_collect: switch to the other list, empty it, and mark the header invalid
-// until k_compact (the last kernel of the call) has run.
-__global__ void k_list_begin(PixelList pl)
+// until k_compact (the last kernel of the call) has run and vouches for the buffers again.
+__global__ __launch_bounds__(256) void k_list_begin(PixelList pl, int32_t *counters, int n_counters, int32_t *status, int batch)
 {
-    WsHeader *h = pl.hdr;
-    const uint32_t cur = (h->magic == WS_MAGIC) ? ((h->cur & 1u) ^ 1u) : 0u;
-    h->magic = 0;
-    h->cur = cur;
-    h->count[cur] = 0;
+    // (also clears the per-call counters and the status words: two fewer launches in the chain)
+    for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] = 0;
+    for (int i = threadIdx.x; i < batch; i += 256) status[i] = 0;
+    if (threadIdx.x == 0) {
+        WsHeader *h = pl.hdr;
+        const uint32_t cur = (h->magic == WS_MAGIC) ? ((h->cur & 1u) ^ 1u) : 0u;
+        h->magic = 0;
+        h->cur = cur;
+        h->count[cur] = 0;
+    }
 }
 
 // Pass A0 (dense, HBM-bound: 1 B/px read): list the pixels that hold any class bit.  Each block
@@ -1357,8 +1351,17 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
 
 // Drop nested components, write final detection list / count / anchors.
 __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__restrict__ det_tmp, float *det,
-                                                 int32_t *det_count, int32_t *anchors)
+                                                 int32_t *det_count, int32_t *anchors, PixelList pl, const uint8_t *labels,
+                                                 const uint8_t *mask, size_t total)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // last kernel of the call: the current list describes these buffers
+        WsHeader *h = pl.hdr;
+        h->labels = (unsigned long long)labels;
+        h->mask = (unsigned long long)mask;
+        h->total = total;
+        __threadfence();
+        h->magic = WS_MAGIC;
+    }
     const int f = blockIdx.x;
     int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
     __shared__ int s_scan[256];
@@ -1542,11 +1545,9 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     if (const char *e = getenv("YSMR_CLEAR_BLOCKS")) clear_blocks = (unsigned)atoi(e);
     unsigned geo_blocks = GEO_BLOCKS;
     if (const char *e = getenv("YSMR_GEO_BLOCKS")) geo_blocks = (unsigned)atoi(e);
-    YSMR_HIP_CHECK(hipMemsetAsync(w.nroots, 0, sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 8), st));
-    YSMR_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t) * batch, st));
     hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, st, w.pixels, reinterpret_cast<uint8_t *>(labels), mask_dev,
                        g.total);
-    hipLaunchKernelGGL(k_list_begin, dim3(1), dim3(1), 0, st, w.pixels);
+    hipLaunchKernelGGL(k_list_begin, dim3(1), dim3(256), 0, st, w.pixels, w.nroots, batch * NR_STRIDE + 8, status_dev, batch);
     const unsigned dense_grid = cgrid < collect_blocks ? cgrid : collect_blocks;
     const dim3 sg(sparse_blocks), tb(256);
     hipLaunchKernelGGL(k_collect, dim3(dense_grid), tb, 0, st, cls_dev, labels, g, nchunks, w.pixels);
@@ -1566,8 +1567,8 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     YSMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_geometry, dim3(geo_blocks), dim3(GEO_THREADS), 0, st,
                        labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
-    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev);
-    hipLaunchKernelGGL(k_list_end, dim3(1), dim3(1), 0, st, w.pixels, reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total);
+    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev, w.pixels,
+                       reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }
