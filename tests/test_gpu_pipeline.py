@@ -158,3 +158,33 @@ def test_track_bacteria_output_equals_the_reference_detour(tmp_path):
     df_ref = sort_list(file_path=str(ref_path), save_file=True)
     pd.testing.assert_frame_equal(df, df_ref, check_exact=True)
     assert open(csv_path, "rb").read() == ref_path.read_bytes()
+
+
+def test_track_bacteria_bgr_file_and_ragged_last_batch(tmp_path, oracle):
+    """Colour input (what cv2.VideoCapture delivers: a1 runs inside the strip kernel) with tinted
+    blobs, a frame count that leaves a last batch of one frame, and a width that is a multiple of 4."""
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    gray = SyntheticVideo(160, 212, 20, seed=31, dropout=0.03, speckle=0.03).frames(49)   # 3 x 16 + 1
+    rng = np.random.default_rng(2)
+    tint = rng.uniform(0.6, 1.0, (1, 1, 1, 3))
+    frames = np.clip(gray[..., None] * tint + rng.integers(0, 6, gray.shape + (3,)), 0, 255).astype(np.uint8)
+    path = tmp_path / "colour.npy"
+    np.save(path, frames)
+    res = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16, max_det=256, capacity=256)
+    assert res is not None
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0)
+    assert len(ref_rows) == len(res[0])
+    compare_rows(_rows_from_df(res[0]), ref_rows)
+
+
+def test_track_bacteria_without_objects_returns_none(tmp_path, caplog):
+    """track_eval.py:389-392: nothing tracked -> warning, None (and no exception)."""
+    import logging
+    from ysmr_amd.track_eval import track_bacteria
+    frames = np.full((48, 64, 80), 40, np.uint8)
+    path = tmp_path / "empty.npy"
+    np.save(path, frames)
+    with caplog.at_level(logging.WARNING, logger="ysmr"):
+        assert track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16) is None
+    assert any("Did not track any objects" in r.getMessage() for r in caplog.records)

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import logging
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -196,7 +197,9 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
             host = video.read(f0, pipe.B)
             if host.shape[0] == 0:
                 break
-            dev = torch.from_numpy(host).to(pipe.device, non_blocking=True)
+            with warnings.catch_warnings():   # (memory-mapped .npy files are read-only; the tensor is only read)
+                warnings.simplefilter("ignore", UserWarning)
+                dev = torch.from_numpy(host).to(pipe.device, non_blocking=True)
             nxt = (pipe.detect_async(dev), f0, host.shape[0])
             if pending is not None:
                 (slot, r, ready), p0, cnt = pending
