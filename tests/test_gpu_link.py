@@ -129,3 +129,38 @@ def test_pipeline_rows_match_oracle(torch_cuda, oracle):
     got = rows_to_numpy(rows, int(count.item()))
     n_loose, worst = compare_rows(got, ref_rows)
     assert n_loose > 0   # the clip does contain lost-track episodes
+
+
+def test_table_grows_and_shrinks_abruptly(torch_cuda, oracle):
+    """5 tracks, then 700 detections appear at once (registration of hundreds of tracks in one frame,
+    CPython set order over a large table), most vanish (mass ageing and deregistration, compaction
+    over several 256-row chunks), then 600 come back."""
+    torch = torch_cuda
+    from ysmr_amd import _lib
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    rng = np.random.default_rng(12)
+    cap = md = 1024
+    def dets(n, jitter, base):
+        xy = base[:n] + rng.normal(0, jitter, (n, 2))
+        whd = np.column_stack([rng.uniform(1, 9, n), rng.uniform(1, 9, n), rng.uniform(-90, 0, n)])
+        return np.column_stack([xy, whd]).astype(np.float32)
+    base = rng.uniform(0, 4000, (700, 2))
+    per_frame = [dets(5, 0.3, base) for _ in range(8)] + [dets(700, 0.3, base) for _ in range(8)] + \
+                [dets(40, 0.3, base) for _ in range(8)] + [dets(600, 0.3, base) for _ in range(8)]
+    ot = oracle.OracleTracker(max_disappeared=3.0, fps=30.0, n_min=0, n_max=30, n_f=3, use_gsff=True)
+    ref_rows = []
+    for f, d in enumerate(per_frame):
+        ids, xy, info, _ = ot.update(oracle.det_to_rects(d))
+        ref_rows += [(f, tid, float(xy[i][0]), float(xy[i][1]), *map(float, info[i])) for i, tid in enumerate(ids)]
+    trk = DeviceTracker(max_disappeared=3.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=cap, max_det=md)
+    rows = torch.empty(len(per_frame) * cap * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for b0 in range(0, len(per_frame), 8):
+        det = torch.zeros(8, md, 5, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(8, dtype=torch.int32, device="cuda")
+        for k, d in enumerate(per_frame[b0:b0 + 8]):
+            det[k, :len(d)] = torch.from_numpy(d).cuda()
+            cnt[k] = len(d)
+        trk.run(det, cnt, b0, rows, count)
+    assert trk.info()[2] == 0
+    compare_rows(rows_to_numpy(rows, int(count.item())), ref_rows)
