@@ -47,7 +47,7 @@ def parse():
                     help="independent video streams processed concurrently on each GPU (the metric's configuration is 1)")
     ap.add_argument("--channels", type=int, default=1, choices=(1, 3),
                     help="1: gray frames (the metric's configuration); 3: the same frames as BGR (B=G=R), which adds a1")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="frames of the clip timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=200, help="frames of the clip timed on the CPU oracle (0 = skip)")
     return ap.parse_args()
 
 
