@@ -34,3 +34,20 @@ print("frame: start offset us | period us | block-0 in-kernel us")
 for f in range(f0, f0 + 64):
     if f in beg and f + 1 in beg:
         print(f"{f:4d}: {(beg[f]-beg[f0])/100:8.1f} | {(beg[f+1]-beg[f])/100:6.1f} | {(end[f]-beg[f])/100:6.1f}")
+# detection kernels (begin stamps) that started within that batch window, merged into the timeline
+names = {1: "threshold", 2: "clear", 3: "list_begin", 4: "collect", 5: "union4", 6: "flag", 7: "union8", 8: "flatten",
+         9: "rank", 10: "bbox_euler", 11: "holes", 12: "nested", 13: "geometry", 14: "compact"}
+dbuf = (ctypes.c_ulonglong * 2048)(); dn = ctypes.c_uint(0)
+if hasattr(L, "ysmr_debug_read_det_ring"):
+    L.ysmr_debug_read_det_ring(dbuf, ctypes.byref(dn))
+    d = np.array(dbuf[:], dtype=np.uint64).reshape(1024, 2)
+    d = d[d[:, 1] > 0]
+    t_lo, t_hi = beg[f0], beg[f0 + 63]
+    ev = sorted((int(t), names.get(int(tag), str(tag))) for tag, t in d if t_lo - 30000 <= int(t) <= t_hi)
+    print("detection kernel starts (us relative to frame %d):" % f0)
+    print("  " + ", ".join(f"{n}@{(t - t_lo)/100:.0f}" for t, n in ev))
+    # slow frames and the detection kernel running when they started
+    for f in range(f0, f0 + 64):
+        if f in beg and f + 1 in beg and beg[f + 1] - beg[f] > 1600:
+            running = [n for t, n in ev if t <= beg[f]]
+            print(f"  slow frame {f} (period {(beg[f+1]-beg[f])/100:.1f} us, in-kernel {(end[f]-beg[f])/100:.1f}) started during: {running[-1] if running else '-'}")

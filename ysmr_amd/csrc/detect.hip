@@ -14,6 +14,16 @@
 #include <cmath>
 #include <cstdlib>
 
+#ifdef YSMR_STAMPS
+// begin stamps of the detection kernels (100 MHz realtime counter), read by scripts/ring_gaps.py
+__device__ unsigned long long g_det_ring[1024 * 2];
+__device__ unsigned int g_det_ring_n;
+#define DET_RING(tag) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); unsigned int i_ = atomicAdd(&g_det_ring_n, 1u) & 1023u; g_det_ring[2 * i_] = (unsigned long long)(tag); g_det_ring[2 * i_ + 1] = t_; } } while (0)
+extern "C" int ysmr_debug_read_det_ring(unsigned long long *out, unsigned int *n) { hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_det_ring), sizeof(unsigned long long) * 2048); if (e == hipSuccess) e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_det_ring_n), 4); return (int)e; }
+#else
+#define DET_RING(tag) do {} while (0)
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -389,6 +399,7 @@ template <int CH>
 __global__ __launch_bounds__(256, CH == 1 ? 4 : 3) void k_threshold_strip(const uint8_t *__restrict__ frames,
                                                          uint8_t *__restrict__ cls, StripParams P, Gauss11 gk)
 {
+    DET_RING(1);
 #if STRIP_LDS_EXCHANGE
     __shared__ float s_x[4][64 * 4 + 16];
 #endif
@@ -562,6 +573,7 @@ constexpr int SPARSE_BLOCKS = 768;  // resident grid of the list-driven passes (
 constexpr int CLEAR_BLOCKS = 512;
 __global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, uint8_t *mask, size_t total)
 {
+    DET_RING(2);
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
     const WsHeader h = *pl.hdr;
     const uint32_t prev = h.cur & 1u;
@@ -592,6 +604,7 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, ui
 // until k_compact (the last kernel of the call) has run and vouches for the buffers again.
 __global__ __launch_bounds__(256) void k_list_begin(PixelList pl, int32_t *counters, int n_counters, int32_t *status, int batch)
 {
+    DET_RING(3);
     // (also clears the per-call counters and the status words: two fewer launches in the chain)
     for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] = 0;
     for (int i = threadIdx.x; i < batch; i += 256) status[i] = 0;
@@ -613,6 +626,7 @@ constexpr int COLLECT_WAVE_BUF = 1280;  // entries buffered per wave before a fl
 __global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls, uint32_t *__restrict__ labels, Geo g,
                                                  size_t nchunks, PixelList pl)
 {
+    DET_RING(4);
     // one buffer per wave: nothing in this kernel needs a block barrier
     __shared__ uint32_t s_buf[4][COLLECT_WAVE_BUF];
     const int lane = threadIdx.x & 63;
@@ -701,6 +715,7 @@ __global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls
 __global__ __launch_bounds__(256) void k_union4(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
                                                 PixelList pl)
 {
+    DET_RING(5);
     FOR_LISTED_PIXELS(pl, g, flat) {
         if (flat >= g.total || !(cls[flat] & 1u)) continue;
         uint32_t f, p; int y, x;
@@ -724,6 +739,7 @@ __device__ __forceinline__ void set_flag(uint8_t *cls, size_t flat)
 // or touches (4-neighbourhood) a marker pixel lying outside the mask.
 __global__ __launch_bounds__(256) void k_flag(uint8_t *cls, const uint32_t *labels, Geo g, PixelList pl)
 {
+    DET_RING(6);
     FOR_LISTED_PIXELS(pl, g, flat) {
         {
             if (flat >= g.total) continue;
@@ -758,6 +774,7 @@ __device__ __forceinline__ bool in_result(const uint8_t *cls_frame, const uint32
 __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
                                                 PixelList pl)
 {
+    DET_RING(7);
     FOR_LISTED_PIXELS(pl, g, flat) {
     {
         if (flat >= g.total) continue;
@@ -795,6 +812,7 @@ __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls
                                                  uint8_t *__restrict__ mask, Geo g, PixelList pl,
                                                  int32_t *nroots, int32_t *roots, int max_det)
 {
+    DET_RING(8);
     FOR_LISTED_PIXELS(pl, g, flat) {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
@@ -842,6 +860,7 @@ constexpr int RANK_THREADS = 1024;
 __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *labels, uint32_t HW, int W, int H,
                                                        int32_t *status)
 {
+    DET_RING(9);
     const int f = blockIdx.x;
     int n = t.nroots[(size_t)f * NR_STRIDE];
     if (n > t.max_det) {
@@ -892,6 +911,7 @@ __device__ __forceinline__ int find_rank(const int32_t *order, int n, int32_t ro
 __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ cls, const uint32_t *__restrict__ labels,
                                                     Geo g, PixelList pl, CompTables t)
 {
+    DET_RING(10);
     // The list keeps the pixels of a 16-pixel chunk on adjacent lanes, so a horizontal run of a
     // component sits on consecutive lanes: its lanes pool their y-extent candidates and quad counts
     // with ballots, and only the run's first lane issues those atomics.  (The loop is kept
@@ -969,6 +989,7 @@ constexpr int HOLED_CAP = 4096;
 __global__ __launch_bounds__(256) void k_holes(CompTables t, int batch, uint32_t *labels, uint32_t HW, int32_t *n_holed,
                                                int2 *holed, int32_t *status)
 {
+    DET_RING(11);
     int i = blockIdx.x * 256 + threadIdx.x;
     int f = i / t.max_det, k = i - f * t.max_det;
     if (f >= batch) return;
@@ -1073,6 +1094,7 @@ __global__ __launch_bounds__(256) void k_nested(const uint32_t *__restrict__ lab
                                                 const int32_t *n_holed, const int2 *holed, float *arena,
                                                 uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
 {
+    DET_RING(12);
     const int nh = min(*n_holed, HOLED_CAP);
     for (int idx = blockIdx.x; idx < nh; idx += gridDim.x) {
         nested_component(labels, g, t, idx, holed, arena, arena_floats, arena_used, status);
@@ -1339,6 +1361,7 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
                                                           int batch, float *det_tmp, float *arena,
                                                           uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
 {
+    DET_RING(13);
     const int most = min(*t.max_roots, t.max_det);
     const long long items = (long long)((most + GEO_COMPS - 1) / GEO_COMPS) * batch;
     for (long long it = blockIdx.x; it < items; it += gridDim.x) {
@@ -1354,6 +1377,7 @@ __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__re
                                                  int32_t *det_count, int32_t *anchors, PixelList pl, const uint8_t *labels,
                                                  const uint8_t *mask, size_t total)
 {
+    DET_RING(14);
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // last kernel of the call: the current list describes these buffers
         WsHeader *h = pl.hdr;
         h->labels = (unsigned long long)labels;
