@@ -69,7 +69,11 @@ struct ysmr_tracker {
 __device__ unsigned long long g_stamps[32];
 #define GSTAMP(k) do { if (blockIdx.x == 1 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_stamps[k] = t_; } } while (0)
 __device__ unsigned long long g_block_stamps[2 * 2048 * 8];
-#define BSTAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_block_stamps[((frame & 1) * 2048 + blockIdx.x) * 8 + (k)] = t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_block_stamps[((frame & 1) * 2048 + blockIdx.x) * 8 + 4 + (k)] = t_; } } while (0)
+#ifndef YSMR_BS_A
+#define YSMR_BS_A 62   // frames (mod 64) whose per-block stamps are kept: slot 0 / slot 1
+#define YSMR_BS_B 63
+#endif
+#define BSTAMP(k) do { const int fs_ = frame; if (threadIdx.x == 0 && (fs_ == YSMR_BS_A || fs_ == YSMR_BS_B)) { const int sl_ = fs_ == YSMR_BS_B; unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_block_stamps[(sl_ * 2048 + blockIdx.x) * 8 + (k)] = t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_block_stamps[(sl_ * 2048 + blockIdx.x) * 8 + 4 + (k)] = t_; } } while (0)
 extern "C" int ysmr_debug_read_block_stamps(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_stamps), sizeof(unsigned long long) * n); }
 __device__ unsigned long long g_ring[4096 * 2];
 __device__ unsigned int g_ring_n;
@@ -923,39 +927,78 @@ __device__ void set_insert_clean16(short *table, unsigned mask, int key)
         i = (unsigned)(((unsigned long long)i * 5ull + 1ull + perturb) & mask);
     }
 }
-__device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_used, int *out, short *tables)
+// Block-cooperative form (all FRAME_THREADS threads call it): only the insertions themselves are
+// order-dependent and stay on thread 0; clearing a table, collecting the occupied slots of a table in
+// slot order (before a resize and for the final iteration order) are done by the whole block.  The
+// one-thread version spent 25 us of a registration frame walking a 512-slot table.
+// `out` doubles as the list of keys to re-insert at a resize.  Returns the number of keys, or -1 if
+// the model would need a table larger than FRAME_TABLE.
+__device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_used, int *out, short *tables, int *s_scan,
+                                 int *s_state)
 {
+    const int tid = threadIdx.x;
     if ((m >> 2) > n_used) {
-        for (int k = 0; k < n_unused; ++k) out[k] = unused[k];
+        for (int k = tid; k < n_unused; k += FRAME_THREADS) out[k] = unused[k];
+        __syncthreads();
         return n_unused;
     }
+    // occupied slots of tab[0..size) in slot order -> out[0..count)
+    auto collect = [&](const short *tab, int size) {
+        int base = 0;
+        for (int i0 = 0; i0 < size; i0 += FRAME_THREADS) {
+            const int i = i0 + tid;
+            const int key = i < size ? tab[i] : -1;
+            int total;
+            const int ex = block_flag_rank(key >= 0, s_scan + ((i0 / FRAME_THREADS) & 1) * 4, &total);
+            if (key >= 0) out[base + ex] = key;
+            base += total;
+        }
+        __syncthreads();
+        return base;
+    };
     short *table = tables, *other = tables + FRAME_TABLE;
     unsigned mask = 7;
-    int fill = 0;
-    for (int i = 0; i < 8; ++i) table[i] = -1;
-    for (int k = 0; k < n_unused; ++k) {
-        set_insert_clean16(table, mask, unused[k]);
-        ++fill;
-        if ((unsigned long long)fill * 5ull >= (unsigned long long)mask * 3ull) {
-            unsigned minused = fill > 50000 ? (unsigned)fill * 2u : (unsigned)fill * 4u;
-            unsigned newsize = 8;
-            while (newsize <= minused) newsize <<= 1;
-            if ((int)newsize > FRAME_TABLE) return -1;
-            for (unsigned i = 0; i < newsize; ++i) other[i] = -1;
-            for (unsigned i = 0; i <= mask; ++i)
-                if (table[i] >= 0) set_insert_clean16(other, newsize - 1, table[i]);
-            short *tmp = table; table = other; other = tmp;
-            mask = newsize - 1;
+    int next = 0;      // next element of `unused` to insert
+    if (tid < 8) table[tid] = -1;
+    __syncthreads();
+    while (true) {
+        if (tid == 0) {   // insert until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
+            int k = next;
+            bool grow = false;
+            while (k < n_unused && !grow) {
+                set_insert_clean16(table, mask, unused[k]);
+                ++k;
+                grow = (unsigned long long)k * 5ull >= (unsigned long long)mask * 3ull;   // fill == k: nothing is ever removed
+            }
+            s_state[0] = k;
+            s_state[1] = grow ? 1 : 0;
         }
+        __syncthreads();
+        next = s_state[0];
+        const bool grow = s_state[1] != 0;
+        __syncthreads();
+        if (!grow) break;
+        const unsigned fill = (unsigned)next;
+        const unsigned minused = fill > 50000u ? fill * 2u : fill * 4u;
+        unsigned newsize = 8;
+        while (newsize <= minused) newsize <<= 1;
+        if ((int)newsize > FRAME_TABLE) return -1;
+        for (unsigned i = tid; i < newsize; i += FRAME_THREADS) other[i] = -1;
+        const int cnt = collect(table, (int)mask + 1);      // (ends with a barrier: `other` is cleared, `out` is complete)
+        if (tid == 0)
+            for (int j = 0; j < cnt; ++j) set_insert_clean16(other, newsize - 1, out[j]);
+        short *tmp = table; table = other; other = tmp;
+        mask = newsize - 1;
+        __syncthreads();
     }
-    int count = 0;
-    for (unsigned i = 0; i <= mask; ++i)
-        if (table[i] >= 0) out[count++] = table[i];
-    return count;
+    return collect(table, (int)mask + 1);
 }
 
 #ifdef YSMR_STAMPS
-#define STAMP(k) do { if (blockIdx.x == 1 && threadIdx.x == 0 && (frame & 63) == 40) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((unsigned long long *)(rows + rows_capacity - 4))[k] = t_; } } while (0)
+#ifndef YSMR_ST_FRAME
+#define YSMR_ST_FRAME 40
+#endif
+#define STAMP(k) do { if (blockIdx.x == 1 && threadIdx.x == 0 && (YSMR_ST_FRAME < 64 ? (frame & 63) == YSMR_ST_FRAME : frame == YSMR_ST_FRAME)) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((unsigned long long *)(rows + rows_capacity - 4))[k] = t_; } } while (0)
 #else
 #define STAMP(k) do {} while (0)
 #endif
@@ -969,7 +1012,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
                                                          const DetT *__restrict__ next_det, const int32_t *next_m_dev)
 {
     extern __shared__ unsigned long long s_raw[];
-    __shared__ int s_n_used, s_n_new, s_n_dead;
+    __shared__ int s_n_used, s_n_dead, s_set_state[2];
     // the link is a chain of short latency-bound kernels sharing SIMDs with throughput kernels of the
     // detection stream: let its waves win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
@@ -1030,7 +1073,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     L.table = reinterpret_cast<short *>(L.scan + 16);
 
     // ---- phase A (redundant in every block): the frame's bookkeeping
-    if (tid == 0) { s_n_used = 0; s_n_new = 0; s_n_dead = 0; }
+    if (tid == 0) { s_n_used = 0; s_n_dead = 0; }
     for (int c = tid; c < m; c += FRAME_THREADS) { L.col_key[c] = ~0ull; L.col_row[c] = 0x7FFFFFFF; }
     slot_s = __builtin_amdgcn_readfirstlane(i < n ? slot_s : -1);
     c_s = __builtin_amdgcn_readfirstlane((i < n && m > 0) ? c_s : -1);
@@ -1132,14 +1175,13 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
             }
             __syncthreads();
             STAMP(12);
-            if (tid == 0) {
-                int cnt = cpython_order_lds(L.unused, base, m, s_n_used, L.newcols, L.table);
-                if (cnt < 0) { if (blockIdx.x == 0) atomicOr(a.err, ERR_TRACK_CAPACITY); cnt = 0; }
-                s_n_new = cnt;
+            {
+                int cnt = cpython_order_lds(L.unused, base, m, s_n_used, L.newcols, L.table, L.scan, s_set_state);
+                if (cnt < 0) { if (blockIdx.x == 0 && tid == 0) atomicOr(a.err, ERR_TRACK_CAPACITY); cnt = 0; }
+                n_new = cnt;
             }
             __syncthreads();
             STAMP(13);
-            n_new = s_n_new;
         }
         __syncthreads();
     }
