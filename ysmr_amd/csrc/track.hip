@@ -61,6 +61,8 @@ struct ysmr_tracker {
     void *block;       // the single device allocation
     size_t block_bytes;
     std::vector<double> gains_host;
+    bool set_base;                 // fused path: the next k_rowmin also sets row_base from base_ptr
+    const long long *base_ptr;
     const TrackerDev &cur() const { return par ? d1 : d; }
     const TrackerDev &nxt() const { return par ? d : d1; }
 };
@@ -223,8 +225,11 @@ __device__ __forceinline__ void rowmin_wave(const TrackerDev &t, int row, double
 // row-min of frame f+1 rides on k_track of frame f.
 template <typename DetT>
 __global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__restrict__ det, int m_host,
-                                                const int32_t *m_dev)
+                                                const int32_t *m_dev, int set_row_base, const long long *row_count_ext)
 {
+    // (fused path, start of ysmr_tracker_run / _update: row_base of the current state := the caller's
+    // running row count; folded in here to save a launch per batch)
+    if (set_row_base && blockIdx.x == 0 && threadIdx.x == 0) t.row_base[0] = row_count_ext ? *row_count_ext : 0;
     const int n = *t.n_tracks;
     const int m = det_count(m_host, m_dev, t.max_det, nullptr);
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1290,13 +1295,6 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     }
 }
 
-// row_base of the current state := the caller's running row count (start of ysmr_tracker_run)
-__global__ void k_set_row_base(TrackerDev t, const long long *row_count_ext)
-{
-    RING(1ull << 40);
-    t.row_base[0] = row_count_ext ? *row_count_ext : 0;
-}
-
 __global__ void k_tracker_reset(TrackerDev t)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1344,7 +1342,10 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
     const dim3 wgrid((t->d.capacity + 3) / 4);
     if (t->fused) {
         const TrackerDev &a = t->cur(), &b = t->nxt();
-        if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, a, det, m, m_dev);
+        if (!rowmin_done) {
+            hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, a, det, m, m_dev, t->set_base ? 1 : 0, t->base_ptr);
+            t->set_base = false;
+        }
         // the filter bank is unrolled at compile time: 3 covers tracking.ini's default (and 1, 2), 8 the rest
         if (a.n_f <= 3)
             hipLaunchKernelGGL((k_frame<DetT, 3>), wgrid, dim3(FRAME_THREADS), t->frame_lds, st, a, b, det, m, m_dev, frame,
@@ -1356,7 +1357,7 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
         t->par ^= 1;
     } else {
         const TrackerDev &d = t->d;
-        if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, d, det, m, m_dev);
+        if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, d, det, m, m_dev, 0, nullptr);
         const size_t link_lds = 12 * (size_t)d.max_det + 4 * (size_t)d.capacity;
         hipLaunchKernelGGL(k_link<DetT>, dim3(1), dim3(LINK_THREADS), link_lds, st, d, det, m, m_dev, frame, rows,
                            rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
@@ -1491,6 +1492,8 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
         q.row_min = (double *)(b + o_rmin1); q.row_arg = (int *)(b + o_rarg1);
     }
     t->par = 0;
+    t->set_base = false;
+    t->base_ptr = nullptr;
     t->frame_lds = frame_lds_bytes(capacity, max_det, (int)gain_doubles);
     const char *mode_env = getenv("YSMR_LINK_MODE");   // "split" forces the two-kernel path (tests)
     t->fused = t->frame_lds <= 150 * 1024 && max_det < 65535 && !(mode_env && !strcmp(mode_env, "split"));
@@ -1540,7 +1543,7 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
     if (m < 0 && !m_dev) return ysmr::fail(YSMR_ERR_ARG, "m < 0 requires m_dev");
     if (m > t->d.max_det) return ysmr::fail(YSMR_ERR_CAPACITY, "m = %d exceeds max_det = %d", m, t->d.max_det);
     if (!det_dev && m != 0) return ysmr::fail(YSMR_ERR_ARG, "det_dev is NULL");
-    if (t->fused) hipLaunchKernelGGL(k_set_row_base, dim3(1), dim3(1), 0, (hipStream_t)stream, t->cur(), nullptr);
+    if (t->fused) { t->set_base = true; t->base_ptr = nullptr; }
     if (det_is_f64)
         return launch_update_t<double>(t, (hipStream_t)stream, (const double *)det_dev, m, m_dev, frame_index, rows_dev,
                                        t->d.capacity, nullptr, n_rows_dev, claim_col_dev, n_before_dev, new_cols_dev,
@@ -1556,9 +1559,7 @@ int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const 
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
     if (!det_dev || !det_count_dev || !rows_dev || !row_count_dev || batch <= 0)
         return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev, rows_dev, row_count_dev must be set and batch > 0");
-    if (t->fused)
-        hipLaunchKernelGGL(k_set_row_base, dim3(1), dim3(1), 0, (hipStream_t)stream, t->cur(),
-                           (const long long *)row_count_dev);
+    if (t->fused) { t->set_base = true; t->base_ptr = (const long long *)row_count_dev; }
     for (int f = 0; f < batch; ++f) {
         const bool has_next = f + 1 < batch;
         int rc = launch_update_t<float>(t, (hipStream_t)stream, det_dev + (size_t)f * t->d.max_det * 5, -1,
