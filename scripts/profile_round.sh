@@ -3,6 +3,7 @@
 # the same command, PMC passes (each in its own run, no tracing domains) for the threshold kernel
 # plus the FETCH/WRITE calibration copy.  Everything lands in gpurun_out/round/.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
+[ -x $R/scripts/ubench/copy_calib ] || make -C $R/scripts/ubench copy_calib >/dev/null
 python $R/bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python3 $R/bench.py --cpu-sample 0 > $O/ktrace.log 2>&1
