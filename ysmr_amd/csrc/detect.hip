@@ -1486,6 +1486,21 @@ int check_geometry(int batch, int H, int W, int channels, int max_det)
     return YSMR_OK;
 }
 
+// Tuning knobs (environment, read once per process): resident grid sizes of the detection kernels
+// and the strip kernel's segment height.  Values <= 0 or unset keep the defaults.
+struct Knobs {
+    int seg_h, thr_blocks, collect_blocks, sparse_blocks, clear_blocks, geo_blocks;
+};
+const Knobs &knobs()
+{
+    static const Knobs k = [] {
+        auto get = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
+        return Knobs{get("YSMR_SEG_H"), get("YSMR_THR_BLOCKS"), get("YSMR_COLLECT_BLOCKS"), get("YSMR_SPARSE_BLOCKS"),
+                     get("YSMR_CLEAR_BLOCKS"), get("YSMR_GEO_BLOCKS")};
+    }();
+    return k;
+}
+
 int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, int W, int channels, int inv, int t_low,
                      int t_high, int use_high, uint8_t *cls)
 {
@@ -1497,14 +1512,14 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
         P.strips_x = (quads + STRIP_MAX_OUT_LANES - 1) / STRIP_MAX_OUT_LANES;
         P.out_lanes = (quads + P.strips_x - 1) / P.strips_x;
         P.seg_h = 45;   // rows per work item (+10 halo rows = 5 x 11 ring rotations; 2.6 items per resident wave)
-        if (const char *e = getenv("YSMR_SEG_H")) P.seg_h = atoi(e);   // tuning knob
+        if (knobs().seg_h > 0) P.seg_h = knobs().seg_h;
         P.segs_y = (H + P.seg_h - 1) / P.seg_h;
         P.inv = inv; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
         const long long waves = (long long)batch * P.strips_x * P.segs_y;
         long long blocks = (waves + 3) / 4;
         int resident = channels == 1 ? 768 : 512;   // 3 (gray, 128 VGPRs) / 2 (BGR, ~140 VGPRs) blocks per CU: a wave slot and
                                                      // >= 128 VGPRs per SIMD stay free for the link kernel's waves
-        if (const char *e = getenv("YSMR_THR_BLOCKS")) resident = atoi(e);
+        if (knobs().thr_blocks > 0) resident = knobs().thr_blocks;
         if (resident > 0 && blocks > resident) blocks = resident;
         if (channels == 1) hipLaunchKernelGGL(k_threshold_strip<1>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
         else hipLaunchKernelGGL(k_threshold_strip<3>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
@@ -1563,12 +1578,11 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     const unsigned cgrid = (unsigned)((nchunks + 255) / 256);
     uint32_t *labels = reinterpret_cast<uint32_t *>(labels_dev);
 
-    unsigned collect_blocks = COLLECT_BLOCKS, sparse_blocks = SPARSE_BLOCKS, clear_blocks = CLEAR_BLOCKS;
-    if (const char *e = getenv("YSMR_COLLECT_BLOCKS")) collect_blocks = (unsigned)atoi(e);   // tuning knobs
-    if (const char *e = getenv("YSMR_SPARSE_BLOCKS")) sparse_blocks = (unsigned)atoi(e);
-    if (const char *e = getenv("YSMR_CLEAR_BLOCKS")) clear_blocks = (unsigned)atoi(e);
-    unsigned geo_blocks = GEO_BLOCKS;
-    if (const char *e = getenv("YSMR_GEO_BLOCKS")) geo_blocks = (unsigned)atoi(e);
+    const Knobs &kn = knobs();
+    const unsigned collect_blocks = kn.collect_blocks > 0 ? (unsigned)kn.collect_blocks : (unsigned)COLLECT_BLOCKS;
+    const unsigned sparse_blocks = kn.sparse_blocks > 0 ? (unsigned)kn.sparse_blocks : (unsigned)SPARSE_BLOCKS;
+    const unsigned clear_blocks = kn.clear_blocks > 0 ? (unsigned)kn.clear_blocks : (unsigned)CLEAR_BLOCKS;
+    const unsigned geo_blocks = kn.geo_blocks > 0 ? (unsigned)kn.geo_blocks : (unsigned)GEO_BLOCKS;
     hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, st, w.pixels, reinterpret_cast<uint8_t *>(labels), mask_dev,
                        g.total);
     hipLaunchKernelGGL(k_list_begin, dim3(1), dim3(256), 0, st, w.pixels, w.nroots, batch * NR_STRIDE + 8, status_dev, batch);
