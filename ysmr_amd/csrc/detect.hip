@@ -1481,7 +1481,7 @@ int check_geometry(int batch, int H, int W, int channels, int max_det)
         return ysmr::fail(YSMR_ERR_ARG, "batch, height, width, max_det must be positive (got %d, %d, %d, %d)", batch, H, W, max_det);
     if (channels != 1 && channels != 3)
         return ysmr::fail(YSMR_ERR_ARG, "channels must be 1 (gray) or 3 (BGR), got %d", channels);
-    if (H > 16384 || W > 16384 || (size_t)batch * H * W >= (1ull << 32))
+    if (H > 16384 || W > 16384 || (size_t)batch * H * W > (1ull << 32) - 64)
         return ysmr::fail(YSMR_ERR_ARG, "batch too large (height and width are limited to 16384, batch*height*width to 2^32 - 1)");
     return YSMR_OK;
 }
