@@ -584,7 +584,12 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, ui
         for (size_t i = tid; i < h.count[prev]; i += stride) {
             const uint32_t flat = idx[i];
             lab[flat] = 0u;
-            if (mask) mask[flat] = 0;
+            // whole dword: its other bytes are either listed themselves or zero already (every non-zero mask
+            // byte belongs to a listed pixel), and a dword store spares the partial-byte write
+            if (mask) {
+                if ((size_t)(flat | 3u) < total) *reinterpret_cast<uint32_t *>(mask + (flat & ~3u)) = 0u;
+                else mask[flat] = 0;
+            }
         }
         return;
     }
