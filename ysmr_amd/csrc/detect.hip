@@ -742,7 +742,7 @@ __device__ __forceinline__ void set_flag(uint8_t *cls, size_t flat)
 
 // Pass C: flag (bit2 on the root's class byte) every thresh-component that holds a marker pixel
 // or touches (4-neighbourhood) a marker pixel lying outside the mask.
-__global__ __launch_bounds__(256) void k_flag(uint8_t *cls, const uint32_t *labels, Geo g, PixelList pl)
+__global__ __launch_bounds__(256) void k_flag(uint8_t *cls, uint32_t *labels, Geo g, PixelList pl)
 {
     DET_RING(6);
     FOR_LISTED_PIXELS(pl, g, flat) {
@@ -752,10 +752,14 @@ __global__ __launch_bounds__(256) void k_flag(uint8_t *cls, const uint32_t *labe
             if (!(b & 2u)) continue;
             uint32_t f, p; int y, x;
             locate(g, flat, f, p, y, x);
-            const uint32_t *L = labels + (size_t)f * g.HW;
+            uint32_t *L = labels + (size_t)f * g.HW;
             size_t fbase = (size_t)f * g.HW;
             if (b & 1u) {
-                set_flag(cls, fbase + find_root_cached(L, p));
+                const uint32_t r = find_root_cached(L, p);
+                set_flag(cls, fbase + r);
+                // no union runs in this pass: point the pixel straight at its root, so that the finds of
+                // the next two passes are one hop (a stale reader still sees an ancestor)
+                if (r != p && r != DEAD) L[p] = r + 1u;
             } else {
                 if (x > 0 && (cls[flat - 1] & 1u)) set_flag(cls, fbase + find_root_cached(L, p - 1));
                 if (x < g.W - 1 && (cls[flat + 1] & 1u)) set_flag(cls, fbase + find_root_cached(L, p + 1));
