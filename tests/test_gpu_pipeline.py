@@ -188,3 +188,60 @@ def test_track_bacteria_without_objects_returns_none(tmp_path, caplog):
     with caplog.at_level(logging.WARNING, logger="ysmr"):
         assert track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16) is None
     assert any("Did not track any objects" in r.getMessage() for r in caplog.records)
+
+
+def test_full_size_batch_properties():
+    """BASELINE's metric configuration at full size (64 frames of 1228x922, ~500 blobs), checked through
+    properties that need no oracle run: the label map against SciPy's 8-connected labelling of the
+    mask (a label is its component's first pixel in raster order + 1), mask == (labels != 0),
+    detections ordered by descending first pixel, a second batch through the SAME detector (sparse
+    clear from the previous pixel list) giving exactly what a fresh detector gives, and rows that
+    are complete and ordered per frame."""
+    import torch
+    from scipy import ndimage
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    from ysmr_amd import _lib
+    B, H, W = 64, 922, 1228
+    frames = SyntheticVideo(H, W, 500, seed=3).frames(2 * B)
+    dev = torch.from_numpy(frames).cuda()
+    p = threshold_params(True, 5, 2.0)
+    det = Detector(B, H, W, max_det=2048, params=p)
+    first = det.detect(dev[:B])
+    labels_a = first.labels.cpu().numpy().copy()
+    res = det.detect(dev[B:])                       # reuses the workspace: sparse clear of what batch 0 wrote
+    labels, mask = res.labels.cpu().numpy(), res.mask.cpu().numpy()
+    cnt, anchors, status = res.det_count.cpu().numpy(), res.anchors.cpu().numpy(), res.status.cpu().numpy()
+    assert (status == 0).all() and (labels_a != 0).any()
+    fresh = Detector(B, H, W, max_det=2048, params=p).detect(dev[B:])
+    assert torch.equal(fresh.labels, res.labels) and torch.equal(fresh.mask, res.mask)
+    assert torch.equal(fresh.det_count, res.det_count)
+    valid = torch.arange(2048, device="cuda")[None, :] < res.det_count[:, None]          # rows past det_count are scratch
+    assert torch.equal(fresh.det[valid], res.det[valid]) and torch.equal(fresh.anchors[valid], res.anchors[valid])
+    np.testing.assert_array_equal(mask, (labels != 0).astype(np.uint8) * 255)
+    flat_index = np.arange(H * W, dtype=np.int64).reshape(H, W)
+    for f in (0, 31, 63):
+        lab, n = ndimage.label(mask[f] != 0, structure=np.ones((3, 3)))
+        first_px = ndimage.minimum(flat_index, lab, index=np.arange(1, n + 1)).astype(np.int64)
+        want = np.zeros(n + 1, np.int64)
+        want[1:] = first_px + 1
+        np.testing.assert_array_equal(labels[f], want[lab])
+        assert cnt[f] <= n and (np.diff(anchors[f][:cnt[f]]) < 0).all()       # reverse raster order, nested ones dropped
+        assert set(anchors[f][:cnt[f]]) <= set(first_px)
+    trk = DeviceTracker(max_disappeared=30.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=2048, max_det=2048)
+    rows = torch.empty(B * 2048 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    trk.run(res.det, res.det_count, 0, rows, count)
+    torch.cuda.synchronize()
+    n_tracks, next_id, err = trk.info()
+    got = rows_to_numpy(rows, int(count.item()))
+    assert err == 0 and len(got) > 0
+    assert (np.diff(got["frame"]) >= 0).all()
+    for f in range(B):
+        ids = got["track_id"][got["frame"] == f]
+        assert (np.diff(ids) > 0).all() and len(ids) >= cnt[f] - 0      # every detection of frame 0 became a track; ids ascend
+        if f == 0:
+            assert len(ids) == cnt[0]
+    assert got["track_id"].max() == next_id - 1 and (got["frame"] == B - 1).sum() == n_tracks
+    assert np.isfinite(got["x"]).all() and np.isfinite(got["y"]).all()
