@@ -1496,7 +1496,9 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     t->base_ptr = nullptr;
     t->frame_lds = frame_lds_bytes(capacity, max_det, (int)gain_doubles);
     const char *mode_env = getenv("YSMR_LINK_MODE");   // "split" forces the two-kernel path (tests)
-    t->fused = t->frame_lds <= 150 * 1024 && max_det < 65535 && !(mode_env && !strcmp(mode_env, "split"));
+    // (max_det <= 2456: the LDS set model holds that many unregistered columns; the split path keeps its
+    // tables in HBM and has no such limit)
+    t->fused = t->frame_lds <= 150 * 1024 && max_det <= 2456 && !(mode_env && !strcmp(mode_env, "split"));
     if (t->fused) {
         const void *variants[4] = {(const void *)k_frame<float, 3>, (const void *)k_frame<double, 3>,
                                    (const void *)k_frame<float, YSMR_MAX_FILTERS>, (const void *)k_frame<double, YSMR_MAX_FILTERS>};
