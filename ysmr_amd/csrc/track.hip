@@ -1498,7 +1498,9 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const char *mode_env = getenv("YSMR_LINK_MODE");   // "split" forces the two-kernel path (tests)
     // (max_det <= 2456: the LDS set model holds that many unregistered columns; the split path keeps its
     // tables in HBM and has no such limit)
-    t->fused = t->frame_lds <= 150 * 1024 && max_det <= 2456 && !(mode_env && !strcmp(mode_env, "split"));
+    // (and a `gone` counter that fits the 15 bits k_frame packs it into)
+    t->fused = t->frame_lds <= 150 * 1024 && max_det <= 2456 && max_disappeared < 32000.0 &&
+               !(mode_env && !strcmp(mode_env, "split"));
     if (t->fused) {
         const void *variants[4] = {(const void *)k_frame<float, 3>, (const void *)k_frame<double, 3>,
                                    (const void *)k_frame<float, YSMR_MAX_FILTERS>, (const void *)k_frame<double, YSMR_MAX_FILTERS>};

@@ -108,7 +108,7 @@ class _SingleFilter:
     def __init__(self, gsff):
         gains = np.concatenate([g[:2].ravel() for g in gsff.gains])
         fps = 1.0 / gsff._delta_t
-        self._trk = DeviceTracker(max_disappeared=1e18, fps=fps, n_min=gsff._n_min, n_max=gsff._n_max,
+        self._trk = DeviceTracker(max_disappeared=30000.0, fps=fps, n_min=gsff._n_min, n_max=gsff._n_max,
                                   n_f=gsff.n_f, use_gsff=True, capacity=1, max_det=1, device=gsff._device,
                                   gains=gains)
         d = self._trk.device
