@@ -1,12 +1,14 @@
-// detect.hip -- a1-a6 of the YSMR hot path on gfx950: fused gray -> 3x3 blur -> 11x11 Gaussian
-// adaptive double threshold (k_threshold), 4-connected hysteresis + 8-connected component
-// labelling on a lock-free union-find that lives in the label map (k_union4 .. k_flatten),
-// RETR_EXTERNAL ordering/nesting (k_rank, k_bbox_euler, k_outside_*), and per-component
-// minAreaRect (k_geometry).  Reference call sites: ysmr/track_eval.py:180-303.
+// detect.hip -- a1-a6 of the YSMR hot path on gfx950: fused (BGR ->) gray -> 3x3 blur -> 11x11
+// Gaussian adaptive double threshold (k_threshold_strip; k_threshold for widths that are not a multiple
+// of 4), 4-connected hysteresis + 8-connected component labelling on a lock-free union-find that lives
+// in the label map (k_collect, k_union4 .. k_flatten), RETR_EXTERNAL ordering/nesting (k_rank,
+// k_bbox_euler, k_holes, k_nested), and per-component minAreaRect (k_geometry, k_compact).
+// Reference call sites: ysmr/track_eval.py:180-303.
 //
-// All kernels are batched over frames (detection is frame-parallel); the per-pixel passes walk
-// the batch as one flat byte array in 16-byte chunks so that any H, W is handled with aligned
-// 128-bit accesses, and do work only for the (sparse) foreground.
+// All kernels are batched over frames (detection is frame-parallel) and launched as RESIDENT grids
+// that stride over their work (a grid larger than the chip holds starves every other HIP stream,
+// i.e. the link, until it has drained).  Only k_threshold_strip, k_collect and the dense fallback of
+// k_clear touch every pixel; everything else walks the list of foreground pixels.
 //
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
 #include "common.h"
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls,
     }
 }
 
-// Pass E: final labels (root + 1), final mask (cleared by a memset beforehand), roots per frame.
+// Pass E: final labels (root + 1), final mask (cleared by k_clear beforehand), roots per frame.
 __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls, uint32_t *labels,
                                                  uint8_t *__restrict__ mask, Geo g, PixelList pl,
                                                  int32_t *nroots, int32_t *roots, int max_det)
@@ -1112,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_nested(const uint32_t *__restrict__ lab
 }
 
 // ------------------------------------------------------------------------------------------
-// k_geometry: a6, one thread per component
+// k_geometry: a6, a 16-lane group per component (column scan), then its lane 0 (hull, calipers)
 // ------------------------------------------------------------------------------------------
 constexpr int GEO_THREADS = 256;
 constexpr int LDS_POINTS = 2 * 16 + 3;  // hull capacity of the in-LDS fast path (components <= 16 columns wide)
@@ -1459,7 +1461,7 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return (char *)base + o; };
     size_t bm = (size_t)batch * max_det;
     w.pixels.hdr = (WsHeader *)take(256);   // persists across calls (ysmr_detect_workspace_init zeroes it)
-    // counters first: one memset clears nroots, n_holed, arena_used
+    // counters first: k_list_begin clears nroots, n_holed, arena_used, max_roots in one go
     w.nroots = (int32_t *)take(sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 8));
     w.n_holed = w.nroots + (size_t)batch * NR_STRIDE;
     w.arena_used = (uint32_t *)(w.n_holed + 1);

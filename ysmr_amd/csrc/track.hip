@@ -2,14 +2,15 @@
 // with the Gaussian-sum FIR filter (ysmr/gsff.py:204-347) and row emission
 // (ysmr/track_eval.py:313-316), device-resident across frames.
 //
-// Per frame two launches, no host round trip:
-//   k_link    (one workgroup)       claim resolution, ageing / deregistration, registration in
-//                                   CPython set order
-//   k_track   (one wave per track)  GSFF correct+predict, the frame's output row, and the nearest
-//                                   detection of the NEXT frame: fused row-min / arg-min of the
-//                                   N x M float64 distance matrix, which is never stored
-//                                   (tracker.py:151-163 only ever reads D.min(1), D.argmin(1))
-//   (k_rowmin does that last step stand-alone for the first frame of a batch.)
+// Per frame ONE launch, no host round trip (k_frame, the fused path): every workgroup recomputes the
+// frame's bookkeeping in LDS (claim resolution, ageing / deregistration, stable compaction of the
+// id-ordered table, registration in CPython set order), then each WAVE handles one track: GSFF
+// correct + predict, the frame's output row, and the nearest detection of the NEXT frame -- the fused
+// row-min / arg-min of the N x M float64 distance matrix, which is never stored (tracker.py:151-163
+// only ever reads D.min(1), D.argmin(1)).  k_rowmin does that last step stand-alone for the first
+// frame of a batch.  Configurations beyond the LDS budget of k_frame (max_det > 2456, very large
+// capacity) run the same device functions as two launches: k_link (one workgroup) + k_track (one
+// wave per track).
 //
 // Claim rule (tracker.py:158-189): proposals are visited in ascending (row minimum, row); a
 // proposal is accepted iff its column is still free.  Each row occurs once, so the winner of a
@@ -600,7 +601,8 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
 // CPython set model: iteration order of set(range(m)).difference(used_cols) (tracker.py:193,216).
 // Ints hash to themselves; table sizes, linear probing (LINEAR_PROBES = 9) and perturbation
 // (PERTURB_SHIFT = 5) as in Objects/setobject.c of CPython 3.7-3.12.
-// Runs on one thread; the number of unused columns per frame is small.
+// The insertions are order-dependent and run on one thread; the number of unused columns per frame
+// is small (k_frame does everything else of the model with the whole block).
 // ------------------------------------------------------------------------------------------
 __device__ void set_insert_clean(int *table, unsigned mask, int key)
 {
