@@ -17,6 +17,9 @@
  *                         GaussianSumFIR.correct/predict    ysmr/gsff.py:204-347
  *                         row emission                      ysmr/track_eval.py:313-316
  *   ysmr_gsff_gains       GaussianSumFIR.generate_n_i/compute_lsf_gain  ysmr/gsff.py:87-153
+ *   ysmr_rows_sort        sort_list (order by TRACK_ID, POSITION_T)  ysmr/helper_file.py:1538-1574
+ *   ysmr_rows_columns,    save_list text + get_data (pandas.read_csv) + save_df_to_csv
+ *   ysmr_rows_format_csv  ysmr/helper_file.py:1403-1478, 860-905, 1366-1400  (host functions)
  */
 #ifndef YSMR_HIP_H
 #define YSMR_HIP_H
