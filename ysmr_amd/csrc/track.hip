@@ -656,20 +656,22 @@ constexpr int LINK_THREADS = 1024;
 
 __device__ int block_exclusive_scan(int v, int *s_scan, int *total)
 {
-    // 1024-thread inclusive scan in LDS (Hillis-Steele); returns exclusive prefix
-    const int tid = threadIdx.x;
-    s_scan[tid] = v;
+    // exclusive rank of a 0/1 flag among the block's 1024 flags: a ballot per wave, the sixteen wave
+    // counts through LDS, two barriers (the Hillis-Steele scan this replaces needed twenty-one)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long bal = __ballot(v != 0);
+    if (lane == 0) s_scan[w] = __popcll(bal);
     __syncthreads();
-    for (int d = 1; d < LINK_THREADS; d <<= 1) {
-        int add = tid >= d ? s_scan[tid - d] : 0;
-        __syncthreads();
-        s_scan[tid] += add;
-        __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < LINK_THREADS / 64; ++k) {
+        const int c = s_scan[k];
+        before += k < w ? c : 0;
+        all += c;
     }
-    int incl = s_scan[tid];
-    *total = s_scan[LINK_THREADS - 1];
-    __syncthreads();
-    return incl - v;
+    *total = all;
+    __syncthreads();      // (s_scan is reused by the caller's next chunk)
+    return before + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
 template <typename DetT>
