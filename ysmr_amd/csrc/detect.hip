@@ -875,14 +875,16 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *l
     const int f = blockIdx.x;
     int n = t.nroots[(size_t)f * NR_STRIDE];
     if (n > t.max_det) {
-        if (threadIdx.x == 0) atomicOr(&status[f], YSMR_DET_OVERFLOW);
+        if (threadIdx.x == 0 && blockIdx.y == 0) atomicOr(&status[f], YSMR_DET_OVERFLOW);
         n = t.max_det;
     }
-    if (threadIdx.x == 0) atomicMax(t.max_roots, n);
+    if (threadIdx.x == 0 && blockIdx.y == 0) atomicMax(t.max_roots, n);
     const int32_t *roots = t.roots + (size_t)f * t.max_det;
     __shared__ int32_t tile[1024];
     const int sub = threadIdx.x & 3;
-    for (int i0 = 0; i0 < n; i0 += RANK_THREADS / 4) {
+    // blockIdx.y splits a frame's roots: the comparison count is quadratic in the components of a frame
+    // (5000 at 4K: one block per frame took 715 us per batch)
+    for (int i0 = (int)blockIdx.y * (RANK_THREADS / 4); i0 < n; i0 += (int)gridDim.y * (RANK_THREADS / 4)) {
         const int i = i0 + (threadIdx.x >> 2);
         const int32_t mine = i < n ? roots[i] : -1;
         int rank = 0;
@@ -1606,7 +1608,8 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     hipLaunchKernelGGL(k_flatten, sg, tb, 0, st, cls_dev, labels, mask_dev, g, w.pixels, w.nroots, w.roots, max_det);
     YSMR_LAUNCH_CHECK();
     CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, w.max_roots, max_det};
-    hipLaunchKernelGGL(k_rank, dim3(batch), dim3(RANK_THREADS), 0, st, t, labels, g.HW, width, height, status_dev);
+    hipLaunchKernelGGL(k_rank, dim3(batch, (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) < 32 ? (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) : 32), dim3(RANK_THREADS), 0, st, t, labels, g.HW,
+                       width, height, status_dev);
     hipLaunchKernelGGL(k_bbox_euler, sg, tb, 0, st, cls_dev, labels, g, w.pixels, t);
     const unsigned comp_threads = (unsigned)((size_t)batch * max_det);
     hipLaunchKernelGGL(k_holes, dim3((comp_threads + 255) / 256), dim3(256), 0, st, t, batch, labels, g.HW, w.n_holed, w.holed,
