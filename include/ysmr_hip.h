@@ -10,6 +10,8 @@
  * Reference interfaces replaced (files under /root/reference):
  *   ysmr_threshold_batch  cv2.cvtColor + cv2.GaussianBlur + 2 x cv2.adaptiveThreshold
  *                         ysmr/track_eval.py:180-208
+ *   ysmr_mean_threshold_batch  cv2.cvtColor + cv2.GaussianBlur + cv2.meanStdDev + threshold_list
+ *                         moving average + cv2.threshold   ysmr/track_eval.py:180-182, 219-253
  *   ysmr_components_batch scipy binary_propagation + cv2.findContours + cv2.minAreaRect +
  *                         reshape_result   ysmr/track_eval.py:211-303, ysmr/helper_file.py:1336-1347
  *   ysmr_detect_batch     both of the above in one call
@@ -37,7 +39,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   2
+#define YSMR_ABI_VERSION   3
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -78,6 +80,27 @@ int ysmr_detect_workspace_init(void *stream, void *workspace_dev, size_t workspa
 int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
                          int channels, int inv, int t_low, int t_high, int use_high,
                          uint8_t *cls_dev);
+
+/* The mean-gray threshold branch, taken by the reference when 'adaptive double threshold' < 0
+ * (ysmr/track_eval.py:219-253): replaces cv2.meanStdDev(gray), the 5 s moving average of
+ * mean +- stddev +- offset kept in `threshold_list`, and cv2.threshold(blurred, int(average)).
+ *   inv      0: white bacteria on dark background (THRESH_BINARY,  level = mean + stddev + offset)
+ *            1: dark on bright              (THRESH_BINARY_INV, level = mean - stddev - offset)
+ *   offset   settings['threshold offset for detection'] as it stands at track_eval.py:222-229,
+ *            i.e. already negated for inv = 1 (track_eval.py:132)
+ *   window   longest list the average is taken over = floor(5 * fps) + 1 (the list is trimmed
+ *            AFTER the average, when it is longer than 5 * fps: track_eval.py:239-242)
+ *   state_dev  ysmr_mean_threshold_state_bytes(window) bytes, 8-byte aligned; all zero = empty
+ *            list (start of a video); carries the list from one call to the next
+ *   stats_dev  f64 [batch][4] out: mean, stddev, this frame's level, averaged integer level
+ *   levels_dev i32 [batch] out: the level each frame was compared with (clamped to [-1, 256])
+ *   cls_dev    u8 [batch][H][W] out: 3 where the blurred pixel is foreground, else 0 -- the class
+ *            map ysmr_components_batch expects (every foreground pixel is its own marker: this
+ *            branch has no binary_propagation step) */
+size_t ysmr_mean_threshold_state_bytes(int window);
+int ysmr_mean_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
+                              int channels, int inv, double offset, int window, void *state_dev,
+                              double *stats_dev, int32_t *levels_dev, uint8_t *cls_dev);
 
 /* a4-a6 from a class map already in HBM (written by ysmr_threshold_batch or by the caller):
  * hysteresis + labelling + RETR_EXTERNAL ordering + minAreaRect.  Same outputs as

@@ -84,10 +84,10 @@ def threshold_params(white_on_dark: bool, offset, adt):
     pixel iff ``s - m > -idelta`` resp. ``s - m <= -idelta``.  The reference negates
     the offset for dark-on-bright videos before use (track_eval.py:132).
     Returns (inv, t_low, t_high, use_high) with use_high False when adt == 0;
-    adt < 0 selects the out-of-scope mean-gray branch and raises.
+    adt < 0 selects the mean-gray branch (MeanGrayLevels below) and raises here.
     """
     if adt < 0:
-        raise ValueError("adaptive double threshold < 0: mean-gray branch is out of scope")
+        raise ValueError("adaptive double threshold < 0 selects the mean-gray branch: use MeanGrayLevels")
     inv = not white_on_dark
     off = -offset if inv else offset
     c1 = off * -1
@@ -199,6 +199,62 @@ def detect_frame(frame, inv=0, t_low=5, t_high=7, use_high=1, max_det=None) -> F
                              _p(anchors, ctypes.c_int32), max_det)
     m = min(n, max_det)
     return FrameDetections(cls, mask, labels, det[:m].copy(), anchors[:m].copy(), n)
+
+
+class MeanGrayLevels:
+    """The mean-gray branch's threshold level (ysmr/track_eval.py:219-242, taken when
+    'adaptive double threshold' < 0).  Per frame: cv2.meanStdDev(gray) -> mean +- stddev +- offset
+    appended to ``threshold_list``; the level is ``int(sum(list) / len(list))``; the list is
+    trimmed AFTER that, when it is longer than 5 * fps.  cv2.meanStdDev on u8 [upstream-
+    recollection]: exact integer sums, then ``mean = s * (1/N)``,
+    ``stddev = sqrt(max(sq * (1/N) - mean * mean, 0))`` in double."""
+
+    def __init__(self, fps, white_on_dark=True, offset=5):
+        self.fps = fps
+        self.white = bool(white_on_dark)
+        self.offset = offset if self.white else offset * -1   # track_eval.py:132
+        self.levels = []
+
+    @staticmethod
+    def mean_stddev(gray):
+        g = np.asarray(gray, np.uint8).astype(np.int64)
+        s, sq = int(g.sum()), int((g * g).sum())
+        scale = 1.0 / g.size
+        mean = s * scale
+        return mean, math.sqrt(max(sq * scale - mean * mean, 0.0))
+
+    def step(self, gray):
+        """-> (integer level, mean, stddev, this frame's level)"""
+        mean, sd = self.mean_stddev(gray)
+        cur = (mean + sd + self.offset) if self.white else (mean - sd - self.offset)
+        self.levels.append(cur)
+        acc = 0
+        for v in self.levels:          # Python's sum(): left to right, starting from int 0
+            acc = acc + v
+        level = int(acc / len(self.levels))
+        if len(self.levels) > self.fps * 5:
+            del self.levels[0]
+        return level, mean, sd, cur
+
+
+def level_classify(blurred, level, inv):
+    """cv2.threshold(blurred, level, 255, THRESH_BINARY / THRESH_BINARY_INV) (track_eval.py:248-253)
+    as a class map: 3 (thresh and marker bit) where set.  u8 source: dst = src > level (BINARY)."""
+    fg = np.asarray(blurred, np.uint8).astype(np.int32) > int(level)
+    if inv:
+        fg = ~fg
+    return np.where(fg, 3, 0).astype(np.uint8)
+
+
+def detect_frame_mean_gray(frame, levels: MeanGrayLevels, max_det=None) -> FrameDetections:
+    """One loop iteration of the mean-gray branch (track_eval.py:180-182, 219-253, 273-303)."""
+    frame = np.ascontiguousarray(frame, np.uint8)
+    gray = frame if frame.ndim == 2 else bgr2gray(frame)
+    level, _, _, _ = levels.step(gray)
+    cls = level_classify(blur3(gray), level, not levels.white)
+    mask = np.where(cls != 0, 255, 0).astype(np.uint8)
+    labels, det, anchors, n = components(mask, max_det if max_det is not None else 65536)
+    return FrameDetections(cls, mask, labels, det, anchors, n)
 
 
 def det_to_rects(det):
@@ -406,13 +462,18 @@ def track_frames(frames, fps=30.0, white_on_dark=True, offset=5, adt=2.0, use_gs
                  n_min=0, n_max=30, n_f=3, max_det=65536, tracker=None, frame0=0):
     """Run detect+link over an iterable of frames.  Returns (rows, tracker) with rows a list of
     (frame, id, x, y, w, h, deg) -- one per live track per frame (track_eval.py:313-316)."""
-    inv, t_low, t_high, use_high = threshold_params(white_on_dark, offset, adt)
+    mean_gray = MeanGrayLevels(fps, white_on_dark, offset) if adt < 0 else None
+    if mean_gray is None:
+        inv, t_low, t_high, use_high = threshold_params(white_on_dark, offset, adt)
     if tracker is None:
         tracker = OracleTracker(max_disappeared=fps, fps=fps, n_min=n_min, n_max=n_max, n_f=n_f,
                                 use_gsff=use_gsff)
     rows = []
     for k, frame in enumerate(frames):
-        fd = detect_frame(frame, inv, t_low, t_high, use_high, max_det)
+        if mean_gray is None:
+            fd = detect_frame(frame, inv, t_low, t_high, use_high, max_det)
+        else:
+            fd = detect_frame_mean_gray(frame, mean_gray, max_det)
         ids, xy, info, _ = tracker.update(det_to_rects(fd.det))
         for i, tid in enumerate(ids):
             w, h, deg = info[i]

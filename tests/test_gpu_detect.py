@@ -215,3 +215,108 @@ def test_detector_reuse_clears_what_the_previous_call_wrote(torch_cuda, oracle):
     torch.cuda.synchronize()
     got = {n: getattr(res, n).cpu().numpy() for n in ("cls", "mask", "labels", "det_count", "det", "anchors", "status")}
     _compare(oracle, clips[0], got, p, max_det=8192)
+
+
+# ---- mean-gray branch ('adaptive double threshold' < 0; track_eval.py:219-253) -------------------
+@pytest.mark.parametrize("channels", [1, 3])
+@pytest.mark.parametrize("white", [True, False])
+def test_mean_gray_branch_matches_oracle(torch_cuda, oracle, channels, white):
+    """Levels, statistics, class map and detections of consecutive ragged batches of one video; fps 2
+    makes the moving average 11 frames long, so the list is trimmed and carried across calls."""
+    from ysmr_amd.detect import Detector, mean_gray_params
+    from ysmr_amd.synth import SyntheticVideo
+    torch = torch_cuda
+    rng = np.random.default_rng(7 + channels)
+    for (h, w) in [(1, 1), (3, 2), (5, 7), (40, 301), (64, 64), (97, 131), (130, 1228)]:
+        n = 30
+        if h >= 64:
+            gray = SyntheticVideo(h, w, 14, seed=h + w).frames(n)
+            gray = (gray.astype(np.int32) + (8 * np.sin(np.arange(n) / 3.0)).astype(np.int32)[:, None, None]).clip(0, 255).astype(np.uint8)
+        else:
+            gray = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        if not white:
+            gray = 255 - gray
+        if channels == 3:
+            frames = np.repeat(gray[..., None], 3, axis=3)
+            frames[:, ::2, ::3, 1] = rng.integers(0, 256, frames[:, ::2, ::3, 1].shape, dtype=np.uint8)
+        else:
+            frames = gray
+        p = mean_gray_params(white, 5, 2.0)
+        assert (p.inv, p.offset, p.window) == (int(not white), 5.0 if white else -5.0, 11)
+        det = Detector(16, h, w, max_det=8192, params=p)
+        lv = oracle.MeanGrayLevels(2.0, white, 5)
+        f0 = 0
+        for b in (16, 1, 13):
+            res = det.detect(torch.from_numpy(np.ascontiguousarray(frames[f0:f0 + b])).cuda())
+            torch.cuda.synchronize()
+            got = {k: getattr(res, k).cpu().numpy() for k in ("cls", "mask", "labels", "det_count", "det", "anchors", "status")}
+            stats, levels = det.mean_stats[:b].cpu().numpy(), det.mean_levels[:b].cpu().numpy()
+            for f in range(b):
+                frame = frames[f0 + f]
+                g = frame if channels == 1 else oracle.bgr2gray(frame)
+                probe = oracle.MeanGrayLevels(2.0, white, 5)
+                probe.levels = list(lv.levels)
+                level, mean, sd, cur = probe.step(g)
+                ref = oracle.detect_frame_mean_gray(frame, lv, 8192)
+                assert (stats[f, 0], stats[f, 1], stats[f, 2]) == (mean, sd, cur), (h, w, f0 + f)
+                assert levels[f] == min(max(level, -1), 256) and stats[f, 3] == levels[f]
+                assert got["status"][f] == 0
+                np.testing.assert_array_equal(got["cls"][f] & 3, ref.cls, err_msg=f"cls {h}x{w} frame {f0 + f}")
+                np.testing.assert_array_equal(got["mask"][f], ref.mask)
+                np.testing.assert_array_equal(got["labels"][f], ref.labels)
+                assert got["det_count"][f] == ref.count
+                k = ref.count
+                np.testing.assert_array_equal(got["anchors"][f][:k], ref.anchors)
+                np.testing.assert_array_equal(got["det"][f][:k, :4], ref.det[:, :4])
+                _assert_angle_close(got["det"][f][:k, 4], ref.det[:, 4])
+            f0 += b
+
+
+def test_mean_gray_long_batch_and_reset(torch_cuda, oracle):
+    """A batch longer than the window (the ring is overwritten within the call), then a state reset."""
+    from ysmr_amd.detect import Detector, mean_gray_params
+    torch = torch_cuda
+    rng = np.random.default_rng(3)
+    frames = np.clip(rng.normal(60, 10, (40, 24, 36)) + 25 * np.sin(np.arange(40) / 2.0)[:, None, None], 0, 255).astype(np.uint8)
+    p = mean_gray_params(True, 5, 1.0)      # window 6
+    det = Detector(40, 24, 36, max_det=512, params=p)
+    for _ in range(2):
+        lv = oracle.MeanGrayLevels(1.0, True, 5)
+        det.threshold(torch.from_numpy(frames).cuda())
+        det.threshold(torch.from_numpy(frames[:7]).cuda())
+        torch.cuda.synchronize()
+        ref = [lv.step(f)[0] for f in np.concatenate([frames, frames[:7]])]
+        assert det.mean_levels[:7].cpu().tolist() == ref[40:]
+        det.mean_state.reset()
+    assert len(set(ref)) > 3
+
+
+def test_mean_gray_bad_arguments(torch_cuda):
+    from ysmr_amd import _lib
+    L = _lib.lib()
+    assert L.ysmr_mean_threshold_state_bytes(0) == 0 and L.ysmr_mean_threshold_state_bytes(151) == 151 * 8 + 8
+    rc = L.ysmr_mean_threshold_batch(None, None, 1, 8, 8, 1, 0, 5.0, 0, None, None, None, None)
+    assert rc == 1 and b"window" in L.ysmr_last_error()
+    rc = L.ysmr_mean_threshold_batch(None, None, 1, 8, 8, 1, 0, 5.0, 3, None, None, None, None)
+    assert rc == 1 and b"NULL" in L.ysmr_last_error()
+
+
+def test_components_on_tiny_frames(torch_cuda, oracle):
+    """Frames of fewer than 16 pixels: several frames share one 16-byte chunk of the class map."""
+    from ysmr_amd.detect import Detector
+    torch = torch_cuda
+    rng = np.random.default_rng(4)
+    for (h, w) in [(1, 1), (1, 2), (3, 2), (2, 5), (3, 5), (4, 4), (1, 17)]:
+        b = 37
+        cls = rng.choice(np.array([0, 1, 2, 3], np.uint8), size=(b, h, w), p=[0.4, 0.3, 0.1, 0.2])
+        det = Detector(b, h, w, max_det=32)
+        res = det.components(cls=torch.from_numpy(cls).cuda())
+        torch.cuda.synchronize()
+        for f in range(b):
+            ref_mask = oracle.propagate(cls[f]).astype(bool)
+            labels, rects, anchors, n = oracle.components(ref_mask.astype(np.uint8) * 255, 32)
+            np.testing.assert_array_equal(res.mask[f].cpu().numpy() > 0, ref_mask, err_msg=f"{h}x{w} frame {f}")
+            np.testing.assert_array_equal(res.labels[f].cpu().numpy(), labels, err_msg=f"{h}x{w} frame {f}")
+            assert int(res.det_count[f]) == n and int(res.status[f]) == 0
+            np.testing.assert_array_equal(res.anchors[f, :n].cpu().numpy(), anchors)
+            np.testing.assert_array_equal(res.det[f, :n, :4].cpu().numpy(), rects[:, :4])

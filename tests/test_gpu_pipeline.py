@@ -245,3 +245,29 @@ def test_full_size_batch_properties():
             assert len(ids) == cnt[0]
     assert got["track_id"].max() == next_id - 1 and (got["frame"] == B - 1).sum() == n_tracks
     assert np.isfinite(got["x"]).all() and np.isfinite(got["y"]).all()
+
+
+@pytest.mark.parametrize("white,offset", [(True, 5), (False, -10)])
+def test_track_bacteria_mean_gray_branch(tmp_path, oracle, white, offset):
+    """'adaptive double threshold' < 0: one level per frame from the 5 s moving average of
+    mean +- stddev +- offset (track_eval.py:219-253); the list runs across the batches of the file.
+    (Dark on bright: the reference negates the offset first, track_eval.py:132, so a POSITIVE setting
+    moves the level towards the background; -10 keeps it 10 below mean - stddev.)"""
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(160, 208, 20, seed=9, dropout=0.03).frames(60)
+    drift = (10 * np.sin(np.arange(60) / 6.0)).astype(np.int32)[:, None, None]
+    frames = (frames.astype(np.int32) + drift).clip(0, 255).astype(np.uint8)
+    if not white:
+        frames = 255 - frames
+    path = tmp_path / "level.npy"
+    np.save(path, frames)
+    with open(tmp_path / "level_meta.json", "w") as fh:
+        fh.write('{"fps": 4.0}')
+    s = _settings(**{"adaptive double threshold": -1.0, "white bacteria on dark background": white,
+                     "threshold offset for detection": offset})
+    res = track_bacteria(str(path), settings=s, result_folder=str(tmp_path), batch=16, max_det=512, capacity=512)
+    assert res is not None and res[1] == 4.0
+    ref_rows, _ = oracle.track_frames(frames, fps=4.0, white_on_dark=white, offset=offset, adt=-1.0)
+    assert len(ref_rows) > 500
+    compare_rows(_rows_from_df(res[0]), ref_rows)

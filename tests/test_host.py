@@ -107,9 +107,9 @@ def test_track_bacteria_error_conventions(tmp_path, caplog):
     short = tmp_path / "short.npy"
     np.save(short, np.zeros((10, 8, 8), np.uint8))
     assert track_bacteria(str(short), settings=s, result_folder=str(tmp_path)) is None   # < minimal frame count
-    s2 = dict(s); s2["adaptive double threshold"] = -1.0
+    s2 = dict(s); s2["include luminosity in tracking calculation"] = True
     s2["minimal frame count"] = 5
-    assert track_bacteria(str(short), settings=s2, result_folder=str(tmp_path)) is None  # mean-gray branch: unsupported
+    assert track_bacteria(str(short), settings=s2, result_folder=str(tmp_path)) is None  # unsupported option
 
 
 def _gloo_worker(rank, world, port, out_dir):

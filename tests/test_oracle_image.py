@@ -197,3 +197,72 @@ def test_cv2_cross_check_if_available(oracle):
     mism = int(((fd.cls & 1) > 0).__xor__(thresh > 0).sum() + ((fd.cls & 2) > 0).__xor__(mark > 0).sum())
     print("cv2 threshold mismatching pixels:", mism)
     assert mism <= 4
+
+
+# ---- mean-gray branch (track_eval.py:219-253; 'adaptive double threshold' < 0) -----------------
+def _literal_levels(grays, fps, white, offset_setting):
+    """The reference's statements with NumPy (1,1) arrays standing in for cv2.meanStdDev's outputs."""
+    offset = offset_setting if white else offset_setting * -1
+    threshold_list, out = [], []
+    for gray in grays:
+        g = gray.astype(np.float64)
+        mean, stddev = np.array([[g.mean()]]), np.array([[g.std()]])
+        if white:
+            cur = mean + stddev + offset
+        else:
+            cur = mean - stddev - offset
+        threshold_list.append(cur)
+        out.append((int((sum(threshold_list) / len(threshold_list)).item()), len(threshold_list)))
+        if len(threshold_list) > fps * 5:
+            del threshold_list[0]
+    return out
+
+
+@pytest.mark.parametrize("fps,white", [(2.0, True), (2.5, False), (0.1, True), (30.0, True)])
+def test_mean_gray_levels(oracle, fps, white):
+    rng = np.random.default_rng(int(fps * 10))
+    grays = [np.clip(rng.normal(40 + 30 * np.sin(k / 5.0), 6 + k % 3, (24, 31)), 0, 255).astype(np.uint8)
+             for k in range(40)]
+    lv = oracle.MeanGrayLevels(fps, white, 5)
+    got = [lv.step(g) for g in grays]
+    ref = _literal_levels(grays, fps, white, 5)
+    window = int(np.floor(fps * 5)) + 1
+    assert max(n for _, n in ref) == min(window, len(grays))       # the window ysmr_mean_threshold_batch is given
+    # np.mean/np.std differ from the integer-sum form in the last bits only: levels may differ where the
+    # average sits within 1e-9 of an integer, nowhere else
+    for (level, mean, sd, cur), (ref_level, _), g in zip(got, ref, grays):
+        assert abs(mean - g.astype(np.float64).mean()) < 1e-12 and abs(sd - g.astype(np.float64).std()) < 1e-10
+        assert level == ref_level
+    flat = np.full((8, 8), 17, np.uint8)
+    assert oracle.MeanGrayLevels.mean_stddev(flat) == (17.0, 0.0)
+
+
+def test_level_classify(oracle):
+    b = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    for level in (-1, 0, 100, 254, 255, 256):
+        np.testing.assert_array_equal(oracle.level_classify(b, level, 0) != 0, b.astype(int) > level)
+        np.testing.assert_array_equal(oracle.level_classify(b, level, 1) != 0, b.astype(int) <= level)
+    assert set(np.unique(oracle.level_classify(b, 100, 0))) == {0, 3}
+
+
+def test_mean_gray_against_cv2_when_available(oracle):
+    cv2 = pytest.importorskip("cv2")
+    rng = np.random.default_rng(5)
+    gray = rng.integers(0, 256, (97, 131), dtype=np.uint8)
+    mean, sd = cv2.meanStdDev(gray)
+    assert oracle.MeanGrayLevels.mean_stddev(gray) == (mean.item(), sd.item())
+    blurred = cv2.GaussianBlur(gray, (3, 3), 0)
+    for level in (-3, 0, 90, 255, 300):
+        for inv, ty in ((0, cv2.THRESH_BINARY), (1, cv2.THRESH_BINARY_INV)):
+            ref = cv2.threshold(blurred, level, 255, ty)[1]
+            np.testing.assert_array_equal((oracle.level_classify(blurred, level, inv) != 0) * 255, ref)
+
+
+def test_detect_frame_mean_gray(oracle):
+    from ysmr_amd.synth import SyntheticVideo
+    vid = SyntheticVideo(120, 160, 10, seed=2)
+    lv = oracle.MeanGrayLevels(30.0, True, 5)
+    fd = oracle.detect_frame_mean_gray(vid.next_frame(), lv)
+    assert fd.count >= 5 and fd.det.shape == (fd.count, 5)
+    assert set(np.unique(fd.cls)) <= {0, 3} and np.array_equal(fd.mask != 0, fd.cls != 0)
+    assert np.array_equal(fd.labels != 0, fd.mask != 0)

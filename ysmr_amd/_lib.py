@@ -23,7 +23,7 @@ ROW_DTYPE = np.dtype([("frame", "<i4"), ("track_id", "<i4"), ("x", "<f8"), ("y",
                       ("w", "<f4"), ("h", "<f4"), ("angle", "<f4"), ("disappeared", "<i4")])
 
 EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_detect_workspace_init",
-           "ysmr_threshold_batch",
+           "ysmr_threshold_batch", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
@@ -57,6 +57,9 @@ def lib():
     L.ysmr_detect_workspace_bytes.restype = ctypes.c_size_t
     L.ysmr_detect_workspace_init.argtypes = [vp, vp, ctypes.c_size_t]
     L.ysmr_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.ysmr_mean_threshold_state_bytes.argtypes = [ci]
+    L.ysmr_mean_threshold_state_bytes.restype = ctypes.c_size_t
+    L.ysmr_mean_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, vp, vp, vp, vp]
     L.ysmr_components_batch.argtypes = [vp, ci, ci, ci, vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, ci, vp]
     L.ysmr_detect_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, vp, vp,
                                     vp, vp, vp, ci, vp]
@@ -78,7 +81,8 @@ def lib():
     L.ysmr_rows_columns.argtypes = [vp, ctypes.c_longlong, ci, vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_abi_version",
-                        "ysmr_rows_sort_workspace_bytes", "ysmr_rows_csv_bound"):
+                        "ysmr_rows_sort_workspace_bytes", "ysmr_rows_csv_bound",
+                        "ysmr_mean_threshold_state_bytes"):
             getattr(L, name).restype = ci
     _lib = L
     return L

@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls
                 n += total;
                 uint32_t rest = bits;
                 const uint32_t first = (uint32_t)(c * 16);
-                const uint32_t frame_start = rest ? first / g.HW * g.HW : 0;   // (a chunk may straddle two frames)
+                const uint32_t frame_start = rest ? first / g.HW * g.HW : 0;   // (a chunk may straddle frames)
                 while (rest) {   // a chunk's pixels stay adjacent in the list: adjacent lanes, adjacent pixels later
                     const int i = __ffs(rest) - 1;
                     rest &= rest - 1;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls
                     buf[at++] = flat;
                     // every listed pixel starts as its own root (the label map was cleared beforehand)
                     uint32_t p = flat - frame_start;
-                    if (p >= g.HW) p -= g.HW;
+                    if (p >= g.HW) p = g.HW >= 16 ? p - g.HW : p % g.HW;   // (frames of < 16 pixels: several per chunk)
                     labels[flat] = p + 1u;
                 }
             }

@@ -14,7 +14,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["ThresholdParams", "threshold_params", "Detector", "DetectResult"]
+__all__ = ["ThresholdParams", "threshold_params", "MeanGrayParams", "mean_gray_params", "MeanGrayState",
+           "Detector", "DetectResult"]
 
 
 @dataclass(frozen=True)
@@ -32,16 +33,50 @@ def threshold_params(white_on_dark: bool, offset, adt) -> ThresholdParams:
     dark-on-bright) and :189-208 passes ``C = -offset`` and ``C = -(offset + adt)``.  OpenCV turns
     C into ``idelta = ceil(C)`` (BINARY) or ``floor(C)`` (INV) and tests ``src - mean > -idelta``
     resp. ``<= -idelta``.  ``adt == 0`` means a single threshold; ``adt < 0`` selects the
-    reference's mean-gray branch, which this path does not implement.
+    reference's mean-gray branch (``mean_gray_params``).
     """
     if adt < 0:
-        raise ValueError("'adaptive double threshold' < 0 (mean-gray threshold) is not supported by the HIP path")
+        raise ValueError("'adaptive double threshold' < 0 selects the mean-gray branch: use mean_gray_params()")
     inv = not white_on_dark
     off = offset * -1 if inv else offset
     c_low, c_high = off * -1, (off + adt) * -1
     if inv:
         return ThresholdParams(1, -math.floor(c_low), -math.floor(c_high), int(adt > 0))
     return ThresholdParams(0, -math.ceil(c_low), -math.ceil(c_high), int(adt > 0))
+
+
+@dataclass(frozen=True)
+class MeanGrayParams:
+    """Arguments of ``ysmr_mean_threshold_batch`` (the branch at ysmr/track_eval.py:219-253)."""
+    inv: int
+    offset: float
+    window: int
+
+
+def mean_gray_params(white_on_dark: bool, offset, fps) -> MeanGrayParams:
+    """``offset`` is the tracking.ini value; the reference negates it for dark-on-bright videos
+    (track_eval.py:132) before it enters ``mean - stddev - offset`` (:226).  The moving average runs
+    over at most floor(5 * fps) + 1 frames: the list is trimmed after the average, when it is longer
+    than ``fps_of_file * 5`` (:239-242)."""
+    if not fps > 0:
+        raise ValueError("fps must be positive")
+    inv = not white_on_dark
+    return MeanGrayParams(int(inv), float(offset * -1 if inv else offset), int(math.floor(fps * 5)) + 1)
+
+
+class MeanGrayState:
+    """The reference's ``threshold_list`` between batches (device buffer; all zero = empty list).
+    One per video; shared by the detectors that take turns on that video's batches."""
+
+    def __init__(self, window, device="cuda:0"):
+        n = _lib.lib().ysmr_mean_threshold_state_bytes(int(window))
+        if n == 0:
+            raise ValueError("window must be >= 1")
+        self.window = int(window)
+        self.buf = torch.zeros(n // 8, dtype=torch.float64, device=device)
+
+    def reset(self):
+        self.buf.zero_()
 
 
 @dataclass
@@ -63,12 +98,19 @@ def _padded(n_bytes, device):
 class Detector:
     """Owns the output/scratch buffers for a fixed (batch, H, W, max_det) geometry."""
 
-    def __init__(self, batch, height, width, max_det=2048, params: ThresholdParams | None = None,
-                 device="cuda:0", want_mask=True):
+    def __init__(self, batch, height, width, max_det=2048, params: ThresholdParams | MeanGrayParams | None = None,
+                 device="cuda:0", want_mask=True, mean_state: MeanGrayState | None = None):
         self.B, self.H, self.W, self.max_det = int(batch), int(height), int(width), int(max_det)
         self.params = params or threshold_params(True, 5, 2.0)
         self.device = torch.device(device)
         L = _lib.lib()
+        self.mean_state = None
+        if isinstance(self.params, MeanGrayParams):
+            self.mean_state = mean_state or MeanGrayState(self.params.window, self.device)
+            if self.mean_state.window != self.params.window:
+                raise ValueError("mean_state was made for another window")
+            self.mean_stats = torch.zeros(self.B, 4, dtype=torch.float64, device=self.device)
+            self.mean_levels = torch.zeros(self.B, dtype=torch.int32, device=self.device)
         n = self.B * self.H * self.W
         ws = L.ysmr_detect_workspace_bytes(self.B, self.H, self.W, self.max_det)
         if ws == 0:
@@ -100,9 +142,18 @@ class Detector:
         return b, ch
 
     def threshold(self, frames: torch.Tensor) -> torch.Tensor:
-        """a1-a3 only: class map u8 [b,H,W] (bit0 thresh, bit1 markers)."""
+        """a1-a3 only: class map u8 [b,H,W] (bit0 thresh, bit1 markers).  In the mean-gray branch the
+        call also advances the moving-average state by these frames; per-frame mean, stddev, level and
+        averaged level are left in ``mean_stats[:b]``, the integer levels in ``mean_levels[:b]``."""
         b, ch = self._check_frames(frames)
         p = self.params
+        if self.mean_state is not None:
+            rc = _lib.lib().ysmr_mean_threshold_batch(
+                _lib.stream_ptr(), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.offset, p.window,
+                self.mean_state.buf.data_ptr(), self.mean_stats.data_ptr(), self.mean_levels.data_ptr(),
+                self._cls.data_ptr())
+            _lib.check(rc, "ysmr_mean_threshold_batch")
+            return self._view(self._cls, b)
         rc = _lib.lib().ysmr_threshold_batch(_lib.stream_ptr(), frames.data_ptr(), b, self.H, self.W, ch,
                                              p.inv, p.t_low, p.t_high, p.use_high, self._cls.data_ptr())
         _lib.check(rc, "ysmr_threshold_batch")
@@ -132,6 +183,9 @@ class Detector:
         """a1-a6 for a batch of frames resident in HBM.  Asynchronous on the current stream."""
         b, ch = self._check_frames(frames)
         p = self.params
+        if self.mean_state is not None:
+            self.threshold(frames)
+            return self.components(b)
         rc = _lib.lib().ysmr_detect_batch(
             _lib.stream_ptr(), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.t_low, p.t_high, p.use_high,
             self._ws.data_ptr(), self._ws.numel(), self._cls.data_ptr(),

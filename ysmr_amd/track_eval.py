@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .detect import Detector, threshold_params
+from .detect import Detector, MeanGrayState, mean_gray_params, threshold_params
 from .frames import open_video
 from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes,
                           rows_to_dataframe, save_list)
@@ -38,10 +38,18 @@ class TrackingPipeline:
         self.device = torch.device(device)
         self.B = int(batch)
         offset = settings["threshold offset for detection"]
-        params = threshold_params(settings["white bacteria on dark background"], offset,
-                                  settings["adaptive double threshold"])
+        mean_state = None
+        if settings["adaptive double threshold"] < 0:
+            # mean-gray branch (track_eval.py:219-253): the moving average runs through the video, so
+            # both detectors share its state (their launches are ordered on the side stream)
+            params = mean_gray_params(settings["white bacteria on dark background"], offset, fps)
+            mean_state = MeanGrayState(params.window, self.device)
+        else:
+            params = threshold_params(settings["white bacteria on dark background"], offset,
+                                      settings["adaptive double threshold"])
         # two detectors: batch b+1 is detected (stream 1) while batch b is linked (stream 0)
-        self.det = [Detector(self.B, height, width, max_det=max_det, params=params, device=self.device)
+        self.det = [Detector(self.B, height, width, max_det=max_det, params=params, device=self.device,
+                             mean_state=mean_state)
                     for _ in range(2)]
         self.trk = DeviceTracker(max_disappeared=fps, fps=fps, n_min=settings["minimum horizon size"],
                                  n_max=settings["maximum horizon size"], n_f=settings["number of LSFFs"],
@@ -143,9 +151,6 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
             return None
     if settings["color filter"] != COLOR_BGR2GRAY:
         logger.critical("Only 'color filter = COLOR_BGR2GRAY' is supported by the HIP path")
-        return None
-    if settings["adaptive double threshold"] < 0:
-        logger.critical("'adaptive double threshold' < 0 (mean-gray threshold) is not supported by the HIP path")
         return None
     try:
         video = open_video(video_path, default_fps=settings["frames per second"])
