@@ -47,11 +47,14 @@ def parse():
                     help="independent video streams processed concurrently on each GPU (the metric's configuration is 1)")
     ap.add_argument("--channels", type=int, default=1, choices=(1, 3),
                     help="1: gray frames (the metric's configuration); 3: the same frames as BGR (B=G=R), which adds a1")
+    ap.add_argument("--adt", type=float, default=2.0,
+                    help="'adaptive double threshold' of tracking.ini (default 2.0); < 0 selects the reference's "
+                         "mean-gray threshold branch (track_eval.py:219-253)")
     ap.add_argument("--cpu-sample", type=int, default=200, help="frames of the clip timed on the CPU oracle (0 = skip)")
     return ap.parse_args()
 
 
-def cpu_baseline(frames_np, sample, fps):
+def cpu_baseline(frames_np, sample, fps, adt=2.0):
     """Time the CPU oracle (single thread, like the reference's one process per video) on the
     first `sample` frames of the clip."""
     if sample <= 0:
@@ -60,7 +63,7 @@ def cpu_baseline(frames_np, sample, fps):
     yo.build()
     sample = min(sample, len(frames_np))
     t0 = time.perf_counter()
-    rows, _ = yo.track_frames(frames_np[:sample], fps=fps)
+    rows, _ = yo.track_frames(frames_np[:sample], fps=fps, adt=adt)
     dt = time.perf_counter() - t0
     return {"value": sample / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"first {sample} frames of the clip ({len(rows)} rows), oracle/ysmr_oracle.{{c,py}} "
@@ -92,6 +95,8 @@ def main():
     F, B, H, W, S = args.frames, args.batch, args.height, args.width, max(1, args.streams_per_gpu)
     fps_video = 30.0
     settings = default_settings()                    # tracking.ini defaults: offset 5, adt 2.0, GSFF 10/20/30
+    settings["adaptive double threshold"] = args.adt
+    mean_gray = args.adt < 0
     clips_np, clips, pipes, link_streams = [], [], [], []
     for k in range(S):                               # one independent stream per (rank, k)
         video = SyntheticVideo(H, W, args.blobs, seed=rank * S + k, fps=fps_video)
@@ -154,12 +159,14 @@ def main():
         px = [b * H * W for _, _, b in thr_events]
         # algorithmic bytes of the fused threshold kernel: 1 B/px read + 1 B/px class map written
         # (3 B/px read for BGR input), per launch of `batch` frames
-        alg_bytes = (1.0 + args.channels) * sum(px) / len(px)
+        # (mean-gray branch: the frame is read twice -- statistics, then blur + compare -- and there are
+        # three launches between the events: k_gray_sums, k_mean_levels, k_level_threshold)
+        alg_bytes = ((2.0 if mean_gray else 1.0) * args.channels + 1.0) * sum(px) / len(px)
         avg_ms = sum(ms) / len(ms)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "threshold_pmc.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and not mean_gray:
             try:
                 rec = json.load(open(pmc))
                 if rec.get("batch") == B and rec.get("height") == H and rec.get("width") == W:
@@ -182,16 +189,17 @@ def main():
             "vs_baseline": None,
             "dtype": "u8 image / f32 threshold+geometry / f64 link",
             "data": "synthetic",
-            "config": {"workload": f"{W}x{H} stream, ~{args.blobs} blobs, detect+link end to end ({which})",
+            "config": {"workload": f"{W}x{H} stream, ~{args.blobs} blobs, detect+link end to end ({which})"
+                                   + (", mean-gray threshold branch (adaptive double threshold < 0)" if mean_gray else ""),
                        "frames_per_step": F, "detect_batch": B, "channels": args.channels, "streams": world * S, "parallelism": f"{S} stream{'s' if S > 1 else ''}/GPU x{world}",
                        "rows_per_step": n_rows, "tracks_alive": n_tracks, "ids_issued": next_id},
-            "roofline": {"kernel": "k_threshold", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_gray_sums+k_mean_levels+k_level_threshold" if mean_gray else "k_threshold", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "launches_timed": len(ms)},
         }
         if world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_sample, fps_video)
+            out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_sample, fps_video, args.adt)
         print(json.dumps(out), flush=True)
     dist.finish(info)
 
