@@ -20,6 +20,7 @@
  *                         row emission                      ysmr/track_eval.py:313-316
  *   ysmr_gsff_gains       GaussianSumFIR.generate_n_i/compute_lsf_gain  ysmr/gsff.py:87-153
  *   ysmr_rows_sort        sort_list (order by TRACK_ID, POSITION_T)  ysmr/helper_file.py:1538-1574
+ *   ysmr_select_tracks    select_tracks + find_good_tracks   ysmr/track_eval.py:408-843
  *   ysmr_rows_columns,    save_list text + get_data (pandas.read_csv) + save_df_to_csv
  *   ysmr_rows_format_csv  ysmr/helper_file.py:1403-1478, 860-905, 1366-1400  (host functions)
  */
@@ -39,7 +40,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   3
+#define YSMR_ABI_VERSION   4
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -212,6 +213,57 @@ int    ysmr_rows_format_csv(const ysmr_row *rows_host, long long n_rows, int wit
  * the reference's; via_pandas = 0 keeps the exact values. */
 int    ysmr_rows_columns(const ysmr_row *rows_host, long long n_rows, int via_pandas, uint32_t *track_id,
                          uint32_t *t, double *x, double *y, double *w, double *h, double *angle);
+
+/* ---- selection: select_tracks / find_good_tracks (ysmr/track_eval.py:408-843) ------------------ */
+
+/* Settings of the selection, as get_configs() stores them (ysmr/helper_file.py:776-788) and as
+ * select_tracks() derives them (track_eval.py:574-583). */
+typedef struct ysmr_select_params {
+    double  area_lo, area_hi;        /* 'extreme area outliers lower / upper end in px*px' */
+    double  area_factor;             /* 'exclude measurement when above x times average area' (0 = off) */
+    double  q_area;                  /* 'percent quantiles excluded area' / 100 (<= 0: no area bounds) */
+    double  motility_stop_fraction;  /* 'stop excluding motility outliers if total count above percent' / 100 */
+    double  max_empty_ratio;         /* 'maximal empty frames in %' / 100 + 1 */
+    double  ratio_min, ratio_max;    /* 'average width/height ratio min. / max.' */
+    double  edge_fraction;           /* 'percent of screen edges to exclude' / 100 */
+    int32_t min_length_frames;       /* int(round(fps) * 'minimal length in seconds') */
+    int32_t limit_frames;            /* int(round(fps) * 'limit track length to x seconds'); 0 = off */
+    int32_t limit_exact;             /* 'limit track length exactly' */
+    int32_t omit_motility;           /* 'try to omit motility outliers' */
+    int32_t max_holes;               /* 'maximal consecutive holes' */
+    int32_t max_recursion;           /* 'maximal recursion depth' */
+    int32_t frame_height, frame_width;
+} ysmr_select_params;
+
+#define YSMR_SELECT_OK                0   /* rows_selected rows were written */
+#define YSMR_SELECT_TOO_SHORT         1   /* fewer rows than min_length_frames (track_eval.py:612-619) */
+#define YSMR_SELECT_TOO_SHORT_CLEANED 2   /* ... after the clean-up (track_eval.py:676-684) */
+#define YSMR_SELECT_NONE              3   /* no acceptable track (track_eval.py:817-820) */
+
+/* What the reference logs along the way (track_eval.py:686-691, 707-708, 721-723, 799-815). */
+typedef struct ysmr_select_summary {
+    int32_t   status;                /* YSMR_SELECT_* */
+    int32_t   outliers_used;         /* 0: distance-outlier exclusion off (setting, or too many outliers) */
+    long long rows_before, tracks_before, rows_after, tracks_after;
+    double    area_lo, area_hi;      /* area quantiles (-1 / inf when q_area <= 0) */
+    double    q1_dist, q3_dist, dist_fence;
+    long long dist_outliers;
+    long long kick_reasons[9];       /* tracks per lowest reached rejection stage; [0] = passed */
+    long long good_tracks, rows_selected;
+} ysmr_select_summary;
+
+/* The table must be ordered by (TRACK_ID, POSITION_T) -- what ysmr_rows_sort / sort_list produce --
+ * and hold the values the reference's DataFrame holds (ysmr_rows_columns with via_pandas = 1).
+ * Outputs: sel_row_dev[i] = row of the input table, sel_index_dev[i] = its index in the cleaned table
+ * (the 'index' column of the reference's result), i < summary->rows_selected, in table order; both
+ * need room for n_rows entries.  Synchronous: returns when the result is complete.
+ * summary is host memory.  Parity note: means follow numpy's pairwise summation, the median pandas'
+ * median_linear, quantiles numpy's 'linear' method (what pandas 2.x / numpy 2.x execute). */
+size_t ysmr_select_workspace_bytes(long long n_rows, int max_recursion);
+int    ysmr_select_tracks(void *stream, long long n_rows, const uint32_t *track_id_dev, const uint32_t *t_dev,
+                          const double *x_dev, const double *y_dev, const double *w_dev, const double *h_dev,
+                          const ysmr_select_params *params, void *workspace_dev, size_t workspace_bytes,
+                          int64_t *sel_row_dev, int64_t *sel_index_dev, ysmr_select_summary *summary);
 
 #ifdef __cplusplus
 }

@@ -480,3 +480,149 @@ def track_frames(frames, fps=30.0, white_on_dark=True, offset=5, adt=2.0, use_gs
             rows.append((frame0 + k, tid, float(xy[i][0]), float(xy[i][1]), float(w), float(h),
                          float(deg)))
     return rows, tracker
+
+
+# ------------------------------------------------------------------------------------------------
+# selection of good tracks: select_tracks / find_good_tracks (ysmr/track_eval.py:408-843)
+# ------------------------------------------------------------------------------------------------
+def select_tracks_oracle(df, settings, fps, frame_height, frame_width):
+    """CPU restatement of the reference's track selection on a (TRACK_ID, POSITION_T)-ordered
+    DataFrame.  Uses the same pandas / numpy primitives as the reference (groupby median, Series
+    quantile, Series mean, diff) so that their arithmetic -- median_linear, numpy's linear
+    percentile, pairwise summation -- is the reference's by construction; the control flow is written
+    out anew: clean-up (track_eval.py:623-684), bounds (:693-733), per-track splitting (:408-533),
+    choice of the longest fragment and the length limit (:745-796), result table (:822-843).
+
+    Returns (selected DataFrame or None, info dict).  info['status']: 0 ok, 1 too short, 2 too short
+    after the clean-up, 3 no acceptable track."""
+    import pandas as pd
+    info = {"status": 0, "kick_reasons": [0] * 9}
+    min_len = int(round(fps, 0) * settings["minimal length in seconds"])
+    limit = int(round(fps, 0) * settings["limit track length to x seconds"])
+    t = df.copy()
+    info["rows_before"] = len(t)
+    if len(t) < min_len or len(t) == 0:
+        info["status"] = 1
+        return None, info
+    info["tracks_before"] = int(t["TRACK_ID"].nunique())
+
+    # ---- clean-up: every rejected measurement gets a NaN area, rows with NaN area are dropped
+    by_track = t.groupby("TRACK_ID")
+    area = t["WIDTH"] * t["HEIGHT"]
+    typical = area.groupby(t["TRACK_ID"]).transform("median")
+    ok = (typical >= settings["extreme area outliers lower end in px*px"]) & \
+         (typical <= settings["extreme area outliers upper end in px*px"])
+    if settings["exclude measurement when above x times average area"]:
+        ok &= area <= typical * settings["exclude measurement when above x times average area"]
+    ok &= area != 0
+    span = (by_track["POSITION_T"].transform("last") - by_track["POSITION_T"].transform("first") + 1).astype(np.uint16)
+    ok &= span >= min_len
+    t["area"] = area
+    t = t[ok].reset_index(drop=True)
+    info["rows_after"] = len(t)
+    if len(t) < min_len or len(t) == 0:
+        info["status"] = 2
+        return None, info
+    ids = t["TRACK_ID"].to_numpy()
+    first_rows = np.flatnonzero(np.r_[True, ids[1:] != ids[:-1]])
+    last_rows = np.r_[first_rows[1:] - 1, len(t) - 1]
+    info["tracks_after"] = len(first_rows)
+
+    # ---- bounds
+    t["ratio_wh"] = np.where(t["HEIGHT"] <= t["WIDTH"], t["HEIGHT"] / t["WIDTH"], t["WIDTH"] / t["HEIGHT"])
+    q = settings["percent quantiles excluded area"]
+    if q > 0:
+        lower, upper = t["area"].quantile(q=[q, 1 - q])
+    else:
+        lower, upper = -1, np.inf
+    info["area_lo"], info["area_hi"] = float(lower), float(upper)
+    flagged = np.zeros(len(t), np.int8)
+    info.update(q1_dist=0.0, q3_dist=0.0, dist_fence=0.0, dist_outliers=0, outliers_used=0)
+    if settings["try to omit motility outliers"]:
+        step = np.sqrt(np.square(t["POSITION_X"].diff()) + np.square(t["POSITION_Y"].diff())) / t["POSITION_T"].diff()
+        step[first_rows] = 0
+        q1, q3 = step.quantile(q=[0.25, 0.75])
+        fence = (q3 - q1) * 3 + q3
+        flagged = np.where(step > fence, 1, 0).astype(np.int8)
+        share = flagged.sum() / len(t)
+        info.update(q1_dist=float(q1), q3_dist=float(q3), dist_fence=float(fence), dist_outliers=int(flagged.sum()),
+                    outliers_used=1)
+        if share > settings["stop excluding motility outliers if total count above percent"]:
+            flagged = np.zeros(len(t), np.int8)
+            info["outliers_used"] = 0
+    t["distance"] = flagged
+
+    # ---- per track: split at holes / outliers until a fragment passes every test
+    times = t["POSITION_T"]
+    edge = settings["percent of screen edges to exclude"]
+    short = 3 if min_len < 3 else min_len
+
+    def examine(lo, hi, depth):
+        """-> (passing fragments in table order, lowest rejection stage reached)"""
+        stage, found, parts = 8, [], []
+        if hi - lo + 1 >= min_len:
+            stage = 7
+            piece = t.iloc[lo:hi + 1]
+            steps = piece["POSITION_T"].diff()
+            if steps.max() <= settings["maximal consecutive holes"]:
+                stage = 6
+                if piece["distance"].sum() == 0:
+                    stage = 5
+                    duration = piece["POSITION_T"].iloc[-1] - piece["POSITION_T"].iloc[0] + 1
+                    if duration / len(piece) < settings["maximal empty frames in %"]:
+                        stage = 4
+                        if lower <= piece["area"].mean() <= upper:
+                            stage = 3
+                            if settings["average width/height ratio min."] < piece["ratio_wh"].mean() \
+                                    < settings["average width/height ratio max."]:
+                                stage = 2
+                                if edge * frame_height < piece["POSITION_Y"].mean() < (1 - edge) * frame_height and \
+                                        edge * frame_width < piece["POSITION_X"].mean() < (1 - edge) * frame_width:
+                                    stage = 1
+                                    outside = (piece["POSITION_X"].min() < 0 or piece["POSITION_X"].max() > frame_width or
+                                               piece["POSITION_Y"].min() < 0 or piece["POSITION_Y"].max() > frame_height)
+                                    if edge == 0 or not outside:
+                                        stage = 0
+                                        found.append((lo, hi))
+                else:
+                    at = int(piece["distance"].idxmax())          # first flagged row; it is left out
+                    parts = [(lo, at - 1), (at + 1, hi)]
+            elif len(piece) >= 2:
+                at = int(steps.idxmax())                          # first row after the largest hole
+                parts = [(lo, at - 1), (at, hi)]
+        if parts and depth < settings["maximal recursion depth"]:
+            for a, b in parts:
+                if b - a + 1 < short:
+                    continue
+                sub_found, sub_stage = examine(a, b, depth + 1)
+                found.extend(sub_found)
+                stage = min(stage, sub_stage)
+        return found, stage
+
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 4000))
+    keep = np.zeros(len(t), bool)
+    n_good = 0
+    for lo, hi in zip(first_rows, last_rows):
+        found, stage = examine(int(lo), int(hi), 0)
+        info["kick_reasons"][stage] += 1
+        if not found:
+            continue
+        a, b = max(found, key=lambda r: (r[1] - r[0], -r[0]))       # the longest, the earliest among equals
+        if limit:
+            until = limit + int(times.iloc[a]) - 1
+            window = times.iloc[a:b + 1]
+            hit = window[window == until] if settings["limit track length exactly"] else window[window <= until]
+            if len(hit) == 0:
+                continue
+            b = int(hit.index[-1])
+        keep[a:b + 1] = True
+        n_good += 1
+    info["good_tracks"] = n_good
+    info["rows_selected"] = int(keep.sum())
+    if not keep.any():
+        info["status"] = 3
+        return None, info
+    cols = ["TRACK_ID", "POSITION_T", "POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE"]
+    out = t.loc[keep, cols].reset_index()      # keeps the cleaned table's index as column 'index'
+    return out, info

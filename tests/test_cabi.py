@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ysmr_abi_version() == 3
+    assert lib.ysmr_abi_version() == 4
 
 
 def test_row_struct_layout():

@@ -73,11 +73,13 @@ def test_analyse_and_ysmr(tmp_path):
         np.save(p, SyntheticVideo(120, 160, 8, seed=i).frames(45))
         paths.append(str(p))
     out = tmp_path / "results"
-    df = analyse(paths[0], settings=_settings(), result_folder=str(out), return_df=True, note="x")
+    from ysmr_amd.main import _OFFLINE_KEYS
+    no_selection = {k: False for k in _OFFLINE_KEYS}   # (45 frames cannot hold a 20 s track: select_tracks has its own tests)
+    df = analyse(paths[0], settings=_settings(**no_selection), result_folder=str(out), return_df=True, note="x")
     assert df is not None and len(df) > 0
     meta = json.load(open(out / "v0_meta.json"))
     assert meta["fps"] == 30.0 and meta["frame_height"] == 120 and meta["frame_width"] == 160 and meta["note"] == "x"
-    done = ysmr(paths + [str(tmp_path / "nope.npy")], settings=_settings(), result_folder=str(out))
+    done = ysmr(paths + [str(tmp_path / "nope.npy")], settings=_settings(**no_selection), result_folder=str(out))
     assert [p for p, _ in done] == paths + [str(tmp_path / "nope.npy")]
     assert done[0][1] is True and done[1][1] is True and done[2][1] is None
     assert (out / "v1_list.csv").exists()

@@ -27,7 +27,28 @@ EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
-           "ysmr_rows_format_csv", "ysmr_rows_columns")
+           "ysmr_rows_format_csv", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks")
+
+SELECT_OK, SELECT_TOO_SHORT, SELECT_TOO_SHORT_CLEANED, SELECT_NONE = 0, 1, 2, 3
+
+
+class SelectParams(ctypes.Structure):
+    """``struct ysmr_select_params``"""
+    _fields_ = [(k, ctypes.c_double) for k in ("area_lo", "area_hi", "area_factor", "q_area", "motility_stop_fraction",
+                                               "max_empty_ratio", "ratio_min", "ratio_max", "edge_fraction")] + \
+               [(k, ctypes.c_int32) for k in ("min_length_frames", "limit_frames", "limit_exact", "omit_motility",
+                                              "max_holes", "max_recursion", "frame_height", "frame_width")]
+
+
+class SelectSummary(ctypes.Structure):
+    """``struct ysmr_select_summary``"""
+    _fields_ = [("status", ctypes.c_int32), ("outliers_used", ctypes.c_int32),
+                ("rows_before", ctypes.c_longlong), ("tracks_before", ctypes.c_longlong),
+                ("rows_after", ctypes.c_longlong), ("tracks_after", ctypes.c_longlong),
+                ("area_lo", ctypes.c_double), ("area_hi", ctypes.c_double), ("q1_dist", ctypes.c_double),
+                ("q3_dist", ctypes.c_double), ("dist_fence", ctypes.c_double), ("dist_outliers", ctypes.c_longlong),
+                ("kick_reasons", ctypes.c_longlong * 9), ("good_tracks", ctypes.c_longlong),
+                ("rows_selected", ctypes.c_longlong)]
 
 
 class YsmrLibraryError(RuntimeError):
@@ -79,8 +100,12 @@ def lib():
     L.ysmr_rows_csv_bound.restype = ctypes.c_size_t
     L.ysmr_rows_format_csv.argtypes = [vp, ctypes.c_longlong, ci, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.ysmr_rows_columns.argtypes = [vp, ctypes.c_longlong, ci, vp, vp, vp, vp, vp, vp, vp]
+    L.ysmr_select_workspace_bytes.argtypes = [ctypes.c_longlong, ci]
+    L.ysmr_select_workspace_bytes.restype = ctypes.c_size_t
+    L.ysmr_select_tracks.argtypes = [vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, ctypes.POINTER(SelectParams), vp,
+                                     ctypes.c_size_t, vp, vp, ctypes.POINTER(SelectSummary)]
     for name in EXPORTS:
-        if name not in ("ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_abi_version",
+        if name not in ("ysmr_select_workspace_bytes", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_abi_version",
                         "ysmr_rows_sort_workspace_bytes", "ysmr_rows_csv_bound",
                         "ysmr_mean_threshold_state_bytes"):
             getattr(L, name).restype = ci

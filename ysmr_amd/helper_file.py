@@ -408,6 +408,27 @@ def sort_list(file_path=None, sort=None, df=None, save_file=False):
     return df
 
 
+def save_df_to_csv(df, save_path, rename_old_file=True):
+    """Write a DataFrame as csv without its index (helper_file.py:1366-1400); an existing file of the
+    same name is first moved aside to ``<yymmddHHMMSS>.<old file name>``."""
+    if rename_old_file:
+        folder, name = os.path.split(save_path)
+        try:
+            moved = os.path.join(folder, "{}.{}".format(datetime.now().strftime("%y%m%d%H%M%S"), name))
+            os.rename(save_path, moved)
+            _logger().critical("Old {} renamed to {}".format(name, moved))
+        except (FileNotFoundError, FileExistsError):
+            pass
+        except OSError as exc:
+            _logger().exception("Could not move previous file {} aside: {}".format(save_path, exc))
+    try:
+        with open(save_path, "w+", newline="\n") as fh:
+            df.to_csv(fh, index=False, encoding="utf-8")
+        _logger().debug("Selected results saved to: {}".format(save_path))
+    except OSError as exc:
+        _logger().exception("Could not save {}: {}".format(save_path, exc))
+
+
 def metadata_file(path=None, verbose=False, additional_search_paths=None, **kwargs):
     """Read/update ``<name>_meta.json`` next to ``path`` (fps, frame_height, frame_width, ...);
     ``None`` values are ignored (helper_file.py:1262-1333, without the parent-folder search)."""

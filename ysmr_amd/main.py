@@ -16,20 +16,24 @@ import os
 from datetime import datetime
 
 from .helper_file import create_results_folder, get_configs, get_loggers, metadata_file
+from .select import select_tracks
 from .track_eval import track_bacteria
 
 __all__ = ["analyse", "ysmr"]
 
-_OFFLINE_KEYS = ("store processed .csv file", "store generated statistical .csv file",
+_EVALUATE_KEYS = ("store generated statistical .csv file",
                  "store final analysed .csv file", "save large plots", "save rose plot", "save time violin plot",
                  "save acr violin plot", "save length violin plot", "save turning point violin plot",
                  "save speed violin plot", "save angle distribution plot / bins", "collate results csv to xlsx",
                  "save video")
+_OFFLINE_KEYS = ("store processed .csv file",) + _EVALUATE_KEYS
 
 
 def analyse(path, settings=None, result_folder=None, return_df=False, device="cuda:0", **kwargs):
-    """Run the detect-and-link stage on one video (main.py:32-172).  ``kwargs`` go to the
-    ``_meta.json`` side file together with fps and frame size (main.py:99-108)."""
+    """Detect-and-link on one video, then ``select_tracks`` on its table (main.py:32-172); a
+    ``*_list.csv`` of an earlier run goes straight to the selection.  ``kwargs`` go to the ``_meta.json``
+    side file together with fps and frame size (main.py:99-108).  Returns the last stage's DataFrame
+    (``return_df``) or True; None after any failure, including "no acceptable tracks"."""
     t0 = datetime.now()
     settings = get_configs(settings)
     if settings is None:
@@ -46,20 +50,32 @@ def analyse(path, settings=None, result_folder=None, return_df=False, device="cu
     if any(tag in path for tag in ("_analysed.csv", "_statistics.csv", "_annotated_output.")):
         logger.warning("File already evaluated. File: {}".format(path))
         return None
-    if ".csv" in path:
-        logger.warning("{}: .csv inputs belong to the offline stages, which this package does not implement".format(path))
+    csv_file = None
+    if ".csv" not in path:   # "as long as it's not a .csv, it should be a video" (main.py:88-97)
+        result = track_bacteria(video_path=path, settings=settings, result_folder=result_folder, device=device)
+        if result is None:
+            logger.warning("Error during video analysis of file {}.".format(path))
+            logger.info("Error during process. PID: {}, elapsed time: {}".format(os.getpid(), datetime.now() - t0))
+            return None
+        df, fps, f_height, f_width, csv_file = result
+    else:                    # a *_list.csv of an earlier run: fps and frame size come from its _meta.json
+        df, fps, f_height, f_width = None, None, None, None
+    meta_all = metadata_file(path=os.path.join(result_folder, os.path.basename(path)), verbose=settings["verbose"], fps=fps,
+                             frame_height=f_height, frame_width=f_width, **kwargs)
+    fps, f_height, f_width = meta_all.get("fps", fps), meta_all.get("frame_height", f_height), meta_all.get("frame_width", f_width)
+    if "selected_data.csv" in path:
+        logger.info("{} is a selection already; evaluate_tracks is not part of the HIP path".format(path))
         return None
-    result = track_bacteria(video_path=path, settings=settings, result_folder=result_folder, device=device)
-    if result is None:
-        logger.warning("Error during video analysis of file {}.".format(path))
-        logger.info("Error during process. PID: {}, elapsed time: {}".format(os.getpid(), datetime.now() - t0))
-        return None
-    df, fps, f_height, f_width, csv_file = result
-    metadata_file(path=os.path.join(result_folder, os.path.basename(path)), verbose=settings["verbose"], fps=fps,
-                  frame_height=f_height, frame_width=f_width, **kwargs)
-    if any(settings.get(k) for k in _OFFLINE_KEYS):
-        logger.info("select_tracks / evaluate_tracks / plots are not part of the HIP path; stopping after "
-                    "{}".format(csv_file))
+    # select_tracks runs when its csv is wanted or a later stage needs it (main.py:111-128)
+    if any(settings.get(k) for k in _OFFLINE_KEYS) or df is None:
+        meta = {"fps": fps, "frame_height": f_height, "frame_width": f_width}
+        df = select_tracks(path_to_file=path, df=df, results_directory=result_folder, settings=settings, device=device, **meta)
+        if df is None:
+            logger.warning("Error during video analysis of file {}.".format(path))
+            logger.info("Error during process. PID: {}, elapsed time: {}".format(os.getpid(), datetime.now() - t0))
+            return None
+    if any(settings.get(k) for k in _EVALUATE_KEYS):
+        logger.info("evaluate_tracks / plots are not part of the HIP path; stopping after select_tracks")
     if settings["delete .csv file after analysis"] and csv_file:
         try:
             os.remove(csv_file)
