@@ -5,7 +5,7 @@ import numpy as np, torch
 from ysmr_amd.helper_file import default_settings
 from ysmr_amd.synth import SyntheticVideo
 from ysmr_amd.track_eval import track_bacteria
-F = int(sys.argv[1]) if len(sys.argv) > 1 else 640
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 ch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 d = tempfile.mkdtemp(dir="/tmp")
 t0 = time.perf_counter()
@@ -14,7 +14,7 @@ if ch == 3: frames = np.repeat(frames[..., None], 3, axis=-1)
 path = os.path.join(d, "clip.npy"); np.save(path, frames); del frames
 print(f"generated {F} frames in {time.perf_counter()-t0:.1f} s, {os.path.getsize(path)/1e6:.0f} MB")
 s = default_settings(**{"user input": False, "select files": False, "display video analysis": False, "log to file": False})
-logging.getLogger("ysmr").setLevel(logging.WARNING)
+logging.getLogger("ysmr").setLevel(logging.DEBUG)
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = track_bacteria(path, settings=dict(s), result_folder=d)

@@ -19,7 +19,7 @@ import os
 
 import numpy as np
 
-__all__ = ["open_video", "NpyVideo", "Y4mVideo", "Cv2Video"]
+__all__ = ["open_video", "NpyVideo", "Y4mVideo", "Cv2Video", "DeviceFrameFeed"]
 
 
 class NpyVideo:
@@ -42,6 +42,20 @@ class NpyVideo:
 
     def read(self, start, count):
         return np.ascontiguousarray(self._a[start:start + count])
+
+    def read_into(self, start, count, out, pool=None):
+        """Copy frames [start, start + count) into ``out[:n]`` (any writable uint8 array of the frame
+        shape, e.g. pinned memory); with a thread pool the copy is split (NumPy releases the GIL)."""
+        n = max(0, min(count, self.frame_count - start))
+        if pool is None or n < 8:
+            np.copyto(out[:n], self._a[start:start + n])
+            return n
+        parts = min(n, pool._max_workers)
+        edges = [start + n * k // parts for k in range(parts + 1)]
+        jobs = [pool.submit(np.copyto, out[a - start:b - start], self._a[a:b]) for a, b in zip(edges[:-1], edges[1:])]
+        for j in jobs:
+            j.result()
+        return n
 
     def close(self):
         self._a = None
@@ -131,6 +145,106 @@ class Cv2Video:
 
     def close(self):
         self._cap.release()
+
+
+class DeviceFrameFeed:
+    """Batches of a video as device tensors, read and uploaded ahead of their use.
+
+    A producer thread copies batch i into one of ``depth`` pinned staging buffers (split over
+    ``readers`` threads) and uploads it on its own HIP stream into one of ``depth`` device buffers,
+    while the consumer works on earlier batches.  Iterating yields ``(frames_dev, first_frame, count,
+    slot)``; the consumer's stream already waits for the upload.  When the kernels that read
+    ``frames_dev`` have been issued, the consumer calls ``release(slot, event)`` with an event recorded
+    behind them: the slot's device buffer is overwritten only after that event."""
+
+    def __init__(self, video, batch, device, depth=3, readers=4):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        import torch
+        self.video, self.B, self.device, self.depth = video, int(batch), torch.device(device), int(depth)
+        shape = (self.B, video.height, video.width) + ((3,) if video.channels == 3 else ())
+        self._pinned = [torch.empty(shape, dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
+        self._dev = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
+        self._copy_stream = torch.cuda.Stream(device=self.device)
+        self._uploaded = [None] * self.depth     # event: H2D copy out of pinned[slot] finished
+        self._released = [None] * self.depth     # event posted by the consumer (or True: never used / free)
+        self._cv = threading.Condition()
+        for k in range(self.depth):
+            self._released[k] = True
+        self._q = queue.Queue(maxsize=self.depth)
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(readers))) if readers > 1 else None
+        self._stop = False
+        self._thread = threading.Thread(target=self._produce, name="ysmr-frame-feed", daemon=True)
+        self._thread.start()
+
+    def _produce(self):
+        import torch
+        try:
+            torch.cuda.set_device(self.device)
+            i = 0
+            for f0 in range(0, self.video.frame_count, self.B):
+                slot = i % self.depth
+                with self._cv:
+                    while self._released[slot] is None and not self._stop:
+                        self._cv.wait(0.05)
+                    if self._stop:
+                        return
+                    released, self._released[slot] = self._released[slot], None
+                if self._uploaded[slot] is not None:
+                    self._uploaded[slot].synchronize()          # staging buffer free again
+                host = self._pinned[slot].numpy()
+                if hasattr(self.video, "read_into"):
+                    n = self.video.read_into(f0, self.B, host, self._pool)
+                else:
+                    got = self.video.read(f0, self.B)
+                    n = got.shape[0]
+                    host[:n] = got
+                if n == 0:
+                    break
+                with torch.cuda.stream(self._copy_stream):
+                    if released is not True:
+                        self._copy_stream.wait_event(released)  # the kernels that read this device buffer are done
+                    self._dev[slot][:n].copy_(self._pinned[slot][:n], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                self._uploaded[slot] = ev
+                self._q.put((slot, f0, n, ev))
+                i += 1
+            self._q.put(None)
+        except BaseException as exc:   # hand the failure to the consumer
+            self._q.put(exc)
+
+    def __iter__(self):
+        import torch
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            slot, f0, n, ev = item
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            yield self._dev[slot][:n], f0, n, slot
+
+    def release(self, slot, event):
+        with self._cv:
+            self._released[slot] = event
+            self._cv.notify_all()
+
+    def close(self):
+        self._stop = True
+        with self._cv:
+            self._cv.notify_all()
+        try:
+            while True:                # unblock a producer waiting on a full queue
+                self._q.get_nowait()
+        except Exception:
+            pass
+        self._thread.join(timeout=5.0)
+        if self._pool is not None:
+            self._pool.shutdown(wait=False)
 
 
 def open_video(path, default_fps=30.0):

@@ -347,6 +347,10 @@ def rows_to_csv_bytes(rows, header=True, via_pandas=True, threads=0):
     a pandas round trip.  ``rows``: structured ``ysmr_row`` array, already in file order.
     ``via_pandas``: reproduce the 1-ulp noise of the reference's text -> read_csv detour
     (include/ysmr_hip.h); False prints the exact values."""
+    return _rows_csv_buffer(rows, header, via_pandas, threads).tobytes()
+
+
+def _rows_csv_buffer(rows, header, via_pandas, threads):
     import ctypes
     from . import _lib
     rows = np.ascontiguousarray(rows, dtype=_lib.ROW_DTYPE)
@@ -356,7 +360,15 @@ def rows_to_csv_bytes(rows, header=True, via_pandas=True, threads=0):
     n = ctypes.c_size_t(0)
     _lib.check(L.ysmr_rows_format_csv(rows.ctypes.data, len(rows), int(bool(header)), int(bool(via_pandas)), int(threads),
                                       out.ctypes.data, cap, ctypes.byref(n)), "ysmr_rows_format_csv")
-    return out[:n.value].tobytes()
+    return out[:n.value]
+
+
+def rows_to_csv_file(rows, path, header=True, via_pandas=True, threads=0):
+    """:func:`rows_to_csv_bytes` written straight to ``path`` (no intermediate ``bytes`` copy)."""
+    buf = _rows_csv_buffer(rows, header, via_pandas, threads)
+    with open(path, "wb") as fh:
+        fh.write(memoryview(buf))
+    return len(buf)
 
 
 def rows_to_dataframe(rows, via_pandas=True):

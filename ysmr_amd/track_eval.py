@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import logging
 import os
+import threading
+import time
 import warnings
 
 import numpy as np
@@ -22,8 +24,8 @@ import torch
 
 from . import _lib
 from .detect import Detector, MeanGrayState, mean_gray_params, threshold_params
-from .frames import open_video
-from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes,
+from .frames import DeviceFrameFeed, open_video
+from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_file,
                           rows_to_dataframe, save_list)
 from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
@@ -114,7 +116,7 @@ class TrackingPipeline:
         cap = self.rows.numel() // _lib.ROW_DTYPE.itemsize
         if n > cap:
             raise _lib.YsmrLibraryError(f"row buffer overflow: {n} rows > capacity {cap}")
-        rows = rows_to_numpy(sort_rows(self.rows, n) if sort else self.rows, n).copy()
+        rows = rows_to_numpy(sort_rows(self.rows, n) if sort else self.rows, n)   # (a fresh host array)
         self.row_count.zero_()
         return rows
 
@@ -184,6 +186,8 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
     error_during_read = False
     frames_done = 0
     sorted_rows = None
+    feed = None
+    t_start = t_frames = time.perf_counter()
     try:
         # Rows stay on the device for the whole video when they fit (capacity rows per frame is the
         # worst case; 32 M rows = 1.3 GB) and are ordered there at the end; otherwise full buffers are
@@ -198,14 +202,10 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
         res = None
         row_capacity = pipe.rows.numel() // _lib.ROW_DTYPE.itemsize
         rows_upper = 0     # host-side bound on the rows in the device buffer (no sync per batch)
-        for f0 in range(0, frame_count, pipe.B):
-            host = video.read(f0, pipe.B)
-            if host.shape[0] == 0:
-                break
-            with warnings.catch_warnings():   # (memory-mapped .npy files are read-only; the tensor is only read)
-                warnings.simplefilter("ignore", UserWarning)
-                dev = torch.from_numpy(host).to(pipe.device, non_blocking=True)
-            nxt = (pipe.detect_async(dev), f0, host.shape[0])
+        feed = DeviceFrameFeed(video, pipe.B, pipe.device)
+        for dev, f0, n_read, feed_slot in feed:
+            nxt = (pipe.detect_async(dev), f0, n_read)
+            feed.release(feed_slot, nxt[0][2])   # the batch's frames are free once its detection has run
             if pending is not None:
                 (slot, r, ready), p0, cnt = pending
                 if rows_upper + cnt * pipe.capacity > row_capacity:
@@ -227,12 +227,13 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
             frames_done = p0 + cnt
         if res is not None:
             torch.cuda.synchronize(pipe.device)
+            t_frames = time.perf_counter()
             pipe.check(res)
             if chunks:      # did not fit: gather on the host, order on the device in one go
                 chunks.append(pipe.take_rows())
                 everything = np.concatenate(chunks)
                 on_dev = torch.from_numpy(everything.view(np.uint8)).to(pipe.device)
-                sorted_rows = rows_to_numpy(sort_rows(on_dev, len(everything)), len(everything)).copy()
+                sorted_rows = rows_to_numpy(sort_rows(on_dev, len(everything)), len(everything))
             else:
                 sorted_rows = pipe.take_rows(sort=True)
         if frames_done < frame_count - 1:   # some containers over-report by one frame (track_eval.py:170-171)
@@ -242,6 +243,8 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
         logger.critical("Device path failed for file {}: {}".format(video_path, exc))
         error_during_read = True
     finally:
+        if feed is not None:
+            feed.close()
         video.close()
 
     if old_list and error_during_read:
@@ -258,13 +261,26 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
     # the csv with pandas, sorts it and rewrites it; the same DataFrame and the same bytes come
     # straight from the rows here (helper_file.rows_to_dataframe / rows_to_csv_bytes).
     n_rows_total, last_id = len(sorted_rows), int(sorted_rows["track_id"][-1])
-    df_for_eval = rows_to_dataframe(sorted_rows)
+    t_rows = time.perf_counter()
+    # the csv is formatted and written on a second thread while the DataFrame is built (both are native
+    # calls that release the GIL)
+    writer, write_error = None, []
     if not settings["delete .csv file after analysis"]:   # (else analyse() removes the file anyway, main.py:156)
-        try:
-            with open(list_name, "wb") as fh:
-                fh.write(rows_to_csv_bytes(sorted_rows))
-        except OSError as exc:
-            logger.exception("Could not write {}: {}".format(list_name, exc))
+        def _write():
+            try:
+                rows_to_csv_file(sorted_rows, list_name)
+            except (OSError, _lib.YsmrLibraryError) as exc:
+                write_error.append(exc)
+        writer = threading.Thread(target=_write, name="ysmr-csv")
+        writer.start()
+    df_for_eval = rows_to_dataframe(sorted_rows)
+    t_df = time.perf_counter()
+    if writer is not None:
+        writer.join()
+        if write_error:
+            logger.error("Could not write {}: {}".format(list_name, write_error[0]))
+    logger.debug("phases: frames {:.1f} ms, rows to host (sorted) {:.1f} ms, DataFrame {:.1f} ms, csv {:.1f} ms".format(
+        (t_frames - t_start) * 1e3, (t_rows - t_frames) * 1e3, (t_df - t_rows) * 1e3, (time.perf_counter() - t_df) * 1e3))
     logger.info("objects: {}, frames: {} of {}, rows: {}, csv: {}".format(last_id + 1, frames_done, frame_count,
                                                                           n_rows_total, list_name))
     if error_during_read:
