@@ -459,7 +459,7 @@ SelLayout sel_layout(long long n, int max_recursion)
     L.leaf_sum = take(sizeof(double) * 4 * (size_t)L.leaf_slots);
     long long cap = (long long)max_recursion + 4;
     if (cap < 16) cap = 16;
-    if (cap > 65536) cap = 65536;
+    if (cap > 8192) cap = 8192;   // (16 B x 1024 waves per entry; a deeper walk is reported as YSMR_ERR_CAPACITY)
     L.stack_cap = (int)cap;
     L.stack = take(sizeof(int4) * (size_t)L.stack_cap * TRACK_BLOCKS * 4);
     size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
