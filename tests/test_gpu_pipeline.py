@@ -273,3 +273,32 @@ def test_track_bacteria_mean_gray_branch(tmp_path, oracle, white, offset):
     ref_rows, _ = oracle.track_frames(frames, fps=4.0, white_on_dark=white, offset=offset, adt=-1.0)
     assert len(ref_rows) > 500
     compare_rows(_rows_from_df(res[0]), ref_rows)
+
+
+def test_device_frame_feed_order_and_reuse(tmp_path):
+    """DeviceFrameFeed: every batch arrives once, in order, with the file's bytes -- also when its two
+    device buffers are reused many times and the consumer is slow to release them."""
+    import time
+    import torch
+    from ysmr_amd.frames import DeviceFrameFeed, open_video
+    rng = np.random.default_rng(8)
+    for shape in [(75, 40, 52), (21, 16, 24, 3)]:
+        clip = rng.integers(0, 256, shape, dtype=np.uint8)
+        path = tmp_path / f"feed{len(shape)}.npy"
+        np.save(path, clip)
+        video = open_video(str(path))
+        feed = DeviceFrameFeed(video, 8, "cuda:0", depth=2, readers=3)
+        seen = 0
+        for k, (dev, f0, n, slot) in enumerate(feed):
+            assert f0 == seen and n == min(8, shape[0] - f0) and dev.shape[0] == n
+            if k % 3 == 0:
+                time.sleep(0.01)                       # let the producer run into the held slot
+            host = dev.cpu().numpy()                   # (synchronises: the upload is complete)
+            np.testing.assert_array_equal(host, clip[f0:f0 + n])
+            done = torch.cuda.Event()
+            done.record()
+            feed.release(slot, done)
+            seen += n
+        assert seen == shape[0]
+        feed.close()
+        video.close()

@@ -84,6 +84,13 @@ def test_frame_sources(tmp_path):
     v = open_video(str(p))
     assert (v.frame_count, v.height, v.width, v.channels, v.fps) == (7, 12, 16, 1, 29.97)
     np.testing.assert_array_equal(v.read(5, 4), clip[5:7])
+    from concurrent.futures import ThreadPoolExecutor
+    big = rng.integers(0, 256, (40, 12, 16), dtype=np.uint8)
+    np.save(tmp_path / "big.npy", big)
+    vb, out = open_video(str(tmp_path / "big.npy")), np.zeros((32, 12, 16), np.uint8)
+    with ThreadPoolExecutor(3) as pool:
+        assert vb.read_into(4, 32, out, pool) == 32 and np.array_equal(out, big[4:36])
+        assert vb.read_into(30, 32, out, pool) == 10 and np.array_equal(out[:10], big[30:])
     # y4m: luma plane only, 4:2:0
     y4 = tmp_path / "b.y4m"
     with open(y4, "wb") as fh:
@@ -93,6 +100,8 @@ def test_frame_sources(tmp_path):
     v = open_video(str(y4))
     assert (v.frame_count, v.height, v.width) == (7, 12, 16) and abs(v.fps - 29.97) < 1e-2
     np.testing.assert_array_equal(v.read(0, 7), clip)
+    out = np.zeros((4, 12, 16), np.uint8)
+    assert v.read_into(5, 4, out) == 2 and np.array_equal(out[:2], clip[5:])
     with pytest.raises(OSError):
         open_video(str(tmp_path / "c.avi"))      # no OpenCV in this image
 

@@ -104,13 +104,21 @@ class Y4mVideo:
     def read(self, start, count):
         n = max(0, min(count, self.frame_count - start))
         out = np.empty((n, self.height, self.width), np.uint8)
+        self.read_into(start, n, out)
+        return out
+
+    def read_into(self, start, count, out, pool=None):
+        """Luma planes of frames [start, start + count) straight into ``out[:n]`` (e.g. pinned memory)."""
+        n = max(0, min(count, self.frame_count - start))
         for i in range(n):
             self._fh.seek(self._data0 + (start + i) * self._stride)
             marker = self._fh.readline()
             if not marker.startswith(b"FRAME"):
                 raise ValueError(f"{self.path}: frame {start + i} has no FRAME marker")
-            out[i] = np.frombuffer(self._fh.read(self.width * self.height), np.uint8).reshape(self.height, self.width)
-        return out
+            plane = memoryview(out[i]).cast("B")
+            if self._fh.readinto(plane) != self.width * self.height:
+                raise ValueError(f"{self.path}: frame {start + i} is truncated")
+        return n
 
     def close(self):
         self._fh.close()
