@@ -72,7 +72,6 @@ def cpu_baseline(frames_np, sample, fps, adt=2.0):
 
 def main():
     args = parse()
-    import numpy as np
     import torch
 
     from ysmr_amd import dist

@@ -495,7 +495,6 @@ def select_tracks_oracle(df, settings, fps, frame_height, frame_width):
 
     Returns (selected DataFrame or None, info dict).  info['status']: 0 ok, 1 too short, 2 too short
     after the clean-up, 3 no acceptable track."""
-    import pandas as pd
     info = {"status": 0, "kick_reasons": [0] * 9}
     min_len = int(round(fps, 0) * settings["minimal length in seconds"])
     limit = int(round(fps, 0) * settings["limit track length to x seconds"])
