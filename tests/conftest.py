@@ -50,7 +50,7 @@ def compare_rows(got, ref_rows, hist=31):
     Var_w(x_hat) [px^2] per frame until one filter wins.  Which one wins is decided by rounding noise
     (BLAS summation order, exp), in the reference itself as much as here; the extrapolated position
     then differs by up to the filters' disagreement, i.e. pixels (observed: weights [0.5, 0.5],
-    predictions 4 px apart, 12 px deviation after 25 lost frames; scripts/debug_inv.py).
+    predictions 4 px apart, 12 px deviation after 25 lost frames; tests/tools/debug_inv.py).
     Rows of tracks lost within the last `hist` frames are therefore checked statistically: >= 90 %
     within north_star's 1e-5 relative (1e-3 px absolute near zero), none off by more than 50 px.
     Returns (number of loose rows, worst loose deviation in px).

@@ -1,6 +1,6 @@
 """Time ysmr_select_tracks on a table of the bench clip's size (device-resident columns, the call is
 synchronous) next to the CPU oracle on a bounded sample of the same table.
-usage: python scripts/bench_select.py [--tracks 900] [--max-len 600] [--reps 20] [--cpu-tracks 60]"""
+usage: python tests/tools/bench_select.py [--tracks 900] [--max-len 600] [--reps 20] [--cpu-tracks 60]"""
 import argparse
 import ctypes
 import json
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -1,8 +1,8 @@
 """One-off large parity run: the bench clip (1228x922, ~500 blobs) through track_bacteria vs the CPU oracle
 on the same frames, for gray and BGR input and both threshold branches.
-usage: python scripts/parity_sweep.py [frames=200]"""
+usage: python tests/tools/parity_sweep.py [frames=200]"""
 import os, sys, time, tempfile, logging
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from conftest import compare_rows
