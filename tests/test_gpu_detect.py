@@ -320,3 +320,24 @@ def test_components_on_tiny_frames(torch_cuda, oracle):
             assert int(res.det_count[f]) == n and int(res.status[f]) == 0
             np.testing.assert_array_equal(res.anchors[f, :n].cpu().numpy(), anchors)
             np.testing.assert_array_equal(res.det[f, :n, :4].cpu().numpy(), rects[:, :4])
+
+
+def test_mean_gray_benchmark_geometry(torch_cuda, oracle):
+    """1228x922, ~500 blobs (several strips, 45-odd segments per strip): levels and detections of a few
+    consecutive frames, gray and BGR."""
+    from ysmr_amd.detect import Detector, mean_gray_params
+    from ysmr_amd.synth import SyntheticVideo
+    torch = torch_cuda
+    gray = SyntheticVideo(922, 1228, 500, seed=4).frames(3)
+    for frames in (gray, np.repeat(gray[..., None], 3, axis=3)):
+        p = mean_gray_params(True, 5, 30.0)
+        det = Detector(3, 922, 1228, max_det=2048, params=p)
+        res = det.detect(torch.from_numpy(np.ascontiguousarray(frames)).cuda())
+        torch.cuda.synchronize()
+        lv = oracle.MeanGrayLevels(30.0, True, 5)
+        for f in range(3):
+            ref = oracle.detect_frame_mean_gray(frames[f], lv, 2048)
+            assert int(res.status[f]) == 0 and int(res.det_count[f]) == ref.count > 300
+            np.testing.assert_array_equal(res.cls[f].cpu().numpy() & 3, ref.cls)
+            np.testing.assert_array_equal(res.labels[f].cpu().numpy(), ref.labels)
+            np.testing.assert_array_equal(res.det[f, :ref.count, :4].cpu().numpy(), ref.det[:, :4])

@@ -28,7 +28,14 @@ from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, ge
                           rows_to_dataframe, save_list)
 from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
-__all__ = ["track_bacteria", "TrackingPipeline"]
+__all__ = ["track_bacteria", "TrackingPipeline", "select_tracks"]
+
+
+def __getattr__(name):   # select_tracks lives in track_eval upstream (track_eval.py:536); here in select.py
+    if name == "select_tracks":
+        from .select import select_tracks
+        return select_tracks
+    raise AttributeError(name)
 
 
 class TrackingPipeline:
