@@ -302,3 +302,22 @@ def test_device_frame_feed_order_and_reuse(tmp_path):
         assert seen == shape[0]
         feed.close()
         video.close()
+
+
+def test_ysmr_multiprocess_two_streams_per_gpu(tmp_path):
+    """ysmr(multiprocess=True): single-use worker processes, two at a time on the one GPU of the box."""
+    from ysmr_amd import ysmr
+    from ysmr_amd.main import _OFFLINE_KEYS
+    from ysmr_amd.synth import SyntheticVideo
+    paths = []
+    for i in range(3):
+        p = tmp_path / f"m{i}.npy"
+        np.save(p, SyntheticVideo(96, 128, 6, seed=10 + i).frames(44))
+        paths.append(str(p))
+    out = tmp_path / "res"
+    done = ysmr(paths, settings=_settings(**{k: False for k in _OFFLINE_KEYS}), result_folder=str(out),
+                multiprocess=True, streams_per_gpu=2)
+    assert [p for p, _ in done] == paths and all(r is True for _, r in done)
+    for i in range(3):
+        text = (out / f"m{i}_list.csv").read_text().splitlines()
+        assert text[0] == "TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE" and len(text) > 100
