@@ -341,3 +341,26 @@ def test_mean_gray_benchmark_geometry(torch_cuda, oracle):
             np.testing.assert_array_equal(res.cls[f].cpu().numpy() & 3, ref.cls)
             np.testing.assert_array_equal(res.labels[f].cpu().numpy(), ref.labels)
             np.testing.assert_array_equal(res.det[f, :ref.count, :4].cpu().numpy(), ref.det[:, :4])
+
+
+def test_mean_gray_levels_outside_the_u8_range(torch_cuda, oracle):
+    """Levels beyond [0, 255] (cv2.threshold then sets everything or nothing): saturated frames with a
+    large offset, black frames with a negative one; both polarities."""
+    from ysmr_amd.detect import Detector, mean_gray_params
+    torch = torch_cuda
+    h, w = 24, 40
+    cases = [(np.full((4, h, w), 255, np.uint8), True, 5), (np.zeros((4, h, w), np.uint8), True, -5),
+             (np.zeros((4, h, w), np.uint8), False, 5), (np.full((4, h, w), 255, np.uint8), False, -5)]
+    for frames, white, offset in cases:
+        det = Detector(4, h, w, max_det=64, params=mean_gray_params(white, offset, 30.0))
+        res = det.detect(torch.from_numpy(frames).cuda())
+        torch.cuda.synchronize()
+        lv = oracle.MeanGrayLevels(30.0, white, offset)
+        for f in range(4):
+            ref = oracle.detect_frame_mean_gray(frames[f], lv, 64)
+            np.testing.assert_array_equal(res.cls[f].cpu().numpy() & 3, ref.cls)
+            assert int(res.det_count[f]) == ref.count and int(res.status[f]) == 0
+            np.testing.assert_array_equal(res.det[f, :ref.count].cpu().numpy(), ref.det)
+        levels = det.mean_levels[:4].cpu().tolist()
+        assert all(v in (-1, 256) or 0 <= v <= 255 for v in levels)
+    assert oracle.MeanGrayLevels(30.0, True, 5).step(np.full((h, w), 255, np.uint8))[0] == 260
