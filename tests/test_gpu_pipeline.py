@@ -321,3 +321,19 @@ def test_ysmr_multiprocess_two_streams_per_gpu(tmp_path):
     for i in range(3):
         text = (out / f"m{i}_list.csv").read_text().splitlines()
         assert text[0] == "TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE" and len(text) > 100
+
+
+def test_track_bacteria_reads_uncompressed_avi(tmp_path):
+    """The same clip as .npy and as a raw 8-bit AVI (bottom-up, padded rows) gives the same table."""
+    from avi_tools import write_avi
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(118, 150, 9, seed=6).frames(50)              # width 150: DIB rows padded to 152
+    np.save(tmp_path / "a.npy", frames)
+    write_avi(tmp_path / "b.avi", frames, 8, fps=(30, 1))
+    os.makedirs(tmp_path / "ra"); os.makedirs(tmp_path / "rb")
+    ra = track_bacteria(str(tmp_path / "a.npy"), settings=_settings(), result_folder=str(tmp_path / "ra"), batch=16)
+    rb = track_bacteria(str(tmp_path / "b.avi"), settings=_settings(), result_folder=str(tmp_path / "rb"), batch=16)
+    assert ra is not None and rb is not None and rb[1:4] == (30.0, 118, 150)
+    assert ra[0].equals(rb[0]) and len(ra[0]) > 200
+    assert open(ra[4], "rb").read() == open(rb[4], "rb").read()

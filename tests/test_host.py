@@ -250,3 +250,35 @@ def test_native_csv_round_trips_through_get_data(tmp_path):
         np.testing.assert_allclose(df[c].to_numpy(), ref[c].to_numpy(), rtol=4e-16, atol=0)
     for c in ("TRACK_ID", "POSITION_T"):
         np.testing.assert_array_equal(df[c].to_numpy(), ref[c].to_numpy())
+
+
+def test_uncompressed_avi_reader(tmp_path):
+    from avi_tools import write_avi as _write_avi
+    from ysmr_amd.frames import AviVideo, open_video
+    rng = np.random.default_rng(4)
+    gray = rng.integers(0, 256, (9, 10, 13), dtype=np.uint8)              # width 13: rows padded to 16 bytes
+    _write_avi(tmp_path / "g.avi", gray, 8)
+    v = open_video(str(tmp_path / "g.avi"))
+    assert isinstance(v, AviVideo) and (v.frame_count, v.height, v.width, v.channels) == (9, 10, 13, 1)
+    assert abs(v.fps - 29.97) < 1e-2
+    np.testing.assert_array_equal(v.read(0, 9), gray)
+    np.testing.assert_array_equal(v.read(7, 5), gray[7:])
+    out = np.zeros((4, 10, 13), np.uint8)
+    assert v.read_into(2, 4, out) == 4 and np.array_equal(out, gray[2:6])
+    _write_avi(tmp_path / "t.avi", gray, 8, top_down=True, split=4)      # top-down, continued in RIFF AVIX
+    v = open_video(str(tmp_path / "t.avi"))
+    assert v.frame_count == 9
+    np.testing.assert_array_equal(v.read(0, 9), gray)
+    bgr = rng.integers(0, 256, (5, 6, 7, 3), dtype=np.uint8)
+    _write_avi(tmp_path / "c.avi", bgr, 24)
+    v = open_video(str(tmp_path / "c.avi"))
+    assert v.channels == 3
+    np.testing.assert_array_equal(v.read(0, 5), bgr)
+    pal = rng.integers(0, 256, (256, 3), dtype=np.uint8)                   # a colour palette: frames come out as BGR
+    _write_avi(tmp_path / "p.avi", gray, 8, palette=pal)
+    v = open_video(str(tmp_path / "p.avi"))
+    assert v.channels == 3
+    np.testing.assert_array_equal(v.read(0, 9), pal[gray])
+    (tmp_path / "bad.avi").write_bytes(b"RIFF" + bytes(60))
+    with pytest.raises(OSError):                                          # not readable natively and no OpenCV here
+        open_video(str(tmp_path / "bad.avi"))

@@ -7,6 +7,8 @@ it happens to be importable:
 * ``.npy``  -- uint8 array [T, H, W] (gray) or [T, H, W, 3] (BGR), memory-mapped; fps from a
                ``<name>_meta.json`` side file (key ``fps``) or the tracking.ini value
 * ``.y4m``  -- YUV4MPEG2; the luma plane is used as the gray frame
+* ``.avi``  -- uncompressed AVI (what many microscope cameras write): 8-bit gray or 24-bit BGR DIB frames,
+               bottom-up or top-down, OpenDML ``AVIX`` extensions included; compressed streams go to cv2
 * anything else -- ``cv2.VideoCapture`` if cv2 can be imported, otherwise an error
 
 Every source exposes ``frame_count``, ``fps``, ``height``, ``width``, ``channels`` and
@@ -19,7 +21,7 @@ import os
 
 import numpy as np
 
-__all__ = ["open_video", "NpyVideo", "Y4mVideo", "Cv2Video", "DeviceFrameFeed"]
+__all__ = ["open_video", "NpyVideo", "Y4mVideo", "AviVideo", "Cv2Video", "DeviceFrameFeed"]
 
 
 class NpyVideo:
@@ -118,6 +120,117 @@ class Y4mVideo:
             plane = memoryview(out[i]).cast("B")
             if self._fh.readinto(plane) != self.width * self.height:
                 raise ValueError(f"{self.path}: frame {start + i} is truncated")
+        return n
+
+    def close(self):
+        self._fh.close()
+
+
+class AviVideo:
+    """Uncompressed AVI (RIFF): stream 0 must be video with BI_RGB 8- or 24-bit frames (or the raw
+    gray fourccs Y800 / GREY / Y8).  8-bit frames whose palette is the gray ramp are delivered as gray
+    [H, W] -- what ``cv2.VideoCapture`` + ``COLOR_BGR2GRAY`` make of them --, other palettes are
+    expanded to BGR; 24-bit frames are BGR as stored.  Raises ValueError for compressed streams."""
+
+    _RAW_GRAY = (b"Y800", b"GREY", b"Y8  ")
+
+    def __init__(self, path, default_fps=30.0):
+        import struct
+        self.path = path
+        self._fh = open(path, "rb")
+        fh = self._fh
+        size = os.path.getsize(path)
+        self.fps = float(default_fps)
+        self._frames = []          # (offset, size) of every video chunk of stream 0
+        bih = palette = None
+        first_stream = True
+
+        def walk(start, end, depth):
+            nonlocal bih, palette, first_stream
+            pos = start
+            while pos + 8 <= end:
+                fh.seek(pos)
+                cid, csz = struct.unpack("<4sI", fh.read(8))
+                body = pos + 8
+                if cid in (b"RIFF", b"LIST"):
+                    kind = fh.read(4)
+                    if kind == b"movi":
+                        walk_movi(body + 4, min(body + csz, end))
+                    elif kind in (b"AVI ", b"AVIX", b"hdrl", b"strl"):
+                        walk(body + 4, min(body + csz, end), depth + 1)
+                elif cid == b"strh":
+                    data = fh.read(min(csz, 56))
+                    if first_stream and data[:4] == b"vids" and len(data) >= 28:
+                        scale, rate = struct.unpack("<II", data[20:28])
+                        if scale and rate:
+                            self.fps = rate / scale
+                elif cid == b"strf" and first_stream:
+                    data = fh.read(csz)
+                    if len(data) >= 40:
+                        bih = struct.unpack("<IiiHHIIiiII", data[:40])
+                        palette = data[40:]
+                    first_stream = False
+                pos = body + csz + (csz & 1)
+
+        def walk_movi(start, end):
+            pos = start
+            while pos + 8 <= end:
+                fh.seek(pos)
+                cid, csz = struct.unpack("<4sI", fh.read(8))
+                body = pos + 8
+                if cid == b"LIST":                       # 'rec ' groups
+                    walk_movi(body + 4, min(body + csz, end))
+                elif cid[:2] == b"00" and cid[2:] in (b"db", b"dc") and csz:
+                    self._frames.append((body, csz))
+                pos = body + csz + (csz & 1)
+
+        if fh.read(4) != b"RIFF":
+            raise ValueError(f"{path}: not a RIFF file")
+        walk(0, size, 0)
+        if bih is None:
+            raise ValueError(f"{path}: no video stream format found")
+        _, width, height, _, bits, compression, *_ = bih
+        fourcc = struct.pack("<I", compression)
+        if not (compression == 0 or (fourcc in self._RAW_GRAY and bits == 8)) or bits not in (8, 24):
+            raise ValueError(f"{path}: only uncompressed 8/24-bit AVI is read natively (fourcc {fourcc!r}, {bits} bit)")
+        self.width, self.height = int(width), abs(int(height))
+        self._bottom_up = height > 0 and compression == 0
+        self._bytes_pp = bits // 8
+        self._stride = (self.width * self._bytes_pp + 3) & ~3 if compression == 0 else self.width
+        self._lut = None
+        self.channels = 1 if bits == 8 else 3
+        if bits == 8 and compression == 0 and len(palette) >= 4:
+            pal = np.frombuffer(palette[: 4 * (len(palette) // 4)], np.uint8).reshape(-1, 4)[:256, :3]   # B, G, R
+            ramp = np.arange(len(pal), dtype=np.uint8)[:, None]
+            if not np.array_equal(pal, np.repeat(ramp, 3, axis=1)):
+                full = np.zeros((256, 3), np.uint8)
+                full[:len(pal)] = pal
+                self._lut, self.channels = full, 3
+        need = self._stride * self.height
+        self._frames = [f for f in self._frames if f[1] >= need]
+        self.frame_count = len(self._frames)
+
+    def read(self, start, count):
+        n = max(0, min(count, self.frame_count - start))
+        out = np.empty((n, self.height, self.width) + ((3,) if self.channels == 3 else ()), np.uint8)
+        self.read_into(start, n, out)
+        return out
+
+    def read_into(self, start, count, out, pool=None):
+        n = max(0, min(count, self.frame_count - start))
+        raw = np.empty((self.height, self._stride), np.uint8)
+        used = self.width * self._bytes_pp
+        for i in range(n):
+            self._fh.seek(self._frames[start + i][0])
+            if self._fh.readinto(memoryview(raw).cast("B")) != raw.size:
+                raise ValueError(f"{self.path}: frame {start + i} is truncated")
+            rows = raw[::-1, :used] if self._bottom_up else raw[:, :used]
+            if self._lut is not None:
+                out[i] = self._lut[rows]
+            elif self.channels == 3:
+                out[i] = rows.reshape(self.height, self.width, 3)
+            else:
+                out[i] = rows
         return n
 
     def close(self):
@@ -261,6 +374,11 @@ def open_video(path, default_fps=30.0):
         return NpyVideo(path, default_fps)
     if ext == ".y4m":
         return Y4mVideo(path, default_fps)
+    if ext == ".avi":
+        try:
+            return AviVideo(path, default_fps)
+        except ValueError:
+            pass                                   # compressed: OpenCV's business
     try:
         return Cv2Video(path, default_fps)
     except ImportError as exc:
