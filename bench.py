@@ -50,11 +50,26 @@ def parse():
     ap.add_argument("--adt", type=float, default=2.0,
                     help="'adaptive double threshold' of tracking.ini (default 2.0); < 0 selects the reference's "
                          "mean-gray threshold branch (track_eval.py:219-253)")
+    ap.add_argument("--detect-only", action="store_true",
+                    help="BASELINE configs[1]: threshold + labelling + minAreaRect only, no link (a parity-test "
+                         "configuration; the metric is quoted on the default, configs[2])")
+    ap.add_argument("--config", type=int, choices=(0, 1, 2, 4), default=None,
+                    help="preset of a BASELINE.json configuration on this GPU: 0 = ~50 blobs, 1 = detection only, "
+                         "2 = the default, 4 = 3840x2160 / ~5000 blobs (batch 8, two-launch link)")
     ap.add_argument("--cpu-sample", type=int, default=200, help="frames of the clip timed on the CPU oracle (0 = skip)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == 0:
+        args.blobs = 50
+    elif args.config == 1:
+        args.detect_only = True
+    elif args.config == 4:
+        args.height, args.width, args.blobs, args.frames, args.batch = 2160, 3840, 5000, 64, 8
+        args.max_det = args.capacity = 8192
+        args.cpu_sample = min(args.cpu_sample, 8)
+    return args
 
 
-def cpu_baseline(frames_np, sample, fps, adt=2.0):
+def cpu_baseline(frames_np, sample, fps, adt=2.0, detect_only=False):
     """Time the CPU oracle (single thread, like the reference's one process per video) on the
     first `sample` frames of the clip."""
     if sample <= 0:
@@ -63,7 +78,12 @@ def cpu_baseline(frames_np, sample, fps, adt=2.0):
     yo.build()
     sample = min(sample, len(frames_np))
     t0 = time.perf_counter()
-    rows, _ = yo.track_frames(frames_np[:sample], fps=fps, adt=adt)
+    if detect_only:
+        rows = []
+        for frame in frames_np[:sample]:
+            rows.extend(yo.detect_frame(frame).det)
+    else:
+        rows, _ = yo.track_frames(frames_np[:sample], fps=fps, adt=adt)
     dt = time.perf_counter() - t0
     return {"value": sample / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"first {sample} frames of the clip ({len(rows)} rows), oracle/ysmr_oracle.{{c,py}} "
@@ -124,7 +144,7 @@ def main():
                     nxt = None
                     if f0 is not None:
                         nxt = (pipes[k].detect_async(clips[k][f0:f0 + B], thr_events if (timed and k == 0) else None), f0)
-                    if pending[k] is not None:
+                    if pending[k] is not None and not args.detect_only:
                         (slot, res, ready), p0 = pending[k]
                         pipes[k].link(slot, res, ready, p0)
                     pending[k] = nxt
@@ -149,7 +169,7 @@ def main():
         n_tracks, next_id, err = p.trk.info()
         rows_k = int(p.row_count.item())
         status = max(int(d.status.max().item()) for d in p.det)
-        if err or status or rows_k <= 0:
+        if err or status or (rows_k <= 0 and not args.detect_only):
             raise SystemExit(f"hot path reported errors: tracker={err} detect_status={status} rows={rows_k}")
         n_rows += rows_k
 
@@ -173,7 +193,7 @@ def main():
             except Exception:
                 traffic = None
         which = {(1228, 922, 500): "BASELINE configs[2], the configuration the metric is quoted on",
-                 (1228, 922, 50): "BASELINE configs[0] geometry", (3840, 2160, 5000): "BASELINE configs[4]"}.get(
+                 (1228, 922, 50): "BASELINE configs[0] geometry and blob count", (3840, 2160, 5000): "BASELINE configs[4]"}.get(
                      (W, H, args.blobs), "custom geometry")
         out = {
             "metric": "frames/sec detect+link, 1228x922 ~500 blobs, 1/2/4/8 GPU; HBM GB/s %peak",
@@ -189,7 +209,8 @@ def main():
             "dtype": "u8 image / f32 threshold+geometry / f64 link",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} stream, ~{args.blobs} blobs, detect+link end to end ({which})"
-                                   + (", mean-gray threshold branch (adaptive double threshold < 0)" if mean_gray else ""),
+                                   + (", mean-gray threshold branch (adaptive double threshold < 0)" if mean_gray else "")
+                                   + (" -- DETECTION ONLY (BASELINE configs[1]), not the metric's configuration" if args.detect_only else ""),
                        "frames_per_step": F, "detect_batch": B, "channels": args.channels, "streams": world * S, "parallelism": f"{S} stream{'s' if S > 1 else ''}/GPU x{world}",
                        "rows_per_step": n_rows, "tracks_alive": n_tracks, "ids_issued": next_id},
             "roofline": {"kernel": "k_gray_sums+k_mean_levels+k_level_threshold" if mean_gray else "k_threshold", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -198,7 +219,7 @@ def main():
                          "launches_timed": len(ms)},
         }
         if world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_sample, fps_video, args.adt)
+            out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_sample, fps_video, args.adt, args.detect_only)
         print(json.dumps(out), flush=True)
     dist.finish(info)
 
