@@ -337,3 +337,21 @@ def test_track_bacteria_reads_uncompressed_avi(tmp_path):
     assert ra is not None and rb is not None and rb[1:4] == (30.0, 118, 150)
     assert ra[0].equals(rb[0]) and len(ra[0]) > 200
     assert open(ra[4], "rb").read() == open(rb[4], "rb").read()
+
+
+def test_track_bacteria_row_buffer_smaller_than_the_video(tmp_path, monkeypatch):
+    """When the rows of a video do not fit the device buffer they are moved to the host in between and
+    ordered in one go at the end: same DataFrame, same csv as the all-on-device run."""
+    from ysmr_amd import track_eval
+    from ysmr_amd.synth import SyntheticVideo
+    frames = SyntheticVideo(120, 160, 18, seed=12, dropout=0.02).frames(90)
+    np.save(tmp_path / "v.npy", frames)
+    os.makedirs(tmp_path / "whole"); os.makedirs(tmp_path / "pieces")
+    kw = dict(batch=16, max_det=64, capacity=64)
+    whole = track_eval.track_bacteria(str(tmp_path / "v.npy"), settings=_settings(), result_folder=str(tmp_path / "whole"), **kw)
+    monkeypatch.setattr(track_eval, "ROW_BUDGET_MAX", 1)
+    small = _settings(**{"list save length interval": 100})       # buffer = 2 batches x 64 rows per frame
+    pieces = track_eval.track_bacteria(str(tmp_path / "v.npy"), settings=small, result_folder=str(tmp_path / "pieces"), **kw)
+    assert whole is not None and pieces is not None and len(whole[0]) > 1200
+    assert whole[0].equals(pieces[0])
+    assert open(whole[4], "rb").read() == open(pieces[4], "rb").read()

@@ -30,6 +30,9 @@ from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
 __all__ = ["track_bacteria", "TrackingPipeline", "select_tracks"]
 
+#: most rows kept on the device for one video (40 B each); longer tables are moved to the host in between
+ROW_BUDGET_MAX = 32 << 20
+
 
 def __getattr__(name):   # select_tracks lives in track_eval upstream (track_eval.py:536); here in select.py
     if name == "select_tracks":
@@ -199,7 +202,7 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
         # worst case; 32 M rows = 1.3 GB) and are ordered there at the end; otherwise full buffers are
         # moved to the host in between.  ('list save length interval' bounded the reference's Python
         # list, helper_file.py:171; here it only sets the smallest buffer.)
-        row_budget = min(max(frame_count, 1) * capacity, 32 << 20)
+        row_budget = min(max(frame_count, 1) * capacity, ROW_BUDGET_MAX)
         row_budget = max(row_budget, 2 * batch * capacity, int(settings["list save length interval"]))
         pipe = TrackingPipeline(frame_height, frame_width, fps_of_file, local, batch=batch, max_det=max_det,
                                 capacity=capacity, device=device, rows_per_flush=row_budget)
