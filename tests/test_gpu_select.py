@@ -109,3 +109,31 @@ def test_analyse_runs_the_selection(tmp_path, oracle):
     df2 = analyse(str(out_dir / "clip_list.csv"), settings=dict(s), result_folder=str(out_dir), return_df=True)
     pd.testing.assert_frame_equal(df2, ref2, check_dtype=False, check_exact=True)
     assert (out_dir / "clip_list_selected_data.csv").read_text() == ref2.to_csv(index=False)
+
+
+def test_select_tracks_wrapper_messages_and_file(tmp_path, caplog, oracle):
+    """The host mirror: the reference's log lines for every exit, and <name>_selected_data.csv."""
+    import logging
+    from ysmr_amd.select import select_tracks
+    caplog.set_level(logging.DEBUG, logger="ysmr")
+    df = make_table(1)
+    s = select_settings(**{"store processed .csv file": True})
+    kw = dict(path_to_file=str(tmp_path / "t_list.csv"), results_directory=str(tmp_path), fps=30.0, frame_height=400,
+              frame_width=600)
+    out = select_tracks(df=df.copy(), settings=s, **kw)
+    ref, _ = oracle.select_tracks_oracle(df, s, 30.0, 400, 600)
+    assert out is not None and out.equals(ref)
+    assert (tmp_path / "t_list_selected_data.csv").read_text() == ref.to_csv(index=False)
+    assert "Tracks before initial cleanup" in caplog.text and "Area quartiles" in caplog.text and "passed:" in caplog.text
+    assert "Low amount of accepted tracks" in caplog.text          # a few of ~50 tracks pass
+    assert select_tracks(df=df.iloc[:10].reset_index(drop=True), settings=s, **kw) is None
+    assert "insufficient length before initial clean-up" in caplog.text
+    flat = df.copy(); flat["HEIGHT"] = 0.0
+    assert select_tracks(df=flat, settings=s, **kw) is None
+    assert "insufficient length after initial clean-up" in caplog.text
+    far = df.copy(); far["POSITION_Y"] -= 9000.0
+    assert select_tracks(df=far, settings=s, **kw) is None
+    assert "has no acceptable tracks" in caplog.text
+    noisy = select_settings(**{"stop excluding motility outliers if total count above percent": 0.0001})
+    select_tracks(df=df.copy(), settings=noisy, **kw)
+    assert "Distance outlier exclusion switched off" in caplog.text

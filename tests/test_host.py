@@ -282,3 +282,30 @@ def test_uncompressed_avi_reader(tmp_path):
     (tmp_path / "bad.avi").write_bytes(b"RIFF" + bytes(60))
     with pytest.raises(OSError):                                          # not readable natively and no OpenCV here
         open_video(str(tmp_path / "bad.avi"))
+
+
+def test_select_tracks_argument_checks(tmp_path, caplog):
+    """select_tracks logs and returns None before any device work (track_eval.py:560-611)."""
+    import logging
+    from select_tables import make_table, select_settings
+    from ysmr_amd.select import select_params, select_tracks
+    df = make_table(0, n_tracks=3)
+    s = select_settings()
+    caplog.set_level(logging.DEBUG, logger="ysmr")
+    assert select_tracks(path_to_file=None, df=df, settings=s) is None
+    bad = dict(s); bad["frames per second"] = 0
+    assert select_tracks(path_to_file=str(tmp_path / "a_list.csv"), df=df, results_directory=str(tmp_path), fps=0, settings=bad) is None
+    bad = dict(s); bad["extreme area outliers lower end in px*px"] = 50
+    assert select_tracks(path_to_file=str(tmp_path / "a_list.csv"), df=df, results_directory=str(tmp_path), fps=30.0, settings=bad) is None
+    assert select_tracks(path_to_file=str(tmp_path / "a_list.csv"), df=df, results_directory=str(tmp_path), fps=30.0,
+                         frame_height=0, frame_width=10, settings=s) is None
+    bad = dict(s); bad["pixel per micrometre"] = 0.0
+    assert select_tracks(path_to_file=str(tmp_path / "a_list.csv"), df=df, results_directory=str(tmp_path), fps=30.0, settings=bad) is None
+    assert select_tracks(path_to_file=str(tmp_path / "missing_list.csv"), results_directory=str(tmp_path), fps=30.0, settings=s) is None
+    text = caplog.text
+    for needle in ("needs path_to_file", "fps value is negative or zero", "Minimal area exclusion", "Frame width or frame height",
+                   "pixel per micrometre", "Error reading data frame"):
+        assert needle in text, needle
+    p = select_params(s, 29.97, 922, 1228)       # lengths use round(fps): 30 frames per second
+    assert (p.min_length_frames, p.limit_frames, p.frame_height, p.frame_width) == (30, 90, 922, 1228)
+    assert abs(p.max_empty_ratio - 1.05) < 1e-12 and abs(p.q_area - 0.1) < 1e-12 and p.max_recursion == 960
