@@ -653,6 +653,7 @@ __device__ int cpython_unused_order(const TrackerDev &t, int m, int n_used, int 
 // k_link: one workgroup
 // ------------------------------------------------------------------------------------------
 constexpr int LINK_THREADS = 1024;
+constexpr int LINK_ROWS = 8;       // rows per thread k_link keeps in registers for tables of more than 1024 rows
 
 __device__ int block_exclusive_scan(int v, int *s_scan, int *total)
 {
@@ -696,6 +697,12 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     if (tid == 0) { s_n_used = 0; s_n_new = 0; s_any_dead = 0; }
     for (int c = tid; c < m; c += LINK_THREADS) { s_col_key[c] = ~0ull; s_col_row[c] = 0x7FFFFFFF; }
     __syncthreads();
+    // rows of a large table held per thread (see the `big` branch below)
+    const bool big = n > LINK_THREADS && n <= LINK_ROWS * LINK_THREADS && m > 0;
+    int pa[LINK_ROWS], po[LINK_ROWS], pg[LINK_ROWS], pd[LINK_ROWS];
+    unsigned long long pk[LINK_ROWS];
+#pragma unroll
+    for (int k = 0; k < LINK_ROWS; ++k) { pa[k] = 0; po[k] = 0; pg[k] = 0; pd[k] = 0; pk[k] = ~0ull; }
 
     // ---- claims: the winner of a column is the proposer with the smallest (distance, row)
     if (n > 0 && m > 0 && n <= LINK_THREADS) {
@@ -729,6 +736,64 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
                 atomicAdd(&s_n_used, 1);
             }
         }
+    } else if (big) {
+        // large tables (the 4K configuration: ~5000 rows): thread tid owns rows tid + 1024 k.  Everything
+        // the LDS rounds, the ageing and the compaction below need is requested up front and kept in
+        // registers, so that a pass costs LDS time instead of a global round trip per 1024 rows
+#pragma unroll
+        for (int k = 0; k < LINK_ROWS; ++k) {
+            const int r = tid + k * LINK_THREADS;
+            if (r < n) {
+                pa[k] = t.row_arg[r];
+                pk[k] = (unsigned long long)__double_as_longlong(t.row_min[r]);
+                po[k] = t.order[r];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LINK_ROWS; ++k)
+            if (tid + k * LINK_THREADS < n) pg[k] = t.gone[po[k]];      // (arrives during the rounds below)
+#pragma unroll
+        for (int k = 0; k < LINK_ROWS; ++k)
+            if (tid + k * LINK_THREADS < n) atomicMin(&s_col_key[pa[k]], pk[k]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LINK_ROWS; ++k) {
+            const int r = tid + k * LINK_THREADS;
+            if (r < n && pk[k] == s_col_key[pa[k]]) atomicMin(&s_col_row[pa[k]], r);
+        }
+        __syncthreads();
+        int used = 0;
+#pragma unroll
+        for (int half = 0; half < LINK_ROWS; half += 4) {   // winners' detections: four rows' loads in flight
+            DetT dv[4][5];
+            bool mine[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = half + j, r = tid + k * LINK_THREADS;
+                mine[j] = r < n && s_col_row[pa[k]] == r;
+                if (r < n) s_claim[r] = mine[j] ? pa[k] : -1;
+                if (mine[j]) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) dv[j][q] = det[(size_t)pa[k] * 5 + q];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = half + j;
+                if (mine[j]) {
+                    const int slot = po[k];
+                    t.pos[slot] = (double)dv[j][0];
+                    t.pos[cap + slot] = (double)dv[j][1];
+                    t.info[slot] = (float)dv[j][2];
+                    t.info[cap + slot] = (float)dv[j][3];
+                    t.info[2 * cap + slot] = (float)dv[j][4];
+                    t.gone[slot] = 0;
+                    pg[k] = -1;          // claimed (ageing below skips it)
+                    ++used;
+                }
+            }
+        }
+        if (used) atomicAdd(&s_n_used, used);
     } else if (n > 0 && m > 0) {
         for (int r = tid; r < n; r += LINK_THREADS)
             atomicMin(&s_col_key[t.row_arg[r]], (unsigned long long)__double_as_longlong(t.row_min[r]));
@@ -762,7 +827,21 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
 
     // ---- ageing (tracker.py:95-107, 198-211): only when there are no detections or N >= M
     const bool age = (m == 0) || (n > 0 && n >= m);
-    if (age) {
+    if (age && big) {
+#pragma unroll
+        for (int k = 0; k < LINK_ROWS; ++k) {
+            const int r = tid + k * LINK_THREADS;
+            if (r >= n) continue;
+            int d = 0;
+            if (pg[k] >= 0) {            // not claimed this frame
+                const int slot = po[k], g = pg[k] + 1;
+                t.gone[slot] = g;
+                t.info[slot] = 0.f; t.info[cap + slot] = 0.f; t.info[2 * cap + slot] = 0.f;
+                if ((double)g > t.max_gone) { d = 1; s_any_dead = 1; }
+            }
+            pd[k] = d;
+        }
+    } else if (age) {
         for (int r = tid; r < n; r += LINK_THREADS) {
             int d = 0;
             if (s_claim[r] < 0) {
@@ -779,7 +858,28 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
 
     // ---- stable compaction of the ordered track table
     int n_live = n;
-    if (s_any_dead) {
+    if (s_any_dead && big) {
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < LINK_ROWS; ++k) {
+            if (k * LINK_THREADS >= n) break;            // (uniform)
+            const int r = tid + k * LINK_THREADS;
+            const int keep = (r < n && !pd[k]) ? 1 : 0;
+            int total;
+            const int ex = block_exclusive_scan(keep, s_scan, &total);
+            if (keep) t.order_tmp[base + ex] = po[k];
+            if (r < n && !keep) {
+                const int q = atomicAdd(t.n_free, 1);
+                t.free_slots[q] = po[k];
+            }
+            base += total;
+        }
+        n_live = base;
+        __threadfence_block();
+        __syncthreads();
+        for (int r = tid; r < n_live; r += LINK_THREADS) t.order[r] = t.order_tmp[r];
+        __syncthreads();
+    } else if (s_any_dead) {
         int base = 0;
         for (int r0 = 0; r0 < n; r0 += LINK_THREADS) {
             int r = r0 + tid;
