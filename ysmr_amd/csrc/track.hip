@@ -83,10 +83,12 @@ __device__ unsigned int g_ring_n;
 #define RING(tag) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); unsigned int i_ = atomicAdd(&g_ring_n, 1u) & 4095u; g_ring[2 * i_] = (unsigned long long)(tag); g_ring[2 * i_ + 1] = t_; } while (0)
 extern "C" int ysmr_debug_read_ring(unsigned long long *out, unsigned int *n) { hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring), sizeof(unsigned long long) * 8192); if (e == hipSuccess) e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_ring_n), 4); return (int)e; }
 extern "C" int ysmr_debug_read_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32); }
+#define LRING(k) do { if (threadIdx.x == 0) RING(((10ull + (k)) << 40) | (unsigned)frame); } while (0)   // k_link phases
 #else
 #define GSTAMP(k) do {} while (0)
 #define BSTAMP(k) do {} while (0)
 #define RING(tag) do {} while (0)
+#define LRING(k) do {} while (0)
 #endif
 
 namespace {
@@ -694,9 +696,11 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     const int cap = t.capacity;
     const int n = *t.n_tracks;
     const int m = det_count(m_host, m_dev, t.max_det, t.err);
+    LRING(0);
     if (tid == 0) { s_n_used = 0; s_n_new = 0; s_any_dead = 0; }
     for (int c = tid; c < m; c += LINK_THREADS) { s_col_key[c] = ~0ull; s_col_row[c] = 0x7FFFFFFF; }
     __syncthreads();
+    LRING(1);
     // rows of a large table held per thread (see the `big` branch below)
     const bool big = n > LINK_THREADS && n <= LINK_ROWS * LINK_THREADS && m > 0;
     int pa[LINK_ROWS], po[LINK_ROWS], pg[LINK_ROWS], pd[LINK_ROWS];
@@ -825,6 +829,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     }
     __syncthreads();
 
+    LRING(2);
     // ---- ageing (tracker.py:95-107, 198-211): only when there are no detections or N >= M
     const bool age = (m == 0) || (n > 0 && n >= m);
     if (age && big) {
@@ -856,6 +861,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     }
     __syncthreads();
 
+    LRING(3);
     // ---- stable compaction of the ordered track table
     int n_live = n;
     if (s_any_dead && big) {
@@ -900,6 +906,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         __syncthreads();
     }
 
+    LRING(4);
     // ---- registration (tracker.py:135-137, 212-217)
     if (m > 0 && (n == 0 || n < m)) {
         if (n == 0) {
@@ -959,6 +966,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         n_live += n_new;
     }
 
+    LRING(5);
     // ---- bookkeeping for k_track
     if (claim_out)
         for (int r = tid; r < n; r += LINK_THREADS) claim_out[r] = s_claim[r];
@@ -972,6 +980,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         if (n_before_out) *n_before_out = n;
         if (n_new_out) *n_new_out = s_n_new;
     }
+    LRING(6);
 }
 
 // ------------------------------------------------------------------------------------------
