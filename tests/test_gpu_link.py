@@ -164,3 +164,23 @@ def test_table_grows_and_shrinks_abruptly(torch_cuda, oracle):
         trk.run(det, cnt, b0, rows, count)
     assert trk.info()[2] == 0
     compare_rows(rows_to_numpy(rows, int(count.item())), ref_rows)
+
+
+def test_centroid_tracker_public_attributes_and_payloads():
+    """The reference's public attributes (objects, disappeared, nextObjectID, additional_info) and its
+    tolerance for arbitrary additional_info payloads (tracker.py:73-82, 111-131)."""
+    from ysmr_amd.tracker import CentroidTracker
+    ct = CentroidTracker(max_disappeared=2, fps=30.0, use_gsff=False, capacity=16, max_det=4)
+    objs, info = ct.update([((10.0, 10.0), (3.0, 1.0, -45.0)), ((50.0, 20.0), "tag")])
+    assert list(objs) == [0, 1] and ct.nextObjectID == 2
+    assert info[0] == (3.0, 1.0, -45.0) and info[1] == "tag"            # payloads come back as given
+    assert list(ct.objects) == [0, 1] and np.allclose(ct.objects[1], [50.0, 20.0])
+    assert dict(ct.disappeared) == {0: 0, 1: 0}
+    objs, info = ct.update([((11.0, 10.0), (3.0, 1.0, -40.0))])
+    assert dict(ct.disappeared) == {0: 0, 1: 1} and info[1] == [0, 0, 0] and ct.last_claims == [(0, 0)]
+    with pytest.raises(ValueError):
+        ct.update([((float(i), 0.0), (1, 1, 0)) for i in range(5)])       # more than max_det
+    with pytest.raises(NotImplementedError):
+        ct.update([((1.0, 2.0, 3.0), (1, 1, 0))])                         # luminosity dimension
+    ct.update([]); ct.update([]); ct.update([])
+    assert list(ct.objects) == [] and ct.nextObjectID == 2
