@@ -6,8 +6,8 @@ def _riff(fourcc, payload):
     return fourcc + len(payload).to_bytes(4, "little") + payload + (b"\0" if len(payload) & 1 else b"")
 
 
-def write_avi(path, frames, bits, fps=(30000, 1001), top_down=False, palette=None, split=None):
-    """Minimal uncompressed AVI: hdrl (avih, strl(strh, strf)), movi with 00db chunks (+ an audio chunk that
+def write_avi(path, frames, bits, fps=(30000, 1001), top_down=False, palette=None, split=None, jpeg=None):
+    """Minimal AVI (uncompressed DIB frames, or the given JPEG blobs as Motion-JPEG): hdrl (avih, strl(strh, strf)), movi with 00db chunks (+ an audio chunk that
     must be skipped), optionally continued in a second RIFF AVIX."""
     import struct
     n, h, w = frames.shape[:3]
@@ -19,12 +19,13 @@ def write_avi(path, frames, bits, fps=(30000, 1001), top_down=False, palette=Non
         out[:, :rows.shape[1]] = rows
         return out.tobytes()
     strh = struct.pack("<4s4sIHHIIIIIIII4H", b"vids", b"DIB ", 0, 0, 0, 0, fps[1], fps[0], 0, n, stride * h, 0, 0, 0, 0, w, h)
-    bih = struct.pack("<IiiHHIIiiII", 40, w, -h if top_down else h, 1, bits, 0, stride * h, 0, 0, 0, 0)
-    if bits == 8:
+    compression = int.from_bytes(b"MJPG", "little") if jpeg is not None else 0
+    bih = struct.pack("<IiiHHIIiiII", 40, w, -h if top_down else h, 1, bits, compression, stride * h, 0, 0, 0, 0)
+    if bits == 8 and jpeg is None:
         pal = palette if palette is not None else np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, axis=1)
         bih += np.concatenate([pal, np.zeros((256, 1), np.uint8)], axis=1).tobytes()
     hdrl = b"hdrl" + _riff(b"avih", bytes(56)) + _riff(b"LIST", b"strl" + _riff(b"strh", strh) + _riff(b"strf", bih))
-    chunks = [_riff(b"00db", dib(f)) for f in frames]
+    chunks = [_riff(b"00db", dib(f)) for f in frames] if jpeg is None else [_riff(b"00dc", blob) for blob in jpeg]
     chunks.insert(1, _riff(b"01wb", b"abc"))                      # odd-sized audio chunk in between
     split = n if split is None else split
     body = _riff(b"RIFF", b"AVI " + _riff(b"LIST", hdrl) + _riff(b"LIST", b"movi" + b"".join(chunks[:split + 1])))

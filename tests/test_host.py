@@ -309,3 +309,35 @@ def test_select_tracks_argument_checks(tmp_path, caplog):
     p = select_params(s, 29.97, 922, 1228)       # lengths use round(fps): 30 frames per second
     assert (p.min_length_frames, p.limit_frames, p.frame_height, p.frame_width) == (30, 90, 922, 1228)
     assert abs(p.max_empty_ratio - 1.05) < 1e-12 and abs(p.q_area - 0.1) < 1e-12 and p.max_recursion == 960
+
+
+def test_motion_jpeg_avi_reader(tmp_path):
+    """Motion-JPEG AVI through Pillow (optional): frames equal Pillow's own decode of the same JPEGs."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from avi_tools import write_avi
+    from ysmr_amd.frames import open_video
+    rng = np.random.default_rng(2)
+    smooth = (np.add.outer(np.arange(48), np.arange(64)) % 200 + 20).astype(np.uint8)
+    gray = np.stack([np.roll(smooth, 3 * k, axis=1) for k in range(6)])
+    for mode, frames in (("L", gray), ("RGB", np.stack([gray, gray[:, ::-1], 255 - gray], axis=-1))):
+        blobs, decoded = [], []
+        for f in frames:
+            buf = io.BytesIO()
+            Image.fromarray(f, mode).save(buf, format="JPEG", quality=92)
+            blobs.append(buf.getvalue())
+            with Image.open(io.BytesIO(blobs[-1])) as im:
+                decoded.append(np.asarray(im.convert(mode)))
+        path = tmp_path / f"m{mode}.avi"
+        write_avi(path, frames[..., 0] if mode == "RGB" else frames, 24, fps=(25, 1), jpeg=blobs)
+        v = open_video(str(path))
+        assert (v.frame_count, v.height, v.width, v.fps) == (6, 48, 64, 25.0)
+        assert v.channels == (1 if mode == "L" else 3)
+        ref = np.stack(decoded) if mode == "L" else np.stack(decoded)[..., ::-1]      # BGR like cv2
+        np.testing.assert_array_equal(v.read(0, 6), ref)
+        out = np.zeros_like(ref[:4])
+        with ThreadPoolExecutor(3) as pool:
+            assert v.read_into(2, 4, out, pool) == 4
+        np.testing.assert_array_equal(out, ref[2:6])
+        assert np.abs(v.read(0, 1)[0].astype(int) - (frames[0] if mode == "L" else frames[0][..., ::-1]).astype(int)).mean() < 6

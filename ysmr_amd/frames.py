@@ -8,7 +8,8 @@ it happens to be importable:
                ``<name>_meta.json`` side file (key ``fps``) or the tracking.ini value
 * ``.y4m``  -- YUV4MPEG2; the luma plane is used as the gray frame
 * ``.avi``  -- uncompressed AVI (what many microscope cameras write): 8-bit gray or 24-bit BGR DIB frames,
-               bottom-up or top-down, OpenDML ``AVIX`` extensions included; compressed streams go to cv2
+               bottom-up or top-down, OpenDML ``AVIX`` extensions included; Motion-JPEG AVI if Pillow can
+               be imported (frames decoded on the reader threads); other compressed streams go to cv2
 * anything else -- ``cv2.VideoCapture`` if cv2 can be imported, otherwise an error
 
 Every source exposes ``frame_count``, ``fps``, ``height``, ``width``, ``channels`` and
@@ -127,8 +128,8 @@ class Y4mVideo:
 
 
 class AviVideo:
-    """Uncompressed AVI (RIFF): stream 0 must be video with BI_RGB 8- or 24-bit frames (or the raw
-    gray fourccs Y800 / GREY / Y8).  8-bit frames whose palette is the gray ramp are delivered as gray
+    """AVI (RIFF) without OpenCV: stream 0 must be video with BI_RGB 8- or 24-bit frames (or the raw
+    gray fourccs Y800 / GREY / Y8), or Motion-JPEG (decoded with Pillow, if installed).  8-bit frames whose palette is the gray ramp are delivered as gray
     [H, W] -- what ``cv2.VideoCapture`` + ``COLOR_BGR2GRAY`` make of them --, other palettes are
     expanded to BGR; 24-bit frames are BGR as stored.  Raises ValueError for compressed streams."""
 
@@ -191,8 +192,23 @@ class AviVideo:
             raise ValueError(f"{path}: no video stream format found")
         _, width, height, _, bits, compression, *_ = bih
         fourcc = struct.pack("<I", compression)
+        self._jpeg = fourcc.upper() in (b"MJPG", b"JPEG")
+        if self._jpeg:
+            try:
+                from PIL import Image
+            except ImportError as exc:
+                raise ValueError(f"{path}: Motion-JPEG AVI needs Pillow ({exc})") from exc
+            self._Image = Image
+            self.width, self.height = int(width), abs(int(height))
+            self.frame_count = len(self._frames)
+            if not self.frame_count:
+                raise ValueError(f"{path}: no frames")
+            with Image.open(self._chunk(0)) as first:
+                self.channels = 1 if first.mode == "L" else 3
+            return
         if not (compression == 0 or (fourcc in self._RAW_GRAY and bits == 8)) or bits not in (8, 24):
-            raise ValueError(f"{path}: only uncompressed 8/24-bit AVI is read natively (fourcc {fourcc!r}, {bits} bit)")
+            raise ValueError(f"{path}: only uncompressed 8/24-bit or Motion-JPEG AVI is read natively "
+                             f"(fourcc {fourcc!r}, {bits} bit)")
         self.width, self.height = int(width), abs(int(height))
         self._bottom_up = height > 0 and compression == 0
         self._bytes_pp = bits // 8
@@ -216,8 +232,30 @@ class AviVideo:
         self.read_into(start, n, out)
         return out
 
+    def _chunk(self, i):
+        import io
+        off, size = self._frames[i]
+        self._fh.seek(off)
+        return io.BytesIO(self._fh.read(size))
+
+    def _decode_jpeg(self, blob, dst):
+        with self._Image.open(blob) as im:
+            if self.channels == 1:
+                dst[...] = np.asarray(im.convert("L"))
+            else:
+                dst[...] = np.asarray(im.convert("RGB"))[:, :, ::-1]     # BGR, what cv2.VideoCapture delivers
+
     def read_into(self, start, count, out, pool=None):
         n = max(0, min(count, self.frame_count - start))
+        if self._jpeg:
+            blobs = [self._chunk(start + i) for i in range(n)]           # file access stays on this thread
+            if pool is None:
+                for i in range(n):
+                    self._decode_jpeg(blobs[i], out[i])
+            else:
+                for job in [pool.submit(self._decode_jpeg, blobs[i], out[i]) for i in range(n)]:
+                    job.result()
+            return n
         raw = np.empty((self.height, self._stride), np.uint8)
         used = self.width * self._bytes_pp
         for i in range(n):
