@@ -1,5 +1,5 @@
 import sys, os, time, tempfile, logging, cProfile, pstats
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ysmr_amd.helper_file import default_settings
 from ysmr_amd.synth import SyntheticVideo
