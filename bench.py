@@ -56,6 +56,11 @@ def parse():
     ap.add_argument("--config", type=int, choices=(0, 1, 2, 4), default=None,
                     help="preset of a BASELINE.json configuration on this GPU: 0 = ~50 blobs, 1 = detection only, "
                          "2 = the default, 4 = 3840x2160 / ~5000 blobs (batch 8, two-launch link)")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend for the barrier and the max-over-ranks time (nccl = RCCL; gloo only "
+                         "to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--device-index", type=int, default=None,
+                    help="GPU of this rank (default LOCAL_RANK); rehearsals put several ranks on one GPU")
     ap.add_argument("--cpu-sample", type=int, default=200, help="frames of the clip timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
     if args.config == 0:
@@ -99,9 +104,11 @@ def main():
     rank, local_rank, world = info.rank, info.local_rank, info.world
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.device_index is not None:
+        local_rank = args.device_index
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist.init(info, backend="nccl", device=dev)   # barrier + max-over-ranks time only; no data-path collective
+    dist.init(info, backend=args.dist_backend, device=dev)   # barrier + max-over-ranks time only; no data-path collective
 
     from ysmr_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
@@ -160,7 +167,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier(info)
     torch.cuda.synchronize()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0, info, device=dev)
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, info, device=dev if args.dist_backend == "nccl" else "cpu")
 
     # the path must have produced sane output: no overflow/arena flags, no tracker errors, rows
     n_rows = 0
