@@ -90,14 +90,40 @@ def _worker(args):
     return path, analyse(path, settings=settings, result_folder=result_folder, device=device)
 
 
+def _gpu_worker(args):
+    """All videos dealt to one GPU: ``streams`` of them at a time, each on a thread with its own HIP
+    stream (two streams inside one process overlap far better than two processes on one device)."""
+    jobs, streams = args
+    if streams <= 1 or len(jobs) <= 1:
+        return [_worker(j) for j in jobs]
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+
+    from . import _lib
+    _lib.lib()                                     # load the library and configure logging once, before the threads start
+    st = jobs[0][1]
+    get_loggers(log_level=st["log_level"], logfile_name=st["log file path"],
+                short_stream_output=st["shorten displayed logging output"],
+                short_file_output=st["shorten logfile logging output"], log_to_file=st["log to file"], settings=st)
+
+    def run(job):
+        device = torch.device(job[3])
+        with torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device=device)):
+            return _worker(job)
+    with ThreadPoolExecutor(max_workers=streams, thread_name_prefix="ysmr-stream") as pool:
+        return list(pool.map(run, jobs))
+
+
 def ysmr(paths=None, settings=None, result_folder=None, multiprocess=False, streams_per_gpu=2):
     """Analyse one or several videos (main.py:175-331); returns ``[(path, result), ...]``.
 
     Interactive settings (``user input``, ``select files``) need a desktop session and are
     rejected; pass paths explicitly.  With ``multiprocess=True`` the paths are dealt round-robin to
-    the visible GPUs and handled by single-use worker processes (main.py:283), ``streams_per_gpu`` at a
-    time per GPU: one video cannot fill a GPU -- its frames are linked one after the other -- so two or
-    three streams on the same device deliver about 1.5 x the frames/s of one.
+    the visible GPUs, one worker process per GPU (main.py:283 starts one per file), and every worker
+    runs ``streams_per_gpu`` videos at a time on threads with their own HIP streams: one video cannot
+    fill a GPU -- its frames are linked one after the other -- so two or three streams on the same device
+    deliver about 1.5 x the frames/s of one.
     """
     settings = get_configs(settings)
     if settings is None:
@@ -127,11 +153,18 @@ def ysmr(paths=None, settings=None, result_folder=None, multiprocess=False, stre
     jobs = [(p, dict(settings), result_folder, "cuda:{}".format(i % n_gpu)) for i, p in enumerate(paths)]
     finished, failed = [], []
     if multiprocess and len(jobs) > 1:
-        import torch.multiprocessing as mp
-        ctx = mp.get_context("spawn")
-        workers = min(n_gpu * max(1, int(streams_per_gpu)), len(jobs))
-        with ctx.Pool(processes=workers, maxtasksperchild=1) as pool:
-            results = pool.map(_worker, jobs, chunksize=1)
+        streams = max(1, int(streams_per_gpu))
+        per_gpu = [([j for j in jobs if j[3] == "cuda:{}".format(g)], streams) for g in range(n_gpu)]
+        per_gpu = [a for a in per_gpu if a[0]]
+        if len(per_gpu) > 1:                       # one worker process per GPU, as many as there are GPUs with work
+            import torch.multiprocessing as mp
+            ctx = mp.get_context("spawn")
+            with ctx.Pool(processes=len(per_gpu), maxtasksperchild=1) as pool:
+                parts = pool.map(_gpu_worker, per_gpu, chunksize=1)
+        else:
+            parts = [_gpu_worker(per_gpu[0])]
+        by_path = {p: r for part in parts for p, r in part}
+        results = [(j[0], by_path.get(j[0])) for j in jobs]
     else:
         results = [_worker(j) for j in jobs]
     for path, res in results:
