@@ -341,3 +341,31 @@ def test_motion_jpeg_avi_reader(tmp_path):
             assert v.read_into(2, 4, out, pool) == 4
         np.testing.assert_array_equal(out, ref[2:6])
         assert np.abs(v.read(0, 1)[0].astype(int) - (frames[0] if mode == "L" else frames[0][..., ::-1]).astype(int)).mean() < 6
+
+
+def test_bench_argument_presets(monkeypatch):
+    """bench.py's command line: the driver's contract flags and the BASELINE configuration presets."""
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup, a.height, a.width, a.blobs, a.batch, a.detect_only, a.adt) == \
+        (1, 5, 1, 922, 1228, 500, 64, False, 2.0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "2", "--config", "4"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup) == (8, 3, 2)
+    assert (a.height, a.width, a.blobs, a.frames, a.batch, a.max_det, a.capacity) == (2160, 3840, 5000, 64, 8, 8192, 8192)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "1"])
+    assert bench.parse().detect_only
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "0"])
+    assert bench.parse().blobs == 50
+
+
+def test_ysmr_rejects_missing_paths_without_a_gpu(tmp_path, caplog):
+    """ysmr(): settings come first, a missing file is reported per path and does not stop the others
+    (main.py:292-313); nothing here touches the device."""
+    from ysmr_amd import ysmr
+    from ysmr_amd.helper_file import default_settings
+    s = default_settings(**{"user input": False, "select files": False, "display video analysis": False, "log to file": False})
+    done = ysmr([str(tmp_path / "a.npy"), str(tmp_path / "b.npy")], settings=s, result_folder=str(tmp_path / "out"))
+    assert [r for _, r in done] == [None, None] and "Failed to analyse 2 of 2" in caplog.text
+    assert ysmr([], settings=dict(s, **{"select files": True}), result_folder=str(tmp_path / "out")) is None
