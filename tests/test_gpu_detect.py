@@ -364,3 +364,21 @@ def test_mean_gray_levels_outside_the_u8_range(torch_cuda, oracle):
         levels = det.mean_levels[:4].cpu().tolist()
         assert all(v in (-1, 256) or 0 <= v <= 255 for v in levels)
     assert oracle.MeanGrayLevels(30.0, True, 5).step(np.full((h, w), 255, np.uint8))[0] == 260
+
+
+def test_detect_extreme_aspect_ratios(torch_cuda, oracle):
+    """The geometry limits of the C ABI (16384 x 16384): a frame as wide / as tall as allowed."""
+    from ysmr_amd.detect import threshold_params
+    rng = np.random.default_rng(9)
+    p = threshold_params(True, 5, 2.0)
+    for (h, w) in [(3, 16384), (16384, 4), (2, 16380)]:
+        frames = np.full((2, h, w), 40, np.uint8) + rng.integers(0, 3, (2, h, w), dtype=np.uint8)
+        ys, xs = rng.integers(0, h, 60), rng.integers(0, w, 60)
+        frames[0, ys, xs] = 200
+        frames[1, ys[:30], xs[:30]] = 230
+        _compare(oracle, frames, _detect_gpu(torch_cuda, frames, p, max_det=512), p, max_det=512)
+    from ysmr_amd import _lib
+    L = _lib.lib()
+    assert L.ysmr_detect_workspace_bytes(1, 16385, 8, 8) > 0          # (the size query does not validate ...)
+    rc = L.ysmr_threshold_batch(None, None, 1, 16385, 8, 1, 0, 5, 7, 1, None)
+    assert rc == 1 and b"16384" in L.ysmr_last_error()                 # ... the calls do
