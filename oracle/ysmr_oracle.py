@@ -299,7 +299,11 @@ class GsffState:
 
 class OracleGSFF:
     def __init__(self, delta_t, n_min=0, n_max=30, n_f=3, a=None, c=None,
-                 likelihood_minimum=10 ** -20, inv_cov=None, x_hat_array_length=2):
+                 likelihood_minimum=10 ** -20, inv_cov=None, x_hat_array_length=2, perturb=0):
+        # perturb = +1 / -1: a SHADOW filter whose FIR outputs and likelihoods are moved by one ulp,
+        # in opposite directions for even and odd filters (see OracleTracker, ``shadows``); 0 = the
+        # reference's arithmetic, pinned by tests/golden/
+        self.perturb = perturb
         self.lik_min = likelihood_minimum
         self.dim = x_hat_array_length
         self.n_f = n_f
@@ -308,15 +312,22 @@ class OracleGSFF:
         self.inv_cov = np.linalg.inv(np.eye(2)) if inv_cov is None else inv_cov
 
     # gsff.py:156-177
+    def _nudge(self, v, idx):
+        up = (idx % 2 == 0) == (self.perturb > 0)
+        return np.nextafter(v, np.inf if up else -np.inf)
+
     def _fir(self, idx, history):
         n = self.n_i[idx]
         flat = [v for m in history[-n:] for v in m]
-        return np.dot(self.gains[idx], flat)
+        out = np.dot(self.gains[idx], flat)
+        return self._nudge(out, idx) if self.perturb else out
 
     # gsff.py:179-202 (the FloatingPointError handlers are dead code under NumPy defaults)
-    def _likelihood(self, z, y_hat):
+    def _likelihood(self, z, y_hat, idx=0):
         d = z - y_hat
         lik = np.exp(-0.5 * np.dot(d.T, np.dot(self.inv_cov, d)))
+        if self.perturb:
+            lik = self._nudge(lik, idx + 1)
         return self.lik_min if lik < self.lik_min else lik
 
     def _refresh(self, st: GsffState):
@@ -347,7 +358,7 @@ class OracleGSFF:
             st.weights = 1 / st.mode * np.ones(st.mode)
             self._refresh(st)
         for i in range(st.mode):
-            st.likelihoods[i] = self._likelihood(z, st.x_hat[:, i][:2])
+            st.likelihoods[i] = self._likelihood(z, st.x_hat[:, i][:2], i)
         st.history.append(z)
         keep = self.n_i[-1] + 1
         if len(st.history) > keep:
@@ -365,6 +376,7 @@ class _Track:
     info: object
     gone: int = 0
     gs: GsffState = field(default_factory=GsffState)
+    shadow: list = field(default_factory=list)   # [[GsffState, pos], ...] one per shadow filter
 
 
 class OracleTracker:
@@ -376,22 +388,38 @@ class OracleTracker:
     Tie order of equal row minima: stable (min, row) -- the reference's default argsort is
     unspecified there.  New-track id order follows CPython set iteration
     (see update()); product code reproduces it with an explicit model of CPython's set table.
+
+    ``shadows`` (0 or 2): conditioning probe for the tests.  Beside every track's filter run two
+    shadow filters that see the same detections and the same claims, but whose FIR outputs and
+    likelihoods are moved by ONE ULP (in opposite directions for even and odd filters, and oppositely
+    in the two shadows), and which, while the track is lost, are fed their OWN prediction just as the
+    real filter is fed its own (tracker.py:219-225).  ``last_sens[i]`` = largest relative deviation
+    |shadow - real| / max(1, |real|) of track i's output this frame.  A row whose value moves by more
+    than ILL_CONDITIONED under a one-ulp change of the reference's own intermediate results is not
+    determined by the reference's arithmetic to better than that (any other BLAS, libm or summation
+    order moves it as much); every other row is.  The real filter's arithmetic is untouched.
     """
 
-    def __init__(self, max_disappeared=50, fps=30, n_min=0, n_max=None, n_f=3, use_gsff=True):
+    ILL_CONDITIONED = 1e-12
+
+    def __init__(self, max_disappeared=50, fps=30, n_min=0, n_max=None, n_f=3, use_gsff=True, shadows=0):
         self.max_gone = max_disappeared
         self.use_gsff = use_gsff
         self.next_id = 0
         self.tracks: list[_Track] = []
+        self.shadow_gsff = []
+        self.last_sens = np.zeros(0)
         if use_gsff:
             if n_max is None:
                 n_max = fps
-            self.gsff = OracleGSFF(delta_t=1 / fps, n_min=n_min, n_max=n_max, n_f=n_f,
-                                   likelihood_minimum=10 ** -20,
-                                   inv_cov=np.linalg.inv(np.eye(2)), x_hat_array_length=2)
+            kw = dict(delta_t=1 / fps, n_min=n_min, n_max=n_max, n_f=n_f, likelihood_minimum=10 ** -20,
+                      inv_cov=np.linalg.inv(np.eye(2)), x_hat_array_length=2)
+            self.gsff = OracleGSFF(**kw)
+            if shadows:
+                self.shadow_gsff = [OracleGSFF(perturb=+1, **kw), OracleGSFF(perturb=-1, **kw)]
 
     def _register(self, pos, info):
-        self.tracks.append(_Track(self.next_id, pos, info))
+        self.tracks.append(_Track(self.next_id, pos, info, shadow=[[GsffState(), pos] for _ in self.shadow_gsff]))
         self.next_id += 1
 
     def _age(self, tr: _Track):
@@ -424,6 +452,8 @@ class OracleTracker:
                         continue
                     tr = self.tracks[r]
                     tr.pos = pts[c]
+                    for sh in tr.shadow:
+                        sh[1] = pts[c]
                     tr.info = infos[c]
                     tr.gone = 0
                     rows_used.add(r)
@@ -447,9 +477,15 @@ class OracleTracker:
         info = [t.info for t in self.tracks]
         if self.use_gsff:
             out = np.zeros((len(self.tracks), 2))
+            sens = np.zeros(len(self.tracks))
             for i, t in enumerate(self.tracks):
                 out[i] = self.gsff.correct(t.pos, t.gs)
                 t.pos = self.gsff.predict(t.gs)
+                for g, sh in zip(self.shadow_gsff, t.shadow):
+                    o = g.correct(sh[1], sh[0])
+                    sh[1] = g.predict(sh[0])
+                    sens[i] = max(sens[i], float(np.max(np.abs(o - out[i]) / np.maximum(1.0, np.abs(out[i])))))
+            self.last_sens = sens
         else:
             out = np.array([t.pos for t in self.tracks], dtype=float).reshape(-1, 2)
         return ids, out, info, claims
@@ -459,15 +495,16 @@ class OracleTracker:
 # whole path: frames -> rows, mirroring the body of track_bacteria (track_eval.py:156-366)
 # ------------------------------------------------------------------------------------------------
 def track_frames(frames, fps=30.0, white_on_dark=True, offset=5, adt=2.0, use_gsff=True,
-                 n_min=0, n_max=30, n_f=3, max_det=65536, tracker=None, frame0=0):
+                 n_min=0, n_max=30, n_f=3, max_det=65536, tracker=None, frame0=0, shadows=0):
     """Run detect+link over an iterable of frames.  Returns (rows, tracker) with rows a list of
-    (frame, id, x, y, w, h, deg) -- one per live track per frame (track_eval.py:313-316)."""
+    (frame, id, x, y, w, h, deg) -- one per live track per frame (track_eval.py:313-316).
+    ``shadows=2``: every row gets an eighth entry, OracleTracker's conditioning probe ``last_sens``."""
     mean_gray = MeanGrayLevels(fps, white_on_dark, offset) if adt < 0 else None
     if mean_gray is None:
         inv, t_low, t_high, use_high = threshold_params(white_on_dark, offset, adt)
     if tracker is None:
         tracker = OracleTracker(max_disappeared=fps, fps=fps, n_min=n_min, n_max=n_max, n_f=n_f,
-                                use_gsff=use_gsff)
+                                use_gsff=use_gsff, shadows=shadows)
     rows = []
     for k, frame in enumerate(frames):
         if mean_gray is None:
@@ -477,8 +514,8 @@ def track_frames(frames, fps=30.0, white_on_dark=True, offset=5, adt=2.0, use_gs
         ids, xy, info, _ = tracker.update(det_to_rects(fd.det))
         for i, tid in enumerate(ids):
             w, h, deg = info[i]
-            rows.append((frame0 + k, tid, float(xy[i][0]), float(xy[i][1]), float(w), float(h),
-                         float(deg)))
+            row = (frame0 + k, tid, float(xy[i][0]), float(xy[i][1]), float(w), float(h), float(deg))
+            rows.append(row + (float(tracker.last_sens[i]),) if tracker.shadow_gsff else row)
     return rows, tracker
 
 

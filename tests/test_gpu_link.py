@@ -115,7 +115,7 @@ def test_pipeline_rows_match_oracle(torch_cuda, oracle):
     from ysmr_amd import _lib
     n_frames, h, w = 48, 240, 320
     frames = SyntheticVideo(h, w, 40, seed=7, dropout=0.05, speckle=0.05).frames(n_frames)
-    ref_rows, _ = oracle.track_frames(frames, fps=30.0)
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, shadows=2)
     det = Detector(16, h, w, max_det=256, params=threshold_params(True, 5, 2.0))
     trk = DeviceTracker(max_disappeared=30.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=256, max_det=256)
     rows = torch.empty(n_frames * 256 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
@@ -127,8 +127,9 @@ def test_pipeline_rows_match_oracle(torch_cuda, oracle):
     torch.cuda.synchronize()
     assert trk.info()[2] == 0
     got = rows_to_numpy(rows, int(count.item()))
+    assert (got["disappeared"] > 0).sum() > 100   # the clip does contain lost-track episodes
     n_loose, worst = compare_rows(got, ref_rows)
-    assert n_loose > 0   # the clip does contain lost-track episodes
+    assert n_loose < 0.05 * len(got)              # ... of which only a few are ill-conditioned in the reference itself
 
 
 def test_table_grows_and_shrinks_abruptly(torch_cuda, oracle):
@@ -147,11 +148,12 @@ def test_table_grows_and_shrinks_abruptly(torch_cuda, oracle):
     base = rng.uniform(0, 4000, (700, 2))
     per_frame = [dets(5, 0.3, base) for _ in range(8)] + [dets(700, 0.3, base) for _ in range(8)] + \
                 [dets(40, 0.3, base) for _ in range(8)] + [dets(600, 0.3, base) for _ in range(8)]
-    ot = oracle.OracleTracker(max_disappeared=3.0, fps=30.0, n_min=0, n_max=30, n_f=3, use_gsff=True)
+    ot = oracle.OracleTracker(max_disappeared=3.0, fps=30.0, n_min=0, n_max=30, n_f=3, use_gsff=True, shadows=2)
     ref_rows = []
     for f, d in enumerate(per_frame):
         ids, xy, info, _ = ot.update(oracle.det_to_rects(d))
-        ref_rows += [(f, tid, float(xy[i][0]), float(xy[i][1]), *map(float, info[i])) for i, tid in enumerate(ids)]
+        ref_rows += [(f, tid, float(xy[i][0]), float(xy[i][1]), *map(float, info[i]), float(ot.last_sens[i]))
+                     for i, tid in enumerate(ids)]
     trk = DeviceTracker(max_disappeared=3.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=cap, max_det=md)
     rows = torch.empty(len(per_frame) * cap * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
     count = torch.zeros(1, dtype=torch.int64, device="cuda")

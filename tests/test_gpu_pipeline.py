@@ -40,7 +40,7 @@ def test_track_bacteria_matches_oracle(tmp_path, oracle):
     assert (fps, h, w) == (30.0, 208, 272) and os.path.basename(csv_path) == "clip_list.csv"
     assert list(df.columns) == ["TRACK_ID", "POSITION_T", "POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE"]
     assert df["TRACK_ID"].is_monotonic_increasing
-    ref_rows, _ = oracle.track_frames(frames, fps=30.0)
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, shadows=2)
     got = _rows_from_df(df)
     # a matched 1-pixel blob also has w = h = angle = 0; use the oracle's notion of "disappeared"
     ref = np.array(ref_rows)
@@ -59,7 +59,7 @@ def test_dark_on_bright_and_offset_sign_quirk(tmp_path, oracle):
     s = _settings(**{"white bacteria on dark background": False})
     res = track_bacteria(str(path), settings=s, result_folder=str(tmp_path), batch=16, max_det=512, capacity=512)
     assert res is not None and s["threshold offset for detection"] == -5     # mutated like upstream
-    ref_rows, _ = oracle.track_frames(frames, fps=30.0, white_on_dark=False, offset=5, adt=2.0)
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, white_on_dark=False, offset=5, adt=2.0, shadows=2)
     compare_rows(_rows_from_df(res[0]), ref_rows)
 
 
@@ -109,7 +109,7 @@ def test_4k_dense_field_config(oracle):
     np.testing.assert_array_equal(res.mask[0].cpu().numpy(), fd.mask)
     assert int(res.det_count[0].item()) == fd.count
     np.testing.assert_array_equal(res.det[0, :fd.count, :4].cpu().numpy(), fd.det[:, :4])
-    ref_rows, _ = oracle.track_frames(frames, fps=30.0, max_det=8192)
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, max_det=8192, shadows=2)
     compare_rows(rows_to_numpy(rows, int(count.item())), ref_rows)
 
 
@@ -175,7 +175,7 @@ def test_track_bacteria_bgr_file_and_ragged_last_batch(tmp_path, oracle):
     np.save(path, frames)
     res = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16, max_det=256, capacity=256)
     assert res is not None
-    ref_rows, _ = oracle.track_frames(frames, fps=30.0)
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, shadows=2)
     assert len(ref_rows) == len(res[0])
     compare_rows(_rows_from_df(res[0]), ref_rows)
 
@@ -270,7 +270,7 @@ def test_track_bacteria_mean_gray_branch(tmp_path, oracle, white, offset):
                      "threshold offset for detection": offset})
     res = track_bacteria(str(path), settings=s, result_folder=str(tmp_path), batch=16, max_det=512, capacity=512)
     assert res is not None and res[1] == 4.0
-    ref_rows, _ = oracle.track_frames(frames, fps=4.0, white_on_dark=white, offset=offset, adt=-1.0)
+    ref_rows, _ = oracle.track_frames(frames, fps=4.0, white_on_dark=white, offset=offset, adt=-1.0, shadows=2)
     assert len(ref_rows) > 500
     compare_rows(_rows_from_df(res[0]), ref_rows)
 
@@ -355,3 +355,37 @@ def test_track_bacteria_row_buffer_smaller_than_the_video(tmp_path, monkeypatch)
     assert whole is not None and pieces is not None and len(whole[0]) > 1200
     assert whole[0].equals(pieces[0])
     assert open(whole[4], "rb").read() == open(pieces[4], "rb").read()
+
+
+def test_bench_config_rows_hold_1e9_outside_the_oracles_ill_conditioned_set(tmp_path, oracle):
+    """BASELINE configs[2] at full size (1228x922, ~500 blobs, 200 frames) through track_bacteria: every
+    row the reference's arithmetic determines is within 1e-9 of the oracle; the rows it does not determine
+    (oracle shadow filters, conftest.compare_rows) are a small, counted fraction.  The numbers go to
+    gpurun_out/parity_bench_config.json (quoted in DESIGN.md section 2)."""
+    import json
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(922, 1228, 500, seed=0, fps=30.0).frames(200)
+    path = tmp_path / "bench.npy"
+    np.save(path, frames)
+    res = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path))
+    assert res is not None
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, shadows=2)
+    got = _rows_from_df(res[0])
+    n_loose, worst = compare_rows(got, ref_rows)
+    ref = np.array(ref_rows)
+    lost = int((got["disappeared"] > 0).sum())
+    dev = np.maximum(np.abs(got["x"] - ref[:, 2]) / np.maximum(1, np.abs(ref[:, 2])),
+                     np.abs(got["y"] - ref[:, 3]) / np.maximum(1, np.abs(ref[:, 3])))
+    well = ref[:, 7] <= oracle.OracleTracker.ILL_CONDITIONED
+    report = {"rows": len(got), "rows_of_lost_tracks": lost, "ill_conditioned_rows": n_loose,
+              "ill_conditioned_fraction": n_loose / len(got), "worst_ill_conditioned_px": worst,
+              "ill_conditioned_rows_beyond_1e-5_relative": int((dev[~well] > 1e-5).sum()),
+              "worst_well_conditioned_relative": float(dev[well].max())}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_bench_config.json"), "w") as fh:
+        json.dump(report, fh, indent=1)
+    assert lost > 5000                          # the clip does lose tracks (2 % dropout)
+    assert n_loose < 0.03 * len(got), report
+    assert report["worst_well_conditioned_relative"] <= 1e-9

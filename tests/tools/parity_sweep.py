@@ -26,7 +26,7 @@ for name, adt, clip in (("gray adaptive", 2.0, frames), ("gray mean-level", -1.0
     t0 = time.perf_counter()
     res = track_bacteria(path, settings=dict(s), result_folder=d)
     t1 = time.perf_counter()
-    ref_rows, _ = yo.track_frames(clip, fps=30.0, adt=adt)
+    ref_rows, _ = yo.track_frames(clip, fps=30.0, adt=adt, shadows=2)
     t2 = time.perf_counter()
     df = res[0].sort_values(["POSITION_T", "TRACK_ID"]).reset_index(drop=True)
     rows = np.zeros(len(df), _lib.ROW_DTYPE)
