@@ -111,9 +111,10 @@ def main():
     dist.init(info, backend=args.dist_backend, device=dev)   # barrier + max-over-ranks time only; no data-path collective
 
     from ysmr_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        import __graft_entry__
-        __graft_entry__.build()
+    if rank == 0 and _lib.LIB_PATH.startswith(ROOT):   # no-op when the library is current (make checks the sources)
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.dirname(_lib.LIB_PATH)], check=not os.path.exists(_lib.LIB_PATH))
+    dist.barrier(info)
     from ysmr_amd.helper_file import default_settings
     from ysmr_amd.synth import SyntheticVideo
     from ysmr_amd.track_eval import TrackingPipeline
@@ -172,7 +173,6 @@ def main():
     # the path must have produced sane output: no overflow/arena flags, no tracker errors, rows
     n_rows = 0
     for p in pipes:
-        p.wait()
         n_tracks, next_id, err = p.trk.info()
         rows_k = int(p.row_count.item())
         status = max(int(d.status.max().item()) for d in p.det)

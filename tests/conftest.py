@@ -32,12 +32,20 @@ def rects_of(det, info):
 
 @pytest.fixture(scope="session", autouse=True)
 def _native_library():
-    """A fresh checkout has no libysmr_hip.so (it is not tracked): build it once (hipcc cross-compiles
-    without a GPU) so that any single test file can be run on its own."""
+    """libysmr_hip.so is not tracked: build it (hipcc cross-compiles without a GPU) so that any single test
+    file can be run on its own, and re-run make every session so that an edit to csrc/*.hip is never tested
+    against a stale binary (a no-op when the library is current; a box without hipcc keeps the prebuilt one)."""
+    import shutil
+    import subprocess
     from ysmr_amd import _lib
+    here = os.path.dirname(_lib.LIB_PATH)
+    if not _lib.LIB_PATH.startswith(ROOT):
+        return                                    # YSMR_HIP_LIB points at a tuning build
     if not os.path.exists(_lib.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
+    elif shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.run(["make", "-s", "-j8", "-C", here], check=True)
 
 
 @pytest.fixture(scope="session")

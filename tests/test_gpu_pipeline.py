@@ -389,3 +389,65 @@ def test_bench_config_rows_hold_1e9_outside_the_oracles_ill_conditioned_set(tmp_
     assert lost > 5000                          # the clip does lose tracks (2 % dropout)
     assert n_loose < 0.03 * len(got), report
     assert report["worst_well_conditioned_relative"] <= 1e-9
+
+
+def test_video_denser_than_the_buffers_is_run_again_with_larger_ones(tmp_path, oracle, caplog):
+    """The reference has no limit on objects per frame; a video that overflows max_det / capacity is found
+    out after its first batch and run again with both doubled -- same table as with ample buffers."""
+    import logging
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(200, 260, 40, seed=3).frames(48)
+    path = tmp_path / "dense.npy"
+    np.save(path, frames)
+    with caplog.at_level(logging.WARNING, logger="ysmr"):
+        res = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16, max_det=16, capacity=16)
+    assert res is not None
+    assert sum("running it again" in r.getMessage() for r in caplog.records) == 2      # 16 -> 32 -> 64
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, shadows=2)
+    compare_rows(_rows_from_df(res[0]), ref_rows)
+    # the limits may also come from the settings dict; analyse() passes its own arguments through
+    from ysmr_amd import analyse
+    from ysmr_amd.main import _OFFLINE_KEYS
+    s = _settings(**{k: False for k in _OFFLINE_KEYS}, **{"hip max detections per frame": 128, "hip max tracks": 128,
+                                                          "hip frames per batch": 8})
+    df = analyse(str(path), settings=s, result_folder=str(tmp_path / "b"), return_df=True)
+    df2 = analyse(str(path), settings=_settings(**{k: False for k in _OFFLINE_KEYS}), result_folder=str(tmp_path / "c"),
+                  return_df=True, batch=24, max_det=64, capacity=96)
+    assert df is not None and df.equals(res[0]) and df2.equals(res[0])
+
+
+def test_no_live_track_in_the_last_frame_means_nothing_tracked(tmp_path, caplog):
+    """track_eval.py:387-392: the reference asks the LAST frame's tracker output for its last object id, so a
+    video that ends on more than a second of empty frames 'did not track any objects' (the list is on disk)."""
+    import logging
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(120, 160, 8, seed=4).frames(90)
+    frames[45:] = 40                                   # nothing to see for 45 frames; tracks linger for 30
+    path = tmp_path / "fade.npy"
+    np.save(path, frames)
+    with caplog.at_level(logging.WARNING, logger="ysmr"):
+        res = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16)
+    assert res is None and any("Did not track any objects" in r.getMessage() for r in caplog.records)
+    assert len((tmp_path / "fade_list.csv").read_text().splitlines()) > 100
+    frames[80:] = SyntheticVideo(120, 160, 8, seed=4).frames(10)      # something alive at the end again
+    np.save(path, frames)
+    assert track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16) is not None
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs")
+def test_track_bacteria_on_the_second_gpu_while_the_first_is_current(tmp_path, oracle):
+    """Every launch goes to the stream of the device its buffers live on, whatever the caller's current
+    device is (a fresh worker's is cuda:0)."""
+    import torch
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(160, 200, 20, seed=8).frames(48)
+    path = tmp_path / "second.npy"
+    np.save(path, frames)
+    torch.cuda.set_device(0)
+    res = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16, device="cuda:1")
+    assert res is not None and torch.cuda.current_device() == 0
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, shadows=2)
+    compare_rows(_rows_from_df(res[0]), ref_rows)

@@ -369,3 +369,64 @@ def test_ysmr_rejects_missing_paths_without_a_gpu(tmp_path, caplog):
     done = ysmr([str(tmp_path / "a.npy"), str(tmp_path / "b.npy")], settings=s, result_folder=str(tmp_path / "out"))
     assert [r for _, r in done] == [None, None] and "Failed to analyse 2 of 2" in caplog.text
     assert ysmr([], settings=dict(s, **{"select files": True}), result_folder=str(tmp_path / "out")) is None
+
+
+def _mgpu_settings():
+    from ysmr_amd.helper_file import default_settings
+    return default_settings(**{"user input": False, "select files": False, "display video analysis": False,
+                               "log to file": False})
+
+
+def test_ysmr_multiprocess_one_worker_process_per_gpu(tmp_path, monkeypatch):
+    """The branch of ysmr(multiprocess=True) that starts one worker PROCESS per GPU (main.py:281-288
+    upstream: one per file) -- on a host that reports two GPUs, with the per-GPU worker replaced by a stub:
+    paths are dealt round-robin, every GPU's share runs in its own spawned process, results come back in
+    the order of the paths."""
+    import torch
+    import mgpu_stub
+    from ysmr_amd import main
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: False)
+    monkeypatch.setattr(main, "_gpu_worker", mgpu_stub.fake_gpu_worker)
+    paths = [str(tmp_path / f"v{i}.npy") for i in range(5)]
+    done = main.ysmr(paths, settings=_mgpu_settings(), result_folder=str(tmp_path), multiprocess=True, streams_per_gpu=3)
+    assert [p for p, _ in done] == paths
+    assert [r["device"] for _, r in done] == ["cuda:0", "cuda:1", "cuda:0", "cuda:1", "cuda:0"]
+    pids = {r["device"]: r["pid"] for _, r in done}
+    assert len(set(pids.values())) == 2 and os.getpid() not in pids.values()     # two workers, neither is this process
+    assert all(r["pid"] == pids[r["device"]] and r["streams"] == 3 for _, r in done)
+
+
+def test_ysmr_multiprocess_stays_in_process_once_the_gpu_is_initialised(tmp_path, monkeypatch, caplog):
+    """A process that already holds a GPU context must not start workers from itself (the worker would be
+    forked/exec'ed out of a GPU-initialised parent): the per-GPU workers then run as threads."""
+    import logging
+    import torch
+    import mgpu_stub
+    from ysmr_amd import main
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    monkeypatch.setattr(main, "_gpu_worker", mgpu_stub.fake_gpu_worker)
+    paths = [str(tmp_path / f"v{i}.npy") for i in range(4)]
+    with caplog.at_level(logging.WARNING, logger="ysmr"):
+        done = main.ysmr(paths, settings=_mgpu_settings(), result_folder=str(tmp_path), multiprocess=True)
+    assert [p for p, _ in done] == paths
+    assert all(r["pid"] == os.getpid() and r["thread"].startswith("ysmr-gpu") for _, r in done)
+    assert {r["device"] for _, r in done} == {"cuda:0", "cuda:1"}
+    assert any("already initialised the GPU" in rec.getMessage() for rec in caplog.records)
+
+
+def test_worker_selects_the_device_of_its_job(monkeypatch):
+    """_worker makes its job's GPU current before anything is allocated (a fresh worker's current device
+    is cuda:0 whatever GPU the job was dealt to)."""
+    from ysmr_amd import _lib, main
+    seen = []
+
+    class Ctx:
+        def __init__(self, dev): self.dev = dev
+        def __enter__(self): seen.append(("enter", self.dev))
+        def __exit__(self, *a): seen.append(("exit", self.dev))
+    monkeypatch.setattr(_lib, "on", lambda dev: Ctx(dev))
+    monkeypatch.setattr(main, "analyse", lambda path, **kw: seen.append(("analyse", kw["device"])) or True)
+    assert main._worker(("x.npy", {}, "out", "cuda:5")) == ("x.npy", True)
+    assert seen == [("enter", "cuda:5"), ("analyse", "cuda:5"), ("exit", "cuda:5")]

@@ -55,6 +55,10 @@ class YsmrLibraryError(RuntimeError):
     pass
 
 
+class YsmrCapacityError(YsmrLibraryError):
+    """A frame held more components than ``max_det`` or the tracker more tracks than ``capacity``."""
+
+
 _lib = None
 
 
@@ -120,7 +124,19 @@ def check(rc, what):
         raise YsmrLibraryError(f"{what} failed (code {rc}): {msg}")
 
 
-def stream_ptr():
-    """The current torch HIP stream as a hipStream_t value."""
+def stream_ptr(device=None):
+    """The current torch HIP stream OF ``device`` as a hipStream_t value (``None``: of the current
+    device).  Every entry point that launches work passes the device its buffers live on: the current
+    device of a fresh worker is cuda:0 whatever GPU its job was dealt to."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on(device):
+    """Context: make ``device`` the current HIP device (kernels are launched on the current device; a
+    stream of another device is an invalid handle there)."""
+    import torch
+    if torch.cuda.device_count() == 0:      # a host without GPUs: let the first device call report it
+        import contextlib
+        return contextlib.nullcontext()
+    return torch.cuda.device(torch.device(device))

@@ -91,6 +91,17 @@ class DetectResult:
     status: torch.Tensor     # i32 [B]  _lib.DET_* bits
 
 
+def _on_own_device(method):
+    """Run a Detector method with the detector's GPU as the current device."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with _lib.on(self.device):
+            return method(self, *args, **kwargs)
+    return wrapped
+
+
 def _padded(n_bytes, device):
     return torch.empty((n_bytes + 15) // 16 * 16, dtype=torch.uint8, device=device)
 
@@ -117,7 +128,9 @@ class Detector:
             raise ValueError("invalid detector geometry")
         self._ws = torch.empty(ws, dtype=torch.uint8, device=self.device)
         # the workspace remembers what the previous call wrote into labels/mask: start it blank
-        _lib.check(L.ysmr_detect_workspace_init(_lib.stream_ptr(), self._ws.data_ptr(), ws), "ysmr_detect_workspace_init")
+        with _lib.on(self.device):
+            _lib.check(L.ysmr_detect_workspace_init(_lib.stream_ptr(self.device), self._ws.data_ptr(), ws),
+                       "ysmr_detect_workspace_init")
         self._cls = _padded(n, self.device)
         self._mask = _padded(n, self.device) if want_mask else None
         self._labels = torch.empty((n + 3) // 4 * 4, dtype=torch.int32, device=self.device)
@@ -141,6 +154,7 @@ class Detector:
         ch = 1 if frames.dim() == 3 else frames.shape[3]
         return b, ch
 
+    @_on_own_device
     def threshold(self, frames: torch.Tensor) -> torch.Tensor:
         """a1-a3 only: class map u8 [b,H,W] (bit0 thresh, bit1 markers).  In the mean-gray branch the
         call also advances the moving-average state by these frames; per-frame mean, stddev, level and
@@ -149,16 +163,17 @@ class Detector:
         p = self.params
         if self.mean_state is not None:
             rc = _lib.lib().ysmr_mean_threshold_batch(
-                _lib.stream_ptr(), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.offset, p.window,
+                _lib.stream_ptr(self.device), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.offset, p.window,
                 self.mean_state.buf.data_ptr(), self.mean_stats.data_ptr(), self.mean_levels.data_ptr(),
                 self._cls.data_ptr())
             _lib.check(rc, "ysmr_mean_threshold_batch")
             return self._view(self._cls, b)
-        rc = _lib.lib().ysmr_threshold_batch(_lib.stream_ptr(), frames.data_ptr(), b, self.H, self.W, ch,
+        rc = _lib.lib().ysmr_threshold_batch(_lib.stream_ptr(self.device), frames.data_ptr(), b, self.H, self.W, ch,
                                              p.inv, p.t_low, p.t_high, p.use_high, self._cls.data_ptr())
         _lib.check(rc, "ysmr_threshold_batch")
         return self._view(self._cls, b)
 
+    @_on_own_device
     def components(self, batch=None, cls: torch.Tensor | None = None) -> DetectResult:
         """a4-a6 on the class map left by ``threshold`` (or on a caller-supplied u8 [b,H,W] map)."""
         if cls is not None:
@@ -166,7 +181,7 @@ class Detector:
             self._view(self._cls, batch).copy_(cls)
         b = self.B if batch is None else int(batch)
         rc = _lib.lib().ysmr_components_batch(
-            _lib.stream_ptr(), b, self.H, self.W, self._ws.data_ptr(), self._ws.numel(), self._cls.data_ptr(),
+            _lib.stream_ptr(self.device), b, self.H, self.W, self._ws.data_ptr(), self._ws.numel(), self._cls.data_ptr(),
             self._mask.data_ptr() if self._mask is not None else None, self._labels.data_ptr(),
             self.det_count.data_ptr(), self.det.data_ptr(), self.anchors.data_ptr(), self.max_det,
             self.status.data_ptr())
@@ -179,6 +194,7 @@ class Detector:
                             self._view(self._labels, b), self.det_count[:b], self.det[:b], self.anchors[:b],
                             self.status[:b])
 
+    @_on_own_device
     def detect(self, frames: torch.Tensor) -> DetectResult:
         """a1-a6 for a batch of frames resident in HBM.  Asynchronous on the current stream."""
         b, ch = self._check_frames(frames)
@@ -187,7 +203,7 @@ class Detector:
             self.threshold(frames)
             return self.components(b)
         rc = _lib.lib().ysmr_detect_batch(
-            _lib.stream_ptr(), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.t_low, p.t_high, p.use_high,
+            _lib.stream_ptr(self.device), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.t_low, p.t_high, p.use_high,
             self._ws.data_ptr(), self._ws.numel(), self._cls.data_ptr(),
             self._mask.data_ptr() if self._mask is not None else None, self._labels.data_ptr(),
             self.det_count.data_ptr(), self.det.data_ptr(), self.anchors.data_ptr(), self.max_det,

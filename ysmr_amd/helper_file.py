@@ -441,21 +441,43 @@ def save_df_to_csv(df, save_path, rename_old_file=True):
         _logger().exception("Could not save {}: {}".format(save_path, exc))
 
 
-def metadata_file(path=None, verbose=False, additional_search_paths=None, **kwargs):
-    """Read/update ``<name>_meta.json`` next to ``path`` (fps, frame_height, frame_width, ...);
-    ``None`` values are ignored (helper_file.py:1262-1333, without the parent-folder search)."""
-    base = path
+def _meta_path_of(path):
+    """``<name>_meta.json`` for a video, one of the pipeline's own csv files, or a meta file itself."""
+    path = os.fspath(path)
+    if path.endswith("_meta.json"):
+        return path
     for ext in ("_analysed.csv", "_list.csv", "_selected_data.csv", "_statistics.csv"):
-        if base.endswith(ext):
-            base = base[: -len(ext)] + ".dummy"
-            break
-    meta_path = os.path.splitext(base)[0] + "_meta.json"
-    meta = {}
-    try:
-        with open(meta_path) as fh:
-            meta.update({k: v for k, v in json.load(fh).items() if v is not None})
-    except (OSError, ValueError):
-        pass
+        if path.endswith(ext):
+            return path[: -len(ext)] + "_meta.json"
+    return os.path.splitext(path)[0] + "_meta.json"
+
+
+def metadata_file(path=None, verbose=False, additional_search_paths=None, **kwargs):
+    """Read/update the ``<name>_meta.json`` side file (fps, frame_height, frame_width, caller's notes).
+    Looked for next to ``path``, in the folder above it, then next to every additional search path; the
+    first one found is read and, when new non-None values are given, rewritten in place (none found: it is
+    created next to ``path``).  New values win over stored ones (helper_file.py:1267-1333)."""
+    path = os.fspath(path)
+    folder, name = os.path.split(path)
+    candidates = [path, os.path.join(os.path.dirname(folder), name)]
+    if additional_search_paths:
+        if isinstance(additional_search_paths, (str, os.PathLike)):
+            candidates.append(additional_search_paths)
+        else:
+            candidates.extend(additional_search_paths)
+    candidates = [_meta_path_of(c) for c in candidates]
+    meta, meta_path = {}, candidates[0]
+    for cand in candidates:
+        if verbose:
+            _logger().debug("Searching for meta file in path: {}".format(cand))
+        try:
+            with open(cand) as fh:
+                stored = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        meta.update({k: v for k, v in stored.items() if v is not None})
+        meta_path = cand
+        break
     new = {k: v for k, v in kwargs.items() if v is not None}
     if new:
         meta.update(new)

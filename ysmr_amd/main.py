@@ -1,9 +1,9 @@
 """``ysmr()`` / ``analyse()`` entry points with the reference's signatures (ysmr/main.py:32, 175).
 
-Only the detect-and-link stage is implemented here (``track_bacteria``); the reference's offline
-stages (``select_tracks``, ``evaluate_tracks``, ``annotate_video``, plots, xlsx collation) are out
-of scope and are skipped with a log message.  ``analyse`` therefore returns the DataFrame of
-``<name>_list.csv`` (``return_df=True``) or ``True``; ``None`` signals an error, as upstream.
+``analyse`` runs detect-and-link (``track_bacteria``) and then ``select_tracks`` on the device; the
+reference's later offline stages (``evaluate_tracks``, ``annotate_video``, plots, xlsx collation) are
+not part of the HIP path and are skipped with a log message.  It returns the last stage's DataFrame
+(``return_df=True``) or ``True``; ``None`` signals an error, as upstream.
 
 Independent videos are embarrassingly parallel (the reference runs one process per path,
 main.py:281-288): ``ysmr(..., multiprocess=True)`` shards the paths one process per GPU, no
@@ -29,11 +29,14 @@ _EVALUATE_KEYS = ("store generated statistical .csv file",
 _OFFLINE_KEYS = ("store processed .csv file",) + _EVALUATE_KEYS
 
 
-def analyse(path, settings=None, result_folder=None, return_df=False, device="cuda:0", **kwargs):
+def analyse(path, settings=None, result_folder=None, return_df=False, device="cuda:0", batch=None, max_det=None,
+            capacity=None, **kwargs):
     """Detect-and-link on one video, then ``select_tracks`` on its table (main.py:32-172); a
     ``*_list.csv`` of an earlier run goes straight to the selection.  ``kwargs`` go to the ``_meta.json``
-    side file together with fps and frame size (main.py:99-108).  Returns the last stage's DataFrame
-    (``return_df``) or True; None after any failure, including "no acceptable tracks"."""
+    side file together with fps and frame size (main.py:99-108).  ``device``, ``batch``, ``max_det`` and
+    ``capacity`` are passed on to ``track_bacteria``.  Returns the last stage's DataFrame (``return_df``) or
+    True; None after any failure, including "no acceptable tracks" and -- as upstream -- a .csv input for
+    which the settings ask for no further stage."""
     t0 = datetime.now()
     settings = get_configs(settings)
     if settings is None:
@@ -47,47 +50,62 @@ def analyse(path, settings=None, result_folder=None, return_df=False, device="cu
         result_folder = create_results_folder(path)
     os.makedirs(result_folder, exist_ok=True)
     logger.debug("Starting process. PID: {} Result folder: {}".format(os.getpid(), result_folder))
-    if any(tag in path for tag in ("_analysed.csv", "_statistics.csv", "_annotated_output.")):
-        logger.warning("File already evaluated. File: {}".format(path))
-        return None
-    csv_file = None
-    if ".csv" not in path:   # "as long as it's not a .csv, it should be a video" (main.py:88-97)
-        result = track_bacteria(video_path=path, settings=settings, result_folder=result_folder, device=device)
-        if result is None:
-            logger.warning("Error during video analysis of file {}.".format(path))
-            logger.info("Error during process. PID: {}, elapsed time: {}".format(os.getpid(), datetime.now() - t0))
-            return None
-        df, fps, f_height, f_width, csv_file = result
-    else:                    # a *_list.csv of an earlier run: fps and frame size come from its _meta.json
+    plots_eval = any(settings.get(k) for k in _EVALUATE_KEYS)
+    produced = {"csv": None}
+
+    def stages():
+        """The body of the reference's ``while True: ... break`` (main.py:82-156): the value of the last
+        stage that ran, None as soon as one fails."""
+        value = None
         df, fps, f_height, f_width = None, None, None, None
-    meta_all = metadata_file(path=os.path.join(result_folder, os.path.basename(path)), verbose=settings["verbose"], fps=fps,
-                             frame_height=f_height, frame_width=f_width, **kwargs)
-    fps, f_height, f_width = meta_all.get("fps", fps), meta_all.get("frame_height", f_height), meta_all.get("frame_width", f_width)
-    if "selected_data.csv" in path:
-        logger.info("{} is a selection already; evaluate_tracks is not part of the HIP path".format(path))
-        return None
-    # select_tracks runs when its csv is wanted or a later stage needs it (main.py:111-128)
-    if any(settings.get(k) for k in _OFFLINE_KEYS) or df is None:
-        meta = {"fps": fps, "frame_height": f_height, "frame_width": f_width}
-        df = select_tracks(path_to_file=path, df=df, results_directory=result_folder, settings=settings, device=device, **meta)
-        if df is None:
-            logger.warning("Error during video analysis of file {}.".format(path))
-            logger.info("Error during process. PID: {}, elapsed time: {}".format(os.getpid(), datetime.now() - t0))
+        if any(tag in path for tag in ("_analysed.csv", "_statistics.csv", "_annotated_output.")):
+            logger.warning("File already evaluated. File: {}".format(path))
             return None
-    if any(settings.get(k) for k in _EVALUATE_KEYS):
-        logger.info("evaluate_tracks / plots are not part of the HIP path; stopping after select_tracks")
-    if settings["delete .csv file after analysis"] and csv_file:
+        if ".csv" not in path:   # "as long as it's not a .csv, it should be a video" (main.py:88-97)
+            result = track_bacteria(video_path=path, settings=settings, result_folder=result_folder, device=device,
+                                    batch=batch, max_det=max_det, capacity=capacity)
+            if result is None:
+                logger.warning("Error during video analysis of file {}.".format(path))
+                return None
+            df, fps, f_height, f_width, produced["csv"] = result
+            value = df
+        # a *_list.csv of an earlier run: fps and frame size come from its _meta.json
+        meta = metadata_file(path=os.path.join(result_folder, os.path.basename(path)), additional_search_paths=path,
+                             verbose=settings["verbose"], fps=fps, frame_height=f_height, frame_width=f_width, **kwargs)
+        if "selected_data.csv" not in path and (plots_eval or settings["store processed .csv file"]):
+            df = select_tracks(path_to_file=path, df=df, results_directory=result_folder, settings=settings, device=device,
+                               **{k: meta.get(k) for k in ("fps", "frame_height", "frame_width")})
+            if df is None:
+                logger.warning("Error during video analysis of file {}.".format(path))
+                return None
+            value = df
+        if plots_eval:
+            logger.info("evaluate_tracks / plots are not part of the HIP path; stopping after select_tracks")
+        elif "selected_data.csv" in path:
+            logger.warning("No evaluation set to True in settings. Did not evaluate {}".format(path))
+        return value
+
+    value = stages()
+    if settings["delete .csv file after analysis"] and produced["csv"]:   # (also after a failed stage, main.py:156-163)
         try:
-            os.remove(csv_file)
+            os.remove(produced["csv"])
         except OSError:
             pass
-    logger.info("Finished with process. PID: {}, elapsed time: {}".format(os.getpid(), datetime.now() - t0))
-    return df if return_df else True
+    logger.info("{} process. PID: {}, elapsed time: {}".format("Finished with" if value is not None else "Error during",
+                                                                os.getpid(), datetime.now() - t0))
+    if value is None:
+        return None
+    return value if return_df else True
 
 
 def _worker(args):
+    """One video on the GPU it was dealt to.  The device is made current here: a fresh worker's current
+    device is cuda:0 whatever its job says (the entry points below it select their device themselves as
+    well; this covers allocations made in between)."""
     path, settings, result_folder, device = args
-    return path, analyse(path, settings=settings, result_folder=result_folder, device=device)
+    from . import _lib
+    with _lib.on(device):
+        return path, analyse(path, settings=settings, result_folder=result_folder, device=device)
 
 
 def _gpu_worker(args):
@@ -156,8 +174,17 @@ def ysmr(paths=None, settings=None, result_folder=None, multiprocess=False, stre
         streams = max(1, int(streams_per_gpu))
         per_gpu = [([j for j in jobs if j[3] == "cuda:{}".format(g)], streams) for g in range(n_gpu)]
         per_gpu = [a for a in per_gpu if a[0]]
-        if len(per_gpu) > 1:                       # one worker process per GPU, as many as there are GPUs with work
-            import torch.multiprocessing as mp
+        if len(per_gpu) > 1 and torch.cuda.is_initialized():
+            # This process already holds a GPU context (a notebook, a test runner, an earlier call): starting
+            # worker processes from it would fork/exec out of a GPU-initialised parent.  Keep everything
+            # in-process instead: one thread per GPU, each running its videos on that GPU's streams.
+            logger.warning("multiprocess=True, but this process has already initialised the GPU: "
+                           "running the {} per-GPU workers as threads of this process".format(len(per_gpu)))
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(per_gpu), thread_name_prefix="ysmr-gpu") as pool:
+                parts = list(pool.map(_gpu_worker, per_gpu))
+        elif len(per_gpu) > 1:                     # one worker process per GPU, as many as there are GPUs with work
+            import multiprocessing as mp           # (started before anything here has touched the GPU)
             ctx = mp.get_context("spawn")
             with ctx.Pool(processes=len(per_gpu), maxtasksperchild=1) as pool:
                 parts = pool.map(_gpu_worker, per_gpu, chunksize=1)

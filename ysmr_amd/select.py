@@ -64,7 +64,7 @@ def select_rows(df, params: _lib.SelectParams, device="cuda:0"):
         ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
         sel_row = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
         sel_index = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-        rc = L.ysmr_select_tracks(_lib.stream_ptr(), n, *[c.data_ptr() for c in cols], ctypes.byref(params),
+        rc = L.ysmr_select_tracks(_lib.stream_ptr(dev), n, *[c.data_ptr() for c in cols], ctypes.byref(params),
                                   ws.data_ptr(), ws.numel(), sel_row.data_ptr(), sel_index.data_ptr(),
                                   ctypes.byref(summary))
         _lib.check(rc, "ysmr_select_tracks")

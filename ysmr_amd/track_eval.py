@@ -41,6 +41,18 @@ def __getattr__(name):   # select_tracks lives in track_eval upstream (track_eva
     raise AttributeError(name)
 
 
+def _on_own_device(method):
+    """Run a TrackingPipeline method with the pipeline's GPU as the current device (the caller's current
+    device is cuda:0 in a fresh worker, whatever GPU its video was dealt to)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with _lib.on(self.device):
+            return method(self, *args, **kwargs)
+    return wrapped
+
+
 class TrackingPipeline:
     """Device-resident detect+link over consecutive batches of one video stream."""
 
@@ -74,6 +86,7 @@ class TrackingPipeline:
         self._done = [None, None]   # event: detector i's outputs consumed by the tracker
         self._k = 0
 
+    @_on_own_device
     def detect_async(self, frames_dev, threshold_events=None):
         """Issue detection of one batch on the side stream; returns (slot, result, ready_event).
         ``threshold_events``: list that receives a (start, stop) HIP event pair bracketing the fused
@@ -99,10 +112,12 @@ class TrackingPipeline:
             ready.record(self.side)
         return slot, res, ready
 
+    @_on_own_device
     def reset(self):
         self.trk.reset()
         self.row_count.zero_()
 
+    @_on_own_device
     def link(self, slot, res, ready, first_frame):
         """Link one detected batch on the current stream; rows accumulate in self.rows."""
         cur = torch.cuda.current_stream(self.device)
@@ -113,11 +128,7 @@ class TrackingPipeline:
         self._done[slot] = done
         return res
 
-    def wait(self):
-        """Detection runs on the side stream, linking on the caller's stream: nothing to join here
-        (kept so that callers need not know which streams the pipeline uses)."""
-        return None
-
+    @_on_own_device
     def take_rows(self, sort=False):
         """Synchronise, download the accumulated rows and reset the row buffer.  ``sort``: order them
         by (TRACK_ID, POSITION_T) on the device first (``sort_list``, helper_file.py:1538-1574)."""
@@ -129,20 +140,32 @@ class TrackingPipeline:
         self.row_count.zero_()
         return rows
 
+    @_on_own_device
     def check(self, res):
         status = int(res.status.max().item())
         _, _, err = self.trk.info()
         if status or err:
-            raise _lib.YsmrLibraryError(f"device path reported errors: detection status {status}, tracker {err} "
-                                        "(raise max_det / capacity)")
+            kind = _lib.YsmrCapacityError if (status & _lib.DET_OVERFLOW or err) else _lib.YsmrLibraryError
+            raise kind(f"device path reported errors: detection status {status}, tracker {err} "
+                       f"(max_det {self.det[0].max_det}, capacity {self.capacity})")
 
 
-def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_det=2048, capacity=2048,
+#: device-side limits when neither the call nor the settings dict name any; a video that exceeds them is
+#: re-run with doubled limits (up to LIMIT_MAX), so they only decide how much HBM the first attempt takes
+DEFAULT_BATCH, DEFAULT_MAX_DET, DEFAULT_CAPACITY, LIMIT_MAX = 64, 2048, 2048, 32768
+
+
+def track_bacteria(video_path, settings=None, result_folder=None, batch=None, max_det=None, capacity=None,
                    device="cuda:0"):
     """Detect and track bright (or dark) spots in a video; write ``<name>_list.csv``.
 
     Returns ``(DataFrame, fps, frame_height, frame_width, csv_path)`` or ``None`` (errors are
     logged on logger 'ysmr', never raised -- track_eval.py:50-77, 389-392, 402-404).
+
+    ``batch`` (frames per detection launch), ``max_det`` (components per frame) and ``capacity`` (live
+    tracks) size the device buffers; the reference has no such limits, so they may also be given as the
+    optional settings keys 'hip frames per batch', 'hip max detections per frame', 'hip max tracks', and a
+    video that overflows them is run again with both doubled (checked after the first batch and at the end).
     """
     logger = logging.getLogger("ysmr").getChild(__name__)
     settings = get_configs(settings)
@@ -192,10 +215,37 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
     local["threshold offset for detection"] = offset_on_entry
 
     frame_height, frame_width = video.height, video.width
+    batch = int(batch or settings.get("hip frames per batch") or DEFAULT_BATCH)
+    max_det = int(max_det or settings.get("hip max detections per frame") or DEFAULT_MAX_DET)
+    capacity = int(capacity or settings.get("hip max tracks") or DEFAULT_CAPACITY)
+    while True:
+        outcome = _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_det, capacity, device,
+                               settings, logger)
+        if outcome[0] == "overflow" and 2 * max(max_det, capacity) <= LIMIT_MAX:
+            max_det, capacity = 2 * max_det, 2 * capacity
+            logger.warning("More objects than the device buffers hold in file {}: running it again with "
+                           "max_det = {}, capacity = {}".format(video_path, max_det, capacity))
+            continue
+        if outcome[0] == "overflow":
+            logger.critical("File {} holds more objects per frame than the largest device buffers ({}); "
+                            "not analysed".format(video_path, LIMIT_MAX))
+        break
+    video.close()
+    _, sorted_rows, frames_done, error_during_read, t_start, t_frames = outcome
+    return _finish(video_path, settings, logger, sorted_rows, frames_done, frame_count, error_during_read, old_list,
+                   list_name, fps_of_file, frame_height, frame_width, t_start, t_frames)
+
+
+def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_det, capacity, device, settings,
+                 logger):
+    """The frame loop of one attempt.  Returns (verdict, sorted rows or None, frames done, error flag,
+    start time, time when the last frame was linked); verdict 'overflow' asks for larger buffers."""
+    frame_height, frame_width = video.height, video.width
     error_during_read = False
     frames_done = 0
     sorted_rows = None
     feed = None
+    verdict = "done"
     t_start = t_frames = time.perf_counter()
     try:
         # Rows stay on the device for the whole video when they fit (capacity rows per frame is the
@@ -209,6 +259,7 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
         chunks = []
         pending = None
         res = None
+        checked_early = False
         row_capacity = pipe.rows.numel() // _lib.ROW_DTYPE.itemsize
         rows_upper = 0     # host-side bound on the rows in the device buffer (no sync per batch)
         feed = DeviceFrameFeed(video, pipe.B, pipe.device)
@@ -225,6 +276,9 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
                 res = pipe.link(slot, r, ready, p0)
                 rows_upper += cnt * pipe.capacity
                 frames_done = p0 + cnt
+                if not checked_early:           # a video too dense for the buffers is found out after its
+                    pipe.check(res)             # first batch, not after its last (one sync per video)
+                    checked_early = True
             pending = nxt
         if pending is not None:
             (slot, r, ready), p0, cnt = pending
@@ -248,14 +302,22 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
         if frames_done < frame_count - 1:   # some containers over-report by one frame (track_eval.py:170-171)
             logger.critical("Error during read with file {}".format(video_path))
             error_during_read = settings["stop evaluation on error"]
+    except _lib.YsmrCapacityError as exc:
+        logger.warning("{} (file {})".format(exc, video_path))
+        verdict, sorted_rows, error_during_read = "overflow", None, True
     except (_lib.YsmrLibraryError, RuntimeError, ValueError) as exc:
         logger.critical("Device path failed for file {}: {}".format(video_path, exc))
         error_during_read = True
     finally:
         if feed is not None:
             feed.close()
-        video.close()
+    return verdict, sorted_rows, frames_done, error_during_read, t_start, t_frames
 
+
+def _finish(video_path, settings, logger, sorted_rows, frames_done, frame_count, error_during_read, old_list, list_name,
+            fps_of_file, frame_height, frame_width, t_start, t_frames):
+    """Everything after the frame loop (track_eval.py:368-405): restore the old list after an error, write
+    the ordered csv, build the DataFrame."""
     if old_list and error_during_read:
         try:
             os.remove(list_name)
@@ -266,10 +328,16 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
     if sorted_rows is None or len(sorted_rows) == 0:
         logger.warning("Did not track any objects. File: {}".format(video_path))
         return None
+    # track_eval.py:387-392 asks the LAST frame's tracker output for its last object id: a video whose final
+    # frame has no live track (nothing seen for more than a second) "did not track any objects" upstream,
+    # whatever the earlier frames held -- and the unsorted list stays on disk.  Same verdict here (the list
+    # is written, ordered, before returning).
+    alive_at_end = sorted_rows["track_id"][sorted_rows["frame"] == frames_done - 1]
     # track_eval.py:393: sort_list(file_path=list_name, save_file=not settings['delete .csv ...']) re-reads
     # the csv with pandas, sorts it and rewrites it; the same DataFrame and the same bytes come
     # straight from the rows here (helper_file.rows_to_dataframe / rows_to_csv_bytes).
-    n_rows_total, last_id = len(sorted_rows), int(sorted_rows["track_id"][-1])
+    n_rows_total = len(sorted_rows)
+    last_id = int(alive_at_end.max()) if len(alive_at_end) else -1
     t_rows = time.perf_counter()
     # the csv is formatted and written on a second thread while the DataFrame is built (both are native
     # calls that release the GIL)
@@ -292,6 +360,9 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=64, max_
         (t_frames - t_start) * 1e3, (t_rows - t_frames) * 1e3, (t_df - t_rows) * 1e3, (time.perf_counter() - t_df) * 1e3))
     logger.info("objects: {}, frames: {} of {}, rows: {}, csv: {}".format(last_id + 1, frames_done, frame_count,
                                                                           n_rows_total, list_name))
+    if len(alive_at_end) == 0:
+        logger.warning("Did not track any objects. File: {}".format(video_path))
+        return None
     if error_during_read:
         logger.critical("Error during read, stopping before evaluation. File: {}".format(video_path))
         return None

@@ -21,6 +21,17 @@ from .gsff import horizon_sizes, lsf_gain_rows
 __all__ = ["sort_rows", "DeviceTracker", "CentroidTracker"]
 
 
+def _on_own_device(method):
+    """Run a DeviceTracker method with the tracker's GPU as the current device."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with _lib.on(self.device):
+            return method(self, *args, **kwargs)
+    return wrapped
+
+
 class DeviceTracker:
     """Owns one ``ysmr_tracker`` handle (one video stream)."""
 
@@ -57,45 +68,50 @@ class DeviceTracker:
         except Exception:
             pass
 
+    @_on_own_device
     def reset(self):
-        _lib.check(_lib.lib().ysmr_tracker_reset(self._handle, _lib.stream_ptr()), "ysmr_tracker_reset")
+        _lib.check(_lib.lib().ysmr_tracker_reset(self._handle, _lib.stream_ptr(self.device)), "ysmr_tracker_reset")
 
+    @_on_own_device
     def update(self, det, m=None, m_dev=None, frame=0, rows=None, n_rows=None, claim=None, n_before=None,
                new_cols=None, n_new=None):
         """One frame.  det: device tensor [m,5] float32 or float64."""
         f64 = int(det.dtype == torch.float64)
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        rc = _lib.lib().ysmr_tracker_update(self._handle, _lib.stream_ptr(), det.data_ptr(), f64,
+        rc = _lib.lib().ysmr_tracker_update(self._handle, _lib.stream_ptr(self.device), det.data_ptr(), f64,
                                             -1 if m is None else int(m), ptr(m_dev), int(frame), ptr(rows),
                                             ptr(n_rows), ptr(claim), ptr(n_before), ptr(new_cols), ptr(n_new))
         _lib.check(rc, "ysmr_tracker_update")
 
+    @_on_own_device
     def run(self, det, det_count, first_frame, rows, row_count):
         """Frames [first_frame, first_frame + B): det f32 [B,max_det,5], det_count i32 [B] on device;
         rows: uint8 buffer viewed as ysmr_row[]; row_count: int64 device scalar (advanced)."""
         b = det_count.numel()
         if det.shape[1] != self.max_det:
             raise ValueError("det must be [B, max_det, 5] with the tracker's max_det")
-        rc = _lib.lib().ysmr_tracker_run(self._handle, _lib.stream_ptr(), det.data_ptr(), det_count.data_ptr(),
+        rc = _lib.lib().ysmr_tracker_run(self._handle, _lib.stream_ptr(self.device), det.data_ptr(), det_count.data_ptr(),
                                          b, int(first_frame), rows.data_ptr(),
                                          rows.numel() // _lib.ROW_DTYPE.itemsize, row_count.data_ptr())
         _lib.check(rc, "ysmr_tracker_run")
 
+    @_on_own_device
     def info(self):
         """(live tracks, next id, sticky error bits); synchronises."""
         a, b, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-        rc = _lib.lib().ysmr_tracker_info(self._handle, _lib.stream_ptr(), ctypes.byref(a), ctypes.byref(b),
+        rc = _lib.lib().ysmr_tracker_info(self._handle, _lib.stream_ptr(self.device), ctypes.byref(a), ctypes.byref(b),
                                           ctypes.byref(c))
         _lib.check(rc, "ysmr_tracker_info")
         return a.value, b.value, c.value
 
+    @_on_own_device
     def peek(self):
         """Current (ids, positions (n,2) float64, disappeared) in id order; synchronises."""
         ids = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
         xy = torch.empty(self.capacity, 2, dtype=torch.float64, device=self.device)
         gone = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
         n = torch.zeros(1, dtype=torch.int32, device=self.device)
-        rc = _lib.lib().ysmr_tracker_peek(self._handle, _lib.stream_ptr(), ids.data_ptr(), xy.data_ptr(),
+        rc = _lib.lib().ysmr_tracker_peek(self._handle, _lib.stream_ptr(self.device), ids.data_ptr(), xy.data_ptr(),
                                           gone.data_ptr(), n.data_ptr())
         _lib.check(rc, "ysmr_tracker_peek")
         k = int(n.item())
@@ -152,7 +168,7 @@ def sort_rows(rows_u8: torch.Tensor, count: int) -> torch.Tensor:
     ws_bytes = L.ysmr_rows_sort_workspace_bytes(count)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=rows_u8.device)
     with torch.cuda.device(rows_u8.device):
-        _lib.check(L.ysmr_rows_sort(_lib.stream_ptr(), rows_u8.data_ptr(), count, ws.data_ptr(), ws_bytes, out.data_ptr()),
+        _lib.check(L.ysmr_rows_sort(_lib.stream_ptr(rows_u8.device), rows_u8.data_ptr(), count, ws.data_ptr(), ws_bytes, out.data_ptr()),
                    "ysmr_rows_sort")
     return out[: count * size]
 
