@@ -40,11 +40,22 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   4
+#define YSMR_ABI_VERSION   5
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
 #define YSMR_DET_ARENA     2   /* geometry scratch arena exhausted: some rectangles missing */
+
+/* cv_flavour: which OpenCV the a1 / a6 arithmetic follows.  opencv-contrib-python is an unpinned third-party
+ * dependency of the reference (setup.py:29, "openCV v3 or v4"); two of its results changed between releases:
+ *   0                    OpenCV 4.0 - 4.5.0: 15-bit BGR2GRAY coefficients, minAreaRect angle in [-90, 0)
+ *   YSMR_CV_ANGLE_451    OpenCV >= 4.5.1: minAreaRect reports the same rectangle with its angle in (0, 90] and
+ *                        width / height named the other way round (axis-aligned: 90 instead of -90)
+ *   YSMR_CV_GRAY_3X      OpenCV 3.x: 14-bit BGR2GRAY coefficients (1868 / 9617 / 4899); no effect on gray input
+ * (upstream-recollection, like the rest of the cv2 restatement: the image half is parity-unpinned) */
+#define YSMR_CV_ANGLE_451    1
+#define YSMR_CV_GRAY_3X      2
+#define YSMR_CV_FLAVOUR_MASK 3
 
 /* One output row: a live track in one frame (ysmr/track_eval.py:313-316,
  * CSV columns TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE). */
@@ -80,7 +91,7 @@ int ysmr_detect_workspace_init(void *stream, void *workspace_dev, size_t workspa
  * use_high = 0 reproduces "adaptive double threshold = 0": bit1 mirrors bit0. */
 int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
                          int channels, int inv, int t_low, int t_high, int use_high,
-                         uint8_t *cls_dev);
+                         uint8_t *cls_dev, int cv_flavour);
 
 /* The mean-gray threshold branch, taken by the reference when 'adaptive double threshold' < 0
  * (ysmr/track_eval.py:219-253): replaces cv2.meanStdDev(gray), the 5 s moving average of
@@ -101,7 +112,7 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
 size_t ysmr_mean_threshold_state_bytes(int window);
 int ysmr_mean_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
                               int channels, int inv, double offset, int window, void *state_dev,
-                              double *stats_dev, int32_t *levels_dev, uint8_t *cls_dev);
+                              double *stats_dev, int32_t *levels_dev, uint8_t *cls_dev, int cv_flavour);
 
 /* a4-a6 from a class map already in HBM (written by ysmr_threshold_batch or by the caller):
  * hysteresis + labelling + RETR_EXTERNAL ordering + minAreaRect.  Same outputs as
@@ -109,7 +120,7 @@ int ysmr_mean_threshold_batch(void *stream, const uint8_t *frames_dev, int batch
 int ysmr_components_batch(void *stream, int batch, int height, int width, void *workspace_dev,
                           size_t workspace_bytes, uint8_t *cls_dev, uint8_t *mask_dev,
                           int32_t *labels_dev, int32_t *det_count_dev, float *det_dev,
-                          int32_t *anchors_dev, int max_det, int32_t *status_dev);
+                          int32_t *anchors_dev, int max_det, int32_t *status_dev, int cv_flavour);
 
 /* a1-a6 = ysmr_threshold_batch followed by ysmr_components_batch.  Outputs (all device):
  *   cls_dev     u8  [batch][H][W]  class map as above (bit2 is used internally as a flag)
@@ -129,7 +140,8 @@ int ysmr_detect_batch(void *stream, const uint8_t *frames_dev, int batch, int he
                       int channels, int inv, int t_low, int t_high, int use_high,
                       void *workspace_dev, size_t workspace_bytes, uint8_t *cls_dev,
                       uint8_t *mask_dev, int32_t *labels_dev, int32_t *det_count_dev,
-                      float *det_dev, int32_t *anchors_dev, int max_det, int32_t *status_dev);
+                      float *det_dev, int32_t *anchors_dev, int max_det, int32_t *status_dev,
+                      int cv_flavour);
 
 /* ---- linking: a7-a19 -------------------------------------------------------------------- */
 

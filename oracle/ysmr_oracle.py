@@ -105,8 +105,16 @@ def gauss11():
     return k
 
 
-def bgr2gray(bgr):
+CV_ANGLE_451, CV_GRAY_3X = 1, 2     # cv_flavour bits (include/ysmr_hip.h)
+
+
+def bgr2gray(bgr, cv_flavour=0):
+    """cv2.cvtColor(BGR2GRAY) on u8: OpenCV 4.x 15-bit fixed point (the C restatement) or, with CV_GRAY_3X,
+    OpenCV 3.x's 14-bit coefficients (upstream-recollection)."""
     bgr = np.ascontiguousarray(bgr, np.uint8)
+    if cv_flavour & CV_GRAY_3X:
+        v = bgr.astype(np.int64)
+        return ((v[..., 0] * 1868 + v[..., 1] * 9617 + v[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
     h, w = bgr.shape[:2]
     out = np.empty((h, w), np.uint8)
     _c().yo_bgr2gray(_p(bgr, ctypes.c_uint8), h, w, _p(out, ctypes.c_uint8))
@@ -181,9 +189,30 @@ class FrameDetections:
     count: int
 
 
-def detect_frame(frame, inv=0, t_low=5, t_high=7, use_high=1, max_det=None) -> FrameDetections:
+def rect_convention(det, cv_flavour=0):
+    """cv2.minAreaRect's result as OpenCV >= 4.5.1 reports it (CV_ANGLE_451): the C restatement follows the
+    releases before, angle in [-90, 0); from 4.5.1 on the same rectangle has its angle in (0, 90] and width /
+    height named the other way round, an axis-aligned one 90 instead of -90 (upstream-
+    recollection; rectangles of 1 or 2 hull points, h == 0, are left as they are)."""
+    det = np.array(det, np.float32, copy=True)
+    if cv_flavour & CV_ANGLE_451 and len(det):
+        box = det[:, 3] > 0
+        axis = box & (det[:, 4] == np.float32(-90))
+        turn = box & ~axis
+        det[axis, 4] = 90
+        det[turn, 2], det[turn, 3] = det[turn, 3].copy(), det[turn, 2].copy()
+        det[turn, 4] = det[turn, 4] + np.float32(90)
+    return det
+
+
+def detect_frame(frame, inv=0, t_low=5, t_high=7, use_high=1, max_det=None, cv_flavour=0) -> FrameDetections:
     """The image half of one loop iteration (track_eval.py:180-303) on an (H,W) or (H,W,3) frame."""
     frame = np.ascontiguousarray(frame, np.uint8)
+    if cv_flavour:
+        gray = frame if frame.ndim == 2 else bgr2gray(frame, cv_flavour)
+        fd = detect_frame(gray, inv, t_low, t_high, use_high, max_det)
+        fd.det = rect_convention(fd.det, cv_flavour)
+        return fd
     h, w = frame.shape[:2]
     ch = 1 if frame.ndim == 2 else frame.shape[2]
     if max_det is None:

@@ -6,7 +6,8 @@ def _riff(fourcc, payload):
     return fourcc + len(payload).to_bytes(4, "little") + payload + (b"\0" if len(payload) & 1 else b"")
 
 
-def write_avi(path, frames, bits, fps=(30000, 1001), top_down=False, palette=None, split=None, jpeg=None):
+def write_avi(path, frames, bits, fps=(30000, 1001), top_down=False, palette=None, split=None, jpeg=None, dropped=(),
+              truncated=None):
     """Minimal AVI (uncompressed DIB frames, or the given JPEG blobs as Motion-JPEG): hdrl (avih, strl(strh, strf)), movi with 00db chunks (+ an audio chunk that
     must be skipped), optionally continued in a second RIFF AVIX."""
     import struct
@@ -26,6 +27,10 @@ def write_avi(path, frames, bits, fps=(30000, 1001), top_down=False, palette=Non
         bih += np.concatenate([pal, np.zeros((256, 1), np.uint8)], axis=1).tobytes()
     hdrl = b"hdrl" + _riff(b"avih", bytes(56)) + _riff(b"LIST", b"strl" + _riff(b"strh", strh) + _riff(b"strf", bih))
     chunks = [_riff(b"00db", dib(f)) for f in frames] if jpeg is None else [_riff(b"00dc", blob) for blob in jpeg]
+    for i in dropped:                                             # empty chunk = "repeat the previous frame"
+        chunks[i] = _riff(b"00db", b"")
+    if truncated is not None:
+        chunks[truncated] = _riff(b"00db", dib(frames[truncated])[:-8])
     chunks.insert(1, _riff(b"01wb", b"abc"))                      # odd-sized audio chunk in between
     split = n if split is None else split
     body = _riff(b"RIFF", b"AVI " + _riff(b"LIST", hdrl) + _riff(b"LIST", b"movi" + b"".join(chunks[:split + 1])))

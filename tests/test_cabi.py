@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ysmr_abi_version() == 4
+    assert lib.ysmr_abi_version() == int(re.search(r"#define YSMR_ABI_VERSION\s+(\d+)", header).group(1)) == 5
 
 
 def test_row_struct_layout():
@@ -39,12 +39,12 @@ def test_row_struct_layout():
 def test_workspace_size_and_bad_arguments(lib):
     assert lib.ysmr_detect_workspace_bytes(0, 10, 10, 10) == 0
     assert lib.ysmr_detect_workspace_bytes(4, 922, 1228, 2048) > 0
-    rc = lib.ysmr_threshold_batch(None, None, 1, 10, 10, 2, 0, 5, 7, 1, None)
+    rc = lib.ysmr_threshold_batch(None, None, 1, 10, 10, 2, 0, 5, 7, 1, None, 0)
     assert rc == 1 and b"channels" in lib.ysmr_last_error()
 
 
 def test_gsff_gains_closed_form_matches_reference_formula(lib):
-    from ysmr_amd.gsff import horizon_sizes, lsf_gain_rows
+    from oracle.ysmr_oracle import horizon_sizes, lsf_gain
     for fps, n_min, n_max, n_f in [(30.0, 0, 30.0, 3), (29.97, 0, -1.0, 3), (25.0, 4, 24.0, 4)]:
         n_i = (ctypes.c_int32 * n_f)()
         assert lib.ysmr_gsff_gains(fps, n_min, n_max, n_f, n_i, None) == 0
@@ -55,7 +55,7 @@ def test_gsff_gains_closed_form_matches_reference_formula(lib):
         assert lib.ysmr_gsff_gains(fps, n_min, n_max, n_f, n_i, gains.ctypes.data) == 0
         off = 0
         for n in expect:
-            np.testing.assert_allclose(gains[off:off + 4 * n].reshape(2, 2 * n), lsf_gain_rows(n, 1 / fps), atol=1e-12)
+            np.testing.assert_allclose(gains[off:off + 4 * n].reshape(2, 2 * n), lsf_gain(n, 1 / fps)[:2], atol=1e-12)
             off += 4 * n
     n_i = (ctypes.c_int32 * 3)()
     assert lib.ysmr_gsff_gains(30.0, 0, 2.0, 3, n_i, None) == 1      # horizons [0,1,2]: rejected

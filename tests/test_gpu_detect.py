@@ -295,9 +295,9 @@ def test_mean_gray_bad_arguments(torch_cuda):
     from ysmr_amd import _lib
     L = _lib.lib()
     assert L.ysmr_mean_threshold_state_bytes(0) == 0 and L.ysmr_mean_threshold_state_bytes(151) == 151 * 8 + 8
-    rc = L.ysmr_mean_threshold_batch(None, None, 1, 8, 8, 1, 0, 5.0, 0, None, None, None, None)
+    rc = L.ysmr_mean_threshold_batch(None, None, 1, 8, 8, 1, 0, 5.0, 0, None, None, None, None, 0)
     assert rc == 1 and b"window" in L.ysmr_last_error()
-    rc = L.ysmr_mean_threshold_batch(None, None, 1, 8, 8, 1, 0, 5.0, 3, None, None, None, None)
+    rc = L.ysmr_mean_threshold_batch(None, None, 1, 8, 8, 1, 0, 5.0, 3, None, None, None, None, 0)
     assert rc == 1 and b"NULL" in L.ysmr_last_error()
 
 
@@ -380,5 +380,117 @@ def test_detect_extreme_aspect_ratios(torch_cuda, oracle):
     from ysmr_amd import _lib
     L = _lib.lib()
     assert L.ysmr_detect_workspace_bytes(1, 16385, 8, 8) > 0          # (the size query does not validate ...)
-    rc = L.ysmr_threshold_batch(None, None, 1, 16385, 8, 1, 0, 5, 7, 1, None)
+    rc = L.ysmr_threshold_batch(None, None, 1, 16385, 8, 1, 0, 5, 7, 1, None, 0)
     assert rc == 1 and b"16384" in L.ysmr_last_error()                 # ... the calls do
+
+
+def test_detection_writes_stay_inside_their_buffers(torch_cuda, oracle):
+    """Every output and the workspace carved out of ONE allocation with guard bands between them: no kernel
+    of the chain may write outside the buffer it was given.  The geometries are the ones in which an index
+    can run past an end: more foreground than the pixel list holds (count > cap: the passes walk every
+    pixel), a batch whose size is neither a multiple of 16 (last class-map chunk) nor of 4 (dword-wide mask
+    clears at the tail), frames that are not a multiple of 16 pixels (chunks straddling two frames), a
+    second call on the same buffers (list-driven clearing), and max_det smaller than the component count.
+    (Round 1 recorded one unexplained GPU memory fault in an uncommitted intermediate state of these passes,
+    gpurun_out/prof_v17.log; this is the test that guards the candidates: DESIGN.md section 9.)"""
+    import ctypes
+    torch = torch_cuda
+    from ysmr_amd import _lib
+    L = _lib.lib()
+    GUARD, FILL = 4096, 0xA5
+    rng = np.random.default_rng(11)
+
+    def run(b, h, w, max_det, maps, from_frames):
+        n = b * h * w
+        ws_bytes = L.ysmr_detect_workspace_bytes(b, h, w, max_det)
+        sizes = {"frames": n, "cls": n, "mask": n, "labels": 4 * n, "det_count": 4 * b, "det": 20 * b * max_det,
+                 "anchors": 4 * b * max_det, "status": 4 * b, "ws": ws_bytes}
+        off, pos = {}, GUARD
+        for k, sz in sizes.items():
+            off[k] = pos
+            pos = (pos + sz + GUARD + 255) // 256 * 256
+        arena = torch.full((pos,), FILL, dtype=torch.uint8, device="cuda")
+        base = arena.data_ptr()
+        assert base % 256 == 0
+        ptr = {k: base + o for k, o in off.items()}
+        for k in ("labels", "mask", "det_count", "det", "anchors", "status"):   # (what a caller's torch.zeros would hold)
+            arena[off[k]:off[k] + sizes[k]] = 0
+        st = _lib.stream_ptr()
+        _lib.check(L.ysmr_detect_workspace_init(st, ptr["ws"], ws_bytes), "ws init")
+        for m in maps:
+            key = "frames" if from_frames else "cls"
+            arena[off[key]:off[key] + n] = torch.from_numpy(np.ascontiguousarray(m).reshape(-1)).cuda()
+            if from_frames:
+                rc = L.ysmr_detect_batch(st, ptr["frames"], b, h, w, 1, 0, 5, 7, 1, ptr["ws"], ws_bytes, ptr["cls"], ptr["mask"],
+                                         ptr["labels"], ptr["det_count"], ptr["det"], ptr["anchors"], max_det, ptr["status"], 0)
+            else:
+                rc = L.ysmr_components_batch(st, b, h, w, ptr["ws"], ws_bytes, ptr["cls"], ptr["mask"], ptr["labels"],
+                                             ptr["det_count"], ptr["det"], ptr["anchors"], max_det, ptr["status"], 0)
+            _lib.check(rc, "detect")
+            torch.cuda.synchronize()
+            host = arena.cpu().numpy()
+            inside = np.zeros(len(host), bool)
+            for k, sz in sizes.items():
+                inside[off[k]:off[k] + sz] = True
+            bad = np.flatnonzero(~inside & (host != FILL))
+            owner = lambda i: max((k for k in off if off[k] <= i), key=lambda k: off[k], default="(front guard)")  # noqa: E731
+            assert len(bad) == 0, f"{len(bad)} guard bytes overwritten, first at +{bad[0] - off.get(owner(bad[0]), 0)} after '{owner(bad[0])}' ({b}x{h}x{w})"
+            labels = host[off["labels"]:off["labels"] + 4 * n].view(np.int32).reshape(b, h, w)
+            mask = host[off["mask"]:off["mask"] + n].reshape(b, h, w)
+            cls = host[off["cls"]:off["cls"] + n].reshape(b, h, w)
+            for f in range(b):                         # and the result is still the oracle's
+                want = oracle.propagate(cls[f] & 3)
+                np.testing.assert_array_equal(mask[f], want)
+                np.testing.assert_array_equal(labels[f] != 0, want != 0)
+
+    dense = lambda b, h, w: rng.choice(np.array([0, 1, 3], np.uint8), size=(b, h, w), p=[0.4, 0.3, 0.3])   # noqa: E731
+    sparse = lambda b, h, w: rng.choice(np.array([0, 1, 3], np.uint8), size=(b, h, w), p=[0.97, 0.02, 0.01])  # noqa: E731
+    run(3, 7, 13, 64, [dense(3, 7, 13), sparse(3, 7, 13), dense(3, 7, 13)], False)        # total 273: % 16 = 1, % 4 = 1
+    run(5, 3, 5, 8, [dense(5, 3, 5), dense(5, 3, 5)], False)                               # frames of 15 px, max_det overflow
+    run(2, 33, 36, 16, [sparse(2, 33, 36), sparse(2, 33, 36), dense(2, 33, 36), sparse(2, 33, 36)], False)
+    from ysmr_amd.synth import SyntheticVideo
+    v = SyntheticVideo(50, 68, 10, seed=2)
+    run(3, 50, 68, 32, [v.frames(3), v.frames(3), rng.integers(0, 256, (3, 50, 68), dtype=np.uint8)], True)
+    run(2, 9, 23, 32, [rng.integers(0, 256, (2, 9, 23), dtype=np.uint8)] * 2, True)       # tile kernel (W % 4 != 0)
+
+
+@pytest.mark.parametrize("version,flags", [("4.5.0", 0), ("4.10.0", 1), ("3.4.18", 2)])
+def test_opencv_flavours(torch_cuda, oracle, version, flags):
+    """cv_flavour: OpenCV 3.x BGR2GRAY coefficients and the minAreaRect convention of OpenCV >= 4.5.1, selected
+    by the optional settings key 'opencv version' -- HIP vs the oracle's statement of the same conventions
+    (adaptive and mean-gray branch, strip and tile kernels)."""
+    from ysmr_amd import _lib
+    from ysmr_amd.detect import Detector, mean_gray_params, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    torch = torch_cuda
+    assert _lib.cv_flavour_of(version) == flags and _lib.cv_flavour_of(None) == 0 and _lib.cv_flavour_of("4.5.1") == 1
+    rng = np.random.default_rng(5)
+    for (h, w) in ((96, 132), (50, 71)):
+        gray = SyntheticVideo(h, w, 14, seed=w).frames(2)
+        tint = rng.uniform(0.5, 1.0, (1, 1, 1, 3))
+        frames = np.clip(gray[..., None] * tint + rng.integers(0, 9, gray.shape + (3,)), 0, 255).astype(np.uint8)
+        p = threshold_params(True, 5, 2.0)
+        d = Detector(2, h, w, max_det=256, params=p, cv_flavour=version)
+        res = d.detect(torch.from_numpy(frames).cuda())
+        torch.cuda.synchronize()
+        for f in range(2):
+            ref = oracle.detect_frame(frames[f], p.inv, p.t_low, p.t_high, p.use_high, 256, cv_flavour=flags)
+            np.testing.assert_array_equal(res.mask[f].cpu().numpy(), ref.mask)
+            n = ref.count
+            assert int(res.det_count[f]) == n and n > 5
+            got = res.det[f, :n].cpu().numpy()
+            np.testing.assert_array_equal(got[:, :4], ref.det[:, :4])
+            _assert_angle_close(got[:, 4], ref.det[:, 4])
+            if flags & 1:
+                boxes = got[:, 3] > 0
+                assert boxes.any() and np.all((got[boxes, 4] > 0) & (got[boxes, 4] <= 90))
+        # mean-gray branch: the statistics are taken over the converted frame
+        mp = mean_gray_params(True, 5, 30.0)
+        d = Detector(2, h, w, max_det=256, params=mp, cv_flavour=version)
+        d.threshold(torch.from_numpy(frames).cuda())
+        lv = oracle.MeanGrayLevels(30.0, True, 5)
+        for f in range(2):
+            _, mean, sd, _ = lv.step(oracle.bgr2gray(frames[f], flags))
+            assert d.mean_stats[f, 0].item() == mean and d.mean_stats[f, 1].item() == sd
+    with pytest.raises(_lib.YsmrLibraryError):
+        Detector(1, 8, 8, cv_flavour=8).threshold(torch.zeros(1, 8, 8, dtype=torch.uint8, device="cuda"))

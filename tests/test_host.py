@@ -282,6 +282,19 @@ def test_uncompressed_avi_reader(tmp_path):
     (tmp_path / "bad.avi").write_bytes(b"RIFF" + bytes(60))
     with pytest.raises(OSError):                                          # not readable natively and no OpenCV here
         open_video(str(tmp_path / "bad.avi"))
+    # an empty chunk is a dropped frame: the previous frame again, still one frame slot (frame numbers keep
+    # their alignment with what cv2.VideoCapture delivers); a short chunk is an error, not a skipped frame
+    _write_avi(tmp_path / "d.avi", gray, 8, dropped=(3, 4, 8))
+    v = open_video(str(tmp_path / "d.avi"))
+    assert v.frame_count == 9
+    np.testing.assert_array_equal(v.read(0, 9), gray[[0, 1, 2, 2, 2, 5, 6, 7, 7]])
+    _write_avi(tmp_path / "s.avi", gray, 8, truncated=5)
+    with pytest.raises(ValueError, match="chunk 5"):
+        AviVideo(str(tmp_path / "s.avi"))
+    import gc, warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", ResourceWarning)                   # the failed constructor closed its file
+        gc.collect()
 
 
 def test_select_tracks_argument_checks(tmp_path, caplog):

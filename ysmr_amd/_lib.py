@@ -17,6 +17,23 @@ LIB_PATH = os.environ.get("YSMR_HIP_LIB") or os.path.join(_HERE, "csrc", "libysm
 YSMR_OK = 0
 DET_OVERFLOW = 1
 DET_ARENA = 2
+#: ``cv_flavour`` bits (include/ysmr_hip.h): which OpenCV release the a1 / a6 arithmetic follows
+CV_DEFAULT, CV_ANGLE_451, CV_GRAY_3X = 0, 1, 2
+
+
+def cv_flavour_of(version):
+    """``cv_flavour`` for an OpenCV version string ('3.4.18', '4.5.0', '4.10.0', ...) or None (the default,
+    OpenCV 4.0 - 4.5.0).  Also accepts the flag value itself."""
+    if version is None or version is False:
+        return CV_DEFAULT
+    if isinstance(version, int):
+        return version
+    parts = [int("".join(ch for ch in p if ch.isdigit()) or 0) for p in str(version).split(".")[:3]]
+    parts += [0] * (3 - len(parts))
+    flags = CV_GRAY_3X if parts[0] < 4 else 0
+    if tuple(parts) >= (4, 5, 1):
+        flags |= CV_ANGLE_451
+    return flags
 
 #: numpy view of ``struct ysmr_row`` (40 bytes)
 ROW_DTYPE = np.dtype([("frame", "<i4"), ("track_id", "<i4"), ("x", "<f8"), ("y", "<f8"),
@@ -81,13 +98,13 @@ def lib():
     L.ysmr_detect_workspace_bytes.argtypes = [ci, ci, ci, ci]
     L.ysmr_detect_workspace_bytes.restype = ctypes.c_size_t
     L.ysmr_detect_workspace_init.argtypes = [vp, vp, ctypes.c_size_t]
-    L.ysmr_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.ysmr_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci]
     L.ysmr_mean_threshold_state_bytes.argtypes = [ci]
     L.ysmr_mean_threshold_state_bytes.restype = ctypes.c_size_t
-    L.ysmr_mean_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, vp, vp, vp, vp]
-    L.ysmr_components_batch.argtypes = [vp, ci, ci, ci, vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, ci, vp]
+    L.ysmr_mean_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, vp, vp, vp, vp, ci]
+    L.ysmr_components_batch.argtypes = [vp, ci, ci, ci, vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, ci, vp, ci]
     L.ysmr_detect_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, vp, vp,
-                                    vp, vp, vp, ci, vp]
+                                    vp, vp, vp, ci, vp, ci]
     L.ysmr_gsff_gains.argtypes = [cd, ci, cd, ci, vp, vp]
     L.ysmr_tracker_create.argtypes = [cd, cd, ci, cd, ci, ci, ci, ci, vp, ctypes.POINTER(vp)]
     L.ysmr_tracker_destroy.argtypes = [vp]

@@ -51,7 +51,7 @@ template <int CH>
 __global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ frames,
                                                    uint8_t *__restrict__ cls, int H, int W,
                                                    Gauss11 gk, int inv, int t_low, int t_high,
-                                                   int use_high)
+                                                   int use_high, ysmr::GrayCoef gc)
 {
     __shared__ uint8_t s_gray[GH][GW + 4];
     __shared__ uint8_t s_blur[BH][BW + 2];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ f
                 v = src[(size_t)gy * W + gx];
             } else {
                 const uint8_t *p = src + ((size_t)gy * W + gx) * 3;
-                v = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + 16384) >> 15);
+                v = (uint8_t)bgr2gray(gc, p[0], p[1], p[2]);
             }
         }
         s_gray[r][c] = v;
@@ -147,6 +147,7 @@ struct StripParams {
     int seg_h;         // output rows per wave
     int segs_y;
     int inv, t_low, t_high;
+    ysmr::GrayCoef gc; // BGR input only
 };
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -202,6 +203,7 @@ struct StripCtx {
     bool writes;
     float sgn, k_lo, k_hi;   // class bit = clamp(sgn * (s - m) + k, 0, 1)
     float *xrow;             // this wave's LDS exchange row (with 8 floats of slack on each side)
+    ysmr::GrayCoef gc;
 };
 
 // The 4 pixels of `row` held by this lane, as loaded (lanes outside the image load a clamped, valid
@@ -220,17 +222,13 @@ __device__ __forceinline__ RawRow<CH> load_row(const StripCtx &c, int row)
     if constexpr (CH == 3) { r.w1 = load_u32_unaligned(p + 4); r.w2 = load_u32_unaligned(p + 8); }
     return r;
 }
-__device__ __forceinline__ uint32_t bgr2gray15(uint32_t b, uint32_t g, uint32_t r)
+__device__ __forceinline__ uint32_t gray_of(const StripCtx &, const RawRow<1> &r) { return r.w0; }
+__device__ __forceinline__ uint32_t gray_of(const StripCtx &c, const RawRow<3> &r)
 {
-    return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15;   // cv2 COLOR_BGR2GRAY, 15-bit fixed point (a1)
-}
-__device__ __forceinline__ uint32_t gray_of(const RawRow<1> &r) { return r.w0; }
-__device__ __forceinline__ uint32_t gray_of(const RawRow<3> &r)
-{
-    const uint32_t g0 = bgr2gray15(r.w0 & 0xFFu, (r.w0 >> 8) & 0xFFu, (r.w0 >> 16) & 0xFFu);
-    const uint32_t g1 = bgr2gray15(r.w0 >> 24, r.w1 & 0xFFu, (r.w1 >> 8) & 0xFFu);
-    const uint32_t g2 = bgr2gray15((r.w1 >> 16) & 0xFFu, r.w1 >> 24, r.w2 & 0xFFu);
-    const uint32_t g3 = bgr2gray15((r.w2 >> 8) & 0xFFu, (r.w2 >> 16) & 0xFFu, r.w2 >> 24);
+    const uint32_t g0 = bgr2gray(c.gc, r.w0 & 0xFFu, (r.w0 >> 8) & 0xFFu, (r.w0 >> 16) & 0xFFu);
+    const uint32_t g1 = bgr2gray(c.gc, r.w0 >> 24, r.w1 & 0xFFu, (r.w1 >> 8) & 0xFFu);
+    const uint32_t g2 = bgr2gray(c.gc, (r.w1 >> 16) & 0xFFu, r.w1 >> 24, r.w2 & 0xFFu);
+    const uint32_t g3 = bgr2gray(c.gc, (r.w2 >> 8) & 0xFFu, (r.w2 >> 16) & 0xFFu, r.w2 >> 24);
     return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
 }
 
@@ -274,8 +272,8 @@ __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
     {   // prologue: window for the first blurred row, and the rows in flight
         const int rbc = YEDGE ? clampi(rb_lo, 0, H - 1) : rb_lo;
         const int ru = YEDGE ? reflect101(rbc - 1, H) : rbc - 1;
-        hc = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, ru))));      // becomes hu after the first slide
-        hd = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, rbc))));     // becomes hc
+        hc = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, ru))));      // becomes hu after the first slide
+        hd = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, rbc))));     // becomes hc
         hu = hc;
         ic = ru; id = rbc;
 #pragma unroll
@@ -295,11 +293,11 @@ __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
                 const int ru = reflect101(rbc - 1, H), rd = reflect101(rbc + 1, H);
                 if (ic == ru && id == rbc) {          // steady state: slide down one row
                     hu = hc; hc = hd; ic = id;
-                    hd = hsum4(patch_row<XEDGE>(c, gray_of(gq[0])));
+                    hd = hsum4(patch_row<XEDGE>(c, gray_of(c, gq[0])));
                 } else {                              // border rows: rebuild the window
-                    hu = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, ru))));
-                    hc = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, rbc))));
-                    hd = hsum4(patch_row<XEDGE>(c, gray_of(load_row<CH>(c, rd))));
+                    hu = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, ru))));
+                    hc = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, rbc))));
+                    hd = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, rd))));
                     ic = rbc;
                 }
                 id = rd;
@@ -308,7 +306,7 @@ __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
                 gq[STRIP_PF - 1] = load_row<CH>(c, reflect101(clampi(rb + STRIP_PF, 0, H - 1) + 1, H));
             } else {
                 hu = hc; hc = hd;
-                hd = hsum4(patch_row<XEDGE>(c, gray_of(gq[0])));
+                hd = hsum4(patch_row<XEDGE>(c, gray_of(c, gq[0])));
 #pragma unroll
                 for (int d = 0; d + 1 < STRIP_PF; ++d) gq[d] = gq[d + 1];
                 gq[STRIP_PF - 1] = load_row<CH>(c, rb + STRIP_PF + 1);
@@ -417,7 +415,7 @@ __global__ __launch_bounds__(256, CH == 1 ? 4 : 3) void k_threshold_strip(const 
     const int rem = (int)(wave - (long long)f * per_frame);
     const int sx = rem % P.strips_x, sy = rem / P.strips_x;
     StripCtx c;
-    c.H = P.H; c.W = P.W; c.lane = lane;
+    c.H = P.H; c.W = P.W; c.lane = lane; c.gc = P.gc;
 #if STRIP_LDS_EXCHANGE
     c.xrow = s_x[wave_in_block] + 8;
 #else
@@ -1388,7 +1386,7 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
 // Drop nested components, write final detection list / count / anchors.
 __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__restrict__ det_tmp, float *det,
                                                  int32_t *det_count, int32_t *anchors, PixelList pl, const uint8_t *labels,
-                                                 const uint8_t *mask, size_t total)
+                                                 const uint8_t *mask, size_t total, bool angle_451)
 {
     DET_RING(14);
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // last kernel of the call: the current list describes these buffers
@@ -1420,7 +1418,16 @@ __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__re
         int pos = s_base + s_scan[threadIdx.x] - keep;
         if (keep) {
             size_t q = (size_t)f * t.max_det + pos;
-            for (int j = 0; j < 5; ++j) det[q * 5 + j] = det_tmp[o * 5 + j];
+            float r[5];
+            for (int j = 0; j < 5; ++j) r[j] = det_tmp[o * 5 + j];
+            // k_geometry reports cv::minAreaRect's convention of OpenCV < 4.5.1: angle in [-90, 0).  From 4.5.1
+            // on the same rectangle is reported with its angle in (0, 90] and the sides named the other way
+            // round (YSMR_CV_ANGLE_451; only rectangles from the rotating calipers, i.e. with two non-zero sides)
+            if (angle_451 && r[3] > 0.f) {
+                if (r[4] == -90.f) r[4] = 90.f;
+                else { const float w = r[2]; r[2] = r[3]; r[3] = w; r[4] += 90.f; }
+            }
+            for (int j = 0; j < 5; ++j) det[q * 5 + j] = r[j];
             if (anchors) anchors[q] = t.order[o];
         }
         __syncthreads();
@@ -1499,25 +1506,31 @@ int check_geometry(int batch, int H, int W, int channels, int max_det)
     return YSMR_OK;
 }
 
-// Tuning knobs (environment, read once per process): resident grid sizes of the detection kernels
-// and the strip kernel's segment height.  Values <= 0 or unset keep the defaults.
+// Tuning knobs: resident grid sizes of the detection kernels and the strip kernel's segment height; values
+// <= 0 keep the defaults.  The shipped library has none (a drop-in library does not read its caller's
+// environment); a build with EXTRA=-DYSMR_TUNING reads them once per process for the sweeps in scripts/.
 struct Knobs {
     int seg_h, thr_blocks, collect_blocks, sparse_blocks, clear_blocks, geo_blocks;
 };
 const Knobs &knobs()
 {
+#ifdef YSMR_TUNING
     static const Knobs k = [] {
         auto get = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
         return Knobs{get("YSMR_SEG_H"), get("YSMR_THR_BLOCKS"), get("YSMR_COLLECT_BLOCKS"), get("YSMR_SPARSE_BLOCKS"),
                      get("YSMR_CLEAR_BLOCKS"), get("YSMR_GEO_BLOCKS")};
     }();
+#else
+    static const Knobs k = {0, 0, 0, 0, 0, 0};
+#endif
     return k;
 }
 
 int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, int W, int channels, int inv, int t_low,
-                     int t_high, int use_high, uint8_t *cls)
+                     int t_high, int use_high, uint8_t *cls, int cv_flavour)
 {
     Gauss11 gk = make_gauss11();
+    const ysmr::GrayCoef gc = ysmr::gray_coef(cv_flavour);
     if ((W & 3) == 0 && W >= 16 && H >= 2 && t_low > -100000 && t_low < 100000 && t_high > -100000 && t_high < 100000) {
         StripParams P;
         P.H = H; P.W = W; P.batch = batch;
@@ -1527,7 +1540,7 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
         P.seg_h = 45;   // rows per work item (+10 halo rows = 5 x 11 ring rotations; 2.6 items per resident wave)
         if (knobs().seg_h > 0) P.seg_h = knobs().seg_h;
         P.segs_y = (H + P.seg_h - 1) / P.seg_h;
-        P.inv = inv; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
+        P.inv = inv; P.t_low = t_low; P.t_high = use_high ? t_high : t_low; P.gc = gc;
         const long long waves = (long long)batch * P.strips_x * P.segs_y;
         long long blocks = (waves + 3) / 4;
         int resident = channels == 1 ? 768 : 512;   // 3 (gray, 128 VGPRs) / 2 (BGR, ~140 VGPRs) blocks per CU: a wave slot and
@@ -1539,9 +1552,9 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
     } else {
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, batch);
         if (channels == 1)
-            hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high);
+            hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high, gc);
         else
-            hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high);
+            hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high, gc);
     }
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
@@ -1565,19 +1578,21 @@ int ysmr_detect_workspace_init(void *stream, void *workspace_dev, size_t workspa
 }
 
 int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels,
-                         int inv, int t_low, int t_high, int use_high, uint8_t *cls_dev)
+                         int inv, int t_low, int t_high, int use_high, uint8_t *cls_dev, int cv_flavour)
 {
     if (int rc = check_geometry(batch, height, width, channels, 1)) return rc;
     if (!frames_dev || !cls_dev) return ysmr::fail(YSMR_ERR_ARG, "frames_dev and cls_dev must not be NULL");
+    if (cv_flavour & ~YSMR_CV_FLAVOUR_MASK) return ysmr::fail(YSMR_ERR_ARG, "unknown cv_flavour bits 0x%x", cv_flavour);
     return launch_threshold((hipStream_t)stream, frames_dev, batch, height, width, channels, inv, t_low, t_high,
-                            use_high, cls_dev);
+                            use_high, cls_dev, cv_flavour);
 }
 
 int ysmr_components_batch(void *stream, int batch, int height, int width, void *workspace_dev, size_t workspace_bytes,
                           uint8_t *cls_dev, uint8_t *mask_dev, int32_t *labels_dev, int32_t *det_count_dev,
-                          float *det_dev, int32_t *anchors_dev, int max_det, int32_t *status_dev)
+                          float *det_dev, int32_t *anchors_dev, int max_det, int32_t *status_dev, int cv_flavour)
 {
     if (int rc = check_geometry(batch, height, width, 1, max_det)) return rc;
+    if (cv_flavour & ~YSMR_CV_FLAVOUR_MASK) return ysmr::fail(YSMR_ERR_ARG, "unknown cv_flavour bits 0x%x", cv_flavour);
     if (!cls_dev || !labels_dev || !det_count_dev || !det_dev || !status_dev || !workspace_dev)
         return ysmr::fail(YSMR_ERR_ARG, "a required device pointer is NULL");
     if (((uintptr_t)cls_dev & 15) || ((uintptr_t)labels_dev & 15) || (mask_dev && ((uintptr_t)mask_dev & 15)))
@@ -1620,7 +1635,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     hipLaunchKernelGGL(k_geometry, dim3(geo_blocks), dim3(GEO_THREADS), 0, st,
                        labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
     hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev, w.pixels,
-                       reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total);
+                       reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total, (cv_flavour & YSMR_CV_ANGLE_451) != 0);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }
@@ -1628,13 +1643,13 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
 int ysmr_detect_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels, int inv,
                       int t_low, int t_high, int use_high, void *workspace_dev, size_t workspace_bytes,
                       uint8_t *cls_dev, uint8_t *mask_dev, int32_t *labels_dev, int32_t *det_count_dev, float *det_dev,
-                      int32_t *anchors_dev, int max_det, int32_t *status_dev)
+                      int32_t *anchors_dev, int max_det, int32_t *status_dev, int cv_flavour)
 {
     if (int rc = ysmr_threshold_batch(stream, frames_dev, batch, height, width, channels, inv, t_low, t_high, use_high,
-                                      cls_dev))
+                                      cls_dev, cv_flavour))
         return rc;
     return ysmr_components_batch(stream, batch, height, width, workspace_dev, workspace_bytes, cls_dev, mask_dev,
-                                 labels_dev, det_count_dev, det_dev, anchors_dev, max_det, status_dev);
+                                 labels_dev, det_count_dev, det_dev, anchors_dev, max_det, status_dev, cv_flavour);
 }
 
 }  // extern "C"

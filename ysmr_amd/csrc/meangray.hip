@@ -39,29 +39,25 @@ __device__ __forceinline__ uint32_t load_u32(const uint8_t *p)
     __builtin_memcpy(&v, p, 4);
     return v;
 }
-__device__ __forceinline__ uint32_t bgr2gray15(uint32_t b, uint32_t g, uint32_t r)
-{
-    return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15;   // cv2 COLOR_BGR2GRAY (a1)
-}
 // gray value of pixel p of a frame
 template <int CH>
-__device__ __forceinline__ uint32_t gray_at(const uint8_t *frame, uint32_t p)
+__device__ __forceinline__ uint32_t gray_at(const ysmr::GrayCoef &gc, const uint8_t *frame, uint32_t p)
 {
     if constexpr (CH == 1) return frame[p];
-    else return bgr2gray15(frame[3 * (size_t)p], frame[3 * (size_t)p + 1], frame[3 * (size_t)p + 2]);
+    else return bgr2gray(gc, frame[3 * (size_t)p], frame[3 * (size_t)p + 1], frame[3 * (size_t)p + 2]);
 }
 // the 4 gray pixels p .. p+3 (all inside the frame) packed into one dword
 template <int CH>
-__device__ __forceinline__ uint32_t gray4_at(const uint8_t *frame, uint32_t p)
+__device__ __forceinline__ uint32_t gray4_at(const ysmr::GrayCoef &gc, const uint8_t *frame, uint32_t p)
 {
     if constexpr (CH == 1) return load_u32(frame + p);
     else {
         const uint8_t *q = frame + 3 * (size_t)p;
         const uint32_t w0 = load_u32(q), w1 = load_u32(q + 4), w2 = load_u32(q + 8);
-        const uint32_t g0 = bgr2gray15(w0 & 0xFFu, (w0 >> 8) & 0xFFu, (w0 >> 16) & 0xFFu);
-        const uint32_t g1 = bgr2gray15(w0 >> 24, w1 & 0xFFu, (w1 >> 8) & 0xFFu);
-        const uint32_t g2 = bgr2gray15((w1 >> 16) & 0xFFu, w1 >> 24, w2 & 0xFFu);
-        const uint32_t g3 = bgr2gray15((w2 >> 8) & 0xFFu, (w2 >> 16) & 0xFFu, w2 >> 24);
+        const uint32_t g0 = bgr2gray(gc, w0 & 0xFFu, (w0 >> 8) & 0xFFu, (w0 >> 16) & 0xFFu);
+        const uint32_t g1 = bgr2gray(gc, w0 >> 24, w1 & 0xFFu, (w1 >> 8) & 0xFFu);
+        const uint32_t g2 = bgr2gray(gc, (w1 >> 16) & 0xFFu, w1 >> 24, w2 & 0xFFu);
+        const uint32_t g3 = bgr2gray(gc, (w2 >> 8) & 0xFFu, (w2 >> 16) & 0xFFu, w2 >> 24);
         return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
     }
 }
@@ -71,7 +67,7 @@ __device__ __forceinline__ uint32_t gray4_at(const uint8_t *frame, uint32_t p)
 // per 4 pixels (BGR), several in flight, ONE block reduction and one pair of atomics per step.
 template <int CH>
 __global__ __launch_bounds__(256) void k_gray_sums(const uint8_t *__restrict__ frames, uint32_t HW, int batch, int parts,
-                                                   unsigned long long *__restrict__ sums, int stride)
+                                                   unsigned long long *__restrict__ sums, int stride, ysmr::GrayCoef gc)
 {
     __shared__ unsigned long long s_part[2][4];
     const uint32_t span = ((HW + parts - 1) / parts + 15u) & ~15u;   // pixels per part
@@ -109,14 +105,14 @@ __global__ __launch_bounds__(256) void k_gray_sums(const uint8_t *__restrict__ f
 #pragma unroll 4
                 for (uint32_t i = threadIdx.x; i < n4; i += 256) {
                     uint32_t ps = 0, pq = 0;
-                    add4(gray4_at<CH>(frame, lo + 4u * i), ps, pq);
+                    add4(gray4_at<CH>(gc, frame, lo + 4u * i), ps, pq);
                     s += ps; q += pq;
                 }
             }
             const uint32_t ends = (body_lo - lo) + (hi - body_hi);   // < 32 pixels
             if (threadIdx.x < ends) {
                 const uint32_t e = threadIdx.x < body_lo - lo ? lo + threadIdx.x : body_hi + (threadIdx.x - (body_lo - lo));
-                const uint32_t v = gray_at<CH>(frame, e);
+                const uint32_t v = gray_at<CH>(gc, frame, e);
                 s += v; q += v * v;
             }
         }
@@ -214,7 +210,7 @@ __device__ __forceinline__ void hsum4(uint32_t g, uint32_t left, uint32_t right,
 // One thread: 4 adjacent columns x LEVEL_SEG rows, sliding a 3-row window of horizontal sums.
 template <int CH>
 __global__ __launch_bounds__(256) void k_level_threshold(const uint8_t *__restrict__ frames, uint8_t *__restrict__ cls,
-                                                         LevelGeo G, const int32_t *__restrict__ levels)
+                                                         LevelGeo G, const int32_t *__restrict__ levels, ysmr::GrayCoef gc)
 {
     const int H = G.H, W = G.W;
     const long long per_frame = (long long)G.groups_x * G.segs_y;
@@ -241,15 +237,15 @@ __global__ __launch_bounds__(256) void k_level_threshold(const uint8_t *__restri
                 const uint8_t *q = frame + (size_t)(base + c) * CH;
                 v.w0 = load_u32(q);
                 if constexpr (CH == 3) { v.w1 = load_u32(q + 4); v.w2 = load_u32(q + 8); }
-                v.left = gray_at<CH>(frame, base + c - 1);
-                v.right = gray_at<CH>(frame, base + c + 4);
+                v.left = gray_at<CH>(gc, frame, base + c - 1);
+                v.right = gray_at<CH>(gc, frame, base + c + 4);
             } else {
                 // border groups: columns beyond the image take their BORDER_REFLECT_101 source (columns
                 // that only exist as padding of a partial group are never stored)
                 for (int o = 0; o < 4; ++o)
-                    v.w0 |= gray_at<CH>(frame, base + border_index(c + o, W)) << (8 * o);
-                v.left = gray_at<CH>(frame, base + cl);
-                v.right = gray_at<CH>(frame, base + cr);
+                    v.w0 |= gray_at<CH>(gc, frame, base + border_index(c + o, W)) << (8 * o);
+                v.left = gray_at<CH>(gc, frame, base + cl);
+                v.right = gray_at<CH>(gc, frame, base + cr);
             }
             return v;
         };
@@ -257,10 +253,10 @@ __global__ __launch_bounds__(256) void k_level_threshold(const uint8_t *__restri
             uint32_t g = v.w0;
             if constexpr (CH == 3) {
                 if (inner) {
-                    const uint32_t g0 = bgr2gray15(v.w0 & 0xFFu, (v.w0 >> 8) & 0xFFu, (v.w0 >> 16) & 0xFFu);
-                    const uint32_t g1 = bgr2gray15(v.w0 >> 24, v.w1 & 0xFFu, (v.w1 >> 8) & 0xFFu);
-                    const uint32_t g2 = bgr2gray15((v.w1 >> 16) & 0xFFu, v.w1 >> 24, v.w2 & 0xFFu);
-                    const uint32_t g3 = bgr2gray15((v.w2 >> 8) & 0xFFu, (v.w2 >> 16) & 0xFFu, v.w2 >> 24);
+                    const uint32_t g0 = bgr2gray(gc, v.w0 & 0xFFu, (v.w0 >> 8) & 0xFFu, (v.w0 >> 16) & 0xFFu);
+                    const uint32_t g1 = bgr2gray(gc, v.w0 >> 24, v.w1 & 0xFFu, (v.w1 >> 8) & 0xFFu);
+                    const uint32_t g2 = bgr2gray(gc, (v.w1 >> 16) & 0xFFu, v.w1 >> 24, v.w2 & 0xFFu);
+                    const uint32_t g3 = bgr2gray(gc, (v.w2 >> 8) & 0xFFu, (v.w2 >> 16) & 0xFFu, v.w2 >> 24);
                     g = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
                 }
             }
@@ -326,7 +322,7 @@ __device__ __forceinline__ uint32_t wave_shl1(uint32_t v)   // value of lane+1 (
 
 template <int CH>
 __global__ __launch_bounds__(256) void k_level_strip(const uint8_t *__restrict__ frames, uint8_t *__restrict__ cls,
-                                                     LevelStrip P, const int32_t *__restrict__ levels)
+                                                     LevelStrip P, const int32_t *__restrict__ levels, ysmr::GrayCoef gc)
 {
     // everything derived from the wave index is wave-uniform: say so, or row counters end up in VGPRs
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -362,10 +358,10 @@ __global__ __launch_bounds__(256) void k_level_strip(const uint8_t *__restrict__
         auto row_sums = [&](const Raw &v, uint32_t &a, uint32_t &b) {
             uint32_t g = v.w0;
             if constexpr (CH == 3) {
-                const uint32_t g0 = bgr2gray15(v.w0 & 0xFFu, (v.w0 >> 8) & 0xFFu, (v.w0 >> 16) & 0xFFu);
-                const uint32_t g1 = bgr2gray15(v.w0 >> 24, v.w1 & 0xFFu, (v.w1 >> 8) & 0xFFu);
-                const uint32_t g2 = bgr2gray15((v.w1 >> 16) & 0xFFu, v.w1 >> 24, v.w2 & 0xFFu);
-                const uint32_t g3 = bgr2gray15((v.w2 >> 8) & 0xFFu, (v.w2 >> 16) & 0xFFu, v.w2 >> 24);
+                const uint32_t g0 = bgr2gray(gc, v.w0 & 0xFFu, (v.w0 >> 8) & 0xFFu, (v.w0 >> 16) & 0xFFu);
+                const uint32_t g1 = bgr2gray(gc, v.w0 >> 24, v.w1 & 0xFFu, (v.w1 >> 8) & 0xFFu);
+                const uint32_t g2 = bgr2gray(gc, (v.w1 >> 16) & 0xFFu, v.w1 >> 24, v.w2 & 0xFFu);
+                const uint32_t g3 = bgr2gray(gc, (v.w2 >> 8) & 0xFFu, (v.w2 >> 16) & 0xFFu, v.w2 >> 24);
                 g = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
             }
             if (left_edge) {    // column -1 (byte 3 of lane 0) := column 1 (byte 1 of lane 1)
@@ -435,8 +431,10 @@ size_t ysmr_mean_threshold_state_bytes(int window)
 
 int ysmr_mean_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels,
                               int inv, double offset, int window, void *state_dev, double *stats_dev,
-                              int32_t *levels_dev, uint8_t *cls_dev)
+                              int32_t *levels_dev, uint8_t *cls_dev, int cv_flavour)
 {
+    if (cv_flavour & ~YSMR_CV_FLAVOUR_MASK) return ysmr::fail(YSMR_ERR_ARG, "unknown cv_flavour bits 0x%x", cv_flavour);
+    const ysmr::GrayCoef gc = ysmr::gray_coef(cv_flavour);
     if (batch <= 0 || height <= 0 || width <= 0)
         return ysmr::fail(YSMR_ERR_ARG, "batch, height, width must be positive (got %d, %d, %d)", batch, height, width);
     if (channels != 1 && channels != 3) return ysmr::fail(YSMR_ERR_ARG, "channels must be 1 (gray) or 3 (BGR), got %d", channels);
@@ -457,8 +455,8 @@ int ysmr_mean_threshold_batch(void *stream, const uint8_t *frames_dev, int batch
     const long long sum_items = (long long)batch * parts;
     const unsigned sum_blocks = (unsigned)(sum_items < MG_BLOCKS ? sum_items : MG_BLOCKS);
     unsigned long long *sums = reinterpret_cast<unsigned long long *>(stats_dev);
-    if (channels == 1) hipLaunchKernelGGL(k_gray_sums<1>, dim3(sum_blocks), dim3(256), 0, st, frames_dev, HW, batch, parts, sums, 4);
-    else hipLaunchKernelGGL(k_gray_sums<3>, dim3(sum_blocks), dim3(256), 0, st, frames_dev, HW, batch, parts, sums, 4);
+    if (channels == 1) hipLaunchKernelGGL(k_gray_sums<1>, dim3(sum_blocks), dim3(256), 0, st, frames_dev, HW, batch, parts, sums, 4, gc);
+    else hipLaunchKernelGGL(k_gray_sums<3>, dim3(sum_blocks), dim3(256), 0, st, frames_dev, HW, batch, parts, sums, 4, gc);
     LevelState ls{reinterpret_cast<double *>(state_dev), reinterpret_cast<long long *>(reinterpret_cast<double *>(state_dev) + window)};
     hipLaunchKernelGGL(k_mean_levels, dim3(1), dim3(256), 0, st, stats_dev, batch, (double)HW, inv, offset, window, ls, levels_dev);
     if ((width & 3) == 0 && width >= 8 && (((uintptr_t)cls_dev | (uintptr_t)frames_dev) & 3) == 0) {
@@ -482,15 +480,15 @@ int ysmr_mean_threshold_batch(void *stream, const uint8_t *frames_dev, int batch
         const long long waves = columns * P.segs_y;
         const long long want = (waves + 3) / 4;
         const unsigned blocks = (unsigned)(want < resident ? want : resident);
-        if (channels == 1) hipLaunchKernelGGL(k_level_strip<1>, dim3(blocks), dim3(256), 0, st, frames_dev, cls_dev, P, levels_dev);
-        else hipLaunchKernelGGL(k_level_strip<3>, dim3(blocks), dim3(256), 0, st, frames_dev, cls_dev, P, levels_dev);
+        if (channels == 1) hipLaunchKernelGGL(k_level_strip<1>, dim3(blocks), dim3(256), 0, st, frames_dev, cls_dev, P, levels_dev, gc);
+        else hipLaunchKernelGGL(k_level_strip<3>, dim3(blocks), dim3(256), 0, st, frames_dev, cls_dev, P, levels_dev, gc);
     } else {
         LevelGeo G{height, width, batch, (width + 3) / 4, (height + LEVEL_SEG - 1) / LEVEL_SEG, inv};
         const long long thr_items = (long long)G.groups_x * G.segs_y * batch;
         const long long want = (thr_items + 255) / 256;
         const unsigned thr_blocks = (unsigned)(want < MG_BLOCKS ? want : MG_BLOCKS);
-        if (channels == 1) hipLaunchKernelGGL(k_level_threshold<1>, dim3(thr_blocks), dim3(256), 0, st, frames_dev, cls_dev, G, levels_dev);
-        else hipLaunchKernelGGL(k_level_threshold<3>, dim3(thr_blocks), dim3(256), 0, st, frames_dev, cls_dev, G, levels_dev);
+        if (channels == 1) hipLaunchKernelGGL(k_level_threshold<1>, dim3(thr_blocks), dim3(256), 0, st, frames_dev, cls_dev, G, levels_dev, gc);
+        else hipLaunchKernelGGL(k_level_threshold<3>, dim3(thr_blocks), dim3(256), 0, st, frames_dev, cls_dev, G, levels_dev, gc);
     }
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;

@@ -1608,7 +1608,11 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     t->set_base = false;
     t->base_ptr = nullptr;
     t->frame_lds = frame_lds_bytes(capacity, max_det, (int)gain_doubles);
-    const char *mode_env = getenv("YSMR_LINK_MODE");   // "split" forces the two-kernel path (tests)
+#ifdef YSMR_TUNING
+    const char *mode_env = getenv("YSMR_LINK_MODE");   // "split" forces the two-kernel path (tuning builds only)
+#else
+    const char *mode_env = nullptr;
+#endif
     // (max_det <= 2456: the LDS set model holds that many unregistered columns; the split path keeps its
     // tables in HBM and has no such limit)
     // (and a `gone` counter that fits the 15 bits k_frame packs it into)

@@ -110,8 +110,9 @@ class Detector:
     """Owns the output/scratch buffers for a fixed (batch, H, W, max_det) geometry."""
 
     def __init__(self, batch, height, width, max_det=2048, params: ThresholdParams | MeanGrayParams | None = None,
-                 device="cuda:0", want_mask=True, mean_state: MeanGrayState | None = None):
+                 device="cuda:0", want_mask=True, mean_state: MeanGrayState | None = None, cv_flavour=0):
         self.B, self.H, self.W, self.max_det = int(batch), int(height), int(width), int(max_det)
+        self.cv_flavour = _lib.cv_flavour_of(cv_flavour)   # which OpenCV release a1 / a6 follow (_lib.CV_*)
         self.params = params or threshold_params(True, 5, 2.0)
         self.device = torch.device(device)
         L = _lib.lib()
@@ -165,11 +166,11 @@ class Detector:
             rc = _lib.lib().ysmr_mean_threshold_batch(
                 _lib.stream_ptr(self.device), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.offset, p.window,
                 self.mean_state.buf.data_ptr(), self.mean_stats.data_ptr(), self.mean_levels.data_ptr(),
-                self._cls.data_ptr())
+                self._cls.data_ptr(), self.cv_flavour)
             _lib.check(rc, "ysmr_mean_threshold_batch")
             return self._view(self._cls, b)
         rc = _lib.lib().ysmr_threshold_batch(_lib.stream_ptr(self.device), frames.data_ptr(), b, self.H, self.W, ch,
-                                             p.inv, p.t_low, p.t_high, p.use_high, self._cls.data_ptr())
+                                             p.inv, p.t_low, p.t_high, p.use_high, self._cls.data_ptr(), self.cv_flavour)
         _lib.check(rc, "ysmr_threshold_batch")
         return self._view(self._cls, b)
 
@@ -184,7 +185,7 @@ class Detector:
             _lib.stream_ptr(self.device), b, self.H, self.W, self._ws.data_ptr(), self._ws.numel(), self._cls.data_ptr(),
             self._mask.data_ptr() if self._mask is not None else None, self._labels.data_ptr(),
             self.det_count.data_ptr(), self.det.data_ptr(), self.anchors.data_ptr(), self.max_det,
-            self.status.data_ptr())
+            self.status.data_ptr(), self.cv_flavour)
         _lib.check(rc, "ysmr_components_batch")
         return self._result(b)
 
@@ -207,6 +208,6 @@ class Detector:
             self._ws.data_ptr(), self._ws.numel(), self._cls.data_ptr(),
             self._mask.data_ptr() if self._mask is not None else None, self._labels.data_ptr(),
             self.det_count.data_ptr(), self.det.data_ptr(), self.anchors.data_ptr(), self.max_det,
-            self.status.data_ptr())
+            self.status.data_ptr(), self.cv_flavour)
         _lib.check(rc, "ysmr_detect_batch")
         return self._result(b)

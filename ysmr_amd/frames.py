@@ -136,9 +136,16 @@ class AviVideo:
     _RAW_GRAY = (b"Y800", b"GREY", b"Y8  ")
 
     def __init__(self, path, default_fps=30.0):
-        import struct
         self.path = path
         self._fh = open(path, "rb")
+        try:
+            self._parse(path, default_fps)
+        except BaseException:
+            self._fh.close()           # (open_video falls through to OpenCV on ValueError: do not leak the handle)
+            raise
+
+    def _parse(self, path, default_fps):
+        import struct
         fh = self._fh
         size = os.path.getsize(path)
         self.fps = float(default_fps)
@@ -181,8 +188,14 @@ class AviVideo:
                 body = pos + 8
                 if cid == b"LIST":                       # 'rec ' groups
                     walk_movi(body + 4, min(body + csz, end))
-                elif cid[:2] == b"00" and cid[2:] in (b"db", b"dc") and csz:
-                    self._frames.append((body, csz))
+                elif cid[:2] == b"00" and cid[2:] in (b"db", b"dc"):
+                    # an EMPTY chunk is AVI's "frame dropped by the capture, show the previous one again":
+                    # it still occupies a frame slot (cv2.VideoCapture delivers the repeated frame, so
+                    # POSITION_T and the frame count stay aligned with the reference)
+                    if csz:
+                        self._frames.append((body, csz))
+                    elif self._frames:
+                        self._frames.append(self._frames[-1])
                 pos = body + csz + (csz & 1)
 
         if fh.read(4) != b"RIFF":
@@ -223,7 +236,9 @@ class AviVideo:
                 full[:len(pal)] = pal
                 self._lut, self.channels = full, 3
         need = self._stride * self.height
-        self._frames = [f for f in self._frames if f[1] >= need]
+        short = [i for i, f in enumerate(self._frames) if f[1] < need]
+        if short:      # dropping them silently would shift every later frame number
+            raise ValueError(f"{path}: video chunk {short[0]} holds {self._frames[short[0]][1]} bytes, a frame needs {need}")
         self.frame_count = len(self._frames)
 
     def read(self, start, count):

@@ -1,47 +1,39 @@
-"""Gaussian-sum FIR filter (Pak 2019) -- host-side set-up and the reference-compatible class.
+"""Gaussian-sum FIR filter (Pak 2019) -- the reference-compatible class over the device filter.
 
-Set-up (``horizon_sizes``, ``lsf_gain``) runs once per tracker on the host and follows
-``GaussianSumFIR.generate_n_i`` / ``compute_lsf_gain`` (ysmr/gsff.py:87-153) so that the device
-kernels are handed the very coefficients the reference would use.  The per-measurement arithmetic
-(``correct`` / ``predict``, gsff.py:204-347) runs in ``csrc/track.hip`` (``gsff_step``): inside the
-tracker for the hot path, and through a one-track device tracker for this stand-alone class.
+Horizons and least-squares gains come from the library (``ysmr_gsff_gains``, ``csrc/track.hip``): for the
+constant-velocity model the reference always uses (gsff.py:111-126), rows 0/1 of ``(L^T L)^-1 L^T`` are the
+closed form c_N[j] = 1/N + t_j ((N + 1) / 2) / sum t^2, t_j = j - (N - 1)/2, exactly decoupled in x and y;
+it agrees with the reference's NumPy/LAPACK evaluation to 4e-16 (tests/test_cabi.py compares it with the
+oracle's restatement of gsff.py:87-153).  The per-measurement arithmetic (``correct`` / ``predict``,
+gsff.py:204-347) runs in ``csrc/track.hip`` (``gsff_step``): inside the tracker for the hot path, and
+through a one-track device tracker for this stand-alone class.
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 
-__all__ = ["GaussianSumFIR", "horizon_sizes", "lsf_gain", "lsf_gain_rows"]
+from . import _lib
+
+__all__ = ["GaussianSumFIR", "horizons_and_gains"]
 
 
-def horizon_sizes(n_min=0, n_max=30, n_f=3):
-    """Filter horizons N_i = int(n_min + i * (n_max - n_min) / n_f), i = 1..n_f (Pak eq. 17;
-    gsff.py:87-109).  With the defaults: [10, 20, 30]; with n_max = 29.97 fps: [9, 19, 29]."""
-    step = (n_max - n_min) / n_f
-    return [int(n_min + step * k) for k in range(1, n_f + 1)]
-
-
-def lsf_gain(size, delta_t, a=None, c=None):
-    """Least-squares FIR gain (L^T L)^-1 L^T, L = [C; CA; ..; CA^(N-1)] A^-N (Pak eqs. 13-14;
-    gsff.py:111-153).  Shape (4, 2N) for the default constant-velocity model."""
-    if a is None:
-        a = np.array([[1, 0, delta_t, 0],
-                      [0, 1, 0, delta_t],
-                      [0, 0, 1, 0],
-                      [0, 0, 0, 1]], dtype=np.float64)
-    if c is None:
-        c = np.array([[1, 0, 0, 0],
-                      [0, 1, 0, 0]])
-    stacked, a_pow = c, a
-    for _ in range(size - 1):
-        stacked = np.concatenate((stacked, np.dot(c, a_pow)), axis=0)
-        a_pow = np.dot(a_pow, a)
-    ell = np.dot(stacked, np.linalg.matrix_power(np.linalg.inv(a), size))
-    return np.dot(np.linalg.inv(np.dot(ell.T, ell)), ell.T)
-
-
-def lsf_gain_rows(size, delta_t, a=None, c=None):
-    """Rows 0 and 1 (the position estimates) of ``lsf_gain`` -- what the device kernels consume."""
-    return np.ascontiguousarray(lsf_gain(size, delta_t, a, c)[:2])
+def horizons_and_gains(fps, n_min=0, n_max=None, n_f=3):
+    """-> (n_i, gains): the filter horizons N_i (gsff.py:87-109; ``n_max=None`` means fps, tracker.py:55-56)
+    and, per filter, the two position rows of its gain as a (2, 2 N_i) array -- from ``ysmr_gsff_gains``."""
+    L = _lib.lib()
+    n_i = (ctypes.c_int32 * int(n_f))()
+    top = float(-1 if n_max is None else n_max)
+    _lib.check(L.ysmr_gsff_gains(float(fps), int(n_min), top, int(n_f), n_i, None), "ysmr_gsff_gains")
+    sizes = list(n_i)
+    flat = np.zeros(4 * sum(sizes), np.float64)
+    _lib.check(L.ysmr_gsff_gains(float(fps), int(n_min), top, int(n_f), n_i, flat.ctypes.data), "ysmr_gsff_gains")
+    gains, off = [], 0
+    for n in sizes:
+        gains.append(flat[off:off + 4 * n].reshape(2, 2 * n).copy())
+        off += 4 * n
+    return sizes, gains
 
 
 class GaussianSumFIR:
@@ -61,11 +53,14 @@ class GaussianSumFIR:
             raise NotImplementedError("only the identity inverse covariance is supported")
         if likelihood_minimum != 10 ** -20:
             raise NotImplementedError("likelihood_minimum is fixed at 1e-20 (tracker.py:67)")
+        if a is not None or c is not None:
+            raise NotImplementedError("only the constant-velocity model (a = c = None, gsff.py:111-126) is supported")
         self.likelihood_minimum = likelihood_minimum
         self.x_hat_array_length = x_hat_array_length
         self.n_f = n_f
-        self.n_i = horizon_sizes(n_min=n_min, n_max=n_max, n_f=n_f)
-        self.gains = [lsf_gain(n, delta_t, a, c) for n in self.n_i]
+        #: horizons, and per filter the two position rows (2, 2 N) of its gain (upstream keeps all four rows;
+        #: rows 2/3, the velocity estimates, are never read: gsff.py:240)
+        self.n_i, self.gains = horizons_and_gains(1.0 / delta_t, n_min, n_max, n_f)
         self.inv_cov = np.eye(2) if inv_cov is None else inv_cov
         self._delta_t, self._n_min, self._n_max = delta_t, n_min, n_max
         self._device = device

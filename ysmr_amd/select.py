@@ -89,29 +89,27 @@ def select_tracks(path_to_file=None, df=None, results_directory=None, fps=None, 
         results_directory = create_results_folder(path_to_file)
     file_name = os.path.splitext(os.path.basename(path_to_file))[0]
     if fps is None or fps <= 0 or settings["force tracking.ini fps settings"]:
-        if settings["frames per second"] > 0:
-            fps = settings["frames per second"]
-        else:
-            logger.critical("fps value is negative or zero; cannot continue.")
-            return None
-    if settings["extreme area outliers lower end in px*px"] >= settings["extreme area outliers upper end in px*px"]:
-        logger.critical(
-            "Minimal area exclusion in px^2 larger or equal to maximum; will not be able to find tracks. "
-            "Please update tracking.ini. extreme area outliers lower end in px*px: {}, "
-            "extreme area outliers upper end in px*px: {}".format(
-                settings["extreme area outliers lower end in px*px"], settings["extreme area outliers upper end in px*px"]))
-        return None
+        fps = settings["frames per second"]
     if frame_width is None or frame_height is None:
         logger.debug("Retrieving frame width/height from tracking.ini.")
         frame_width, frame_height = settings["frame width"], settings["frame height"]
-    if frame_height <= 0 or frame_width <= 0:
-        logger.critical("Frame width or frame height 0 or negative; cannot continue. Width: {}, height: {}".format(
-            frame_width, frame_height))
-        return None
-    if settings["pixel per micrometre"] <= 0:
-        logger.critical("'pixel per micrometre' setting in tracking.ini 0 or negative. "
-                        "Cannot continue. Value: {}".format(settings["pixel per micrometre"]))
-        return None
+    lo_key, hi_key = "extreme area outliers lower end in px*px", "extreme area outliers upper end in px*px"
+    # what must hold before any device work; the messages are the reference's (track_eval.py:573-611)
+    preconditions = (
+        (fps > 0, "fps value is negative or zero; cannot continue."),
+        (settings[lo_key] < settings[hi_key],
+         "Minimal area exclusion in px^2 larger or equal to maximum; will not be able to find tracks. "
+         "Please update tracking.ini. {}: {}, {}: {}".format(lo_key, settings[lo_key], hi_key, settings[hi_key])),
+        (frame_height > 0 and frame_width > 0,
+         "Frame width or frame height 0 or negative; cannot continue. Width: {}, height: {}".format(frame_width, frame_height)),
+        (settings["pixel per micrometre"] > 0,
+         "'pixel per micrometre' setting in tracking.ini 0 or negative. Cannot continue. Value: {}".format(
+             settings["pixel per micrometre"])),
+    )
+    for holds, complaint in preconditions:
+        if not holds:
+            logger.critical(complaint)
+            return None
     if not isinstance(df, pd.DataFrame):
         df = get_data(path_to_file)
     if df is None:

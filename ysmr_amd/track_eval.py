@@ -71,8 +71,10 @@ class TrackingPipeline:
             params = threshold_params(settings["white bacteria on dark background"], offset,
                                       settings["adaptive double threshold"])
         # two detectors: batch b+1 is detected (stream 1) while batch b is linked (stream 0)
+        # optional settings key 'opencv version' ('4.5.0', '4.10.0', '3.4.18', ...): which release the BGR2GRAY
+        # coefficients and the minAreaRect angle convention follow (include/ysmr_hip.h: cv_flavour)
         self.det = [Detector(self.B, height, width, max_det=max_det, params=params, device=self.device,
-                             mean_state=mean_state)
+                             mean_state=mean_state, cv_flavour=settings.get("opencv version"))
                     for _ in range(2)]
         self.trk = DeviceTracker(max_disappeared=fps, fps=fps, n_min=settings["minimum horizon size"],
                                  n_max=settings["maximum horizon size"], n_f=settings["number of LSFFs"],

@@ -16,7 +16,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from .gsff import horizon_sizes, lsf_gain_rows
 
 __all__ = ["sort_rows", "DeviceTracker", "CentroidTracker"]
 
@@ -36,20 +35,14 @@ class DeviceTracker:
     """Owns one ``ysmr_tracker`` handle (one video stream)."""
 
     def __init__(self, max_disappeared=50, fps=30, n_min=0, n_max=None, n_f=3, use_gsff=True,
-                 capacity=1024, max_det=2048, device="cuda:0", gains="reference"):
+                 capacity=1024, max_det=2048, device="cuda:0", gains=None):
         self.device = torch.device(device)
         self.capacity, self.max_det = int(capacity), int(max_det)
         self.use_gsff = bool(use_gsff)
         self._handle = ctypes.c_void_p()
-        g = None
-        if isinstance(gains, np.ndarray):
-            g = np.ascontiguousarray(gains, np.float64).ravel()
-        elif self.use_gsff and gains == "reference":
-            # rows 0/1 of (L^T L)^-1 L^T computed exactly like gsff.py:111-153 (NumPy/LAPACK);
-            # gains=None lets the library use its closed form instead
-            top = fps if n_max is None else n_max
-            g = np.concatenate([lsf_gain_rows(n, 1 / fps).ravel() for n in horizon_sizes(n_min, top, n_f)])
-            g = np.ascontiguousarray(g, np.float64)
+        # gains: None = the library's closed form of the least-squares gain (gsff.py:111-153); an array laid
+        # out as ysmr_gsff_gains() writes it overrides it (experiments with other gains)
+        g = None if gains is None else np.ascontiguousarray(gains, np.float64).ravel()
         with torch.cuda.device(self.device):
             rc = _lib.lib().ysmr_tracker_create(
                 float(max_disappeared), float(fps), int(n_min), float(-1 if n_max is None else n_max), int(n_f),
@@ -122,7 +115,7 @@ class _SingleFilter:
     """One GaussianSumFIR state on the device (a one-track tracker fed one detection per step)."""
 
     def __init__(self, gsff):
-        gains = np.concatenate([g[:2].ravel() for g in gsff.gains])
+        gains = np.concatenate([g.ravel() for g in gsff.gains])
         fps = 1.0 / gsff._delta_t
         self._trk = DeviceTracker(max_disappeared=30000.0, fps=fps, n_min=gsff._n_min, n_max=gsff._n_max,
                                   n_f=gsff.n_f, use_gsff=True, capacity=1, max_det=1, device=gsff._device,
