@@ -129,6 +129,23 @@ def test_rows_sort_on_device():
         got = rows_to_numpy(sort_rows(dev, n), n)
         ref = rows[np.lexsort((rows["frame"], rows["track_id"]))]
         assert got.tobytes() == ref.tobytes()
+    # The tracker's own table needs no sort (row (id, f) belongs at offset[id] + f - first_frame[id]); tables
+    # of any other shape are recognised on the device and go through the stable radix sort instead:
+    # ids beyond the row count, tracks with gaps in their frames, and equal keys (input order kept)
+    for n, shape in ((9000, "sparse ids"), (9000, "gaps"), (70001, "duplicates")):
+        rows = np.zeros(n, _lib.ROW_DTYPE)
+        perm = rng.permutation(n)
+        if shape == "sparse ids":
+            rows["track_id"], rows["frame"] = (perm % 31) * 1_000_003 + 17, perm // 31
+        elif shape == "gaps":
+            rows["track_id"], rows["frame"] = perm % 31, (perm // 31) * 3 + (perm % 2)
+        else:
+            rows["track_id"], rows["frame"] = perm % 50, (perm // 50) % 40
+        rows["x"] = np.arange(n)
+        dev = torch.from_numpy(rows.view(np.uint8)).cuda()
+        got = rows_to_numpy(sort_rows(dev, n), n)
+        order = np.lexsort((np.arange(n), rows["frame"], rows["track_id"]))      # stable
+        assert got.tobytes() == rows[order].tobytes(), shape
 
 
 def test_track_bacteria_output_equals_the_reference_detour(tmp_path):

@@ -7,7 +7,6 @@
 // pandas_parse below), shortest-repr text again -- so they are produced here directly, without the
 // Python string formatting (0.5 s per 250 k rows) and the two pandas passes.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <charconv>
@@ -18,8 +17,57 @@
 #include <vector>
 
 #include "common.h"
+#include "prim.h"
 
 namespace {
+
+// ---- ordering by (TRACK_ID, POSITION_T) ------------------------------------------------------------------
+// The link emits rows frame by frame, ids ascending within a frame; an id is never reused and a live track has
+// a row in EVERY frame from its first to its last (disappeared tracks included, track_eval.py:313-316).  So the
+// place of row (id, f) in the ordered table is known without sorting anything:
+//     offset[id] + (f - first_frame[id]),   offset = exclusive prefix sum of the rows per track.
+// One pass gathers rows per track and first/last frame (atomics on 12 bytes per track), a prefix sum turns the
+// counts into offsets, one pass checks that every track's frames are gapless and scatters.  A table that does
+// not have this shape (ids beyond the row count, gaps, duplicates -- e.g. rows assembled by a caller) is
+// reported by the check and goes through the stable radix sort of prim.h instead.
+struct TrackSpan { uint32_t rows, first, last; };
+
+__global__ __launch_bounds__(256) void k_span_clear(TrackSpan *span, uint32_t *counts, long long n, uint32_t *bad)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        span[i] = TrackSpan{0u, 0xFFFFFFFFu, 0u};
+        counts[i] = 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *bad = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_span_gather(const ysmr_row *__restrict__ rows, long long n, TrackSpan *span,
+                                                     uint32_t *counts, uint32_t *bad)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const uint32_t id = (uint32_t)rows[i].track_id, f = (uint32_t)rows[i].frame;
+        if ((long long)id >= n) { *bad = 1u; continue; }       // (every track has at least one row, ids start at 0)
+        atomicAdd(&counts[id], 1u);
+        atomicMin(&span[id].first, f);
+        atomicMax(&span[id].last, f);
+    }
+}
+
+// counts_incl: inclusive prefix sum of the rows per track
+__global__ __launch_bounds__(256) void k_span_scatter(const ysmr_row *__restrict__ rows, long long n, const TrackSpan *span,
+                                                      const uint32_t *__restrict__ counts_incl, uint32_t *bad,
+                                                      ysmr_row *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const ysmr_row r = rows[i];
+        const uint32_t id = (uint32_t)r.track_id;
+        if ((long long)id >= n) continue;
+        const uint32_t end = counts_incl[id], begin = id ? counts_incl[id - 1] : 0u;
+        const TrackSpan s = span[id];
+        if (s.last - s.first + 1u != end - begin) { *bad = 1u; continue; }   // a gap or a duplicate (frame, id) pair
+        out[begin + ((uint32_t)r.frame - s.first)] = r;
+    }
+}
 
 __global__ __launch_bounds__(256) void k_row_keys(const ysmr_row *__restrict__ rows, long long n,
                                                   unsigned long long *__restrict__ keys, uint32_t *__restrict__ idx)
@@ -39,7 +87,7 @@ __global__ __launch_bounds__(256) void k_row_gather(const ysmr_row *__restrict__
 }
 
 struct SortLayout {
-    size_t keys_in, keys_out, idx_in, idx_out, temp, temp_bytes, total;
+    size_t span, counts, bad, keys_a, keys_b, idx_a, idx_b, temp, total;
 };
 
 SortLayout sort_layout(long long n)
@@ -47,15 +95,18 @@ SortLayout sort_layout(long long n)
     SortLayout L{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return o; };
-    L.keys_in = take(sizeof(unsigned long long) * (size_t)n);
-    L.keys_out = take(sizeof(unsigned long long) * (size_t)n);
-    L.idx_in = take(sizeof(uint32_t) * (size_t)n);
-    L.idx_out = take(sizeof(uint32_t) * (size_t)n);
-    size_t tb = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 64, (hipStream_t)0);
-    L.temp_bytes = tb;
-    L.temp = take(tb);
+    L.bad = take(256);
+    // the two orderings never run at the same time: their buffers share the workspace
+    L.span = take(sizeof(TrackSpan) * (size_t)n);
+    L.counts = take(sizeof(uint32_t) * (size_t)n);
+    const size_t after_span = off;
+    off = L.span;
+    L.keys_a = take(sizeof(unsigned long long) * (size_t)n);
+    L.keys_b = take(sizeof(unsigned long long) * (size_t)n);
+    L.idx_a = take(sizeof(uint32_t) * (size_t)n);
+    L.idx_b = take(sizeof(uint32_t) * (size_t)n);
+    off = std::max(off, after_span);
+    L.temp = take(std::max(ysmr::prim::radix_temp_bytes((size_t)n), sizeof(uint32_t) * ysmr::prim::scan_temp_words((size_t)n)));
     L.total = off;
     return L;
 }
@@ -232,14 +283,26 @@ int ysmr_rows_sort(void *stream, const ysmr_row *rows_dev, long long n_rows, voi
     if (workspace_bytes < L.total)
         return ysmr::fail(YSMR_ERR_CAPACITY, "sort workspace too small: %zu < %zu bytes", workspace_bytes, L.total);
     char *w = (char *)workspace_dev;
-    auto *keys_in = (unsigned long long *)(w + L.keys_in), *keys_out = (unsigned long long *)(w + L.keys_out);
-    auto *idx_in = (uint32_t *)(w + L.idx_in), *idx_out = (uint32_t *)(w + L.idx_out);
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)std::min<long long>((n_rows + 255) / 256, 1024);   // resident grid (see detect.hip)
-    hipLaunchKernelGGL(k_row_keys, dim3(grid), dim3(256), 0, st, rows_dev, n_rows, keys_in, idx_in);
-    size_t tb = L.temp_bytes;
-    YSMR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(w + L.temp, tb, keys_in, keys_out, idx_in, idx_out, (int)n_rows, 0, 64, st));
-    hipLaunchKernelGGL(k_row_gather, dim3(grid), dim3(256), 0, st, rows_dev, idx_out, n_rows, sorted_dev);
+    // the tracker's table: no sort needed
+    TrackSpan *span = (TrackSpan *)(w + L.span);
+    uint32_t *counts = (uint32_t *)(w + L.counts), *bad = (uint32_t *)(w + L.bad);
+    hipLaunchKernelGGL(k_span_clear, dim3(grid), dim3(256), 0, st, span, counts, n_rows, bad);
+    hipLaunchKernelGGL(k_span_gather, dim3(grid), dim3(256), 0, st, rows_dev, n_rows, span, counts, bad);
+    ysmr::prim::inclusive_scan_u32(st, counts, counts, (size_t)n_rows, (uint32_t *)(w + L.temp));
+    hipLaunchKernelGGL(k_span_scatter, dim3(grid), dim3(256), 0, st, rows_dev, n_rows, span, counts, bad, sorted_dev);
+    YSMR_LAUNCH_CHECK();
+    uint32_t irregular = 0;
+    YSMR_HIP_CHECK(hipMemcpyAsync(&irregular, bad, sizeof(irregular), hipMemcpyDeviceToHost, st));
+    YSMR_HIP_CHECK(hipStreamSynchronize(st));
+    if (!irregular) return YSMR_OK;
+    // any other table: stable radix sort of (TRACK_ID << 32 | POSITION_T) with the row number as payload
+    auto *keys_a = (unsigned long long *)(w + L.keys_a), *keys_b = (unsigned long long *)(w + L.keys_b);
+    auto *idx_a = (uint32_t *)(w + L.idx_a), *idx_b = (uint32_t *)(w + L.idx_b);
+    hipLaunchKernelGGL(k_row_keys, dim3(grid), dim3(256), 0, st, rows_dev, n_rows, keys_a, idx_a);
+    const int where = ysmr::prim::radix_sort(st, keys_a, keys_b, idx_a, idx_b, (size_t)n_rows, 64, w + L.temp);
+    hipLaunchKernelGGL(k_row_gather, dim3(grid), dim3(256), 0, st, rows_dev, where ? idx_b : idx_a, n_rows, sorted_dev);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }

@@ -18,13 +18,13 @@
 // The call is synchronous (it sizes its later stages from counts it reads back); it runs once per
 // video.  All grids are resident-sized.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 
 #include "common.h"
+#include "prim.h"
 
 namespace {
 
@@ -462,16 +462,7 @@ SelLayout sel_layout(long long n, int max_recursion)
     if (cap > 8192) cap = 8192;   // (16 B x 1024 waves per entry; a deeper walk is reported as YSMR_ERR_CAPACITY)
     L.stack_cap = (int)cap;
     L.stack = take(sizeof(int4) * (size_t)L.stack_cap * TRACK_BLOCKS * 4);
-    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-    const int ni = (int)std::min<long long>((long long)N, 0x7FFFFFFFll);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, ni, 0, 64, (hipStream_t)0);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                             (const unsigned long long *)nullptr, (unsigned long long *)nullptr, ni, 0, 32, (hipStream_t)0);
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t3, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, ni, 0, 64,
-                                            (hipStream_t)0);
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, t4, (const uint32_t *)nullptr, (uint32_t *)nullptr, ni, (hipStream_t)0);
-    L.temp_bytes = std::max(std::max(t1, t2), std::max(t3, t4));
+    L.temp_bytes = std::max(ysmr::prim::radix_temp_bytes(N), sizeof(uint32_t) * ysmr::prim::scan_temp_words(N));
     L.temp = take(L.temp_bytes);
     L.total = off;
     return L;
@@ -517,31 +508,32 @@ int ysmr_select_tracks(void *stream, long long n_rows, const uint32_t *track_id_
     auto *val_a = (unsigned long long *)P(L.val_a), *val_b = (unsigned long long *)P(L.val_b);   // (values of pass 2 / distance keys)
     uint32_t *key32_a = (uint32_t *)P(L.key32_a), *key32_b = (uint32_t *)P(L.key32_b);
     void *temp = P(L.temp);
-    size_t tb;
     const long long n = n_rows;
-    const int ni = (int)n;
     const unsigned g = grid_for(n);
 
     // ---- clean-up
     hipLaunchKernelGGL(k_sel_area, dim3(g), dim3(256), 0, st, track_id_dev, w_dev, h_dev, n, area, start);
-    tb = L.temp_bytes;
-    YSMR_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(temp, tb, start, incl, ni, st));
+    ysmr::prim::inclusive_scan_u32(st, start, incl, (size_t)n, (uint32_t *)temp);
     hipLaunchKernelGGL(k_sel_segments, dim3(g), dim3(256), 0, st, start, incl, n, seg, first, last);
     uint32_t n_tracks = 0;
     YSMR_HIP_CHECK(hipMemcpyAsync(&n_tracks, incl + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    // per-track median of the area: stable sort by area, then stable sort by track
-    hipLaunchKernelGGL(k_sel_bits, dim3(g), dim3(256), 0, st, area, n, bits_a);
-    tb = L.temp_bytes;
-    YSMR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, tb, bits_a, bits_b, seg, key32_a, ni, 0, 64, st));
-    tb = L.temp_bytes;
-    YSMR_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, tb, key32_a, key32_b, bits_b, val_b, ni, 0, 32, st));
     YSMR_HIP_CHECK(hipStreamSynchronize(st));
     summary->tracks_before = n_tracks;
-    hipLaunchKernelGGL(k_sel_median, dim3(grid_for(n_tracks)), dim3(256), 0, st, val_b, first, last, n_tracks, median);
+    // per-track median of the area: stable sort by area (non-negative doubles order like their bit patterns),
+    // then stable sort by track (as many digits as the track count needs)
+    hipLaunchKernelGGL(k_sel_bits, dim3(g), dim3(256), 0, st, area, n, bits_a);
+    YSMR_HIP_CHECK(hipMemcpyAsync(key32_a, seg, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    int at = ysmr::prim::radix_sort(st, bits_a, bits_b, key32_a, key32_b, (size_t)n, 64, temp);
+    int track_bits = 8;
+    while (track_bits < 32 && (n_tracks >> track_bits)) track_bits += 8;
+    unsigned long long *area_sorted = at ? bits_b : bits_a, *area_other = at ? bits_a : bits_b;
+    uint32_t *seg_sorted = at ? key32_b : key32_a, *seg_other = at ? key32_a : key32_b;
+    at = ysmr::prim::radix_sort(st, seg_sorted, seg_other, area_sorted, area_other, (size_t)n, track_bits, temp);
+    const unsigned long long *area_by_track = at ? area_other : area_sorted;
+    hipLaunchKernelGGL(k_sel_median, dim3(grid_for(n_tracks)), dim3(256), 0, st, area_by_track, first, last, n_tracks, median);
     CleanParams cp{prm->area_lo, prm->area_hi, prm->area_factor, prm->area_factor != 0.0 ? 1 : 0, (uint32_t)prm->min_length_frames};
     hipLaunchKernelGGL(k_sel_keep, dim3(g), dim3(256), 0, st, area, seg, median, first, last, t_dev, n, cp, keep);
-    tb = L.temp_bytes;
-    YSMR_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(temp, tb, keep, pos, ni, st));
+    ysmr::prim::inclusive_scan_u32(st, keep, pos, (size_t)n, (uint32_t *)temp);
     uint32_t n_kept = 0;
     YSMR_HIP_CHECK(hipMemcpyAsync(&n_kept, pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
     Table c{(uint32_t *)P(L.c_id), (uint32_t *)P(L.c_t), (uint32_t *)P(L.c_orig), (double *)P(L.c_x), (double *)P(L.c_y),
@@ -554,29 +546,27 @@ int ysmr_select_tracks(void *stream, long long n_rows, const uint32_t *track_id_
 
     // ---- the cleaned table: tracks, distances, bounds
     const long long m = n_kept;
-    const int mi = (int)m;
     const unsigned gm = grid_for(m);
     hipLaunchKernelGGL(k_sel_dist, dim3(gm), dim3(256), 0, st, c, m, start);
-    tb = L.temp_bytes;
-    YSMR_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(temp, tb, start, incl, mi, st));
+    ysmr::prim::inclusive_scan_u32(st, start, incl, (size_t)m, (uint32_t *)temp);
     hipLaunchKernelGGL(k_sel_segments, dim3(gm), dim3(256), 0, st, start, incl, m, seg, first, last);
     uint32_t n_tracks2 = 0;
     YSMR_HIP_CHECK(hipMemcpyAsync(&n_tracks2, incl + (m - 1), 4, hipMemcpyDeviceToHost, st));
     const int use_area = prm->q_area > 0.0 ? 1 : 0, use_dist = prm->omit_motility ? 1 : 0;
+    const unsigned long long *areas_ordered = bits_a, *dists_ordered = val_a;
+    ysmr::prim::NoValue *none = nullptr;
     if (use_area) {
         hipLaunchKernelGGL(k_sel_bits, dim3(gm), dim3(256), 0, st, c.area, m, bits_a);
-        tb = L.temp_bytes;
-        YSMR_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(temp, tb, bits_a, bits_b, mi, 0, 64, st));
+        areas_ordered = ysmr::prim::radix_sort(st, bits_a, bits_b, none, none, (size_t)m, 64, temp) ? bits_b : bits_a;
     }
     if (use_dist) {
         hipLaunchKernelGGL(k_sel_bits, dim3(gm), dim3(256), 0, st, c.dist, m, val_a);
-        tb = L.temp_bytes;
-        YSMR_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(temp, tb, val_a, val_b, mi, 0, 64, st));
+        dists_ordered = ysmr::prim::radix_sort(st, val_a, val_b, none, none, (size_t)m, 64, temp) ? val_b : val_a;
     }
     Bounds *bounds = (Bounds *)P(L.bounds);
     // pandas hands numpy q * 100 and numpy divides by 100 again
     const double q_lo = prm->q_area * 100.0 / 100.0, q_hi = (1.0 - prm->q_area) * 100.0 / 100.0;
-    hipLaunchKernelGGL(k_sel_bounds, dim3(1), dim3(1), 0, st, bits_b, val_b, m, q_lo, q_hi, use_area, use_dist, bounds);
+    hipLaunchKernelGGL(k_sel_bounds, dim3(1), dim3(1), 0, st, areas_ordered, dists_ordered, m, q_lo, q_hi, use_area, use_dist, bounds);
     uint8_t *flag = (uint8_t *)P(L.flag), *good = (uint8_t *)P(L.good);
     YSMR_HIP_CHECK(hipMemsetAsync(flag, 0, (size_t)m, st));
     YSMR_HIP_CHECK(hipMemsetAsync(good, 0, (size_t)m, st));
@@ -611,8 +601,7 @@ int ysmr_select_tracks(void *stream, long long n_rows, const uint32_t *track_id_
 
     // ---- output
     hipLaunchKernelGGL(k_sel_good32, dim3(gm), dim3(256), 0, st, good, m, keep);
-    tb = L.temp_bytes;
-    YSMR_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(temp, tb, keep, pos, mi, st));
+    ysmr::prim::inclusive_scan_u32(st, keep, pos, (size_t)m, (uint32_t *)temp);
     hipLaunchKernelGGL(k_sel_emit, dim3(gm), dim3(256), 0, st, good, pos, c.orig, m, sel_row_dev, sel_index_dev);
     uint32_t n_sel = 0;
     unsigned long long h_counters[11];
