@@ -48,12 +48,14 @@ extern "C" {
 
 /* cv_flavour: which OpenCV the a1 / a6 arithmetic follows.  opencv-contrib-python is an unpinned third-party
  * dependency of the reference (setup.py:29, "openCV v3 or v4"); two of its results changed between releases:
- *   0                    OpenCV 4.0 - 4.5.0: 15-bit BGR2GRAY coefficients, minAreaRect angle in [-90, 0)
- *   YSMR_CV_ANGLE_451    OpenCV >= 4.5.1: minAreaRect reports the same rectangle with its angle in (0, 90] and
- *                        width / height named the other way round (axis-aligned: 90 instead of -90)
- *   YSMR_CV_GRAY_3X      OpenCV 3.x: 14-bit BGR2GRAY coefficients (1868 / 9617 / 4899); no effect on gray input
+ *   0                     OpenCV >= 4.5.1: 15-bit BGR2GRAY coefficients; cv::minAreaRect angle in (0, 90] (the
+ *                         restated hull order + rotating calipers produce [0, 90]: an axis-aligned box is
+ *                         reported with angle 90, or 0, whichever of its equal-area sides is visited last)
+ *   YSMR_CV_ANGLE_PRE451  OpenCV < 4.5.1: the same rectangle with its angle in [-90, 0) and width / height named
+ *                         the other way round (angle 90 becomes -90 with the sides as they are)
+ *   YSMR_CV_GRAY_3X       OpenCV 3.x: 14-bit BGR2GRAY coefficients (1868 / 9617 / 4899); no effect on gray input
  * (upstream-recollection, like the rest of the cv2 restatement: the image half is parity-unpinned) */
-#define YSMR_CV_ANGLE_451    1
+#define YSMR_CV_ANGLE_PRE451 1
 #define YSMR_CV_GRAY_3X      2
 #define YSMR_CV_FLAVOUR_MASK 3
 

@@ -28,7 +28,10 @@
  *     - contours: one detection per 8-connected component that is not enclosed by another
  *       component, emitted in reverse raster order of the component's first pixel
  *     - minAreaRect: strict convex hull (order: rightmost -> max-y side -> leftmost -> min-y side),
- *       f32 rotating calipers, "area <= minarea" (last minimum wins), pre-4.5.1 angle convention.
+ *       f32 rotating calipers, "area <= minarea" (last minimum wins).  With this hull order the
+ *       angles come out in [0, 90] (an axis-aligned box: 90, or 0), the range OpenCV documents from 4.5.1
+ *       on; the [-90, 0) convention of earlier releases is a relabelling (ysmr_oracle.py: rect_convention).
+ *       (Round 1's header called this the pre-4.5.1 convention; the values never were.)
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; fmaf() is used explicitly where the
  * restated algorithm fuses).

@@ -105,7 +105,7 @@ def gauss11():
     return k
 
 
-CV_ANGLE_451, CV_GRAY_3X = 1, 2     # cv_flavour bits (include/ysmr_hip.h)
+CV_ANGLE_PRE451, CV_GRAY_3X = 1, 2     # cv_flavour bits (include/ysmr_hip.h)
 
 
 def bgr2gray(bgr, cv_flavour=0):
@@ -190,18 +190,19 @@ class FrameDetections:
 
 
 def rect_convention(det, cv_flavour=0):
-    """cv2.minAreaRect's result as OpenCV >= 4.5.1 reports it (CV_ANGLE_451): the C restatement follows the
-    releases before, angle in [-90, 0); from 4.5.1 on the same rectangle has its angle in (0, 90] and width /
-    height named the other way round, an axis-aligned one 90 instead of -90 (upstream-
-    recollection; rectangles of 1 or 2 hull points, h == 0, are left as they are)."""
+    """cv2.minAreaRect's result as OpenCV < 4.5.1 reports it (CV_ANGLE_PRE451).  The C restatement's hull order
+    and rotating calipers give angles in [0, 90] -- the range OpenCV documents from 4.5.1 on; earlier releases
+    report the same rectangle with its angle in [-90, 0) and width / height named the other way round, 90
+    becoming -90 with the sides as they are (upstream-recollection; rectangles of 1 or 2 hull
+    points, h == 0, are left as they are)."""
     det = np.array(det, np.float32, copy=True)
-    if cv_flavour & CV_ANGLE_451 and len(det):
+    if cv_flavour & CV_ANGLE_PRE451 and len(det):
         box = det[:, 3] > 0
-        axis = box & (det[:, 4] == np.float32(-90))
+        axis = box & (det[:, 4] == np.float32(90))
         turn = box & ~axis
-        det[axis, 4] = 90
+        det[axis, 4] = -90
         det[turn, 2], det[turn, 3] = det[turn, 3].copy(), det[turn, 2].copy()
-        det[turn, 4] = det[turn, 4] + np.float32(90)
+        det[turn, 4] = det[turn, 4] - np.float32(90)
     return det
 
 

@@ -454,16 +454,16 @@ def test_detection_writes_stay_inside_their_buffers(torch_cuda, oracle):
     run(2, 9, 23, 32, [rng.integers(0, 256, (2, 9, 23), dtype=np.uint8)] * 2, True)       # tile kernel (W % 4 != 0)
 
 
-@pytest.mark.parametrize("version,flags", [("4.5.0", 0), ("4.10.0", 1), ("3.4.18", 2)])
+@pytest.mark.parametrize("version,flags", [("4.10.0", 0), ("4.5.0", 1), ("3.4.18", 3)])
 def test_opencv_flavours(torch_cuda, oracle, version, flags):
-    """cv_flavour: OpenCV 3.x BGR2GRAY coefficients and the minAreaRect convention of OpenCV >= 4.5.1, selected
+    """cv_flavour: OpenCV 3.x BGR2GRAY coefficients and the minAreaRect convention of OpenCV < 4.5.1, selected
     by the optional settings key 'opencv version' -- HIP vs the oracle's statement of the same conventions
     (adaptive and mean-gray branch, strip and tile kernels)."""
     from ysmr_amd import _lib
     from ysmr_amd.detect import Detector, mean_gray_params, threshold_params
     from ysmr_amd.synth import SyntheticVideo
     torch = torch_cuda
-    assert _lib.cv_flavour_of(version) == flags and _lib.cv_flavour_of(None) == 0 and _lib.cv_flavour_of("4.5.1") == 1
+    assert _lib.cv_flavour_of(version) == flags and _lib.cv_flavour_of(None) == 0 and _lib.cv_flavour_of("4.5.1") == 0
     rng = np.random.default_rng(5)
     for (h, w) in ((96, 132), (50, 71)):
         gray = SyntheticVideo(h, w, 14, seed=w).frames(2)
@@ -481,9 +481,12 @@ def test_opencv_flavours(torch_cuda, oracle, version, flags):
             got = res.det[f, :n].cpu().numpy()
             np.testing.assert_array_equal(got[:, :4], ref.det[:, :4])
             _assert_angle_close(got[:, 4], ref.det[:, 4])
+            boxes = got[:, 3] > 0
+            assert boxes.any()
             if flags & 1:
-                boxes = got[:, 3] > 0
-                assert boxes.any() and np.all((got[boxes, 4] > 0) & (got[boxes, 4] <= 90))
+                assert np.all((got[boxes, 4] >= -90) & (got[boxes, 4] < 0))
+            else:
+                assert np.all((got[boxes, 4] >= 0) & (got[boxes, 4] <= 90))
         # mean-gray branch: the statistics are taken over the converted frame
         mp = mean_gray_params(True, 5, 30.0)
         d = Detector(2, h, w, max_det=256, params=mp, cv_flavour=version)

@@ -18,12 +18,12 @@ YSMR_OK = 0
 DET_OVERFLOW = 1
 DET_ARENA = 2
 #: ``cv_flavour`` bits (include/ysmr_hip.h): which OpenCV release the a1 / a6 arithmetic follows
-CV_DEFAULT, CV_ANGLE_451, CV_GRAY_3X = 0, 1, 2
+CV_DEFAULT, CV_ANGLE_PRE451, CV_GRAY_3X = 0, 1, 2
 
 
 def cv_flavour_of(version):
-    """``cv_flavour`` for an OpenCV version string ('3.4.18', '4.5.0', '4.10.0', ...) or None (the default,
-    OpenCV 4.0 - 4.5.0).  Also accepts the flag value itself."""
+    """``cv_flavour`` for an OpenCV version string ('3.4.18', '4.5.0', '4.10.0', ...) or None (the default:
+    OpenCV >= 4.5.1).  Also accepts the flag value itself."""
     if version is None or version is False:
         return CV_DEFAULT
     if isinstance(version, int):
@@ -31,8 +31,8 @@ def cv_flavour_of(version):
     parts = [int("".join(ch for ch in p if ch.isdigit()) or 0) for p in str(version).split(".")[:3]]
     parts += [0] * (3 - len(parts))
     flags = CV_GRAY_3X if parts[0] < 4 else 0
-    if tuple(parts) >= (4, 5, 1):
-        flags |= CV_ANGLE_451
+    if tuple(parts) < (4, 5, 1):
+        flags |= CV_ANGLE_PRE451
     return flags
 
 #: numpy view of ``struct ysmr_row`` (40 bytes)

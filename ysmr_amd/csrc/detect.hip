@@ -14,6 +14,7 @@
 #include "common.h"
 #include <cfloat>
 #include <cmath>
+#include <algorithm>
 #include <cstdlib>
 
 #ifdef YSMR_STAMPS
@@ -131,12 +132,6 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t *__restrict__ f
 //   -> symmetric column filter, round-half-even, SWAR compare, 4 class bytes = one dword store.
 // Nothing but the input frame and the class map touches HBM: 1 B/px read + 1 B/px written.
 // ------------------------------------------------------------------------------------------
-#ifndef STRIP_LDS_EXCHANGE
-#define STRIP_LDS_EXCHANGE 1   // measured 3 % faster than 14 v_cvt_f32_ubyte + 4 DPP shifts per row
-#endif
-#ifndef STRIP_PF
-#define STRIP_PF 3   // gray rows kept in flight per lane
-#endif
 constexpr int STRIP_HALO_LANES = 3;
 constexpr int STRIP_MAX_OUT_LANES = 64 - 2 * STRIP_HALO_LANES;   // 58 lanes = 232 columns
 
@@ -147,6 +142,7 @@ struct StripParams {
     int seg_h;         // output rows per wave
     int segs_y;
     int inv, t_low, t_high;
+    int by_xcd;        // frames are dealt to the 8 XCDs (needs batch % 8 == 0 and a grid that is a multiple of 8)
     ysmr::GrayCoef gc; // BGR input only
 };
 
@@ -201,8 +197,12 @@ struct StripCtx {
     bool left_edge, right_edge;
     int edge_lane;        // lane holding the last image column (W % 4 == 0: in its byte 3)
     bool writes;
-    float sgn, k_lo, k_hi;   // class bit = clamp(sgn * (s - m) + k, 0, 1)
+    // classification (see strip_body): margin = sgn * (s - m) + k_max; thresh = margin >= c_lo, markers = margin >= c_hi
+    float sgn, nsgn, k_p;          // k_p = k_max + sgn * 1.5 * 2^23
+    uint32_t swar_lo, swar_hi;     // (128 - c) in every byte
     float *xrow;             // this wave's LDS exchange row (with 8 floats of slack on each side)
+    const uint32_t *q;       // this wave's LDS ring of gray rows in flight, and its LDS byte address
+    uint32_t q_lds;
     ysmr::GrayCoef gc;
 };
 
@@ -251,144 +251,287 @@ __device__ __forceinline__ uint32_t patch_row(const StripCtx &c, uint32_t g)
     return g;
 }
 
-// One strip.  XEDGE: the strip touches the left/right image border.  YEDGE: the segment's halo
-// leaves the image at the top/bottom (rows are clamped/reflected and the 3-row window may have to
-// be reloaded); interior segments slide unconditionally.
-template <int CH, bool XEDGE, bool YEDGE>
-__device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
-{
-    const int H = c.H, W = c.W, lane = c.lane;
-    float ring[11][4];    // row-filtered values of the last 11 blurred rows
-    float fring[11][4];   // the blurred pixels themselves (only the last 6 rows are live)
-#pragma unroll
-    for (int s = 0; s < 11; ++s)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) { ring[s][o] = 0.f; fring[s][o] = 0.f; }
+// ---- asynchronous row loads -----------------------------------------------------------------------------
+// The gray rows are fetched STRIP_PF steps ahead.  Issued from C++ into registers, the compiler's wait-count
+// pass merges its bookkeeping at every control-flow join of the unrolled body and ends up waiting for (nearly)
+// all loads in flight at every step, which exposes the memory latency of every row (ISA of round 1:
+// s_waitcnt vmcnt(3) with six operations younger than the row it needed; vmcnt(1) once the body had one more
+// branch).  So the rows travel by LDS DMA (global_load_lds_dword: no destination registers, nothing for the
+// register allocator to move while a load is in flight) into a per-wave ring of STRIP_PF rows, issued by
+// inline assembly, invisible to that pass, and are waited for with an explicit s_waitcnt vmcnt(N): vmcnt
+// retires in order and the row wanted next always has STRIP_PF - 1 younger rows behind it, so "at most
+// STRIP_PF - 1 rows' worth of operations outstanding" implies that it has landed, however many class-map
+// stores were issued in between.  The row is then read from LDS one step before it is used.
+constexpr int STRIP_PF = 8;   // rows in flight per wave (a power of two)
 
-    const int rb_lo = c.y0 - 5, rb_hi = c.y1 - 1 + 5;
-    HSum hu, hc, hd;
-    int ic, id;
-    RawRow<CH> gq[STRIP_PF];
-    {   // prologue: window for the first blurred row, and the rows in flight
-        const int rbc = YEDGE ? clampi(rb_lo, 0, H - 1) : rb_lo;
-        const int ru = YEDGE ? reflect101(rbc - 1, H) : rbc - 1;
-        hc = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, ru))));      // becomes hu after the first slide
-        hd = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, rbc))));     // becomes hc
-        hu = hc;
-        ic = ru; id = rbc;
-#pragma unroll
-        for (int d = 0; d < STRIP_PF; ++d) {
-            const int r = YEDGE ? reflect101(clampi(rb_lo + d, 0, H - 1) + 1, H) : rb_lo + d + 1;
-            gq[d] = load_row<CH>(c, r);
-        }
+template <int CH>
+struct StripState {
+    float ring[11][4];    // row-filtered values of the last 11 blurred rows (slot = step mod 11)
+    uint32_t bring[11];   // the blurred pixels themselves, packed (only the last 7 rows are live)
+    HSum hc, hd;          // horizontal 1-2-1 sums of the two newest gray rows under the blur
+    RawRow<CH> next;      // the gray row that enters the window at the next fresh step
+    int k;                // its index in feed order (ring slot k % STRIP_PF)
+    int row0;             // fed row k is reflect101(row0 + k): the rows fed are consecutive (see strip_body)
+};
+
+// LDS ring of one wave: slot t, dword j of a row (1 for gray, 3 for BGR), lane l at q + ((t * CH + j) * 64 + l)
+template <int CH>
+__device__ __forceinline__ void request_row(const StripCtx &c, const StripState<CH> &st, int k)
+{
+    // (rows past the image are never consumed; min() keeps their address inside the frame)
+    const int r = reflect101(min(st.row0 + k, c.H), c.H);
+    const uint32_t off = ((uint32_t)r * (uint32_t)c.W + c.ld_col) * CH;
+    const uint32_t lds = c.q_lds + (uint32_t)((k & (STRIP_PF - 1)) * CH) * 256u;   // wave-uniform
+    if constexpr (CH == 1) {
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds), "v"(off), "s"(c.src) : "memory");
+    } else {
+        // (no instruction offsets: the offset field of an LDS-DMA load moves the LDS address as well)
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %3, %4\n\t"
+                     "s_mov_b32 m0, %1\n\tglobal_load_lds_dword %3, %5\n\t"
+                     "s_mov_b32 m0, %2\n\tglobal_load_lds_dword %3, %6"
+                     ::"s"(lds), "s"(lds + 256u), "s"(lds + 512u), "v"(off), "s"(c.src), "s"(c.src + 4), "s"(c.src + 8) : "memory");
     }
-    for (int rb0 = rb_lo; rb0 <= rb_hi; rb0 += 11) {
-#pragma unroll
-        for (int s = 0; s < 11; ++s) {
-            const int rb = rb0 + s;
-            if (rb <= rb_hi) {   // (no break: the slot index s must stay a compile-time constant)
-            // ---- blurred row rbc = clamp(rb): REPLICATE for the Gaussian outside the image
-            if (YEDGE) {
-                const int rbc = clampi(rb, 0, H - 1);
-                const int ru = reflect101(rbc - 1, H), rd = reflect101(rbc + 1, H);
-                if (ic == ru && id == rbc) {          // steady state: slide down one row
-                    hu = hc; hc = hd; ic = id;
-                    hd = hsum4(patch_row<XEDGE>(c, gray_of(c, gq[0])));
-                } else {                              // border rows: rebuild the window
-                    hu = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, ru))));
-                    hc = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, rbc))));
-                    hd = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, rd))));
-                    ic = rbc;
-                }
-                id = rd;
-#pragma unroll
-                for (int d = 0; d + 1 < STRIP_PF; ++d) gq[d] = gq[d + 1];
-                gq[STRIP_PF - 1] = load_row<CH>(c, reflect101(clampi(rb + STRIP_PF, 0, H - 1) + 1, H));
-            } else {
-                hu = hc; hc = hd;
-                hd = hsum4(patch_row<XEDGE>(c, gray_of(c, gq[0])));
-#pragma unroll
-                for (int d = 0; d + 1 < STRIP_PF; ++d) gq[d] = gq[d + 1];
-                gq[STRIP_PF - 1] = load_row<CH>(c, rb + STRIP_PF + 1);
-            }
-            uint32_t b = vblur4(hu, hc, hd);
-            if (XEDGE) {
-                if (c.left_edge) {
-                    uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)b, STRIP_HALO_LANES) & 0xFFu;
-                    if (lane < STRIP_HALO_LANES) b = e * 0x01010101u;
-                }
-                if (c.right_edge) {
-                    uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)b, c.edge_lane) >> 24;
-                    if (lane > c.edge_lane) b = e * 0x01010101u;
-                }
-            }
-#if STRIP_LDS_EXCHANGE
-            // ---- row filter: convert once, exchange floats with the neighbour lanes through one LDS row
-            // (a wave's LDS accesses complete in order; the fences only pin the compiler)
-            const float4 mine = make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu),
-                                            (float)(b >> 24));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            *reinterpret_cast<float4 *>(c.xrow + 4 * lane) = mine;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const float4 l1 = *reinterpret_cast<const float4 *>(c.xrow + 4 * lane - 4);
-            const float4 r1 = *reinterpret_cast<const float4 *>(c.xrow + 4 * lane + 4);
-            const float l2 = c.xrow[4 * lane - 5];
-            const float r2 = c.xrow[4 * lane + 8];
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const float v[14] = {l2, l1.x, l1.y, l1.z, l1.w, mine.x, mine.y, mine.z, mine.w, r1.x, r1.y, r1.z, r1.w, r2};
+}
+// wait until fed row k has landed (k + 1 .. k + STRIP_PF - 1 may still be in flight) and read it
+template <int CH>
+__device__ __forceinline__ RawRow<CH> take_row(const StripCtx &c, int k)
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STRIP_PF - 1) * CH) : "memory");
+    const uint32_t *q = c.q + (uint32_t)((k & (STRIP_PF - 1)) * CH) * 64u + c.lane;
+    RawRow<CH> r;
+    r.w0 = q[0];
+    if constexpr (CH == 3) { r.w1 = q[64]; r.w2 = q[128]; }
+    asm volatile("" ::: "memory");   // (the ring is rewritten behind the compiler's back: no reuse of these loads)
+    return r;
+}
+
+// One step of a strip = one blurred row rb entering (feed) and one finished output row y = rb - 6 leaving (out_row).
+//   * feed: the next gray row slides into the 3-row window -- or (hold) the previous blurred row is repeated:
+//     rows above / below the image are BORDER_REPLICATE for the Gaussian; the blurred pixels are converted
+//     once and sent to the neighbour lanes through one LDS row;
+//   * out_row, issued while those floats travel: column filter, rounding, classification and store of row y,
+//     which only needs rows up to rb - 1, all of them in the register ring;
+//   * then the row filter of rb overwrites the ring slot of row rb - 11, which the column filter has just read
+//     for the last time.
+// (Round 1 issued the column filter of row rb - 5 behind the row filter of rb and sat out the LDS round trip of
+// every row.)  S, the ring slot, is a compile-time constant.  In the steady-state loop the three flags are
+// literal constants too and the body has no branch at all; the first and last steps of a strip pass them as
+// run-time (wave-uniform) values.
+template <int CH, bool XEDGE, int S>
+__device__ __forceinline__ void strip_step(const StripCtx &c, const float (&kw)[6], StripState<CH> &st, int rb, bool feed,
+                                           bool hold, bool out_row)
+{
+    const int lane = c.lane;
+    float4 mine = make_float4(0.f, 0.f, 0.f, 0.f), l1 = mine, r1 = mine;
+    float l2 = 0.f, r2 = 0.f;
+    uint32_t b_new = 0u;
+    const bool fresh = feed && !hold;
+    if (fresh) {
+        // the row read from the ring in the step before enters the window; its ring slot is requested again
+        // (row k + STRIP_PF), and the row for the next step is read as soon as it is known to have landed
+        const RawRow<CH> row = st.next;
+        const HSum hu = st.hc;
+        st.hc = st.hd;
+#ifdef STRIP_DBG_NOBLUR   // (the STRIP_DBG_* builds delete one part each to time the rest: scripts/thr_parts.sh)
+        st.hd.a = row.w0; st.hd.b = row.w0 >> 3;
 #else
-            // ---- row filter: neighbour pixels arrive as packed dwords through whole-wave DPP shifts
-            // (no LDS round trip, no wait counters), then one v_cvt_f32_ubyteN per tap
-            const uint32_t bm1 = wave_shr1(b), bm2 = wave_shr1(bm1), bp1 = wave_shl1(b), bp2 = wave_shl1(bp1);
-            const float v[14] = {(float)(bm2 >> 24),
-                                 (float)(bm1 & 0xFFu), (float)((bm1 >> 8) & 0xFFu), (float)((bm1 >> 16) & 0xFFu), (float)(bm1 >> 24),
-                                 (float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu), (float)(b >> 24),
-                                 (float)(bp1 & 0xFFu), (float)((bp1 >> 8) & 0xFFu), (float)((bp1 >> 16) & 0xFFu), (float)(bp1 >> 24),
-                                 (float)(bp2 & 0xFFu)};
+        st.hd = hsum4(patch_row<XEDGE>(c, gray_of(c, row)));
 #endif
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 11; ++k) acc = fmaf(v[o + k], gk.k[k], acc);
-                ring[s][o] = acc;
+#ifndef STRIP_DBG_NOLOAD
+        request_row<CH>(c, st, st.k + STRIP_PF);
+        st.next = take_row<CH>(c, st.k + 1);
+#else
+        st.next.w0 += 0x01010101u;
+#endif
+        ++st.k;
+#ifdef STRIP_DBG_NOBLUR
+        uint32_t b = hu.a + st.hc.b + st.hd.a;
+#else
+        uint32_t b = vblur4(hu, st.hc, st.hd);
+#endif
+        if (XEDGE) {
+            if (c.left_edge) {
+                uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)b, STRIP_HALO_LANES) & 0xFFu;
+                if (lane < STRIP_HALO_LANES) b = e * 0x01010101u;
             }
-            fring[s][0] = v[5]; fring[s][1] = v[6]; fring[s][2] = v[7]; fring[s][3] = v[8];
-            // ---- column filter for output row y = rb - 5 (slot of row y+j is (s - 5 + j) mod 11)
-            const int y = rb - 5;
-            if (y >= c.y0) {
-                const int sc = (s + 6) % 11;   // slot of the centre row y
-                // Everything below stays in full-rate f32 ops (on gfx950 v_fma/v_add issue in 2 cycles,
-                // integer, conversion and rounding ops in 4): round-half-even by the 1.5*2^23 trick,
-                // the two comparisons as clamped adds (s - m is an integer, so
-                // clamp(s - m - t, 0, 1) == (s - m > t)), classes 0..3 packed by v_cvt_pk_u8_f32.
-                uint32_t out = 0;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float acc = fmaf(ring[sc][o], gk.k[5], 0.0f);
-#pragma unroll
-                    for (int j = 1; j <= 5; ++j)
-                        acc = fmaf(ring[(sc + j) % 11][o] + ring[(sc + 11 - j) % 11][o], gk.k[5 + j], acc);
-                    float m = (acc + 12582912.0f) - 12582912.0f;       // rintf for 0 <= acc < 2^22
-                    float d = fring[sc][o] - m;
-                    float lo = __builtin_amdgcn_fmed3f(fmaf(d, c.sgn, c.k_lo), 0.0f, 1.0f);
-                    float hi = __builtin_amdgcn_fmed3f(fmaf(d, c.sgn, c.k_hi), 0.0f, 1.0f);
-                    out = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(hi, 2.0f, lo), o, out);
-                }
-                if (c.writes) {
-                    // the lane's column is rebuilt from a fresh lane id: kept live across the loop it is
-                    // the one value that got spilled, and its reload came with an s_waitcnt vmcnt(0) that
-                    // also waited for the row prefetches in flight
-                    uint32_t l;
-                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-                    *reinterpret_cast<uint32_t *>(c.dst + ((uint32_t)y * (uint32_t)W + (uint32_t)c.c0_base + 4u * l)) = out;
-                }
-            }
+            if (c.right_edge) {
+                uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)b, c.edge_lane) >> 24;
+                if (lane > c.edge_lane) b = e * 0x01010101u;
             }
         }
+        // convert once, exchange floats with the neighbour lanes through one LDS row
+        // (a wave's LDS accesses complete in order; the fences only pin the compiler)
+        b_new = b;
+        mine = make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu), (float)(b >> 24));
+#ifdef STRIP_DBG_NOEXCH
+        l1 = mine; r1 = mine; l2 = mine.x; r2 = mine.w;
+        if (false) {
+#else
+        {
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        *reinterpret_cast<float4 *>(c.xrow + 4 * lane) = mine;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        l1 = *reinterpret_cast<const float4 *>(c.xrow + 4 * lane - 4);
+        r1 = *reinterpret_cast<const float4 *>(c.xrow + 4 * lane + 4);
+        l2 = c.xrow[4 * lane - 5];
+        r2 = c.xrow[4 * lane + 8];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
+    // ---- column filter for output row y = rb - 6 (slot of row y + j is (S + 5 + j) mod 11; slot S still holds
+    // row rb - 11 = y - 5)
+    if (out_row) {
+        constexpr int sc = (S + 5) % 11;   // slot of the centre row y
+        // On gfx950 v_fma / v_add / v_sub and two-operand integer ops issue in ~2.6 cycles per wave, three-operand
+        // integer ops, conversions, v_med3 / v_max in ~4.4 (scripts/ubench/mfma_probe.hip), so:
+        // R = acc + 1.5 * 2^23 is round-half-even of the mean (as a float whose value is 1.5 * 2^23 + m);
+        // P = sgn * s + k + sgn * 1.5 * 2^23 (the centre pixels are kept packed, one register per row, and
+        // converted here: four floats per row for seven rows do not fit beside the ring at 128 VGPRs);
+        // margin = P - sgn * R = sgn * (s - m) + k, by which the pixel passes the LOOSER of the two comparisons, is
+        // an exact integer; v_cvt_pk_u8_f32 clamps it to a byte; the two class bits of four pixels then come from
+        // two per-byte comparisons on the packed dword (bit = margin >= c, c <= 128).
+        uint32_t margin = 0;
+        const uint32_t bc = st.bring[sc];
+        const float sf[4] = {(float)(bc & 0xFFu), (float)((bc >> 8) & 0xFFu), (float)((bc >> 16) & 0xFFu), (float)(bc >> 24)};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float acc = fmaf(st.ring[sc][o], kw[5], 0.0f);
+#ifndef STRIP_DBG_NOCOL
+#pragma unroll
+            for (int j = 1; j <= 5; ++j)
+                acc = fmaf(st.ring[(sc + j) % 11][o] + st.ring[(sc + 11 - j) % 11][o], kw[5 - j], acc);
+#else
+            acc += st.ring[(sc + 5) % 11][o] + st.ring[(sc + 6) % 11][o];
+#endif
+            const float r = acc + 12582912.0f;                      // rintf for 0 <= acc < 2^22
+            margin = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(r, c.nsgn, fmaf(sf[o], c.sgn, c.k_p)), o, margin);
+        }
+        const uint32_t low7 = margin & 0x7F7F7F7Fu;
+        const uint32_t ge_lo = (low7 + c.swar_lo) | margin, ge_hi = (low7 + c.swar_hi) | margin;   // bit 7 of each byte
+        uint32_t out = ((ge_lo >> 7) & 0x01010101u) | ((ge_hi >> 6) & 0x02020202u);
+        // (computed by every lane: tucked under the store's lane mask, the whole block above becomes a branch
+        // target and the steady-state body is no longer straight-line code)
+        asm volatile("" : "+v"(out));
+#ifdef STRIP_DBG_NOSTORE
+        if (c.writes && out == 0x12345678u) {
+#else
+        if (c.writes) {
+#endif
+            // the lane's column is rebuilt from a fresh lane id: kept live across the loop it is
+            // the one value that got spilled
+            uint32_t l;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            const int y = rb - 6;
+            *reinterpret_cast<uint32_t *>(c.dst + ((uint32_t)y * (uint32_t)c.W + (uint32_t)c.c0_base + 4u * l)) = out;
+        }
+    }
+    if (fresh) {
+        // ---- row filter of row rb (ascending FMA chain) into slot S
+        const float v[14] = {l2, l1.x, l1.y, l1.z, l1.w, mine.x, mine.y, mine.z, mine.w, r1.x, r1.y, r1.z, r1.w, r2};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float acc = 0.0f;
+#ifndef STRIP_DBG_NOROW
+#pragma unroll
+            for (int k = 0; k < 11; ++k) acc = fmaf(v[o + k], kw[k <= 5 ? k : 10 - k], acc);
+#else
+            acc = v[o] + v[o + 5] * kw[2] + v[o + 10];
+#endif
+            st.ring[S][o] = acc;
+        }
+        st.bring[S] = b_new;
+    } else if (feed) {
+        // BORDER_REPLICATE: blurred row rb is the blurred row of the step before
+        constexpr int prev = (S + 10) % 11;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) st.ring[S][o] = st.ring[prev][o];
+        st.bring[S] = st.bring[prev];
+    }
+}
+
+template <int CH, bool XEDGE, int S = 0>
+__device__ __forceinline__ void strip_group(const StripCtx &c, const float (&gk)[6], StripState<CH> &st, int rb0, bool out_rows)
+{
+    // eleven branch-free steps: every row is fresh; out_rows is a literal at both call sites
+    if constexpr (S < 11) {
+        strip_step<CH, XEDGE, S>(c, gk, st, rb0 + S, true, false, out_rows);
+        strip_group<CH, XEDGE, S + 1>(c, gk, st, rb0, out_rows);
+    }
+}
+
+template <int CH, bool XEDGE, int S = 0>
+__device__ __forceinline__ void strip_group_checked(const StripCtx &c, const float (&gk)[6], StripState<CH> &st, int rb0, int rb_hi)
+{
+    // eleven steps with run-time flags: the first group of a strip at the top of the image and the last steps
+    // of every strip (rows beyond the image are repeats; one extra step flushes the last output row)
+    if constexpr (S < 11) {
+        const int rb = rb0 + S;
+        if (rb <= rb_hi + 1) {
+            const bool feed = rb <= rb_hi;
+            const bool hold = (rb <= 0 && rb > c.y0 - 5) || rb > c.H - 1;
+            strip_step<CH, XEDGE, S>(c, gk, st, rb, feed, hold, rb - 6 >= c.y0);
+        }
+        strip_group_checked<CH, XEDGE, S + 1>(c, gk, st, rb0, rb_hi);
+    }
+}
+
+// One strip: blurred rows rb_lo = y0 - 5 .. rb_hi = y1 + 4 enter one per step, output row rb - 6 leaves.
+// The gray rows fed into the blur's 3-row window are CONSECUTIVE: the first step sets the window up so that row
+// g0 = max(rb_lo, 0) + 1 completes it (at the top of the image REFLECT_101 makes that window (1, 0, 1)), every
+// later fresh step feeds the next row, and the image's last row is followed by its reflection, row H - 2.
+// XEDGE: the strip touches the left / right image border.
+template <int CH, bool XEDGE>
+__device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gauss)
+{
+    const int H = c.H;
+    // The 88 multiply-adds of the two filter passes take their weight from a VECTOR register: on gfx950 a
+    // scalar-register source operand halves the issue rate of v_fma / v_fmac / v_add (4.6 instead of 2.8 cycles per
+    // wave-instruction, scripts/ubench/sgpr_operand.hip), which is where the compiler puts kernel arguments.  The
+    // kernel is symmetric (k[i] == k[10 - i] bit for bit, make_gauss11), so six registers hold it; the empty asm
+    // hides where the values came from, or the operands would be folded back into scalar registers.
+    float gk[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        gk[i] = gauss.k[i];
+        asm volatile("" : "+v"(gk[i]));
+    }
+    StripState<CH> st;
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+        st.bring[s] = 0u;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) st.ring[s][o] = 0.f;
+    }
+    const int rb_lo = c.y0 - 5, rb_hi = c.y1 - 1 + 5;
+    {   // the two gray rows above the first fed one, and the rows in flight
+        const int rbc = max(rb_lo, 0);
+        st.hc = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, reflect101(rbc - 1, H)))));
+        st.hd = hsum4(patch_row<XEDGE>(c, gray_of(c, load_row<CH>(c, rbc))));
+        st.row0 = rbc + 1;
+        st.k = 0;
+#pragma unroll
+        for (int d = 0; d < STRIP_PF; ++d) request_row<CH>(c, st, d);
+        st.next = take_row<CH>(c, 0);
+    }
+    // steady state: whole groups of eleven steps whose rows are all fresh (rb <= min(rb_hi, H - 1)); the first
+    // group produces no output (y = rb - 6 < y0) and, at the top of the image, repeats rows
+    const int last_fresh = min(rb_hi, H - 1);
+    int rb0 = rb_lo;
+    if (rb0 + 10 <= last_fresh && rb_lo >= 0) {
+        strip_group<CH, XEDGE>(c, gk, st, rb0, false);
+        rb0 += 11;
+    } else {
+        strip_group_checked<CH, XEDGE>(c, gk, st, rb0, rb_hi);
+        rb0 += 11;
+    }
+    for (; rb0 + 10 <= last_fresh; rb0 += 11) strip_group<CH, XEDGE>(c, gk, st, rb0, true);
+    for (; rb0 <= rb_hi + 1; rb0 += 11) strip_group_checked<CH, XEDGE>(c, gk, st, rb0, rb_hi);
+    // rows requested beyond the last one consumed are still on their way: they must not land in the ring of
+    // the wave's next strip
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // Requires W % 4 == 0 and W >= 16 (else the tile kernel above is used).
@@ -396,31 +539,39 @@ __device__ __forceinline__ void strip_body(const StripCtx &c, const Gauss11 &gk)
 // 15 % faster (101 us), but the link kernel's waves then find no registers while it runs and the
 // end-to-end rate is no better; the BGR variant needs ~140 VGPRs and runs 2 blocks per CU)
 template <int CH>
-__global__ __launch_bounds__(256, CH == 1 ? 4 : 3) void k_threshold_strip(const uint8_t *__restrict__ frames,
+__global__ __launch_bounds__(256, 4) void k_threshold_strip(const uint8_t *__restrict__ frames,
                                                          uint8_t *__restrict__ cls, StripParams P, Gauss11 gk)
 {
     DET_RING(1);
-#if STRIP_LDS_EXCHANGE
     __shared__ float s_x[4][64 * 4 + 16];
-#endif
+    __shared__ uint32_t s_q[4][STRIP_PF * CH * 64];
     // everything derived from the wave index is wave-uniform: say so (readfirstlane), or the compiler
     // keeps row counters in VGPRs and turns every loop test into a divergent branch + vmcnt(0)
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int per_frame = P.strips_x * P.segs_y;
-    const long long n_items = (long long)P.batch * per_frame;
     // resident grid, strided over the (frame, strip, segment) items: a grid larger than the chip
-    // can hold keeps the dispatcher busy and starves every other stream until it has drained
-    for (long long wave = (long long)blockIdx.x * 4 + wave_in_block; wave < n_items; wave += (long long)gridDim.x * 4) {
-    const int f = (int)(wave / per_frame);
-    const int rem = (int)(wave - (long long)f * per_frame);
+    // can hold keeps the dispatcher busy and starves every other stream until it has drained.
+    // Workgroups b and b + 8 run on the same XCD (observed dispatch order; a matter of speed only): with
+    // by_xcd every XCD works through whole frames, so the segment above and below an item -- whose ten halo
+    // rows it re-reads -- was fetched into the same L2, not into another XCD's.
+    long long first, step, count;
+    int f_mul, f_add;
+    if (P.by_xcd) {
+        first = (long long)(blockIdx.x >> 3) * 4 + wave_in_block; step = (long long)(gridDim.x >> 3) * 4;
+        count = (long long)(P.batch >> 3) * per_frame; f_mul = 8; f_add = (int)(blockIdx.x & 7u);
+    } else {
+        first = (long long)blockIdx.x * 4 + wave_in_block; step = (long long)gridDim.x * 4;
+        count = (long long)P.batch * per_frame; f_mul = 1; f_add = 0;
+    }
+    for (long long wave = first; wave < count; wave += step) {
+    const int f = (int)(wave / per_frame) * f_mul + f_add;
+    const int rem = (int)(wave % per_frame);
     const int sx = rem % P.strips_x, sy = rem / P.strips_x;
     StripCtx c;
     c.H = P.H; c.W = P.W; c.lane = lane; c.gc = P.gc;
-#if STRIP_LDS_EXCHANGE
     c.xrow = s_x[wave_in_block] + 8;
-#else
-    c.xrow = nullptr;
-#endif
+    c.q = s_q[wave_in_block];
+    c.q_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)s_q[wave_in_block]);
     const int xs = sx * P.out_lanes * 4;
     c.c0_base = xs - 4 * STRIP_HALO_LANES;
     c.c0 = c.c0_base + 4 * lane;
@@ -434,17 +585,18 @@ __global__ __launch_bounds__(256, CH == 1 ? 4 : 3) void k_threshold_strip(const 
     c.right_edge = last_col_rel < 252;           // column W falls inside this wave's lanes
     c.edge_lane = min(last_col_rel >> 2, 63);
     c.writes = lane >= STRIP_HALO_LANES && lane < STRIP_HALO_LANES + P.out_lanes && c.c0 < P.W;
-    // THRESH_BINARY: bit = (d > t) = clamp(d - t);  THRESH_BINARY_INV: bit = (d <= t) = clamp(t + 1 - d)
+    // THRESH_BINARY: bit = (d > t) = (d - t >= 1);  THRESH_BINARY_INV: bit = (d <= t) = (t + 1 - d >= 1)
     c.sgn = P.inv ? -1.0f : 1.0f;
-    c.k_lo = P.inv ? (float)(P.t_low + 1) : (float)(-P.t_low);
-    c.k_hi = P.inv ? (float)(P.t_high + 1) : (float)(-P.t_high);
-    const bool xedge = c.left_edge || c.right_edge;
-    const bool yedge = (c.y0 - 6 < 0) || (c.y1 + 5 + STRIP_PF + 1 >= P.H);
-    if (xedge) {
-        if (yedge) strip_body<CH, true, true>(c, gk); else strip_body<CH, true, false>(c, gk);
-    } else {
-        if (yedge) strip_body<CH, false, true>(c, gk); else strip_body<CH, false, false>(c, gk);
+    c.nsgn = -c.sgn;
+    {
+        const int k_lo = P.inv ? P.t_low + 1 : -P.t_low, k_hi = P.inv ? P.t_high + 1 : -P.t_high;
+        const int k_max = k_lo > k_hi ? k_lo : k_hi;
+        c.k_p = (float)k_max + c.sgn * 12582912.0f;
+        c.swar_lo = (uint32_t)(128 - (1 + k_max - k_lo)) * 0x01010101u;    // (the launcher guarantees |t_low - t_high| <= 127)
+        c.swar_hi = (uint32_t)(128 - (1 + k_max - k_hi)) * 0x01010101u;
     }
+    if (c.left_edge || c.right_edge) strip_body<CH, true>(c, gk);
+    else strip_body<CH, false>(c, gk);
     }
 }
 
@@ -1386,7 +1538,7 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
 // Drop nested components, write final detection list / count / anchors.
 __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__restrict__ det_tmp, float *det,
                                                  int32_t *det_count, int32_t *anchors, PixelList pl, const uint8_t *labels,
-                                                 const uint8_t *mask, size_t total, bool angle_451)
+                                                 const uint8_t *mask, size_t total, bool angle_pre451)
 {
     DET_RING(14);
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // last kernel of the call: the current list describes these buffers
@@ -1420,12 +1572,13 @@ __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__re
             size_t q = (size_t)f * t.max_det + pos;
             float r[5];
             for (int j = 0; j < 5; ++j) r[j] = det_tmp[o * 5 + j];
-            // k_geometry reports cv::minAreaRect's convention of OpenCV < 4.5.1: angle in [-90, 0).  From 4.5.1
-            // on the same rectangle is reported with its angle in (0, 90] and the sides named the other way
-            // round (YSMR_CV_ANGLE_451; only rectangles from the rotating calipers, i.e. with two non-zero sides)
-            if (angle_451 && r[3] > 0.f) {
-                if (r[4] == -90.f) r[4] = 90.f;
-                else { const float w = r[2]; r[2] = r[3]; r[3] = w; r[4] += 90.f; }
+            // k_geometry's hull order + rotating calipers give the angle in [0, 90], cv::minAreaRect's range from
+            // OpenCV 4.5.1 on.  Earlier releases report the same rectangle with its angle in [-90, 0) and the
+            // sides named the other way round (YSMR_CV_ANGLE_PRE451; only rectangles from the rotating
+            // calipers, i.e. with two non-zero sides)
+            if (angle_pre451 && r[3] > 0.f) {
+                if (r[4] == 90.f) r[4] = -90.f;
+                else { const float w = r[2]; r[2] = r[3]; r[3] = w; r[4] -= 90.f; }
             }
             for (int j = 0; j < 5; ++j) det[q * 5 + j] = r[j];
             if (anchors) anchors[q] = t.order[o];
@@ -1531,22 +1684,34 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
 {
     Gauss11 gk = make_gauss11();
     const ysmr::GrayCoef gc = ysmr::gray_coef(cv_flavour);
-    if ((W & 3) == 0 && W >= 16 && H >= 2 && t_low > -100000 && t_low < 100000 && t_high > -100000 && t_high < 100000) {
+    const int t_gap = use_high ? (t_high > t_low ? t_high - t_low : t_low - t_high) : 0;
+    if ((W & 3) == 0 && W >= 16 && H >= 2 && t_low > -100000 && t_low < 100000 && t_high > -100000 && t_high < 100000 && t_gap <= 127) {
         StripParams P;
         P.H = H; P.W = W; P.batch = batch;
         const int quads = (W + 3) / 4;
         P.strips_x = (quads + STRIP_MAX_OUT_LANES - 1) / STRIP_MAX_OUT_LANES;
         P.out_lanes = (quads + P.strips_x - 1) / P.strips_x;
-        P.seg_h = 45;   // rows per work item (+10 halo rows = 5 x 11 ring rotations; 2.6 items per resident wave)
+        int resident = 768;   // 3 blocks per CU (105 / 111 VGPRs, allocated as 112): a wave slot and 176 VGPRs per
+                              // SIMD stay free for the link kernel's waves
+        if (knobs().thr_blocks > 0) resident = knobs().thr_blocks;
+        // rows per work item: every item re-reads and re-filters 10 halo rows, so items are as tall as they can
+        // be while there is still one for every resident wave (1228x922, 64 frames: 384 strip columns x 8
+        // segments of 116 rows = 3072 items = 768 blocks x 4 waves; it was 45 rows, 2.6 items per wave); never
+        // shorter than 32 rows
+        {
+            const long long columns = (long long)batch * P.strips_x;
+            const long long segs = std::max<long long>(1, (long long)resident * 4 / columns);
+            P.seg_h = (int)std::max<long long>(32, (H + segs - 1) / segs);
+        }
         if (knobs().seg_h > 0) P.seg_h = knobs().seg_h;
         P.segs_y = (H + P.seg_h - 1) / P.seg_h;
         P.inv = inv; P.t_low = t_low; P.t_high = use_high ? t_high : t_low; P.gc = gc;
         const long long waves = (long long)batch * P.strips_x * P.segs_y;
         long long blocks = (waves + 3) / 4;
-        int resident = channels == 1 ? 768 : 512;   // 3 (gray, 128 VGPRs) / 2 (BGR, ~140 VGPRs) blocks per CU: a wave slot and
-                                                     // >= 128 VGPRs per SIMD stay free for the link kernel's waves
-        if (knobs().thr_blocks > 0) resident = knobs().thr_blocks;
         if (resident > 0 && blocks > resident) blocks = resident;
+        P.by_xcd = (batch % 8 == 0 && blocks % 8 == 0) ? 1 : 0;
+        if (P.by_xcd && blocks / 8 * 4 > (long long)(batch / 8) * P.strips_x * P.segs_y)    // (no more waves than an XCD has items)
+            blocks = (((long long)(batch / 8) * P.strips_x * P.segs_y + 3) / 4) * 8;
         if (channels == 1) hipLaunchKernelGGL(k_threshold_strip<1>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
         else hipLaunchKernelGGL(k_threshold_strip<3>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
     } else {
@@ -1635,7 +1800,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     hipLaunchKernelGGL(k_geometry, dim3(geo_blocks), dim3(GEO_THREADS), 0, st,
                        labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
     hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev, w.pixels,
-                       reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total, (cv_flavour & YSMR_CV_ANGLE_451) != 0);
+                       reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total, (cv_flavour & YSMR_CV_ANGLE_PRE451) != 0);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }
