@@ -407,6 +407,7 @@ class _Track:
     gone: int = 0
     gs: GsffState = field(default_factory=GsffState)
     shadow: list = field(default_factory=list)   # [[GsffState, pos], ...] one per shadow filter
+    tied: bool = False    # its assignment once hung on a distance tie (see OracleTracker, ``shadows``)
 
 
 class OracleTracker:
@@ -428,9 +429,17 @@ class OracleTracker:
     than ILL_CONDITIONED under a one-ulp change of the reference's own intermediate results is not
     determined by the reference's arithmetic to better than that (any other BLAS, libm or summation
     order moves it as much); every other row is.  The real filter's arithmetic is untouched.
+
+    The probe also watches the ASSIGNMENT: a track whose claim hangs on a distance tie -- two tracks equally
+    far (to TIE relative) from the detection both want, e.g. two blobs that merge into one component exactly
+    between them, or two detections equally far from one track -- is assigned by the last bits of the
+    predicted positions, i.e. by how LAPACK rounded the reference's gain matrices (their rows sum to 1 + 1e-15,
+    which moves x = 2996 to 2996.0000000000036).  Such tracks are marked ``tied`` for the rest of their
+    life and report ``last_sens = inf``: which of the two got the detection is not a property of the algorithm.
     """
 
     ILL_CONDITIONED = 1e-12
+    TIE = 1e-9
 
     def __init__(self, max_disappeared=50, fps=30, n_min=0, n_max=None, n_f=3, use_gsff=True, shadows=0):
         self.max_gone = max_disappeared
@@ -447,6 +456,28 @@ class OracleTracker:
             self.gsff = OracleGSFF(**kw)
             if shadows:
                 self.shadow_gsff = [OracleGSFF(perturb=+1, **kw), OracleGSFF(perturb=-1, **kw)]
+
+    def _mark_ties(self, d):
+        """Tracks whose claim this frame depends on a distance tie (conditioning probe only)."""
+        n, m = d.shape
+        dmin, arg = d.min(axis=1), d.argmin(axis=1)
+        tol = self.TIE * np.maximum(1.0, dmin)
+        if m > 1:    # two detections equally near one track
+            second = np.partition(d, 1, axis=1)[:, 1]
+            for r in np.flatnonzero(second - dmin <= tol):
+                self.tracks[r].tied = True
+        by_col = np.argsort(arg, kind="stable")          # tracks proposing the same detection
+        cols = arg[by_col]
+        start = 0
+        for end in list(np.flatnonzero(cols[1:] != cols[:-1]) + 1) + [n]:
+            if end - start > 1:
+                rows = by_col[start:end]
+                best = dmin[rows].min()
+                close = rows[dmin[rows] - best <= self.TIE * max(1.0, best)]
+                if len(close) > 1:
+                    for r in close:
+                        self.tracks[r].tied = True
+            start = end
 
     def _register(self, pos, info):
         self.tracks.append(_Track(self.next_id, pos, info, shadow=[[GsffState(), pos] for _ in self.shadow_gsff]))
@@ -476,6 +507,8 @@ class OracleTracker:
                 d = cdist(cur, pts)
                 order = np.argsort(d.min(axis=1), kind="stable")
                 nearest = d.argmin(axis=1)[order]
+                if self.shadow_gsff:
+                    self._mark_ties(d)
                 rows_used, cols_used = set(), set()
                 for r, c in zip(order, nearest):
                     if r in rows_used or c in cols_used:
@@ -515,6 +548,8 @@ class OracleTracker:
                     o = g.correct(sh[1], sh[0])
                     sh[1] = g.predict(sh[0])
                     sens[i] = max(sens[i], float(np.max(np.abs(o - out[i]) / np.maximum(1.0, np.abs(out[i])))))
+                if t.tied:
+                    sens[i] = np.inf
             self.last_sens = sens
         else:
             out = np.array([t.pos for t in self.tracks], dtype=float).reshape(-1, 2)

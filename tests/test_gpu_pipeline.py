@@ -395,9 +395,11 @@ def test_bench_config_rows_hold_1e9_outside_the_oracles_ill_conditioned_set(tmp_
     dev = np.maximum(np.abs(got["x"] - ref[:, 2]) / np.maximum(1, np.abs(ref[:, 2])),
                      np.abs(got["y"] - ref[:, 3]) / np.maximum(1, np.abs(ref[:, 3])))
     well = ref[:, 7] <= oracle.OracleTracker.ILL_CONDITIONED
+    tied = np.isinf(ref[:, 7])
     report = {"rows": len(got), "rows_of_lost_tracks": lost, "ill_conditioned_rows": n_loose,
               "ill_conditioned_fraction": n_loose / len(got), "worst_ill_conditioned_px": worst,
-              "ill_conditioned_rows_beyond_1e-5_relative": int((dev[~well] > 1e-5).sum()),
+              "ill_conditioned_rows_beyond_1e-5_relative": int((dev[~well & ~tied] > 1e-5).sum()),
+              "rows_of_tie_assigned_tracks": int(tied.sum()),
               "worst_well_conditioned_relative": float(dev[well].max())}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)

@@ -44,3 +44,27 @@ for i in bad[:10]:
         dist = np.sqrt((d[:, 0].astype(float) - px) ** 2 + (d[:, 1].astype(float) - py) ** 2)
         o = np.argsort(dist)[:4]
         print("   previous output", px, py, "nearest detections", [(int(j), float(d[j, 0]), float(d[j, 1]), float(dist[j])) for j in o])
+
+# ---- the same three frames one update at a time, with the claims
+print("---- per-frame updates with claims")
+trk2 = DeviceTracker(max_disappeared=30.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=8192, max_det=8192)
+ot2 = yo.OracleTracker(max_disappeared=30.0, fps=30.0, n_min=0, n_max=30, n_f=3)
+rows1 = torch.empty(8192 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+claim = torch.empty(8192, dtype=torch.int32, device="cuda")
+newc = torch.empty(8192, dtype=torch.int32, device="cuda")
+scal = torch.zeros(4, dtype=torch.int32, device="cuda")
+for k in range(3):
+    d = dets[k]
+    det64 = torch.from_numpy(np.ascontiguousarray(d, np.float32)).cuda()
+    ids_before = [t.tid for t in ot2.tracks]
+    trk2.update(det64, m=len(d), frame=k, rows=rows1, n_rows=scal[0:1], claim=claim, n_before=scal[1:2], new_cols=newc, n_new=scal[2:3])
+    nb = int(scal[1].item())
+    dev_claim = claim[:nb].cpu().numpy()
+    ids, xy, info, claims = ot2.update(yo.det_to_rects(d))
+    ref_claim = -np.ones(nb, int)
+    for r, c in claims:
+        ref_claim[r] = c
+    diff = np.flatnonzero(dev_claim != ref_claim)
+    print("frame", k, "tracks before", nb, "claims differing", len(diff))
+    for r in diff[:10]:
+        print("   row", r, "id", ids_before[r], "device col", dev_claim[r], "oracle col", ref_claim[r])
