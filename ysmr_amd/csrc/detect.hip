@@ -723,54 +723,73 @@ constexpr int SPARSE_BLOCKS = 768;  // resident grid of the list-driven passes (
 // grid instead of hipMemsetAsync: the runtime's fill kernels use grids far larger than the chip
 // holds, and such a grid starves every other stream (the link) until it has drained.
 constexpr int CLEAR_BLOCKS = 512;
-__global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, uint8_t *mask, size_t total)
+// (also: the per-call counters and status words are zeroed here, and the block that finishes last switches the
+// workspace to its other pixel list, empties it and marks the header invalid until k_compact, the last kernel
+// of the call, vouches for the buffers again -- one launch instead of two at the head of the chain)
+__global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, uint8_t *mask, size_t total, int32_t *counters,
+                                               int n_counters, int32_t *status, int batch)
 {
     DET_RING(2);
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
     const WsHeader h = *pl.hdr;
     const uint32_t prev = h.cur & 1u;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] = 0;
+        for (int i = threadIdx.x; i < batch; i += 256) status[i] = 0;
+    }
     if (h.magic == WS_MAGIC && h.labels == (unsigned long long)labels && h.mask == (unsigned long long)mask &&
         h.total == total && h.count[prev] <= pl.cap) {
-        const uint32_t *idx = pl.idx[prev];
+        const uint32_t *__restrict__ idx = pl.idx[prev];
         uint32_t *lab = reinterpret_cast<uint32_t *>(labels);
-        for (size_t i = tid; i < h.count[prev]; i += stride) {
-            const uint32_t flat = idx[i];
-            lab[flat] = 0u;
-            // whole dword: its other bytes are either listed themselves or zero already (every non-zero mask
-            // byte belongs to a listed pixel), and a dword store spares the partial-byte write
-            if (mask) {
-                if ((size_t)(flat | 3u) < total) *reinterpret_cast<uint32_t *>(mask + (flat & ~3u)) = 0u;
-                else mask[flat] = 0;
+        const size_t n = h.count[prev];
+        // four list entries per thread and round: the index loads of a round are in flight together (the
+        // stores below cannot be proven not to alias the list, so a plain loop serialises load, store, load, ...)
+        for (size_t i0 = tid; i0 < n; i0 += 4 * stride) {
+            uint32_t flat[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = i0 + (size_t)u * stride;
+                flat[u] = i < n ? idx[i] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (flat[u] == 0xFFFFFFFFu) continue;
+                lab[flat[u]] = 0u;
+                // whole dword: its other bytes are either listed themselves or zero already (every non-zero mask
+                // byte belongs to a listed pixel), and a dword store spares the partial-byte write
+                if (mask) {
+                    if ((size_t)(flat[u] | 3u) < total) *reinterpret_cast<uint32_t *>(mask + (flat[u] & ~3u)) = 0u;
+                    else mask[flat[u]] = 0;
+                }
             }
         }
-        return;
+    } else {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int which = 0; which < 2; ++which) {
+            uint8_t *p = which ? mask : labels;
+            const size_t bytes = which ? total : total * sizeof(uint32_t);
+            if (!p) continue;
+            uint4 *q = reinterpret_cast<uint4 *>(p);       // (16-byte aligned: checked by the caller)
+            const size_t n16 = bytes / 16;
+            for (size_t i = tid; i < n16; i += stride) q[i] = z;
+            for (size_t i = n16 * 16 + tid; i < bytes; i += stride) p[i] = 0;
+        }
     }
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    for (int which = 0; which < 2; ++which) {
-        uint8_t *p = which ? mask : labels;
-        const size_t bytes = which ? total : total * sizeof(uint32_t);
-        if (!p) continue;
-        uint4 *q = reinterpret_cast<uint4 *>(p);       // (16-byte aligned: checked by the caller)
-        const size_t n16 = bytes / 16;
-        for (size_t i = tid; i < n16; i += stride) q[i] = z;
-        for (size_t i = n16 * 16 + tid; i < bytes; i += stride) p[i] = 0;
-    }
-}
-
-// Between k_clear and k_collect: switch to the other list, empty it, and mark the header invalid
-// until k_compact (the last kernel of the call) has run and vouches for the buffers again.
-__global__ __launch_bounds__(256) void k_list_begin(PixelList pl, int32_t *counters, int n_counters, int32_t *status, int batch)
-{
-    DET_RING(3);
-    // (also clears the per-call counters and the status words: two fewer launches in the chain)
-    for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] = 0;
-    for (int i = threadIdx.x; i < batch; i += 256) status[i] = 0;
+    // every block has read the header by now; the last one to get here rewrites it
+    __shared__ uint32_t s_ticket;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        WsHeader *h = pl.hdr;
-        const uint32_t cur = (h->magic == WS_MAGIC) ? ((h->cur & 1u) ^ 1u) : 0u;
-        h->magic = 0;
-        h->cur = cur;
-        h->count[cur] = 0;
+        __threadfence();
+        s_ticket = atomicAdd(&pl.hdr->pad, 1u);
+    }
+    __syncthreads();
+    if (s_ticket == gridDim.x - 1 && threadIdx.x == 0) {
+        WsHeader *hd = pl.hdr;
+        const uint32_t cur = (h.magic == WS_MAGIC) ? ((h.cur & 1u) ^ 1u) : 0u;
+        hd->magic = 0;
+        hd->cur = cur;
+        hd->count[cur] = 0;
+        hd->pad = 0;
     }
 }
 
@@ -1418,13 +1437,17 @@ extern "C" int ysmr_debug_read_geo_stamps(unsigned long long *out) { return (int
 #define GEOSTAMP(k) do {} while (0)
 #endif
 
-// 16 lanes per component: lane `sub` scans column minx+sub of the bounding box for the top-most and
-// bottom-most pixel of the component (the only hull candidates of that column; all loads of a
-// column are independent), lane 0 then builds the chains from the 16 (top, bottom) pairs and runs
-// the calipers.  Components wider than 16 columns take the serial path with arena storage.
-constexpr int GEO_GROUP = 16;
+// 8 lanes per component: lane `sub` scans columns minx+sub and minx+sub+8 of the bounding box for the top-most
+// and bottom-most pixel of the component (the only hull candidates of a column; all loads are independent, so
+// two columns cost one round trip), lane 0 then builds the chains from the (top, bottom) pairs and runs the
+// calipers.  The kernel is bound by that serial chain (~15 us per component), i.e. by how many components are
+// in flight: 8 lanes instead of 16 per component hold twice as many per resident wave (32 k at 4 blocks per
+// CU: the benchmark batch in one round instead of two).  Components wider than GEO_COLS columns take the
+// serial path with arena storage.
+constexpr int GEO_GROUP = 8;
+constexpr int GEO_COLS = 16;
 constexpr int GEO_COMPS = GEO_THREADS / GEO_GROUP;          // components per block
-constexpr int GEO_LDS_STRIDE = LDS_POINTS * 5 + 1;          // +1: keep the 4 active lanes of a wave off one bank
+constexpr int GEO_LDS_STRIDE = LDS_POINTS * 5 + 2;          // 177 floats: the 8 active lanes of a wave start on 8 different banks
 
 __device__ __forceinline__ void column_extent(const uint32_t *L, int W, int x, int miny, int maxy, uint32_t want,
                                               int &top, int &bot)
@@ -1440,12 +1463,33 @@ __device__ __forceinline__ void column_extent(const uint32_t *L, int W, int x, i
     }
 }
 
+// two columns at once (their loads in flight together)
+__device__ __forceinline__ void column_extent2(const uint32_t *L, int W, int xa, int xb, int miny, int maxy, uint32_t want,
+                                               int (&top)[2], int (&bot)[2])
+{
+    top[0] = top[1] = -1; bot[0] = bot[1] = -1;
+    for (int y0 = miny; y0 <= maxy; y0 += 8) {
+        uint32_t va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t row = (size_t)min(y0 + u, maxy) * W;
+            va[u] = L[row + xa];
+            vb[u] = L[row + xb];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (y0 + u <= maxy && va[u] == want) { if (top[0] < 0) top[0] = y0 + u; bot[0] = y0 + u; }
+            if (y0 + u <= maxy && vb[u] == want) { if (top[1] < 0) top[1] = y0 + u; bot[1] = y0 + u; }
+        }
+    }
+}
+
 __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g, const CompTables &t, int f, int k,
                                float *det_tmp, float *arena, uint32_t arena_floats, uint32_t *arena_used,
                                int32_t *status)
 {
     __shared__ float lds[GEO_COMPS * GEO_LDS_STRIDE];
-    __shared__ int s_top[GEO_COMPS][GEO_GROUP], s_bot[GEO_COMPS][GEO_GROUP];
+    __shared__ int s_top[GEO_COMPS][GEO_COLS], s_bot[GEO_COMPS][GEO_COLS];
     GEOSTAMP(0);
     const int grp = threadIdx.x / GEO_GROUP, sub = threadIdx.x % GEO_GROUP;
     bool live = k < min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
@@ -1460,13 +1504,20 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
     const int bwid = maxx - minx + 1;
     const uint32_t *L = labels + (size_t)(live ? f : 0) * g.HW;
     const int W = g.W;
-    const bool narrow = live && bwid <= GEO_GROUP;
+    const bool narrow = live && bwid <= GEO_COLS;
     GEOSTAMP(1);
     if (narrow && sub < bwid) {
-        int top, bot;
-        column_extent(L, W, minx + sub, miny, maxy, want, top, bot);
-        s_top[grp][sub] = top;
-        s_bot[grp][sub] = bot;
+        if (sub + GEO_GROUP < bwid) {
+            int top[2], bot[2];
+            column_extent2(L, W, minx + sub, minx + sub + GEO_GROUP, miny, maxy, want, top, bot);
+            s_top[grp][sub] = top[0]; s_bot[grp][sub] = bot[0];
+            s_top[grp][sub + GEO_GROUP] = top[1]; s_bot[grp][sub + GEO_GROUP] = bot[1];
+        } else {
+            int top, bot;
+            column_extent(L, W, minx + sub, miny, maxy, want, top, bot);
+            s_top[grp][sub] = top;
+            s_bot[grp][sub] = bot;
+        }
     }
     __syncthreads();
     GEOSTAMP(2);
@@ -1623,7 +1674,7 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return (char *)base + o; };
     size_t bm = (size_t)batch * max_det;
     w.pixels.hdr = (WsHeader *)take(256);   // persists across calls (ysmr_detect_workspace_init zeroes it)
-    // counters first: k_list_begin clears nroots, n_holed, arena_used, max_roots in one go
+    // counters first: k_clear zeroes nroots, n_holed, arena_used, max_roots in one go
     w.nroots = (int32_t *)take(sizeof(int32_t) * ((size_t)batch * NR_STRIDE + 8));
     w.n_holed = w.nroots + (size_t)batch * NR_STRIDE;
     w.arena_used = (uint32_t *)(w.n_holed + 1);
@@ -1777,8 +1828,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     const unsigned clear_blocks = kn.clear_blocks > 0 ? (unsigned)kn.clear_blocks : (unsigned)CLEAR_BLOCKS;
     const unsigned geo_blocks = kn.geo_blocks > 0 ? (unsigned)kn.geo_blocks : (unsigned)GEO_BLOCKS;
     hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, st, w.pixels, reinterpret_cast<uint8_t *>(labels), mask_dev,
-                       g.total);
-    hipLaunchKernelGGL(k_list_begin, dim3(1), dim3(256), 0, st, w.pixels, w.nroots, batch * NR_STRIDE + 8, status_dev, batch);
+                       g.total, w.nroots, batch * NR_STRIDE + 8, status_dev, batch);
     const unsigned dense_grid = cgrid < collect_blocks ? cgrid : collect_blocks;
     const dim3 sg(sparse_blocks), tb(256);
     hipLaunchKernelGGL(k_collect, dim3(dense_grid), tb, 0, st, cls_dev, labels, g, nchunks, w.pixels);
