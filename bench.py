@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=512, help="distinct frames per clip (512 x 1.13 MB > 256 MiB L3)")
-    ap.add_argument("--batch", type=int, default=64, help="frames per detection launch")
+    ap.add_argument("--batch", type=int, default=None, help="frames per detection launch")
     ap.add_argument("--height", type=int, default=922)
     ap.add_argument("--width", type=int, default=1228)
     ap.add_argument("--blobs", type=int, default=500)
@@ -68,9 +68,11 @@ def parse():
     elif args.config == 1:
         args.detect_only = True
     elif args.config == 4:
-        args.height, args.width, args.blobs, args.frames, args.batch = 2160, 3840, 5000, 64, 8
+        args.height, args.width, args.blobs, args.frames = 2160, 3840, 5000, 64
+        args.batch = args.batch or 16
         args.max_det = args.capacity = 8192
         args.cpu_sample = min(args.cpu_sample, 8)
+    args.batch = args.batch or 64
     return args
 
 

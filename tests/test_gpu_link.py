@@ -186,3 +186,53 @@ def test_centroid_tracker_public_attributes_and_payloads():
         ct.update([((1.0, 2.0, 3.0), (1, 1, 0))])                         # luminosity dimension
     ct.update([]); ct.update([]); ct.update([])
     assert list(ct.objects) == [] and ct.nextObjectID == 2
+
+
+def test_capacity_beyond_the_lds_tables(torch_cuda, oracle):
+    """capacity / max_det = 16384: k_link's per-column and per-row tables no longer fit in LDS and live in HBM;
+    the row minima of a batch come from the detection grid (ysmr_tracker_run) or from all pairs
+    (ysmr_tracker_update).  Same rows as the oracle either way, including tracks far from every detection
+    (the grid search gives up after four rings and falls back to all pairs)."""
+    torch = torch_cuda
+    from ysmr_amd import _lib
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    rng = np.random.default_rng(3)
+    cap = 16384
+    base = rng.uniform(0, 3000, (900, 2))
+    base[:5] += 40000.0                                   # a far-away cluster: most of the grid is empty
+    frames = []
+    for f in range(10):
+        keep = rng.random(len(base)) > (0.15 if f % 3 else 0.5)      # heavy dropout every third frame: lost tracks
+        xy = base[keep] + rng.normal(0, 0.4, (int(keep.sum()), 2))
+        whd = np.column_stack([rng.uniform(1, 9, len(xy)), rng.uniform(1, 9, len(xy)), rng.uniform(0, 90, len(xy))])
+        frames.append(np.column_stack([xy, whd]).astype(np.float32))
+        base += rng.normal(0, 0.3, base.shape)
+    ot = oracle.OracleTracker(max_disappeared=3.0, fps=30.0, n_min=0, n_max=30, n_f=3, shadows=2)
+    ref_rows = []
+    for f, d in enumerate(frames):
+        ids, xy, info, _ = ot.update(oracle.det_to_rects(d))
+        ref_rows += [(f, tid, float(xy[i][0]), float(xy[i][1]), *map(float, info[i]), float(ot.last_sens[i]))
+                     for i, tid in enumerate(ids)]
+    for mode in ("run", "update"):
+        trk = DeviceTracker(max_disappeared=3.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=cap, max_det=cap)
+        rows = torch.empty(len(frames) * 1024 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        count = torch.zeros(1, dtype=torch.int64, device="cuda")
+        if mode == "run":
+            for b0 in range(0, len(frames), 5):
+                det = torch.zeros(5, cap, 5, dtype=torch.float32, device="cuda")
+                cnt = torch.zeros(5, dtype=torch.int32, device="cuda")
+                for k, d in enumerate(frames[b0:b0 + 5]):
+                    det[k, :len(d)] = torch.from_numpy(d).cuda()
+                    cnt[k] = len(d)
+                trk.run(det, cnt, b0, rows, count)
+            got = rows_to_numpy(rows, int(count.item()))
+        else:
+            parts = []
+            one = torch.empty(cap * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+            n1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for f, d in enumerate(frames):
+                trk.update(torch.from_numpy(d).cuda(), m=len(d), frame=f, rows=one, n_rows=n1)
+                parts.append(rows_to_numpy(one, int(n1.item())).copy())
+            got = np.concatenate(parts)
+        assert trk.info()[2] == 0
+        compare_rows(got, ref_rows)

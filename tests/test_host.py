@@ -366,7 +366,9 @@ def test_bench_argument_presets(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "2", "--config", "4"])
     a = bench.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 3, 2)
-    assert (a.height, a.width, a.blobs, a.frames, a.batch, a.max_det, a.capacity) == (2160, 3840, 5000, 64, 8, 8192, 8192)
+    assert (a.height, a.width, a.blobs, a.frames, a.batch, a.max_det, a.capacity) == (2160, 3840, 5000, 64, 16, 8192, 8192)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "4", "--batch", "8"])
+    assert bench.parse().batch == 8
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "1"])
     assert bench.parse().detect_only
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "0"])

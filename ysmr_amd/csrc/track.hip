@@ -51,6 +51,20 @@ struct TrackerDev {
     int *new_cols;                // [max_det]
     int *set_table;               // [2][table_cap] CPython set model
     long long *row_base;          // first output row of the current frame (k_link -> k_gsff)
+    // split path (tables too large for LDS): k_link's per-column winners and per-row claims
+    unsigned long long *link_key; // [max_det]
+    int *link_row;                // [max_det]
+    int *link_claim;              // [capacity]
+};
+
+// Uniform grid over one frame's detections (split path): the nearest detection of a track is looked for in the
+// cells around it instead of among all of them (25 M distances per frame at 5000 x 5000).
+constexpr int GRID_N = 128;                         // cells per side
+constexpr int GRID_CELLS = GRID_N * GRID_N;
+struct DetGrid {
+    const int *start;     // [GRID_CELLS + 1] first item of each cell (cells row-major: cy * GRID_N + cx)
+    const int *items;     // [max_det] detection columns, cell by cell (any order inside a cell)
+    const float *hdr;     // x0, y0, cell size, 1 / cell size
 };
 
 struct ysmr_tracker {
@@ -64,6 +78,19 @@ struct ysmr_tracker {
     std::vector<double> gains_host;
     bool set_base;                 // fused path: the next k_rowmin also sets row_base from base_ptr
     const long long *base_ptr;
+    void *grid_block = nullptr;    // split path: DetGrid arrays for grid_frames frames (allocated by ysmr_tracker_run)
+    int grid_frames = 0;
+    DetGrid grid(int f) const
+    {
+        char *b = (char *)grid_block;
+        const size_t per = grid_bytes_per_frame(d.max_det);
+        return DetGrid{(const int *)(b + per * f), (const int *)(b + per * f + sizeof(int) * (GRID_CELLS + 64)),
+                       (const float *)(b + per * f + sizeof(int) * (GRID_CELLS + 64) + sizeof(int) * (size_t)d.max_det)};
+    }
+    static size_t grid_bytes_per_frame(int max_det)
+    {
+        return ysmr::align_up(sizeof(int) * (GRID_CELLS + 64) + sizeof(int) * (size_t)max_det + 64, 256);
+    }
     const TrackerDev &cur() const { return par ? d1 : d; }
     const TrackerDev &nxt() const { return par ? d : d1; }
 };
@@ -224,11 +251,156 @@ __device__ __forceinline__ void rowmin_wave(const TrackerDev &t, int row, double
     }
 }
 
+// One block per frame: bounding box of the detection centres, 128 x 128 cells over it (one cell of margin), a
+// counting sort of the detection columns by cell.  Runs once per batch, off the frame-to-frame chain.
+template <typename DetT>
+__global__ __launch_bounds__(1024) void k_grid_build(const DetT *__restrict__ det_all, const int32_t *__restrict__ det_count,
+                                                     int max_det, char *grid_block, size_t per_frame)
+{
+    __shared__ int s_cnt[GRID_CELLS];          // counts, then cursors
+    __shared__ float s_red[4][16];
+    __shared__ int s_wave_sum[16];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const DetT *det = det_all + (size_t)f * max_det * 5;
+    int m = det_count[f];
+    m = m < 0 ? 0 : (m > max_det ? max_det : m);
+    int *start = (int *)(grid_block + per_frame * f);
+    int *items = start + GRID_CELLS + 64;
+    float *hdr = (float *)(items + max_det);
+    for (int c = tid; c < GRID_CELLS; c += 1024) s_cnt[c] = 0;
+    float lo_x = 3.0e38f, lo_y = 3.0e38f, hi_x = -3.0e38f, hi_y = -3.0e38f;
+    for (int j = tid; j < m; j += 1024) {
+        const float x = (float)det[(size_t)j * 5], y = (float)det[(size_t)j * 5 + 1];
+        lo_x = fminf(lo_x, x); hi_x = fmaxf(hi_x, x); lo_y = fminf(lo_y, y); hi_y = fmaxf(hi_y, y);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo_x = fminf(lo_x, __shfl_xor(lo_x, d)); hi_x = fmaxf(hi_x, __shfl_xor(hi_x, d));
+        lo_y = fminf(lo_y, __shfl_xor(lo_y, d)); hi_y = fmaxf(hi_y, __shfl_xor(hi_y, d));
+    }
+    if (lane == 0) { s_red[0][w] = lo_x; s_red[1][w] = hi_x; s_red[2][w] = lo_y; s_red[3][w] = hi_y; }
+    __syncthreads();
+    lo_x = s_red[0][0]; hi_x = s_red[1][0]; lo_y = s_red[2][0]; hi_y = s_red[3][0];
+    for (int k = 1; k < 16; ++k) {
+        lo_x = fminf(lo_x, s_red[0][k]); hi_x = fmaxf(hi_x, s_red[1][k]);
+        lo_y = fminf(lo_y, s_red[2][k]); hi_y = fmaxf(hi_y, s_red[3][k]);
+    }
+    float extent = fmaxf(fmaxf(hi_x - lo_x, hi_y - lo_y), 1.0f);
+    const float cell = extent / (float)(GRID_N - 2), inv = 1.0f / cell;
+    const float x0 = lo_x - cell, y0 = lo_y - cell;
+    if (tid == 0) { hdr[0] = x0; hdr[1] = y0; hdr[2] = cell; hdr[3] = inv; }
+    auto cell_of = [&](int j) {
+        int cx = (int)floorf(((float)det[(size_t)j * 5] - x0) * inv), cy = (int)floorf(((float)det[(size_t)j * 5 + 1] - y0) * inv);
+        cx = cx < 0 ? 0 : (cx > GRID_N - 1 ? GRID_N - 1 : cx);
+        cy = cy < 0 ? 0 : (cy > GRID_N - 1 ? GRID_N - 1 : cy);
+        return cy * GRID_N + cx;
+    };
+    for (int j = tid; j < m; j += 1024) atomicAdd(&s_cnt[cell_of(j)], 1);
+    __syncthreads();
+    // exclusive scan of the 16384 counts: 16 consecutive cells per thread, wave scan of the thread sums, wave sums
+    int local[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { local[k] = sum; sum += s_cnt[tid * 16 + k]; }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) s_wave_sum[w] = incl;
+    __syncthreads();
+    int before = incl - sum;
+    for (int k = 0; k < w; ++k) before += s_wave_sum[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int at = before + local[k];
+        start[tid * 16 + k] = at;
+        s_cnt[tid * 16 + k] = at;
+    }
+    if (tid == 1023) start[GRID_CELLS] = before + sum;
+    __syncthreads();
+    for (int j = tid; j < m; j += 1024) items[atomicAdd(&s_cnt[cell_of(j)], 1)] = j;
+}
+
+// Row minimum through the grid: rings of cells around the track until no unseen detection can be as near as the
+// best one found (the block of cells' boundary is farther, with a margin far above rounding), then the same tie
+// rule as rowmin_wave on the detections of that block -- lowest column among the equal rounded distances.
+// Returns false when four rings were not enough (a track far from every detection): the caller falls back to
+// all pairs.
+template <typename DetT>
+__device__ __forceinline__ bool rowmin_grid(const TrackerDev &t, int row, double px, double py, const DetT *__restrict__ det,
+                                            const DetGrid &g, int lane)
+{
+    const double x0 = (double)g.hdr[0], y0 = (double)g.hdr[1], cell = (double)g.hdr[2], inv = (double)g.hdr[3];
+    int cx = (int)floor((px - x0) * inv), cy = (int)floor((py - y0) * inv);
+    cx = cx < 0 ? 0 : (cx > GRID_N - 1 ? GRID_N - 1 : cx);
+    cy = cy < 0 ? 0 : (cy > GRID_N - 1 ? GRID_N - 1 : cy);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    for (int k = 0; k <= 3; ++k) {
+        const int side = 2 * k + 1;
+        const int ix = cx - k + lane % side, iy = cy - k + lane / side;
+        const bool have = lane < side * side && ix >= 0 && ix < GRID_N && iy >= 0 && iy < GRID_N;
+        int a = 0, b = 0;
+        if (have) { a = g.start[iy * GRID_N + ix]; b = g.start[iy * GRID_N + ix + 1]; }
+        double lane_min = inf;
+        for (int q = a; q < b; ++q) {
+            const int j = g.items[q];
+            const double dx = px - (double)det[(size_t)j * 5 + 0];
+            const double dy = py - (double)det[(size_t)j * 5 + 1];
+            double s = dx * dx;
+            s = s + dy * dy;
+            lane_min = s < lane_min ? s : lane_min;
+        }
+        const double s_min = wave_min(lane_min);
+        // distance from the track to the outside of the block [cx-k, cx+k] x [cy-k, cy+k]; a side of the block on
+        // the edge of the grid has nothing beyond it (every detection lies inside the grid)
+        double bound = inf;
+        if (cx - k > 0) bound = fmin(bound, px - (x0 + (cx - k) * cell));
+        if (cx + k < GRID_N - 1) bound = fmin(bound, (x0 + (cx + k + 1) * cell) - px);
+        if (cy - k > 0) bound = fmin(bound, py - (y0 + (cy - k) * cell));
+        if (cy + k < GRID_N - 1) bound = fmin(bound, (y0 + (cy + k + 1) * cell) - py);
+        bound -= 1e-3 * cell;       // (cells were assigned in float arithmetic)
+        const bool done = bound == inf || (s_min < inf && bound > 0.0 && bound * bound > s_min * (1.0 + 1e-9));
+        if (!done) continue;
+        if (!(s_min < inf)) return false;   // no detection at all in a block that covers the grid: m == 0 is the caller's
+        const double near_limit = s_min + s_min * 0x1p-48;
+        const double d_min = sqrt(s_min);
+        int cand = 0x7FFFFFFF;
+        bool inexact = false;
+        for (int q = a; q < b; ++q) {
+            const int j = g.items[q];
+            const double dx = px - (double)det[(size_t)j * 5 + 0];
+            const double dy = py - (double)det[(size_t)j * 5 + 1];
+            double s = dx * dx;
+            s = s + dy * dy;
+            const bool near = s <= near_limit;
+            cand = near ? min(cand, j) : cand;
+            inexact = inexact || (near && s != s_min);
+        }
+        if (__any(inexact)) {   // some s differs from min s by a few ulps: compare the rounded roots
+            cand = 0x7FFFFFFF;
+            for (int q = a; q < b; ++q) {
+                const int j = g.items[q];
+                const double dx = px - (double)det[(size_t)j * 5 + 0];
+                const double dy = py - (double)det[(size_t)j * 5 + 1];
+                double s = dx * dx;
+                s = s + dy * dy;
+                if (s <= near_limit && sqrt(s) == d_min) cand = min(cand, j);
+            }
+        }
+        const int best = wave_min(cand);
+        if (lane == 0) {
+            t.row_min[row] = d_min;
+            t.row_arg[row] = best;
+        }
+        return true;
+    }
+    return false;
+}
+
 // Stand-alone row-min pass (first frame of a batch / single-frame updates); inside a batch the
 // row-min of frame f+1 rides on k_track of frame f.
 template <typename DetT>
 __global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__restrict__ det, int m_host,
-                                                const int32_t *m_dev, int set_row_base, const long long *row_count_ext)
+                                                const int32_t *m_dev, int set_row_base, const long long *row_count_ext,
+                                                DetGrid grid)
 {
     // (fused path, start of ysmr_tracker_run / _update: row_base of the current state := the caller's
     // running row count; folded in here to save a launch per batch)
@@ -239,6 +411,7 @@ __global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__rest
     if (row >= n || m == 0) return;
     const int slot = t.order[row];
     const int lane = threadIdx.x & 63;
+    if (grid.start && rowmin_grid(t, row, t.pos[slot], t.pos[t.capacity + slot], det, grid, lane)) return;
     DetChunk<DetT> first;
     load_chunk(first, det, m, 0, lane);
     rowmin_wave(t, row, t.pos[slot], t.pos[t.capacity + slot], det, m, lane, first);
@@ -564,7 +737,7 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
 template <typename DetT, int NF>
 __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row *rows, long long rows_capacity,
                                                const DetT *__restrict__ next_det, int next_m_host,
-                                               const int32_t *next_m_dev)
+                                               const int32_t *next_m_dev, DetGrid next_grid)
 {
     const int n_live = *t.n_tracks;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -574,7 +747,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     // the next frame's detections do not depend on this frame's state: fetch them first
     const int m_next = next_det ? det_count(next_m_host, next_m_dev, t.max_det, nullptr) : 0;
     DetChunk<DetT> first;
-    if (m_next > 0) load_chunk(first, next_det, m_next, 0, lane);
+    if (m_next > 0 && !next_grid.start) load_chunk(first, next_det, m_next, 0, lane);
     const int slot = __builtin_amdgcn_readfirstlane(t.order[i]);
     const double z0 = t.pos[slot], z1 = t.pos[cap + slot];
     double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
@@ -596,7 +769,13 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
         }
     }
     // ---- nearest detection of the NEXT frame for this track (tracker.py:151-163)
-    if (m_next > 0) rowmin_wave(t, i, p0, p1, next_det, m_next, lane, first);
+    if (m_next > 0) {
+        if (next_grid.start) {
+            if (rowmin_grid(t, i, p0, p1, next_det, next_grid, lane)) return;
+            load_chunk(first, next_det, m_next, 0, lane);
+        }
+        rowmin_wave(t, i, p0, p1, next_det, m_next, lane, first);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -677,19 +856,29 @@ __device__ int block_exclusive_scan(int v, int *s_scan, int *total)
     return before + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
-template <typename DetT>
+// LDS_TABLES: the per-column winner tables and per-row claims fit in LDS (12 B per detection column + 4 B per track
+// row <= 140 KiB, e.g. 8192 / 8192): the claim rounds cost LDS atomics.  Otherwise they live in HBM (three rounds of
+// device-scope atomics, ~6 us more at 5000 rows) and capacity / max_det are only bounded by 65536.
+template <typename DetT, bool LDS_TABLES>
 __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT *__restrict__ det, int m_host,
                                                        const int32_t *m_dev, int frame, ysmr_row *rows,
                                                        long long rows_capacity, long long *row_count,
                                                        int32_t *n_rows_out, int32_t *claim_out, int32_t *n_before_out,
                                                        int32_t *new_cols_out, int32_t *n_new_out)
 {
-    // dynamic LDS: per-column winner tables and per-row claims live on chip, so the claim
-    // resolution costs LDS atomics and barriers instead of global round trips
     extern __shared__ unsigned long long s_dyn[];
-    unsigned long long *s_col_key = s_dyn;                                // [max_det]
-    int *s_col_row = reinterpret_cast<int *>(s_col_key + t.max_det);      // [max_det]
-    int *s_claim = s_col_row + t.max_det;                                 // [capacity]
+    unsigned long long *s_col_key = LDS_TABLES ? s_dyn : t.link_key;                                        // [max_det]
+    int *s_col_row = LDS_TABLES ? reinterpret_cast<int *>(s_dyn + t.max_det) : t.link_row;                  // [max_det]
+    int *s_claim = LDS_TABLES ? reinterpret_cast<int *>(s_dyn + t.max_det) + t.max_det : t.link_claim;     // [capacity]
+    // (in HBM, a value another wave has just changed with an atomic is read past this CU's L1)
+    auto key_of = [&](int c) {
+        if constexpr (LDS_TABLES) return s_col_key[c];
+        else return __hip_atomic_load(&s_col_key[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto row_of = [&](int c) {
+        if constexpr (LDS_TABLES) return s_col_row[c];
+        else return __hip_atomic_load(&s_col_row[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     __shared__ int s_scan[LINK_THREADS];
     __shared__ int s_n_used, s_n_new, s_any_dead;
     const int tid = threadIdx.x;
@@ -698,7 +887,13 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     const int m = det_count(m_host, m_dev, t.max_det, t.err);
     LRING(0);
     if (tid == 0) { s_n_used = 0; s_n_new = 0; s_any_dead = 0; }
-    for (int c = tid; c < m; c += LINK_THREADS) { s_col_key[c] = ~0ull; s_col_row[c] = 0x7FFFFFFF; }
+    for (int c = tid; c < m; c += LINK_THREADS) {
+        if constexpr (LDS_TABLES) { s_col_key[c] = ~0ull; s_col_row[c] = 0x7FFFFFFF; }
+        else {
+            __hip_atomic_store(&s_col_key[c], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&s_col_row[c], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     __syncthreads();
     LRING(1);
     // rows of a large table held per thread (see the `big` branch below)
@@ -725,10 +920,10 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             atomicMin(&s_col_key[c], key);
         }
         __syncthreads();
-        if (r < n && key == s_col_key[c]) atomicMin(&s_col_row[c], r);
+        if (r < n && key == key_of(c)) atomicMin(&s_col_row[c], r);
         __syncthreads();
         if (r < n) {
-            const bool mine = (s_col_row[c] == r);
+            const bool mine = (row_of(c) == r);
             s_claim[r] = mine ? c : -1;
             if (mine) {
                 t.pos[slot] = (double)d0;
@@ -741,9 +936,9 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             }
         }
     } else if (big) {
-        // large tables (the 4K configuration: ~5000 rows): thread tid owns rows tid + 1024 k.  Everything
+        // large tables (the 4K configuration: ~5000 rows): thread tid owns rows tid + LINK_THREADS * k.  Everything
         // the LDS rounds, the ageing and the compaction below need is requested up front and kept in
-        // registers, so that a pass costs LDS time instead of a global round trip per 1024 rows
+        // registers, so that a pass costs one round of loads or atomics instead of a global round trip per row chunk
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k) {
             const int r = tid + k * LINK_THREADS;
@@ -763,7 +958,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k) {
             const int r = tid + k * LINK_THREADS;
-            if (r < n && pk[k] == s_col_key[pa[k]]) atomicMin(&s_col_row[pa[k]], r);
+            if (r < n && pk[k] == key_of(pa[k])) atomicMin(&s_col_row[pa[k]], r);
         }
         __syncthreads();
         int used = 0;
@@ -774,7 +969,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = half + j, r = tid + k * LINK_THREADS;
-                mine[j] = r < n && s_col_row[pa[k]] == r;
+                mine[j] = r < n && row_of(pa[k]) == r;
                 if (r < n) s_claim[r] = mine[j] ? pa[k] : -1;
                 if (mine[j]) {
 #pragma unroll
@@ -804,13 +999,13 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         __syncthreads();
         for (int r = tid; r < n; r += LINK_THREADS) {
             int c = t.row_arg[r];
-            if ((unsigned long long)__double_as_longlong(t.row_min[r]) == s_col_key[c]) atomicMin(&s_col_row[c], r);
+            if ((unsigned long long)__double_as_longlong(t.row_min[r]) == key_of(c)) atomicMin(&s_col_row[c], r);
         }
         __syncthreads();
         int used = 0;
         for (int r = tid; r < n; r += LINK_THREADS) {
             int c = t.row_arg[r];
-            int mine = (s_col_row[c] == r) ? c : -1;
+            int mine = (row_of(c) == r) ? c : -1;
             s_claim[r] = mine;
             if (mine >= 0) {
                 int slot = t.order[r];
@@ -917,7 +1112,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             int base = 0;
             for (int c0 = 0; c0 < m; c0 += LINK_THREADS) {
                 int c = c0 + tid;
-                int un = (c < m && s_col_row[c] == 0x7FFFFFFF) ? 1 : 0;
+                int un = (c < m && row_of(c) == 0x7FFFFFFF) ? 1 : 0;
                 int total;
                 int ex = block_exclusive_scan(un, s_scan, &total);
                 if (un) t.unused[base + ex] = c;
@@ -1450,13 +1645,15 @@ template <typename DetT>
 int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, const int32_t *m_dev, int frame,
                     ysmr_row *rows, long long rows_capacity, long long *row_count, int32_t *n_rows, int32_t *claim,
                     int32_t *n_before, int32_t *new_cols, int32_t *n_new, bool rowmin_done, const DetT *next_det,
-                    const int32_t *next_m_dev)
+                    const int32_t *next_m_dev, DetGrid grid = DetGrid{nullptr, nullptr, nullptr},
+                    DetGrid next_grid = DetGrid{nullptr, nullptr, nullptr})
 {
+    const DetGrid no_grid{nullptr, nullptr, nullptr};
     const dim3 wgrid((t->d.capacity + 3) / 4);
     if (t->fused) {
         const TrackerDev &a = t->cur(), &b = t->nxt();
         if (!rowmin_done) {
-            hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, a, det, m, m_dev, t->set_base ? 1 : 0, t->base_ptr);
+            hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, a, det, m, m_dev, t->set_base ? 1 : 0, t->base_ptr, no_grid);
             t->set_base = false;
         }
         // the filter bank is unrolled at compile time: 3 covers tracking.ini's default (and 1, 2), 8 the rest
@@ -1470,15 +1667,20 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
         t->par ^= 1;
     } else {
         const TrackerDev &d = t->d;
-        if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, d, det, m, m_dev, 0, nullptr);
+        if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, d, det, m, m_dev, 0, nullptr, grid);
         const size_t link_lds = 12 * (size_t)d.max_det + 4 * (size_t)d.capacity;
-        hipLaunchKernelGGL(k_link<DetT>, dim3(1), dim3(LINK_THREADS), link_lds, st, d, det, m, m_dev, frame, rows,
-                           rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
+        if (link_lds <= 140 * 1024)
+            hipLaunchKernelGGL((k_link<DetT, true>), dim3(1), dim3(LINK_THREADS), link_lds, st, d, det, m, m_dev, frame, rows,
+                               rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
+        else
+            hipLaunchKernelGGL((k_link<DetT, false>), dim3(1), dim3(LINK_THREADS), 0, st, d, det, m, m_dev, frame, rows,
+                               rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
         if (d.n_f <= 3)
-            hipLaunchKernelGGL((k_track<DetT, 3>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det, -1, next_m_dev);
+            hipLaunchKernelGGL((k_track<DetT, 3>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det, -1, next_m_dev,
+                               next_grid);
         else
             hipLaunchKernelGGL((k_track<DetT, YSMR_MAX_FILTERS>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det,
-                               -1, next_m_dev);
+                               -1, next_m_dev, next_grid);
     }
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
@@ -1519,10 +1721,9 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
 {
     if (!out) return ysmr::fail(YSMR_ERR_ARG, "out must not be NULL");
     *out = nullptr;
-    // k_link keeps 12 B per detection column and 4 B per track row in LDS (160 KiB per CU)
-    if (capacity <= 0 || max_det <= 0 || 12 * (size_t)max_det + 4 * (size_t)capacity > 140 * 1024)
-        return ysmr::fail(YSMR_ERR_ARG, "capacity/max_det out of range: need 12*max_det + 4*capacity <= 140 KiB "
-                                        "(e.g. 8192/8192), got %d/%d", capacity, max_det);
+    // (the tables of the two-launch path live in HBM; the bound only keeps 32-bit indices and the state block sane)
+    if (capacity <= 0 || max_det <= 0 || capacity > 65536 || max_det > 65536)
+        return ysmr::fail(YSMR_ERR_ARG, "capacity/max_det out of range: need 1 .. 65536, got %d/%d", capacity, max_det);
     ysmr_tracker *t = new ysmr_tracker();
     TrackerDev &d = t->d;
     std::memset(&d, 0, sizeof(d));
@@ -1572,6 +1773,8 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const size_t o_rmin = take(sizeof(double) * cap), o_rarg = take(sizeof(int) * cap);
     const size_t o_dead = take(sizeof(int) * cap);
     const size_t o_new = take(sizeof(int) * max_det), o_table = take(sizeof(int) * 2 * (size_t)d.table_cap);
+    const size_t o_lkey = take(sizeof(unsigned long long) * max_det), o_lrow = take(sizeof(int) * max_det);
+    const size_t o_lclaim = take(sizeof(int) * cap);
     // parity-1 copies of the arrays k_frame double-buffers
     const size_t o_scal1 = take(sizeof(int) * 16), o_order1 = take(sizeof(int) * cap), o_gone1 = take(sizeof(int) * cap);
     const size_t o_rmin1 = take(sizeof(double) * cap), o_rarg1 = take(sizeof(int) * cap);
@@ -1595,6 +1798,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     d.row_min = (double *)(b + o_rmin); d.row_arg = (int *)(b + o_rarg);
     d.dead = (int *)(b + o_dead);
     d.new_cols = (int *)(b + o_new); d.set_table = (int *)(b + o_table);
+    d.link_key = (unsigned long long *)(b + o_lkey); d.link_row = (int *)(b + o_lrow); d.link_claim = (int *)(b + o_lclaim);
     t->d1 = d;
     {
         TrackerDev &q = t->d1;
@@ -1651,6 +1855,7 @@ int ysmr_tracker_destroy(ysmr_tracker *t)
 {
     if (!t) return YSMR_OK;
     hipError_t e = hipFree(t->block);
+    if (t->grid_block) (void)hipFree(t->grid_block);
     delete t;
     if (e != hipSuccess) return ysmr::fail(YSMR_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
     return YSMR_OK;
@@ -1681,13 +1886,31 @@ int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const 
     if (!det_dev || !det_count_dev || !rows_dev || !row_count_dev || batch <= 0)
         return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev, rows_dev, row_count_dev must be set and batch > 0");
     if (t->fused) { t->set_base = true; t->base_ptr = (const long long *)row_count_dev; }
+    const DetGrid no_grid{nullptr, nullptr, nullptr};
+    bool grids = false;
+    if (!t->fused) {
+        // large tables: a uniform grid over every frame's detections, built for the whole batch in one launch
+        // (the detections of a batch are all there before the first frame is linked)
+        const size_t per = ysmr_tracker::grid_bytes_per_frame(t->d.max_det);
+        if (batch > t->grid_frames) {
+            if (t->grid_block) { YSMR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); YSMR_HIP_CHECK(hipFree(t->grid_block)); }
+            t->grid_block = nullptr; t->grid_frames = 0;
+            YSMR_HIP_CHECK(hipMalloc(&t->grid_block, per * (size_t)batch));
+            t->grid_frames = batch;
+        }
+        hipLaunchKernelGGL(k_grid_build<float>, dim3(batch), dim3(1024), 0, (hipStream_t)stream, det_dev, det_count_dev,
+                           t->d.max_det, (char *)t->grid_block, per);
+        YSMR_LAUNCH_CHECK();
+        grids = true;
+    }
     for (int f = 0; f < batch; ++f) {
         const bool has_next = f + 1 < batch;
         int rc = launch_update_t<float>(t, (hipStream_t)stream, det_dev + (size_t)f * t->d.max_det * 5, -1,
                                         det_count_dev + f, first_frame_index + f, rows_dev, (long long)rows_capacity,
                                         (long long *)row_count_dev, nullptr, nullptr, nullptr, nullptr, nullptr,
                                         f > 0, has_next ? det_dev + (size_t)(f + 1) * t->d.max_det * 5 : nullptr,
-                                        has_next ? det_count_dev + f + 1 : nullptr);
+                                        has_next ? det_count_dev + f + 1 : nullptr, grids ? t->grid(f) : no_grid,
+                                        grids && has_next ? t->grid(f + 1) : no_grid);
         if (rc) return rc;
     }
     return YSMR_OK;
