@@ -21,6 +21,7 @@
  *   ysmr_gsff_gains       GaussianSumFIR.generate_n_i/compute_lsf_gain  ysmr/gsff.py:87-153
  *   ysmr_rows_sort        sort_list (order by TRACK_ID, POSITION_T)  ysmr/helper_file.py:1538-1574
  *   ysmr_select_tracks    select_tracks + find_good_tracks   ysmr/track_eval.py:408-843
+ *   ysmr_evaluate_tracks  evaluate_tracks (statistics, not the plots)  ysmr/track_eval.py:846-1318
  *   ysmr_rows_columns,    save_list text + get_data (pandas.read_csv) + save_df_to_csv
  *   ysmr_rows_format_csv  ysmr/helper_file.py:1403-1478, 860-905, 1366-1400  (host functions)
  */
@@ -40,7 +41,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   5
+#define YSMR_ABI_VERSION   6
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -278,6 +279,33 @@ int    ysmr_select_tracks(void *stream, long long n_rows, const uint32_t *track_
                           const double *x_dev, const double *y_dev, const double *w_dev, const double *h_dev,
                           const ysmr_select_params *params, void *workspace_dev, size_t workspace_bytes,
                           int64_t *sel_row_dev, int64_t *sel_index_dev, ysmr_select_summary *summary);
+
+/* ---- per-track statistics of the selected tracks: evaluate_tracks, ysmr/track_eval.py:846-1318 ---- */
+
+typedef struct ysmr_evaluate_params {
+    double pixel_per_micrometre;   /* settings['pixel per micrometre'] */
+    double fps;
+    double min_turn_angle;         /* settings['minimal angle in degrees for turning point'] */
+    int32_t angle_lag;             /* settings['compare angle between n frames'] */
+    int32_t reach_lag;             /* int(round(fps * min(10, min length / 2, length limit / 2))), track_eval.py:990-1000 */
+    int32_t median_kernel;         /* round(fps), made odd: the second medfilt of `moving` (track_eval.py:931-939) */
+    int32_t reserved;
+} ysmr_evaluate_params;
+
+/* Input: the six columns of the table evaluate_tracks receives (rows ordered by TRACK_ID, POSITION_T; row i has
+ * DataFrame index i), device pointers.  Outputs, device, n_rows entries each: WIDTH and HEIGHT in micrometres,
+ * angle_diff (int32), moving, turn_points, motility_phenotype (int8), tp_of_tracks (f64, NaN where not moving),
+ * travelled_dist -- the columns of <name>_analysed.csv -- and stats_dev f64 [tracks][12], the columns of
+ * <name>_statistics.csv in the reference's order (Turn Points (TP/s), Distance, Speed, Time, Displacement, Perc.
+ * Motile, Arc-Chord Ratio, Bacteria Length (a float32 value), Displacement divided by length, Motility Phenotype,
+ * TRACK_ID, Median Speed); room for n_rows tracks.  *n_tracks_out: the number of tracks.  Synchronous. */
+size_t ysmr_evaluate_workspace_bytes(long long n_rows);
+int ysmr_evaluate_tracks(void *stream, long long n_rows, const uint32_t *track_id_dev, const uint32_t *t_dev,
+                         const double *x_dev, const double *y_dev, const double *w_dev, const double *h_dev,
+                         const ysmr_evaluate_params *params, void *workspace_dev, size_t workspace_bytes,
+                         double *width_um_dev, double *height_um_dev, int32_t *angle_diff_dev, int8_t *moving_dev,
+                         int8_t *turn_points_dev, double *tp_of_tracks_dev, double *travelled_dist_dev,
+                         int8_t *motility_phenotype_dev, double *stats_dev, long long *n_tracks_out);
 
 #ifdef __cplusplus
 }

@@ -727,3 +727,107 @@ def select_tracks_oracle(df, settings, fps, frame_height, frame_width):
     cols = ["TRACK_ID", "POSITION_T", "POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE"]
     out = t.loc[keep, cols].reset_index()      # keeps the cleaned table's index as column 'index'
     return out, info
+
+
+# ------------------------------------------------------------------------------------------------
+# per-track statistics: evaluate_tracks (ysmr/track_eval.py:846-1318), the numerical part
+# ------------------------------------------------------------------------------------------------
+EVAL_STATS_COLUMNS = ["Turn Points (TP/s)", "Distance (µm)", "Speed (µm/s)", "Time (s)", "Displacement (µm)",
+                      "Perc. Motile", "Arc-Chord Ratio", "Bacteria Length", "Displacement divided by length",
+                      "Motility Phenotype", "TRACK_ID", "Median Speed"]
+EVAL_ROW_COLUMNS = ["TRACK_ID", "POSITION_T", "POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE", "angle_diff",
+                    "moving", "turn_points", "tp_of_tracks", "travelled_dist", "motility_phenotype"]
+
+
+def evaluate_tracks_oracle(df, settings, fps):
+    """CPU restatement of the arithmetic of ``evaluate_tracks`` on a table of selected tracks (ordered by
+    TRACK_ID, POSITION_T, default RangeIndex): the per-row columns of ``*_analysed.csv`` and the per-track
+    table of ``*_statistics.csv``.  Parity unpinned, like select_tracks_oracle: track_eval.py imports cv2 at
+    module level, so the reference's own function cannot be run here and it ships no vectors.  The same pandas /
+    NumPy / SciPy primitives are used where their arithmetic matters (groupby sum / mean = Kahan summation,
+    float16 ``bac_length`` whose group mean pandas returns as float32, ``scipy.signal.medfilt``,
+    ``scipy.signal.argrelextrema``, ``scipy.spatial.distance.pdist``), the control flow is written out anew.
+    Plots, logging and file output are not part of it.  Returns (rows DataFrame, statistics DataFrame)."""
+    import pandas as pd
+    from scipy.signal import argrelextrema, medfilt
+    from scipy.spatial.distance import pdist
+    t = df.reset_index(drop=True).copy()
+    n = len(t)
+    px = settings["pixel per micrometre"]
+    tid = t["TRACK_ID"].to_numpy()
+    first_row = np.r_[True, tid[1:] != tid[:-1]]                       # different_tracks(): starts of tracks
+    starts = np.flatnonzero(first_row)
+    by_track = t.groupby("TRACK_ID")
+    # ---- steps between consecutive rows of a track (track_eval.py:900-905)
+    xd, yd, td = t["POSITION_X"].diff(), t["POSITION_Y"].diff(), t["POSITION_T"].diff()
+    xd[first_row], yd[first_row], td[first_row] = 0, 0, 1
+    t_norm = (t["POSITION_T"] - by_track["POSITION_T"].transform("first")).astype(np.int32)
+    t["WIDTH"] = t["WIDTH"] / px
+    t["HEIGHT"] = t["HEIGHT"] / px
+    t["bac_length"] = np.where(t["WIDTH"] >= t["HEIGHT"], t["WIDTH"], t["HEIGHT"]).astype(np.float16)
+    t["travelled_dist"] = np.sqrt(np.square(xd) + np.square(yd)) / px
+    # ---- moving: speed above 1e-3, median filtered over 3 rows and over about a second (:927-939)
+    moving = np.where(t["travelled_dist"] / td > 10 ** -3, 1, 0).astype(np.int8)
+    second = int(round(fps, 0))
+    for k in (3, second + 1 if second % 2 == 0 else second):
+        moving = pd.Series(moving).groupby(tid).transform(medfilt, kernel_size=k).to_numpy()
+    t["moving"] = moving
+    # ---- change of heading between rows, heading taken over `compare angle between n frames` rows (:941-961)
+    lag = settings["compare angle between n frames"]
+    heading = np.degrees(np.arctan2(by_track["POSITION_X"].diff(lag), by_track["POSITION_Y"].diff(lag)))
+    turn = abs(pd.Series(heading).groupby(tid).diff().fillna(0))
+    t["angle_diff"] = np.where(360 - turn <= turn, 360 - turn, turn).astype(np.int32)
+    candidates = np.where((t["angle_diff"] > settings["minimal angle in degrees for turning point"]) & (t["moving"] == 1),
+                          t["angle_diff"], 0).astype(np.int32)
+    # ---- turning points: the candidates that are the largest within 10 rows either side (:968-975;
+    # argrelextrema_groupby's shift loop never runs: range(-1, -5) is empty)
+    tp = np.zeros(n, np.int8)
+    for a, b in zip(starts, np.r_[starts[1:], n]):
+        seg = candidates[a:b]
+        peaks = argrelextrema(seg, np.greater_equal, order=10)[0]
+        tp[a:b][peaks] = np.where(seg[peaks] != 0, 1, 0)
+    tp[first_row] = 1
+    # ---- stretches between turning points, numbered through the whole table (:976-989).  A stretch starts where
+    # the column turns from 0 to 1 (a track start right behind a turning point does not start a new one) and the
+    # table's last row keeps number 0: it is the loop's stop index.
+    run_start = tp.astype(bool) & np.r_[True, tp[:-1] == 0]
+    number = np.cumsum(run_start) - 1
+    number[-1] = 0
+    t["tp_of_tracks"] = np.where(t["moving"] == 0, np.nan, number.astype(np.uint64))
+    tp_dist = t.groupby("tp_of_tracks")["travelled_dist"].transform("sum")
+    # ---- displacement within about ten seconds, longest stretch, both in body lengths (:990-1006)
+    t["x_norm"] = (t["POSITION_X"] - by_track["POSITION_X"].transform("first")) / px
+    t["y_norm"] = (t["POSITION_Y"] - by_track["POSITION_Y"].transform("first")) / px
+    by_track = t.groupby("TRACK_ID")
+    body = by_track["bac_length"].transform("mean")
+    spans = [10] + [v / 2 for v in (settings["minimal length in seconds"], settings["limit track length to x seconds"])
+                    if 0 < v / 2 < 10]
+    lag_s = int(round(fps * min(spans), 0))
+    reach = np.sqrt(np.square(by_track["x_norm"].diff(lag_s)) + np.square(by_track["y_norm"].diff(lag_s)))
+    reach = reach.groupby(tid).transform("max") / body
+    stretch = tp_dist.groupby(tid).transform("max") / body
+    phenotype = np.where((reach > 1.5) & (stretch > 5), 2, np.where((reach > 1.5) & (stretch <= 5), 1, 0)).astype(np.int8)
+    t["motility_phenotype"] = phenotype
+    # ---- per track (:1029-1090)
+    widest = by_track.apply(lambda g: pdist(np.column_stack([g["x_norm"], g["y_norm"]])).max(), include_groups=False)
+    frames_last = pd.Series(t_norm.to_numpy()).groupby(tid).agg("last")
+    per_second = t.groupby(["TRACK_ID", t.index // fps])["travelled_dist"].sum().groupby(level=0).median()
+    moving_rows = by_track["moving"].agg("sum")
+    percent_motile = moving_rows / (frames_last + 1) * 100
+    seconds = (frames_last + 1) / fps
+    path = by_track["travelled_dist"].agg("sum")
+    chord = np.sqrt(np.square(by_track["x_norm"].agg("last")) + np.square(by_track["y_norm"].agg("last")))
+    speed = np.where(moving_rows != 0, path / seconds, 0)
+    arc_chord = np.where(path != 0, chord / path, 0)
+    t["turn_points"] = np.where(phenotype != 0, tp, 0).astype(np.int8)
+    t.loc[first_row, "turn_points"] = 1
+    turns = (t.groupby("TRACK_ID")["turn_points"].agg("sum") - 1) * fps
+    turns = np.where(moving_rows != 0, turns / moving_rows, 0)
+    length = by_track["bac_length"].agg("mean")
+    in_lengths = np.where(length != 0, widest / length, 0)
+    idx = frames_last.index
+    stats = pd.concat([pd.Series(turns, index=idx), path, pd.Series(speed, index=idx), seconds, widest, percent_motile,
+                       pd.Series(arc_chord, index=idx), pd.Series(length), pd.Series(in_lengths, index=idx),
+                       by_track["motility_phenotype"].agg("last"), by_track["TRACK_ID"].agg("last"),
+                       pd.Series(per_second, index=idx)], keys=EVAL_STATS_COLUMNS, axis=1)
+    return t.loc[:, EVAL_ROW_COLUMNS], stats

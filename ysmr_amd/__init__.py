@@ -2,13 +2,13 @@
 
 The public surface mirrors the reference package (``ysmr/__init__.py`` re-exports ``main``,
 ``plot_functions``, ``track_eval``): ``ysmr()``, ``analyse()``, ``track_bacteria()``,
-``select_tracks()``, ``CentroidTracker``, ``GaussianSumFIR`` and the tracking.ini helpers.  Importing this package does
+``select_tracks()``, ``evaluate_tracks()``, ``CentroidTracker``, ``GaussianSumFIR`` and the tracking.ini helpers.  Importing this package does
 not touch the GPU; the HIP library (``csrc/libysmr_hip.so``) is loaded on first use and there is no
 CPU fallback.
 """
 __version__ = "0.1.0"
 
-__all__ = ["ysmr", "analyse", "track_bacteria", "select_tracks", "CentroidTracker", "GaussianSumFIR", "get_configs",
+__all__ = ["ysmr", "analyse", "track_bacteria", "select_tracks", "evaluate_tracks", "CentroidTracker", "GaussianSumFIR", "get_configs",
            "create_configs", "default_settings"]
 
 
@@ -22,6 +22,9 @@ def __getattr__(name):   # lazy: keep `import ysmr_amd.synth` usable without tor
     if name == "select_tracks":
         from .select import select_tracks
         return select_tracks
+    if name == "evaluate_tracks":
+        from .evaluate import evaluate_tracks
+        return evaluate_tracks
     if name == "CentroidTracker":
         from .tracker import CentroidTracker
         return CentroidTracker

@@ -44,7 +44,8 @@ EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
-           "ysmr_rows_format_csv", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks")
+           "ysmr_rows_format_csv", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks",
+           "ysmr_evaluate_workspace_bytes", "ysmr_evaluate_tracks")
 
 SELECT_OK, SELECT_TOO_SHORT, SELECT_TOO_SHORT_CLEANED, SELECT_NONE = 0, 1, 2, 3
 
@@ -66,6 +67,13 @@ class SelectSummary(ctypes.Structure):
                 ("q3_dist", ctypes.c_double), ("dist_fence", ctypes.c_double), ("dist_outliers", ctypes.c_longlong),
                 ("kick_reasons", ctypes.c_longlong * 9), ("good_tracks", ctypes.c_longlong),
                 ("rows_selected", ctypes.c_longlong)]
+
+
+class EvaluateParams(ctypes.Structure):
+    """``struct ysmr_evaluate_params``"""
+    _fields_ = [("pixel_per_micrometre", ctypes.c_double), ("fps", ctypes.c_double), ("min_turn_angle", ctypes.c_double),
+                ("angle_lag", ctypes.c_int32), ("reach_lag", ctypes.c_int32), ("median_kernel", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class YsmrLibraryError(RuntimeError):
@@ -125,8 +133,12 @@ def lib():
     L.ysmr_select_workspace_bytes.restype = ctypes.c_size_t
     L.ysmr_select_tracks.argtypes = [vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, ctypes.POINTER(SelectParams), vp,
                                      ctypes.c_size_t, vp, vp, ctypes.POINTER(SelectSummary)]
+    L.ysmr_evaluate_workspace_bytes.argtypes = [ctypes.c_longlong]
+    L.ysmr_evaluate_workspace_bytes.restype = ctypes.c_size_t
+    L.ysmr_evaluate_tracks.argtypes = [vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, ctypes.POINTER(EvaluateParams), vp,
+                                       ctypes.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_longlong)]
     for name in EXPORTS:
-        if name not in ("ysmr_select_workspace_bytes", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_abi_version",
+        if name not in ("ysmr_evaluate_workspace_bytes", "ysmr_select_workspace_bytes", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_abi_version",
                         "ysmr_rows_sort_workspace_bytes", "ysmr_rows_csv_bound",
                         "ysmr_mean_threshold_state_bytes"):
             getattr(L, name).restype = ci

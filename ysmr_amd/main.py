@@ -1,9 +1,9 @@
 """``ysmr()`` / ``analyse()`` entry points with the reference's signatures (ysmr/main.py:32, 175).
 
-``analyse`` runs detect-and-link (``track_bacteria``) and then ``select_tracks`` on the device; the
-reference's later offline stages (``evaluate_tracks``, ``annotate_video``, plots, xlsx collation) are
-not part of the HIP path and are skipped with a log message.  It returns the last stage's DataFrame
-(``return_df=True``) or ``True``; ``None`` signals an error, as upstream.
+``analyse`` runs detect-and-link (``track_bacteria``), ``select_tracks`` and the statistics of
+``evaluate_tracks`` on the device; plots, ``annotate_video`` and the xlsx collation are presentation, not part
+of the HIP path, and are skipped with a log message.  It returns the last stage's result (``return_df=True``:
+a DataFrame, or evaluate_tracks' ``(df, df_stats)``) or ``True``; ``None`` signals an error, as upstream.
 
 Independent videos are embarrassingly parallel (the reference runs one process per path,
 main.py:281-288): ``ysmr(..., multiprocess=True)`` shards the paths one process per GPU, no
@@ -16,6 +16,7 @@ import os
 from datetime import datetime
 
 from .helper_file import create_results_folder, get_configs, get_loggers, metadata_file
+from .evaluate import evaluate_tracks
 from .select import select_tracks
 from .track_eval import track_bacteria
 
@@ -79,8 +80,11 @@ def analyse(path, settings=None, result_folder=None, return_df=False, device="cu
                 logger.warning("Error during video analysis of file {}.".format(path))
                 return None
             value = df
-        if plots_eval:
-            logger.info("evaluate_tracks / plots are not part of the HIP path; stopping after select_tracks")
+        if plots_eval:     # statistics of the selected tracks (main.py:131-139); None after an error, as upstream
+            value = evaluate_tracks(path_to_file=path, results_directory=result_folder, df=df, settings=settings,
+                                    device=device, fps=meta.get("fps"))
+            if settings["save video"]:
+                logger.warning("'save video' is enabled: annotating videos is not part of the HIP path")
         elif "selected_data.csv" in path:
             logger.warning("No evaluation set to True in settings. Did not evaluate {}".format(path))
         return value

@@ -28,16 +28,19 @@ from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, ge
                           rows_to_dataframe, save_list)
 from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
-__all__ = ["track_bacteria", "TrackingPipeline", "select_tracks"]
+__all__ = ["track_bacteria", "TrackingPipeline", "select_tracks", "evaluate_tracks"]
 
 #: most rows kept on the device for one video (40 B each); longer tables are moved to the host in between
 ROW_BUDGET_MAX = 32 << 20
 
 
-def __getattr__(name):   # select_tracks lives in track_eval upstream (track_eval.py:536); here in select.py
+def __getattr__(name):   # select_tracks / evaluate_tracks live in track_eval upstream (track_eval.py:536, 846)
     if name == "select_tracks":
         from .select import select_tracks
         return select_tracks
+    if name == "evaluate_tracks":
+        from .evaluate import evaluate_tracks
+        return evaluate_tracks
     raise AttributeError(name)
 
 
