@@ -103,3 +103,31 @@ def test_evaluate_tracks_entry_point_and_files(tmp_path, oracle):
     assert (tmp_path / "clip_selected_data_statistics.csv").read_bytes() == (tmp_path / "ref_stats.csv").read_bytes()
     assert (tmp_path / "clip_selected_data_analysed.csv").read_bytes() == (tmp_path / "ref_rows.csv").read_bytes()
     assert evaluate_tracks(str(tmp_path / "x.csv"), str(tmp_path), df=df, settings=dict(s, **{"frames per second": 0.0}), fps=None) is None
+
+
+def test_analyse_goes_on_to_the_statistics(tmp_path, oracle):
+    """analyse() with an evaluation key set: video -> table -> selection -> evaluate_tracks, whose (df, df_stats)
+    is what it returns (main.py:131-139), next to <name>_statistics.csv."""
+    import pandas as pd
+    from select_tables import select_settings
+    from ysmr_amd import analyse
+    from ysmr_amd.evaluate import STATS_COLUMNS
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(200, 260, 14, seed=3, dropout=0.01).frames(120)
+    path = tmp_path / "clip.npy"
+    np.save(path, frames)
+    s = select_settings(**{"minimal frame count": 40, "store generated statistical .csv file": True})
+    os.makedirs(tmp_path / "first")
+    table = track_bacteria(str(path), settings=dict(s), result_folder=str(tmp_path / "first"))[0]
+    selected, info = oracle.select_tracks_oracle(table, s, 30.0, 200, 260)
+    assert selected is not None and info["good_tracks"] >= 3
+    res = analyse(str(path), settings=dict(s), result_folder=str(tmp_path / "res"), return_df=True)
+    assert isinstance(res, tuple) and len(res) == 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_rows, ref_stats = oracle.evaluate_tracks_oracle(selected, s, 30.0)
+    pd.testing.assert_frame_equal(res[0], ref_rows, check_exact=True)
+    pd.testing.assert_frame_equal(res[1][STATS_COLUMNS], ref_stats, check_exact=True, check_names=False)
+    assert (tmp_path / "res" / "clip_statistics.csv").exists()
+    assert analyse(str(path), settings=dict(s), result_folder=str(tmp_path / "res2")) is True

@@ -90,7 +90,10 @@ def test_analyse_runs_the_selection(tmp_path, oracle):
     frames = SyntheticVideo(200, 260, 14, seed=3, dropout=0.01).frames(90)
     path = tmp_path / "clip.npy"
     np.save(path, frames)
-    s = select_settings(**{"minimal frame count": 40, "store processed .csv file": True})
+    from ysmr_amd.main import _EVALUATE_KEYS
+    # the selection is the last stage here (with any evaluation key set, analyse() goes on to evaluate_tracks
+    # and returns ITS result, as upstream: tests/test_gpu_evaluate.py)
+    s = select_settings(**{"minimal frame count": 40, "store processed .csv file": True, **{k: False for k in _EVALUATE_KEYS}})
     out_dir = tmp_path / "res"
     from ysmr_amd.track_eval import track_bacteria
     # what select_tracks is handed in the reference: the DataFrame track_bacteria returns (values parsed

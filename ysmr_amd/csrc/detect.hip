@@ -680,30 +680,38 @@ __device__ __forceinline__ uint32_t chunk_byte(const uint4 &v, int i)
     return (w >> (8 * (i & 3))) & 0xFFu;
 }
 
-// The foreground is sparse (bacteria cover ~1 % of a frame), so every pass after the dense collect
-// walks a compacted list of the pixels that carry class bits, one lane per listed pixel.  (A list
-// of 16-pixel chunks was tried first: on the benchmark clip only 19 % of its lane slots held a
-// foreground pixel.)  The list has room for 1/8 of the batch; a denser batch makes the passes fall
-// back to walking every pixel (`count` keeps counting past `cap`, which is how they know).
-// The workspace remembers, across calls, which pixels of the caller's label map / final mask the
-// previous call made non-zero: if the next call gets the same buffers and geometry, clearing those
-// pixels replaces a dense memset (362 MB per 64-frame batch at 1228x922 -- more HBM traffic than the
-// threshold kernel itself).  Hence two lists, used alternately, and a header that says which one is
-// current and for which buffers it is valid.
-constexpr unsigned long long WS_MAGIC = 0x59534D5248495031ull;   // "YSMRHIP1"
+// The foreground is sparse (bacteria cover ~1 % of a frame) and made of small islands.  k_windows (below)
+// settles every island whose bounding box is at most 16 x 16 pixels in registers; the pixels of larger ones
+// -- the RESIDUE -- are listed, one entry per pixel, and go through the union-find passes k_union4 ..
+// k_bbox_euler, one lane per listed pixel.  The list has room for 1/8 of the batch; a denser residue makes
+// the passes fall back to walking every pixel (`count` keeps counting past `cap`, which is how they know;
+// pixels settled by k_windows carry bit3 of their class byte and are skipped).
+// The workspace remembers, across calls, the components of the previous call (first pixel and bounding box
+// of each): if the next call gets the same buffers and geometry, clearing the label map and the final mask
+// inside those boxes replaces a dense memset (362 MB per 64-frame batch at 1228x922 -- more HBM traffic
+// than the threshold kernel itself).
+constexpr unsigned long long WS_MAGIC = 0x59534D5248495032ull;   // "YSMRHIP2"
+constexpr int WS_BIG = 16;              // components too large for the per-component clear that a header can name
+constexpr int WS_BIG_AREA = 64 * 64;    // bounding-box area from which a component counts as large
 struct WsHeader {
     unsigned long long magic;    // WS_MAGIC while the fields below describe a completed call
-    unsigned long long labels;   // label map / final mask the current list refers to
+    unsigned long long labels;   // label map / final mask the component tables refer to
     unsigned long long mask;
     unsigned long long total;    // batch * H * W of that call
-    uint32_t cur;                // index of the current list
-    uint32_t count[2];           // foreground pixels found (may exceed cap: list incomplete)
-    uint32_t pad;
+    uint32_t cur;                // (always 0: one list)
+    uint32_t count[2];           // [0] residue pixels found (may exceed cap: list incomplete)
+    uint32_t pad;                // ticket counter of k_clear
+    int32_t batch, H, W, max_det;
+    uint32_t dense;              // the tables do not cover everything written (a frame overflowed max_det, or
+                                 // more than WS_BIG large components): the next call clears everything
+    uint32_t n_big;
+    int32_t big[WS_BIG][2];      // (frame, rank) of the large components
 };
+static_assert(sizeof(WsHeader) <= 256, "the header is the first 256 bytes of the workspace");
 struct PixelList {
-    uint32_t *idx[2];  // flat pixel indices (frame * H * W + y * W + x); chunk-local order, chunks unordered
+    uint32_t *idx[2];  // [0]: flat pixel indices (frame * H * W + y * W + x) of the residue, unordered
     WsHeader *hdr;
-    uint32_t cap;      // entries each list can hold
+    uint32_t cap;      // entries the list can hold
 };
 
 constexpr int SPARSE_BLOCKS = 768;  // resident grid of the list-driven passes (grid-stride over the list)
@@ -711,57 +719,104 @@ constexpr int SPARSE_BLOCKS = 768;  // resident grid of the list-driven passes (
 // The passes are bound by chains of dependent L2 round trips (union-find), so they want many
 // short threads: one lane per pixel, grid-stride.
 #define FOR_LISTED_PIXELS(pl, g, flat)                                                                           \
-    if (const uint32_t cur_ = (pl).hdr->cur & 1u; true)                                                          \
-        if (const uint32_t *idx_ = (pl).idx[cur_]; true)                                                         \
-            for (size_t cnt_ = (pl).hdr->count[cur_], dense_ = cnt_ > (pl).cap, ln_ = dense_ ? (g).total : cnt_, \
-                        li_ = (size_t)blockIdx.x * 256 + threadIdx.x;                                            \
-                 li_ < ln_; li_ += (size_t)gridDim.x * 256)                                                      \
-                if (const size_t flat = dense_ ? li_ : (size_t)idx_[li_]; true)
+    if (const uint32_t *idx_ = (pl).idx[0]; true)                                                                \
+        for (size_t cnt_ = (pl).hdr->count[0], dense_ = cnt_ > (pl).cap, ln_ = dense_ ? (g).total : cnt_,        \
+                    li_ = (size_t)blockIdx.x * 256 + threadIdx.x;                                                \
+             li_ < ln_; li_ += (size_t)gridDim.x * 256)                                                          \
+            if (const size_t flat = dense_ ? li_ : (size_t)idx_[li_]; true)
 
-// Clears the label map and the final mask (both are written sparsely afterwards): only the pixels
-// the previous call listed if the header vouches for these buffers, everything otherwise.  A resident
-// grid instead of hipMemsetAsync: the runtime's fill kernels use grids far larger than the chip
+constexpr uint32_t CLS_LOCAL = 8u;   // bit3 of a class byte: the pixel's island was settled by k_windows
+
+struct CompTables {
+    int32_t *nroots;   // [B * NR_STRIDE]: one counter per 128-byte line (same-line atomics serialise)
+    int32_t *roots;    // [B][max_det] unordered
+    int32_t *order;    // [B][max_det] roots sorted descending (= findContours order)
+    int32_t *bbox;     // [B][max_det][4] minx, maxx, miny, maxy
+    int32_t *euler4;   // [B][max_det] 4 * Euler number (8-connectivity)
+    int32_t *nested;   // [B][max_det] component lies in a hole of another one
+    int32_t *max_roots; // largest per-frame component count of the batch (k_rank)
+    int32_t *bbox_tmp; // [B][max_det][4], [B][max_det]: box and Euler number of the components k_windows
+    int32_t *euler_tmp; //   settled, in the order of `roots` (k_rank moves them to their rank)
+    int max_det;
+};
+
+// Clears the label map and the final mask (both are written sparsely afterwards): only inside the bounding
+// boxes of the previous call's components if the header vouches for these buffers, everything otherwise.  A
+// resident grid instead of hipMemsetAsync: the runtime's fill kernels use grids far larger than the chip
 // holds, and such a grid starves every other stream (the link) until it has drained.
+// (also: the per-call counters and status words are zeroed here, by the block that finishes last -- the others
+// still read the previous call's counts -- which also marks the header invalid until k_compact, the last kernel
+// of the call, vouches for the buffers again)
 constexpr int CLEAR_BLOCKS = 512;
-// (also: the per-call counters and status words are zeroed here, and the block that finishes last switches the
-// workspace to its other pixel list, empties it and marks the header invalid until k_compact, the last kernel
-// of the call, vouches for the buffers again -- one launch instead of two at the head of the chain)
-__global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, uint8_t *mask, size_t total, int32_t *counters,
-                                               int n_counters, int32_t *status, int batch)
+__device__ __forceinline__ void clear_box(uint32_t *__restrict__ lab, uint8_t *__restrict__ mask, int W, int x0, int x1, int y0,
+                                          int y1, int first, int step)
+{
+    const int bw = x1 - x0 + 1, cells = bw * (y1 - y0 + 1);
+    for (int i = first; i < cells; i += step) {
+        const int r = i / bw, c = i - r * bw;
+        const size_t at = (size_t)(y0 + r) * W + (x0 + c);
+        if (lab[at] != 0u) {
+            lab[at] = 0u;
+            if (mask) mask[at] = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8_t *labels, uint8_t *mask, size_t total,
+                                               int n_counters, int32_t *status, int batch, int H, int W)
 {
     DET_RING(2);
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
-    const WsHeader h = *pl.hdr;
-    const uint32_t prev = h.cur & 1u;
-    if (blockIdx.x == 0) {
-        for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] = 0;
+    const WsHeader *hp = pl.hdr;
+    struct { unsigned long long magic, labels, mask, total; int32_t batch, H, W, max_det; uint32_t dense, n_big; } h =
+        {hp->magic, hp->labels, hp->mask, hp->total, hp->batch, hp->H, hp->W, hp->max_det, hp->dense, hp->n_big};
+    if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < batch; i += 256) status[i] = 0;
-    }
+    const size_t HW = (size_t)H * W;
     if (h.magic == WS_MAGIC && h.labels == (unsigned long long)labels && h.mask == (unsigned long long)mask &&
-        h.total == total && h.count[prev] <= pl.cap) {
-        const uint32_t *__restrict__ idx = pl.idx[prev];
-        uint32_t *lab = reinterpret_cast<uint32_t *>(labels);
-        const size_t n = h.count[prev];
-        // four list entries per thread and round: the index loads of a round are in flight together (the
-        // stores below cannot be proven not to alias the list, so a plain loop serialises load, store, load, ...)
-        for (size_t i0 = tid; i0 < n; i0 += 4 * stride) {
-            uint32_t flat[4];
+        h.total == total && h.batch == batch && h.H == H && h.W == W && h.max_det == t.max_det && !h.dense &&
+        h.n_big <= (uint32_t)WS_BIG) {
+        // Work items are (16 consecutive ranks, frame), frame fastest: the populated ranks come first in every
+        // frame, so the live items are spread evenly over the waves.  16 lanes per component, one per row of its
+        // box; the loads of a row are issued together (a load - test - store loop per pixel is a chain of L2
+        // round trips: 92 us per batch)
+        const int lane = threadIdx.x & 63, sub = lane & 15;
+        const long long items = (long long)((t.max_det + 15) / 16) * batch, waves = (long long)(stride / 64);
+        for (long long it = (long long)(tid / 64); it < items; it += waves) {
+            const int kb = (int)(it / batch), f = (int)(it - (long long)kb * batch);
+            const int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
+            if (kb * 16 >= n) break;   // (items are rank-major: every later item of this wave is empty too)
+            uint32_t *lab = reinterpret_cast<uint32_t *>(labels) + (size_t)f * HW;
+            uint8_t *msk = mask ? mask + (size_t)f * HW : nullptr;
+#pragma unroll 1
+            for (int pass = 0; pass < 4; ++pass) {
+                const int k = kb * 16 + pass * 4 + (lane >> 4);
+                if (k >= n) continue;
+                const size_t s = (size_t)f * t.max_det + k;
+                const int x0 = t.bbox[s * 4 + 0], x1 = t.bbox[s * 4 + 1], y0 = t.bbox[s * 4 + 2], y1 = t.bbox[s * 4 + 3];
+                const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+                if (bw <= 0 || bh <= 0 || bw * bh >= WS_BIG_AREA) continue;   // (large ones are in h.big: every block helps below)
+                for (int r = sub; r < bh; r += 16) {
+                    const size_t at = (size_t)(y0 + r) * W + x0;
+                    for (int c0 = 0; c0 < bw; c0 += 16) {
+                        uint32_t v[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const size_t i = i0 + (size_t)u * stride;
-                flat[u] = i < n ? idx[i] : 0xFFFFFFFFu;
-            }
+                        for (int c = 0; c < 16; ++c) v[c] = c0 + c < bw ? lab[at + c0 + c] : 0u;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (flat[u] == 0xFFFFFFFFu) continue;
-                lab[flat[u]] = 0u;
-                // whole dword: its other bytes are either listed themselves or zero already (every non-zero mask
-                // byte belongs to a listed pixel), and a dword store spares the partial-byte write
-                if (mask) {
-                    if ((size_t)(flat[u] | 3u) < total) *reinterpret_cast<uint32_t *>(mask + (flat[u] & ~3u)) = 0u;
-                    else mask[flat[u]] = 0;
+                        for (int c = 0; c < 16; ++c)
+                            if (v[c] != 0u) {
+                                lab[at + c0 + c] = 0u;
+                                if (msk) msk[at + c0 + c] = 0;
+                            }
+                    }
                 }
             }
+        }
+        for (uint32_t b = 0; b < h.n_big; ++b) {
+            const int f = hp->big[b][0];
+            const size_t s = (size_t)f * t.max_det + hp->big[b][1];
+            clear_box(reinterpret_cast<uint32_t *>(labels) + (size_t)f * HW, mask ? mask + (size_t)f * HW : nullptr, W, t.bbox[s * 4 + 0],
+                      t.bbox[s * 4 + 1], t.bbox[s * 4 + 2], t.bbox[s * 4 + 3], (int)tid, (int)stride);
         }
     } else {
         const uint4 z = make_uint4(0, 0, 0, 0);
@@ -775,7 +830,7 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, ui
             for (size_t i = n16 * 16 + tid; i < bytes; i += stride) p[i] = 0;
         }
     }
-    // every block has read the header by now; the last one to get here rewrites it
+    // every block has read the header and the tables by now; the last one to get here resets them
     __shared__ uint32_t s_ticket;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -783,108 +838,276 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, uint8_t *labels, ui
         s_ticket = atomicAdd(&pl.hdr->pad, 1u);
     }
     __syncthreads();
-    if (s_ticket == gridDim.x - 1 && threadIdx.x == 0) {
-        WsHeader *hd = pl.hdr;
-        const uint32_t cur = (h.magic == WS_MAGIC) ? ((h.cur & 1u) ^ 1u) : 0u;
-        hd->magic = 0;
-        hd->cur = cur;
-        hd->count[cur] = 0;
-        hd->pad = 0;
+    if (s_ticket == gridDim.x - 1) {
+        for (int i = threadIdx.x; i < n_counters; i += 256) t.nroots[i] = 0;
+        if (threadIdx.x == 0) {
+            WsHeader *hd = pl.hdr;
+            hd->magic = 0;
+            hd->cur = 0;
+            hd->count[0] = 0;
+            hd->dense = 0;
+            hd->n_big = 0;
+            hd->pad = 0;
+        }
     }
 }
 
-// Pass A0 (dense, HBM-bound: 1 B/px read): list the pixels that hold any class bit.  Each block
-// gathers its finds in LDS and publishes them with ONE global atomicAdd (a single hot counter
-// serves only ~90 atomics/us on this chip).
-constexpr int COLLECT_BLOCKS = 1024;
-constexpr int COLLECT_WAVE_BUF = 1280;  // entries buffered per wave before a flush (a round adds <= 1024)
+// ------------------------------------------------------------------------------------------
+// k_windows: a4 (binary_propagation) and the labelling of a5 for every small island, in registers.
+//
+// An ISLAND is an 8-connected component of the pixels that carry any class bit.  The final mask
+// R = binary_propagation(markers, mask=thresh) lies inside the islands, a thresh 4-component and an
+// 8-component of R each lie inside one island, and nothing about an island depends on pixels outside it: the
+// islands are independent problems.  An island is SMALL if its bounding box is at most 16 x 16 pixels.
+//
+// The frame is tiled by 32 x 32 CORES; the WINDOW of a core is the core grown by 16 pixels on every side:
+// 64 rows x 64 columns, held by one wave as a 64-bit row mask per lane (bit k = column k) for each class
+// bit.  Dilations are shifts within the lane and wave_shr:1 / wave_shl:1 moves between lanes; "until nothing
+// changes" is a ballot.  From a seed pixel of its core a wave flood-fills (8-connected, over the class pixels
+// it sees) a set F:
+//   * F touches the outermost ring of the window, or its box exceeds 16 x 16: the island is large -- seen from
+//     every window alike, because a small island is completely visible, ring-free, from every window whose core
+//     holds one of its pixels.  The wave lists F's pixels inside its OWN core as residue (cores tile the
+//     frame: every residue pixel is listed exactly once) and seeds their labels for the union-find passes.
+//   * otherwise F is a whole small island.  The window whose core holds the island's first pixel (raster
+//     order) owns it: hysteresis = iterate R |= dilate4(R) & thresh from R = markers (scipy's
+//     binary_propagation, markers outside the mask included); 8-components of R by flood fill (normally R is
+//     the whole island: one component, no second fill); per component the label map, the final mask, the
+//     bounding box and the Euler number from bit-quad counts (three popcounts per lane).
+// The class bytes of a macro-tile of 4 x 4 cores are turned into row masks once, in LDS (v_dot4_u32_u8 gathers
+// the class bit of four pixels), and read by the 16 windows of the tile.
+// ------------------------------------------------------------------------------------------
+constexpr int WIN_CORE = 32, WIN_MARGIN = 16;
+constexpr int WIN_MT = 4;                                        // cores per macro-tile side
+constexpr int WIN_MT_ROWS = WIN_MT * WIN_CORE + 2 * WIN_MARGIN;  // 160 staged rows
+constexpr int WIN_MT_HALVES = 2 * (WIN_MT + 1);                  // 16-pixel half-words per staged row (5 dwords, odd: lanes = rows hit 32 banks)
+constexpr int WINDOW_BLOCKS = 1536;
 
-__global__ __launch_bounds__(256) void k_collect(const uint8_t *__restrict__ cls, uint32_t *__restrict__ labels, Geo g,
-                                                 size_t nchunks, PixelList pl)
+__device__ __forceinline__ uint64_t row_above(uint64_t v)   // lane r: the mask of lane r-1 (0 into lane 0)
+{
+    return (uint64_t)wave_shr1((uint32_t)v) | ((uint64_t)wave_shr1((uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ uint64_t row_below(uint64_t v)   // lane r: the mask of lane r+1 (0 into lane 63)
+{
+    return (uint64_t)wave_shl1((uint32_t)v) | ((uint64_t)wave_shl1((uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ uint64_t grow8(uint64_t m)
+{
+    const uint64_t h = m | (m << 1) | (m >> 1);
+    return h | row_above(h) | row_below(h);
+}
+__device__ __forceinline__ uint64_t grow4(uint64_t m) { return m | (m << 1) | (m >> 1) | row_above(m) | row_below(m); }
+__device__ __forceinline__ uint64_t lane_mask(uint64_t v, int src)   // the mask held by lane `src` (wave-uniform)
+{
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32);
+}
+// 8-connected flood fill of `seed` inside `within`
+__device__ __forceinline__ uint64_t flood8(uint64_t seed, uint64_t within)
+{
+    uint64_t f = seed;
+    while (true) {
+        uint64_t n = grow8(f) & within;
+        n = grow8(n) & within;
+        const bool changed = __ballot(n != f) != 0ull;
+        f = n;
+        if (!changed) return f;
+    }
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_imin(int v) { return min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, CTRL, ROW_MASK, 0xF, false)); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_imax(int v) { return max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, ROW_MASK, 0xF, false)); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_iadd(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
+#define WAVE_REDUCE(fn, v)                                                                                      \
+    (v = fn<0x111, 0xF>(v), v = fn<0x112, 0xF>(v), v = fn<0x114, 0xF>(v), v = fn<0x118, 0xF>(v), v = fn<0x142, 0xA>(v), \
+     v = fn<0x143, 0xC>(v), __builtin_amdgcn_readlane(v, 63))
+
+struct WindowBox { int x0, x1, y0, y1; };   // window coordinates (column = bit, row = lane); wave-uniform
+__device__ __forceinline__ WindowBox box_of(uint64_t m, int lane)
+{
+    WindowBox b;
+    const unsigned long long rows = __ballot(m != 0ull);
+    b.y0 = rows ? __builtin_ctzll(rows) : 64;
+    b.y1 = rows ? 63 - __builtin_clzll(rows) : -1;
+    int lo = m ? __builtin_ctzll(m) : 64, hi = m ? 63 - __builtin_clzll(m) : -1;
+    b.x0 = WAVE_REDUCE(dpp_imin, lo);
+    b.x1 = WAVE_REDUCE(dpp_imax, hi);
+    (void)lane;
+    return b;
+}
+
+struct WindowOut {
+    uint8_t *cls;        // frame base
+    uint32_t *labels;
+    uint8_t *mask;       // may be null
+    int W, H, wx0, wy0;  // frame geometry; frame coordinates of window column 0 / row 0
+    uint32_t fbase;      // flat index of the frame's first pixel
+};
+
+// One component C of the final mask (rows in lanes, wave-uniform box): label map, mask, tables.
+__device__ __forceinline__ void window_component(const WindowOut &o, uint64_t c, const WindowBox &b, int lane, int f,
+                                                 const CompTables &t)
+{
+    const int rx = __builtin_ctzll(lane_mask(c, b.y0));                     // first pixel: top row, leftmost column
+    const uint32_t root = (uint32_t)(o.wy0 + b.y0) * (uint32_t)o.W + (uint32_t)(o.wx0 + rx);
+    const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)o.W + (uint32_t)o.wx0;
+    for (uint64_t rest = c; rest; rest &= rest - 1) {
+        const uint32_t p = row + (uint32_t)__builtin_ctzll(rest);
+        o.labels[p] = root + 1u;
+        if (o.mask) o.mask[p] = 255;
+    }
+    // bit quads: window (rows r, r+1; columns k, k+1) is counted at bit k of lane r.  C touches neither the
+    // ring nor, therefore, row 0 / column 0, so every window that meets C has its top-left cell inside
+    const uint64_t qa = c, qb = c >> 1, qc = row_below(c), qd = qc >> 1;
+    const uint64_t odd = qa ^ qb ^ qc ^ qd, pair = (qa & qb) | (qc & qd);
+    const uint64_t diag = (qa & qd & ~(qb | qc)) | (qb & qc & ~(qa | qd));
+    int q = __popcll(odd & ~pair) - __popcll(odd & pair) - 2 * __popcll(diag);
+    const int euler4 = WAVE_REDUCE(dpp_iadd, q);
+    if (lane == 0) {
+        const int idx = atomicAdd(&t.nroots[(size_t)f * NR_STRIDE], 1);
+        if (idx < t.max_det) {
+            const size_t s = (size_t)f * t.max_det + idx;
+            t.roots[s] = (int32_t)root;
+            t.bbox_tmp[s * 4 + 0] = o.wx0 + b.x0; t.bbox_tmp[s * 4 + 1] = o.wx0 + b.x1;
+            t.bbox_tmp[s * 4 + 2] = o.wy0 + b.y0; t.bbox_tmp[s * 4 + 3] = o.wy0 + b.y1;
+            t.euler_tmp[s] = euler4;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint32_t *__restrict__ labels,
+                                                 uint8_t *__restrict__ mask, Geo g, int batch, PixelList pl, CompTables t)
 {
     DET_RING(4);
-    // one buffer per wave: nothing in this kernel needs a block barrier
-    __shared__ uint32_t s_buf[4][COLLECT_WAVE_BUF];
-    const int lane = threadIdx.x & 63;
-    uint32_t *buf = s_buf[threadIdx.x >> 6];
+    __shared__ __attribute__((aligned(8))) uint16_t s_t[WIN_MT_ROWS * WIN_MT_HALVES], s_m[WIN_MT_ROWS * WIN_MT_HALVES];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = g.H, W = g.W;
+    constexpr int SPAN = WIN_MT * WIN_CORE;   // 128
+    const int tiles_x = (W + SPAN - 1) / SPAN, tiles_y = (H + SPAN - 1) / SPAN;
+    const long long items = (long long)batch * tiles_x * tiles_y;
+    const uint64_t core_rows = (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) ? 0x0000FFFFFFFF0000ull : 0ull;
+    const uint64_t ring = (lane == 0 || lane == 63) ? ~0ull : 0x8000000000000001ull;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const size_t stride = (size_t)gridDim.x * 256;
-    constexpr int U = 4;   // chunks in flight per lane: the pass is a pure HBM stream, it needs the bytes in flight
-    const size_t rounds = (nchunks + stride * U - 1) / (stride * U);
-    const uint32_t cur = pl.hdr->cur & 1u;
-    uint32_t n = 0;   // entries in this wave's buffer (wave-uniform)
-    size_t c0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (size_t r = 0; r < rounds; ++r, c0 += stride * U) {
-        uint4 v[U];
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int f = (int)(it / (tiles_x * tiles_y)), tile = (int)(it - (long long)f * tiles_x * tiles_y);
+        const int Y0 = tile / tiles_x * SPAN, X0 = tile % tiles_x * SPAN;
+        uint8_t *cf = cls + (size_t)f * g.HW;
+        __syncthreads();   // the previous tile's windows are done with the LDS rows
+        // 16-pixel chunks, adjacent lanes on adjacent chunks of a row; all loads of a tile first, then the conversion
+        {
+            constexpr int CHUNKS = WIN_MT_ROWS * WIN_MT_HALVES, ROUNDS = (CHUNKS + 255) / 256;
+            uint4 v[ROUNDS];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const size_t c = c0 + (size_t)u * stride;
-            v[u] = c < nchunks ? load_chunk(cls, c, g.total) : make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < ROUNDS; ++j) {
+                const int q = threadIdx.x + 256 * j, r = q / WIN_MT_HALVES, c = q - r * WIN_MT_HALVES;
+                const int y = Y0 - WIN_MARGIN + r, xs = X0 - WIN_MARGIN + 16 * c;
+                v[j] = make_uint4(0, 0, 0, 0);
+                if (q < CHUNKS && y >= 0 && y < H && xs < W && xs + 16 > 0) {
+                    const uint8_t *src = cf + (size_t)y * W + xs;
+                    if (xs >= 0 && xs + 16 <= W) {
+                        __builtin_memcpy(&v[j], src, 16);   // (any alignment: W need not be a multiple of 4)
+                    } else {
+                        uint32_t d[4] = {0, 0, 0, 0};
+                        for (int k = 0; k < 16; ++k)
+                            if (xs + k >= 0 && xs + k < W) d[k >> 2] |= (uint32_t)src[k] << (8 * (k & 3));
+                        v[j] = make_uint4(d[0], d[1], d[2], d[3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ROUNDS; ++j) {
+                const int q = threadIdx.x + 256 * j;
+                if (q >= CHUNKS) continue;
+                const uint32_t m = 0x01010101u, lo = 0x08040201u, hi = 0x80402010u;   // v_dot4_u32_u8: 4 class bits -> a nibble
+                const uint32_t t0 = __builtin_amdgcn_udot4(v[j].x & m, lo, __builtin_amdgcn_udot4(v[j].y & m, hi, 0u, false), false);
+                const uint32_t t1 = __builtin_amdgcn_udot4(v[j].z & m, lo, __builtin_amdgcn_udot4(v[j].w & m, hi, 0u, false), false);
+                const uint32_t m0 = __builtin_amdgcn_udot4((v[j].x >> 1) & m, lo, __builtin_amdgcn_udot4((v[j].y >> 1) & m, hi, 0u, false), false);
+                const uint32_t m1 = __builtin_amdgcn_udot4((v[j].z >> 1) & m, lo, __builtin_amdgcn_udot4((v[j].w >> 1) & m, hi, 0u, false), false);
+                s_t[q] = (uint16_t)(t0 | (t1 << 8));
+                s_m[q] = (uint16_t)(m0 | (m1 << 8));
+            }
         }
+        __syncthreads();
+        for (int wi = wave; wi < WIN_MT * WIN_MT; wi += 4) {
+            const int cy = wi / WIN_MT, cx = wi - cy * WIN_MT;
+            if (Y0 + cy * WIN_CORE >= H || X0 + cx * WIN_CORE >= W) continue;   // core outside the frame
+            const int at = ((cy * WIN_CORE + lane) * WIN_MT_HALVES + 2 * cx) / 2;
+            const uint32_t *wt = reinterpret_cast<const uint32_t *>(s_t), *wm = reinterpret_cast<const uint32_t *>(s_m);
+            const uint64_t T = (uint64_t)wt[at] | ((uint64_t)wt[at + 1] << 32);
+            const uint64_t M = (uint64_t)wm[at] | ((uint64_t)wm[at + 1] << 32);
+            const uint64_t A = T | M;
+            uint64_t todo = A & core_rows;
+            if (__ballot(todo != 0ull) == 0ull) continue;
+            WindowOut o;
+            o.cls = cf; o.labels = labels + (size_t)f * g.HW; o.mask = mask ? mask + (size_t)f * g.HW : nullptr;
+            o.W = W; o.H = H; o.wx0 = X0 + cx * WIN_CORE - WIN_MARGIN; o.wy0 = Y0 + cy * WIN_CORE - WIN_MARGIN;
+            o.fbase = (uint32_t)((size_t)f * g.HW);
+            const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)W + (uint32_t)o.wx0;   // (wraps for rows above the frame: never used there)
+            while (true) {
+                const unsigned long long rows = __ballot(todo != 0ull);
+                if (!rows) break;
+                const int sy = __builtin_ctzll(rows);
+                const int sx = __builtin_ctzll(lane_mask(todo, sy));
+                const uint64_t F = flood8(lane == sy ? (1ull << sx) : 0ull, A);
+                todo &= ~F;
+                const WindowBox b = box_of(F, lane);
+                const bool large = __ballot((F & ring) != 0ull) != 0ull || b.x1 - b.x0 >= WIN_MARGIN || b.y1 - b.y0 >= WIN_MARGIN;
+                if (large) {
+                    // residue: this core's pixels of F go on the list, each its own root for the union-find passes
+                    const uint64_t E = F & core_rows;
+                    const uint32_t cnt = (uint32_t)__popcll(E);
+                    uint32_t before = 0, total = 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const size_t c = c0 + (size_t)u * stride;
-            uint32_t bits = 0;   // bit i: pixel i of this lane's chunk carries a class bit
-            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t t = w[k] & 0x03030303u;
-                t = (t | (t >> 1)) & 0x01010101u;                      // one flag bit per byte
-                bits |= ((t * 0x00204081u >> 21) & 0xFu) << (4 * k);  // gather bits 0, 8, 16, 24 -> a nibble
-            }
-            const uint32_t cnt = __popc(bits);
-            if (__ballot(cnt != 0)) {
-                // exclusive prefix of cnt (<= 16) over the lanes from five ballots, one per bit of cnt
-                uint32_t before = 0, total = 0;
-#pragma unroll
-                for (int b = 0; b < 5; ++b) {
-                    const unsigned long long m = __ballot((cnt >> b) & 1u);
-                    before += (uint32_t)__popcll(m & below) << b;
-                    total += (uint32_t)__popcll(m) << b;
+                    for (int bit = 0; bit < 6; ++bit) {
+                        const unsigned long long m = __ballot((cnt >> bit) & 1u);
+                        before += (uint32_t)__popcll(m & below) << bit;
+                        total += (uint32_t)__popcll(m) << bit;
+                    }
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&pl.hdr->count[0], total);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    uint32_t slot = base + before;
+                    for (uint64_t rest = E; rest; rest &= rest - 1, ++slot) {
+                        const int k = __builtin_ctzll(rest);
+                        const uint32_t p = row + (uint32_t)k;
+                        if (slot < pl.cap) pl.idx[0][slot] = o.fbase + p;
+                        o.labels[p] = p + 1u;
+                        cf[p] = (uint8_t)(((T >> k) & 1ull) | (((M >> k) & 1ull) << 1));   // (drops stale flag bits of a caller-supplied map)
+                    }
+                    continue;
                 }
-                uint32_t at = n + before;
-                n += total;
-                uint32_t rest = bits;
-                const uint32_t first = (uint32_t)(c * 16);
-                const uint32_t frame_start = rest ? first / g.HW * g.HW : 0;   // (a chunk may straddle frames)
-                while (rest) {   // a chunk's pixels stay adjacent in the list: adjacent lanes, adjacent pixels later
-                    const int i = __ffs(rest) - 1;
-                    rest &= rest - 1;
-                    const uint32_t flat = first + i;
-                    buf[at++] = flat;
-                    // every listed pixel starts as its own root (the label map was cleared beforehand)
-                    uint32_t p = flat - frame_start;
-                    if (p >= g.HW) p = g.HW >= 16 ? p - g.HW : p % g.HW;   // (frames of < 16 pixels: several per chunk)
-                    labels[flat] = p + 1u;
+                if (sy != b.y0 || sx != __builtin_ctzll(lane_mask(F, b.y0))) continue;   // first pixel in another core: not ours
+                // every pixel of the island: settled here
+                for (uint64_t rest = F; rest; rest &= rest - 1) {
+                    const int k = __builtin_ctzll(rest);
+                    cf[row + (uint32_t)k] = (uint8_t)(((T >> k) & 1ull) | (((M >> k) & 1ull) << 1) | CLS_LOCAL);
                 }
-            }
-            // mid-stream flush when the next chunk could overflow the buffer (wave-uniform; rare: the
-            // foreground would have to exceed a quarter of this wave's share of the batch)
-            if (n + 1024 > COLLECT_WAVE_BUF) {
-                __threadfence_block();   // this wave's LDS writes before its LDS reads
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&pl.hdr->count[cur], n);
-                base = __builtin_amdgcn_readfirstlane(base);
-                for (uint32_t i = lane; i < n; i += 64)
-                    if ((size_t)base + i < pl.cap) pl.idx[cur][base + i] = buf[i];
-                __threadfence_block();
-                n = 0;
+                const uint64_t thresh = T & F;
+                uint64_t R = M & F;
+                while (true) {
+                    const uint64_t n = R | (grow4(R) & thresh);
+                    const bool changed = __ballot(n != R) != 0ull;
+                    R = n;
+                    if (!changed) break;
+                }
+                if (__ballot(R != F) == 0ull) {
+                    window_component(o, F, b, lane, f, t);
+                } else {
+                    while (true) {
+                        const unsigned long long rr = __ballot(R != 0ull);
+                        if (!rr) break;
+                        const int cy0 = __builtin_ctzll(rr);
+                        const int cx0 = __builtin_ctzll(lane_mask(R, cy0));
+                        const uint64_t C = flood8(lane == cy0 ? (1ull << cx0) : 0ull, R);
+                        R &= ~C;
+                        window_component(o, C, box_of(C, lane), lane, f, t);
+                    }
+                }
             }
         }
     }
-    // final flush: ONE global atomic per block (a single hot counter serves only ~90 atomics/us)
-    __shared__ uint32_t s_cnt[4], s_base;
-    if (lane == 0) s_cnt[threadIdx.x >> 6] = n;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t all = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        s_base = all ? atomicAdd(&pl.hdr->count[cur], all) : 0;
-    }
-    __syncthreads();
-    uint32_t base = s_base;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_cnt[w];
-    for (uint32_t i = lane; i < n; i += 64)
-        if ((size_t)base + i < pl.cap) pl.idx[cur][base + i] = buf[i];
 }
 
 // Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
@@ -893,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_union4(const uint8_t *__restrict__ cls,
 {
     DET_RING(5);
     FOR_LISTED_PIXELS(pl, g, flat) {
-        if (flat >= g.total || !(cls[flat] & 1u)) continue;
+        if (flat >= g.total || (cls[flat] & (1u | CLS_LOCAL)) != 1u) continue;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
         uint32_t *L = labels + (size_t)f * g.HW;
@@ -920,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_flag(uint8_t *cls, uint32_t *labels, Ge
         {
             if (flat >= g.total) continue;
             uint32_t b = cls[flat];
-            if (!(b & 2u)) continue;
+            if (!(b & 2u) || (b & CLS_LOCAL)) continue;
             uint32_t f, p; int y, x;
             locate(g, flat, f, p, y, x);
             uint32_t *L = labels + (size_t)f * g.HW;
@@ -959,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls,
     {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
-        if (!(b & 3u)) continue;
+        if (!(b & 3u) || (b & CLS_LOCAL)) continue;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
         uint32_t *L = labels + (size_t)f * g.HW;
@@ -989,14 +1212,13 @@ __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls,
 
 // Pass E: final labels (root + 1), final mask (cleared by k_clear beforehand), roots per frame.
 __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls, uint32_t *labels,
-                                                 uint8_t *__restrict__ mask, Geo g, PixelList pl,
-                                                 int32_t *nroots, int32_t *roots, int max_det)
+                                                 uint8_t *__restrict__ mask, Geo g, PixelList pl, CompTables t)
 {
     DET_RING(8);
     FOR_LISTED_PIXELS(pl, g, flat) {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
-        if (!(b & 3u)) continue;
+        if (!(b & 3u) || (b & CLS_LOCAL)) continue;
         uint32_t f = (uint32_t)(flat / g.HW);
         uint32_t p = (uint32_t)(flat - (size_t)f * g.HW);
         uint32_t *L = labels + (size_t)f * g.HW;
@@ -1007,8 +1229,13 @@ __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls
             if (r != p) L[p] = r + 1;   // plain store: write-through agent-scope stores cost a fabric write each
             if (mask) mask[flat] = 255;
             if (r == p) {
-                int idx = atomicAdd(&nroots[(size_t)f * NR_STRIDE], 1);
-                if (idx < max_det) roots[(size_t)f * max_det + idx] = (int32_t)p;
+                int idx = atomicAdd(&t.nroots[(size_t)f * NR_STRIDE], 1);
+                if (idx < t.max_det) {   // box and Euler number: k_bbox_euler, once the component has its rank
+                    const size_t s = (size_t)f * t.max_det + idx;
+                    t.roots[s] = (int32_t)p;
+                    t.bbox_tmp[s * 4 + 0] = g.W; t.bbox_tmp[s * 4 + 1] = -1; t.bbox_tmp[s * 4 + 2] = g.H; t.bbox_tmp[s * 4 + 3] = -1;
+                    t.euler_tmp[s] = 0;
+                }
             }
         } else {
             L[p] = 0u;
@@ -1019,16 +1246,6 @@ __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls
 // ------------------------------------------------------------------------------------------
 // Ordering (reverse raster order of first pixels), bounding boxes, Euler numbers
 // ------------------------------------------------------------------------------------------
-struct CompTables {
-    int32_t *nroots;   // [B * NR_STRIDE]: one counter per 128-byte line (same-line atomics serialise)
-    int32_t *roots;    // [B][max_det] unordered
-    int32_t *order;    // [B][max_det] roots sorted descending (= findContours order)
-    int32_t *bbox;     // [B][max_det][4] minx, maxx, miny, maxy
-    int32_t *euler4;   // [B][max_det] 4 * Euler number (8-connectivity)
-    int32_t *nested;   // [B][max_det] component lies in a hole of another one
-    int32_t *max_roots; // largest per-frame component count of the batch (k_rank)
-    int max_det;
-};
 
 // Rank of every root among its frame's roots (descending pixel index = findContours order); four
 // lanes share a root and split the comparisons.  While k_bbox_euler runs, a ranked root's own label
@@ -1037,14 +1254,17 @@ struct CompTables {
 constexpr uint32_t RANK_TAG = 0x80000000u;
 constexpr int RANK_THREADS = 1024;
 
-__global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *labels, uint32_t HW, int W, int H,
-                                                       int32_t *status)
+__global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *labels, uint32_t HW, int32_t *status,
+                                                       WsHeader *hdr)
 {
     DET_RING(9);
     const int f = blockIdx.x;
     int n = t.nroots[(size_t)f * NR_STRIDE];
     if (n > t.max_det) {
-        if (threadIdx.x == 0 && blockIdx.y == 0) atomicOr(&status[f], YSMR_DET_OVERFLOW);
+        if (threadIdx.x == 0 && blockIdx.y == 0) {
+            atomicOr(&status[f], YSMR_DET_OVERFLOW);
+            hdr->dense = 1u;   // pixels of the components beyond max_det are in no table: the next call clears everything
+        }
         n = t.max_det;
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) atomicMax(t.max_roots, n);
@@ -1069,8 +1289,10 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *l
         if (i < n && sub == 0) {
             size_t o = (size_t)f * t.max_det + rank;
             t.order[o] = mine;
-            t.bbox[o * 4 + 0] = W; t.bbox[o * 4 + 1] = -1; t.bbox[o * 4 + 2] = H; t.bbox[o * 4 + 3] = -1;
-            t.euler4[o] = 0;
+            const size_t from = (size_t)f * t.max_det + i;   // k_windows' components bring their box and Euler number
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t.bbox[o * 4 + q] = t.bbox_tmp[from * 4 + q];
+            t.euler4[o] = t.euler_tmp[from];
             t.nested[o] = 0;
             labels[(size_t)f * HW + (uint32_t)mine] = RANK_TAG | (uint32_t)rank;
         }
@@ -1098,9 +1320,8 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ 
     // component sits on consecutive lanes: its lanes pool their y-extent candidates and quad counts
     // with ballots, and only the run's first lane issues those atomics.  (The loop is kept
     // wave-uniform for the ballots: lanes past the end of the list carry valid = false.)
-    const uint32_t cur = pl.hdr->cur & 1u;
-    const uint32_t *idx = pl.idx[cur];
-    const size_t cnt = pl.hdr->count[cur];
+    const uint32_t *idx = pl.idx[0];
+    const size_t cnt = pl.hdr->count[0];
     const bool dense = cnt > pl.cap;
     const size_t ln = dense ? g.total : cnt;
     const int lane = threadIdx.x & 63;
@@ -1111,7 +1332,7 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ 
         size_t flat = 0;
         if (valid) flat = dense ? li : (size_t)idx[li];
         uint32_t lab_i = 0;
-        if (valid) valid = (cls[flat] & 3u) != 0;
+        if (valid) { const uint32_t b = cls[flat]; valid = (b & 3u) != 0 && !(b & CLS_LOCAL); }
         if (valid) { lab_i = labels[flat]; valid = lab_i != 0; }
         uint32_t f = 0, p = 0; int y = 0, x = 0;
         if (valid) locate(g, flat, f, p, y, x);
@@ -1169,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ 
 constexpr int HOLED_CAP = 4096;
 
 __global__ __launch_bounds__(256) void k_holes(CompTables t, int batch, uint32_t *labels, uint32_t HW, int32_t *n_holed,
-                                               int2 *holed, int32_t *status)
+                                               int2 *holed, int32_t *status, WsHeader *hdr)
 {
     DET_RING(11);
     int i = blockIdx.x * 256 + threadIdx.x;
@@ -1179,6 +1400,12 @@ __global__ __launch_bounds__(256) void k_holes(CompTables t, int batch, uint32_t
     if (k < n) {   // the root's label goes back from RANK_TAG | rank to root + 1
         const uint32_t root = (uint32_t)t.order[(size_t)f * t.max_det + k];
         labels[(size_t)f * HW + root] = root + 1u;
+        // large boxes are named in the header: the next call's k_clear has every block work on them
+        const int32_t *bb = t.bbox + ((size_t)f * t.max_det + k) * 4;
+        if ((bb[1] - bb[0] + 1) * (bb[3] - bb[2] + 1) >= WS_BIG_AREA) {
+            const uint32_t at = atomicAdd(&hdr->n_big, 1u);
+            if (at < (uint32_t)WS_BIG) { hdr->big[at][0] = f; hdr->big[at][1] = k; }
+        }
     }
     if (k < n && t.euler4[(size_t)f * t.max_det + k] != 4) {
         int idx = atomicAdd(n_holed, 1);
@@ -1589,7 +1816,7 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
 // Drop nested components, write final detection list / count / anchors.
 __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__restrict__ det_tmp, float *det,
                                                  int32_t *det_count, int32_t *anchors, PixelList pl, const uint8_t *labels,
-                                                 const uint8_t *mask, size_t total, bool angle_pre451)
+                                                 const uint8_t *mask, size_t total, int batch, int H, int W, bool angle_pre451)
 {
     DET_RING(14);
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // last kernel of the call: the current list describes these buffers
@@ -1597,6 +1824,7 @@ __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__re
         h->labels = (unsigned long long)labels;
         h->mask = (unsigned long long)mask;
         h->total = total;
+        h->batch = batch; h->H = H; h->W = W; h->max_det = t.max_det;
         __threadfence();
         h->magic = WS_MAGIC;
     }
@@ -1658,7 +1886,7 @@ Gauss11 make_gauss11()
 }
 
 struct Workspace {
-    int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed, *max_roots;
+    int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed, *max_roots, *bbox_tmp, *euler_tmp;
     int2 *holed;
     PixelList pixels;
     uint32_t *arena_used;
@@ -1681,13 +1909,15 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     w.max_roots = w.n_holed + 3;
     w.pixels.cap = (uint32_t)(((size_t)batch * H * W + 7) / 8);
     w.pixels.idx[0] = (uint32_t *)take(sizeof(uint32_t) * w.pixels.cap);
-    w.pixels.idx[1] = (uint32_t *)take(sizeof(uint32_t) * w.pixels.cap);
+    w.pixels.idx[1] = nullptr;
     w.holed = (int2 *)take(sizeof(int2) * HOLED_CAP);
     w.roots = (int32_t *)take(sizeof(int32_t) * bm);
     w.order = (int32_t *)take(sizeof(int32_t) * bm);
     w.bbox = (int32_t *)take(sizeof(int32_t) * bm * 4);
     w.euler4 = (int32_t *)take(sizeof(int32_t) * bm);
     w.nested = (int32_t *)take(sizeof(int32_t) * bm);
+    w.bbox_tmp = (int32_t *)take(sizeof(int32_t) * bm * 4);
+    w.euler_tmp = (int32_t *)take(sizeof(int32_t) * bm);
     w.det_tmp = (float *)take(sizeof(float) * bm * 5);
     // scratch arena shared by k_geometry (hulls wider than the LDS fast path) and k_nested (windows
     // larger than LDS): room for 16 full-width hulls per frame, and at least one full-frame window
@@ -1818,39 +2048,42 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
         return ysmr::fail(YSMR_ERR_CAPACITY, "workspace too small: %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
     Geo g{height, width, (uint32_t)((size_t)height * width), (size_t)batch * height * width};
-    const size_t nchunks = (g.total + 15) / 16;
-    const unsigned cgrid = (unsigned)((nchunks + 255) / 256);
     uint32_t *labels = reinterpret_cast<uint32_t *>(labels_dev);
 
     const Knobs &kn = knobs();
-    const unsigned collect_blocks = kn.collect_blocks > 0 ? (unsigned)kn.collect_blocks : (unsigned)COLLECT_BLOCKS;
+    const unsigned window_blocks = kn.collect_blocks > 0 ? (unsigned)kn.collect_blocks : (unsigned)WINDOW_BLOCKS;
     const unsigned sparse_blocks = kn.sparse_blocks > 0 ? (unsigned)kn.sparse_blocks : (unsigned)SPARSE_BLOCKS;
     const unsigned clear_blocks = kn.clear_blocks > 0 ? (unsigned)kn.clear_blocks : (unsigned)CLEAR_BLOCKS;
     const unsigned geo_blocks = kn.geo_blocks > 0 ? (unsigned)kn.geo_blocks : (unsigned)GEO_BLOCKS;
-    hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, st, w.pixels, reinterpret_cast<uint8_t *>(labels), mask_dev,
-                       g.total, w.nroots, batch * NR_STRIDE + 8, status_dev, batch);
-    const unsigned dense_grid = cgrid < collect_blocks ? cgrid : collect_blocks;
+    CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, w.max_roots, w.bbox_tmp, w.euler_tmp, max_det};
+    hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, st, w.pixels, t, reinterpret_cast<uint8_t *>(labels), mask_dev,
+                       g.total, batch * NR_STRIDE + 8, status_dev, batch, height, width);
     const dim3 sg(sparse_blocks), tb(256);
-    hipLaunchKernelGGL(k_collect, dim3(dense_grid), tb, 0, st, cls_dev, labels, g, nchunks, w.pixels);
+    {
+        constexpr int SPAN = WIN_MT * WIN_CORE;
+        const long long tiles = (long long)batch * ((height + SPAN - 1) / SPAN) * ((width + SPAN - 1) / SPAN);
+        hipLaunchKernelGGL(k_windows, dim3((unsigned)std::min<long long>(tiles, window_blocks)), tb, 0, st, cls_dev, labels, mask_dev, g,
+                           batch, w.pixels, t);
+    }
     hipLaunchKernelGGL(k_union4, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
     hipLaunchKernelGGL(k_flag, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
     hipLaunchKernelGGL(k_union8, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
-    hipLaunchKernelGGL(k_flatten, sg, tb, 0, st, cls_dev, labels, mask_dev, g, w.pixels, w.nroots, w.roots, max_det);
+    hipLaunchKernelGGL(k_flatten, sg, tb, 0, st, cls_dev, labels, mask_dev, g, w.pixels, t);
     YSMR_LAUNCH_CHECK();
-    CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, w.max_roots, max_det};
     hipLaunchKernelGGL(k_rank, dim3(batch, (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) < 32 ? (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) : 32), dim3(RANK_THREADS), 0, st, t, labels, g.HW,
-                       width, height, status_dev);
+                       status_dev, w.pixels.hdr);
     hipLaunchKernelGGL(k_bbox_euler, sg, tb, 0, st, cls_dev, labels, g, w.pixels, t);
     const unsigned comp_threads = (unsigned)((size_t)batch * max_det);
     hipLaunchKernelGGL(k_holes, dim3((comp_threads + 255) / 256), dim3(256), 0, st, t, batch, labels, g.HW, w.n_holed, w.holed,
-                       status_dev);
+                       status_dev, w.pixels.hdr);
     hipLaunchKernelGGL(k_nested, dim3(NEST_BLOCKS), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
                        w.arena_floats, w.arena_used, status_dev);
     YSMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_geometry, dim3(geo_blocks), dim3(GEO_THREADS), 0, st,
                        labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
     hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev, w.pixels,
-                       reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total, (cv_flavour & YSMR_CV_ANGLE_PRE451) != 0);
+                       reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total, batch, height, width,
+                       (cv_flavour & YSMR_CV_ANGLE_PRE451) != 0);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }
