@@ -46,6 +46,7 @@ extern "C" {
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
 #define YSMR_DET_ARENA     2   /* geometry scratch arena exhausted: some rectangles missing */
+#define YSMR_DET_STALLED   4   /* an internal grid barrier timed out: this batch has no valid result */
 
 /* cv_flavour: which OpenCV the a1 / a6 arithmetic follows.  opencv-contrib-python is an unpinned third-party
  * dependency of the reference (setup.py:29, "openCV v3 or v4"); two of its results changed between releases:

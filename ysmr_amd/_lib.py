@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("YSMR_HIP_LIB") or os.path.join(_HERE, "csrc", "libysm
 YSMR_OK = 0
 DET_OVERFLOW = 1
 DET_ARENA = 2
+DET_STALLED = 4
 #: ``cv_flavour`` bits (include/ysmr_hip.h): which OpenCV release the a1 / a6 arithmetic follows
 CV_DEFAULT, CV_ANGLE_PRE451, CV_GRAY_3X = 0, 1, 2
 

@@ -1,14 +1,15 @@
 // detect.hip -- a1-a6 of the YSMR hot path on gfx950: fused (BGR ->) gray -> 3x3 blur -> 11x11
 // Gaussian adaptive double threshold (k_threshold_strip; k_threshold for widths that are not a multiple
-// of 4), 4-connected hysteresis + 8-connected component labelling on a lock-free union-find that lives
-// in the label map (k_collect, k_union4 .. k_flatten), RETR_EXTERNAL ordering/nesting (k_rank,
-// k_bbox_euler, k_holes, k_nested), and per-component minAreaRect (k_geometry, k_compact).
+// of 4); 4-connected hysteresis + 8-connected component labelling, for small islands of foreground in
+// registers as 64 x 64 bit windows (k_windows) and for the rest on a lock-free union-find that lives in
+// the label map (k_residue: pass_union4 .. pass_bbox_euler); RETR_EXTERNAL ordering / nesting (k_rank,
+// k_nested); per-component minAreaRect (k_geometry, k_compact).
 // Reference call sites: ysmr/track_eval.py:180-303.
 //
 // All kernels are batched over frames (detection is frame-parallel) and launched as RESIDENT grids
 // that stride over their work (a grid larger than the chip holds starves every other HIP stream,
-// i.e. the link, until it has drained).  Only k_threshold_strip, k_collect and the dense fallback of
-// k_clear touch every pixel; everything else walks the list of foreground pixels.
+// i.e. the link, until it has drained).  Only k_threshold_strip, k_windows and the dense fallback of
+// k_clear touch every pixel.
 //
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
 #include "common.h"
@@ -747,7 +748,7 @@ struct CompTables {
 // (also: the per-call counters and status words are zeroed here, by the block that finishes last -- the others
 // still read the previous call's counts -- which also marks the header invalid until k_compact, the last kernel
 // of the call, vouches for the buffers again)
-constexpr int CLEAR_BLOCKS = 512;
+constexpr int CLEAR_BLOCKS = 128;
 __device__ __forceinline__ void clear_box(uint32_t *__restrict__ lab, uint8_t *__restrict__ mask, int W, int x0, int x1, int y0,
                                           int y1, int first, int step)
 {
@@ -776,40 +777,34 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
     if (h.magic == WS_MAGIC && h.labels == (unsigned long long)labels && h.mask == (unsigned long long)mask &&
         h.total == total && h.batch == batch && h.H == H && h.W == W && h.max_det == t.max_det && !h.dense &&
         h.n_big <= (uint32_t)WS_BIG) {
-        // Work items are (16 consecutive ranks, frame), frame fastest: the populated ranks come first in every
-        // frame, so the live items are spread evenly over the waves.  16 lanes per component, one per row of its
-        // box; the loads of a row are issued together (a load - test - store loop per pixel is a chain of L2
-        // round trips: 92 us per batch)
-        const int lane = threadIdx.x & 63, sub = lane & 15;
-        const long long items = (long long)((t.max_det + 15) / 16) * batch, waves = (long long)(stride / 64);
+        // Work items are (64 consecutive ranks, frame), frame fastest: the populated ranks come first in every
+        // frame, so the live items are spread evenly over the waves.  Lane = component for the box loads (one
+        // coalesced 16-byte load each); then the wave zeroes the boxes one after the other, 4 x 16 cells a step, with
+        // blind stores (test-then-store is a dependent L2 round trip per cell: 92 us per batch that way)
+        const int lane = threadIdx.x & 63;
+        const long long items = (long long)((t.max_det + 63) / 64) * batch, waves = (long long)(stride / 64);
         for (long long it = (long long)(tid / 64); it < items; it += waves) {
             const int kb = (int)(it / batch), f = (int)(it - (long long)kb * batch);
             const int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
-            if (kb * 16 >= n) break;   // (items are rank-major: every later item of this wave is empty too)
+            if (kb * 64 >= n) break;   // (items are rank-major: every later item of this wave is empty too)
             uint32_t *lab = reinterpret_cast<uint32_t *>(labels) + (size_t)f * HW;
             uint8_t *msk = mask ? mask + (size_t)f * HW : nullptr;
-#pragma unroll 1
-            for (int pass = 0; pass < 4; ++pass) {
-                const int k = kb * 16 + pass * 4 + (lane >> 4);
-                if (k >= n) continue;
-                const size_t s = (size_t)f * t.max_det + k;
-                const int x0 = t.bbox[s * 4 + 0], x1 = t.bbox[s * 4 + 1], y0 = t.bbox[s * 4 + 2], y1 = t.bbox[s * 4 + 3];
-                const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-                if (bw <= 0 || bh <= 0 || bw * bh >= WS_BIG_AREA) continue;   // (large ones are in h.big: every block helps below)
-                for (int r = sub; r < bh; r += 16) {
-                    const size_t at = (size_t)(y0 + r) * W + x0;
-                    for (int c0 = 0; c0 < bw; c0 += 16) {
-                        uint32_t v[16];
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) v[c] = c0 + c < bw ? lab[at + c0 + c] : 0u;
-#pragma unroll
-                        for (int c = 0; c < 16; ++c)
-                            if (v[c] != 0u) {
-                                lab[at + c0 + c] = 0u;
-                                if (msk) msk[at + c0 + c] = 0;
-                            }
+            const int k = kb * 64 + lane;
+            int4 box = make_int4(0, -1, 0, -1);
+            if (k < n) box = *reinterpret_cast<const int4 *>(t.bbox + ((size_t)f * t.max_det + k) * 4);
+            const int bw_l = box.y - box.x + 1, bh_l = box.w - box.z + 1;
+            unsigned long long live = __ballot(bw_l > 0 && bh_l > 0 && bw_l * bh_l < WS_BIG_AREA);   // (large ones are in h.big: every block helps below)
+            while (live) {
+                const int src = __builtin_ctzll(live);
+                live &= live - 1;
+                const int x0 = __builtin_amdgcn_readlane(box.x, src), y0 = __builtin_amdgcn_readlane(box.z, src);
+                const int bw = __builtin_amdgcn_readlane(bw_l, src), bh = __builtin_amdgcn_readlane(bh_l, src);
+                for (int r = lane >> 4; r < bh; r += 4)          // 4 rows x 16 columns of the box per step
+                    for (int c = lane & 15; c < bw; c += 16) {
+                        const size_t at = (size_t)(y0 + r) * W + (x0 + c);
+                        lab[at] = 0u;
+                        if (msk) msk[at] = 0;
                     }
-                }
             }
         }
         for (uint32_t b = 0; b < h.n_big; ++b) {
@@ -878,10 +873,12 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
 // the class bit of four pixels), and read by the 16 windows of the tile.
 // ------------------------------------------------------------------------------------------
 constexpr int WIN_CORE = 32, WIN_MARGIN = 16;
-constexpr int WIN_MT = 4;                                        // cores per macro-tile side
-constexpr int WIN_MT_ROWS = WIN_MT * WIN_CORE + 2 * WIN_MARGIN;  // 160 staged rows
-constexpr int WIN_MT_HALVES = 2 * (WIN_MT + 1);                  // 16-pixel half-words per staged row (5 dwords, odd: lanes = rows hit 32 banks)
-constexpr int WINDOW_BLOCKS = 1536;
+constexpr int WIN_GROUP = 4;                                     // cores per work item, side by side
+constexpr int WIN_HALVES = 2 * (WIN_GROUP + 1);                  // 16-pixel half-words per staged row (5 dwords, odd: lanes = rows hit 32 banks)
+#ifndef WINDOW_BLOCKS_N
+#define WINDOW_BLOCKS_N 2048
+#endif
+constexpr int WINDOW_BLOCKS = WINDOW_BLOCKS_N;
 
 __device__ __forceinline__ uint64_t row_above(uint64_t v)   // lane r: the mask of lane r-1 (0 into lane 0)
 {
@@ -891,12 +888,23 @@ __device__ __forceinline__ uint64_t row_below(uint64_t v)   // lane r: the mask 
 {
     return (uint64_t)wave_shl1((uint32_t)v) | ((uint64_t)wave_shl1((uint32_t)(v >> 32)) << 32);
 }
+// m << 1 / m >> 1 as two 32-bit operations each (v_lshlrev_b64 is a quarter-rate instruction)
+__device__ __forceinline__ uint64_t shl1(uint64_t m)
+{
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    return (uint64_t)(lo << 1) | ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 31) << 32);
+}
+__device__ __forceinline__ uint64_t shr1(uint64_t m)
+{
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    return (uint64_t)__builtin_amdgcn_alignbit(hi, lo, 1) | ((uint64_t)(hi >> 1) << 32);
+}
 __device__ __forceinline__ uint64_t grow8(uint64_t m)
 {
-    const uint64_t h = m | (m << 1) | (m >> 1);
+    const uint64_t h = m | shl1(m) | shr1(m);
     return h | row_above(h) | row_below(h);
 }
-__device__ __forceinline__ uint64_t grow4(uint64_t m) { return m | (m << 1) | (m >> 1) | row_above(m) | row_below(m); }
+__device__ __forceinline__ uint64_t grow4(uint64_t m) { return m | shl1(m) | shr1(m) | row_above(m) | row_below(m); }
 __device__ __forceinline__ uint64_t lane_mask(uint64_t v, int src)   // the mask held by lane `src` (wave-uniform)
 {
     return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src) |
@@ -977,144 +985,204 @@ __device__ __forceinline__ void window_component(const WindowOut &o, uint64_t c,
     }
 }
 
-__global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint32_t *__restrict__ labels,
-                                                 uint8_t *__restrict__ mask, Geo g, int batch, PixelList pl, CompTables t)
+// The islands a window's core holds a pixel of (see above).  T / M: thresh / marker rows of the window.
+__device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const WindowOut &o, int lane, int f, uint8_t *cf,
+                                               const PixelList &pl, const CompTables &t)
 {
-    DET_RING(4);
-    __shared__ __attribute__((aligned(8))) uint16_t s_t[WIN_MT_ROWS * WIN_MT_HALVES], s_m[WIN_MT_ROWS * WIN_MT_HALVES];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int H = g.H, W = g.W;
-    constexpr int SPAN = WIN_MT * WIN_CORE;   // 128
-    const int tiles_x = (W + SPAN - 1) / SPAN, tiles_y = (H + SPAN - 1) / SPAN;
-    const long long items = (long long)batch * tiles_x * tiles_y;
     const uint64_t core_rows = (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) ? 0x0000FFFFFFFF0000ull : 0ull;
     const uint64_t ring = (lane == 0 || lane == 63) ? ~0ull : 0x8000000000000001ull;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
-        const int f = (int)(it / (tiles_x * tiles_y)), tile = (int)(it - (long long)f * tiles_x * tiles_y);
-        const int Y0 = tile / tiles_x * SPAN, X0 = tile % tiles_x * SPAN;
-        uint8_t *cf = cls + (size_t)f * g.HW;
-        __syncthreads();   // the previous tile's windows are done with the LDS rows
-        // 16-pixel chunks, adjacent lanes on adjacent chunks of a row; all loads of a tile first, then the conversion
-        {
-            constexpr int CHUNKS = WIN_MT_ROWS * WIN_MT_HALVES, ROUNDS = (CHUNKS + 255) / 256;
-            uint4 v[ROUNDS];
+    const uint64_t A = T | M;
+    uint64_t todo = A & core_rows;
+    const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)o.W + (uint32_t)o.wx0;   // (wraps for rows above the frame: never used there)
+    while (true) {
+        const unsigned long long rows = __ballot(todo != 0ull);
+        if (!rows) break;
+        const int sy = __builtin_ctzll(rows);
+        const int sx = __builtin_ctzll(lane_mask(todo, sy));
+        const uint64_t F = flood8(lane == sy ? (1ull << sx) : 0ull, A);
+        todo &= ~F;
+        const WindowBox b = box_of(F, lane);
+        const bool large = __ballot((F & ring) != 0ull) != 0ull || b.x1 - b.x0 >= WIN_MARGIN || b.y1 - b.y0 >= WIN_MARGIN;
+        if (large) {
+            // residue: this core's pixels of F go on the list, each its own root for the union-find passes
+            const uint64_t E = F & core_rows;
+            const uint32_t cnt = (uint32_t)__popcll(E);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            uint32_t before = 0, total = 0;
 #pragma unroll
-            for (int j = 0; j < ROUNDS; ++j) {
-                const int q = threadIdx.x + 256 * j, r = q / WIN_MT_HALVES, c = q - r * WIN_MT_HALVES;
-                const int y = Y0 - WIN_MARGIN + r, xs = X0 - WIN_MARGIN + 16 * c;
-                v[j] = make_uint4(0, 0, 0, 0);
-                if (q < CHUNKS && y >= 0 && y < H && xs < W && xs + 16 > 0) {
-                    const uint8_t *src = cf + (size_t)y * W + xs;
-                    if (xs >= 0 && xs + 16 <= W) {
-                        __builtin_memcpy(&v[j], src, 16);   // (any alignment: W need not be a multiple of 4)
-                    } else {
-                        uint32_t d[4] = {0, 0, 0, 0};
-                        for (int k = 0; k < 16; ++k)
-                            if (xs + k >= 0 && xs + k < W) d[k >> 2] |= (uint32_t)src[k] << (8 * (k & 3));
-                        v[j] = make_uint4(d[0], d[1], d[2], d[3]);
-                    }
-                }
+            for (int bit = 0; bit < 6; ++bit) {
+                const unsigned long long m = __ballot((cnt >> bit) & 1u);
+                before += (uint32_t)__popcll(m & below) << bit;
+                total += (uint32_t)__popcll(m) << bit;
             }
-#pragma unroll
-            for (int j = 0; j < ROUNDS; ++j) {
-                const int q = threadIdx.x + 256 * j;
-                if (q >= CHUNKS) continue;
-                const uint32_t m = 0x01010101u, lo = 0x08040201u, hi = 0x80402010u;   // v_dot4_u32_u8: 4 class bits -> a nibble
-                const uint32_t t0 = __builtin_amdgcn_udot4(v[j].x & m, lo, __builtin_amdgcn_udot4(v[j].y & m, hi, 0u, false), false);
-                const uint32_t t1 = __builtin_amdgcn_udot4(v[j].z & m, lo, __builtin_amdgcn_udot4(v[j].w & m, hi, 0u, false), false);
-                const uint32_t m0 = __builtin_amdgcn_udot4((v[j].x >> 1) & m, lo, __builtin_amdgcn_udot4((v[j].y >> 1) & m, hi, 0u, false), false);
-                const uint32_t m1 = __builtin_amdgcn_udot4((v[j].z >> 1) & m, lo, __builtin_amdgcn_udot4((v[j].w >> 1) & m, hi, 0u, false), false);
-                s_t[q] = (uint16_t)(t0 | (t1 << 8));
-                s_m[q] = (uint16_t)(m0 | (m1 << 8));
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&pl.hdr->count[0], total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            uint32_t slot = base + before;
+            for (uint64_t rest = E; rest; rest &= rest - 1, ++slot) {
+                const int k = __builtin_ctzll(rest);
+                const uint32_t p = row + (uint32_t)k;
+                if (slot < pl.cap) pl.idx[0][slot] = o.fbase + p;
+                o.labels[p] = p + 1u;
+                cf[p] = (uint8_t)(((T >> k) & 1ull) | (((M >> k) & 1ull) << 1));   // (drops stale flag bits of a caller-supplied map)
             }
+            continue;
         }
-        __syncthreads();
-        for (int wi = wave; wi < WIN_MT * WIN_MT; wi += 4) {
-            const int cy = wi / WIN_MT, cx = wi - cy * WIN_MT;
-            if (Y0 + cy * WIN_CORE >= H || X0 + cx * WIN_CORE >= W) continue;   // core outside the frame
-            const int at = ((cy * WIN_CORE + lane) * WIN_MT_HALVES + 2 * cx) / 2;
-            const uint32_t *wt = reinterpret_cast<const uint32_t *>(s_t), *wm = reinterpret_cast<const uint32_t *>(s_m);
-            const uint64_t T = (uint64_t)wt[at] | ((uint64_t)wt[at + 1] << 32);
-            const uint64_t M = (uint64_t)wm[at] | ((uint64_t)wm[at + 1] << 32);
-            const uint64_t A = T | M;
-            uint64_t todo = A & core_rows;
-            if (__ballot(todo != 0ull) == 0ull) continue;
-            WindowOut o;
-            o.cls = cf; o.labels = labels + (size_t)f * g.HW; o.mask = mask ? mask + (size_t)f * g.HW : nullptr;
-            o.W = W; o.H = H; o.wx0 = X0 + cx * WIN_CORE - WIN_MARGIN; o.wy0 = Y0 + cy * WIN_CORE - WIN_MARGIN;
-            o.fbase = (uint32_t)((size_t)f * g.HW);
-            const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)W + (uint32_t)o.wx0;   // (wraps for rows above the frame: never used there)
+        if (sy != b.y0 || sx != __builtin_ctzll(lane_mask(F, b.y0))) continue;   // first pixel in another core: not ours
+#ifdef WIN_DBG_NO_FINAL
+        if (F != 0x123456789ull) continue;
+#endif
+        // every pixel of the island: settled here
+        for (uint64_t rest = F; rest; rest &= rest - 1) {
+            const int k = __builtin_ctzll(rest);
+            cf[row + (uint32_t)k] = (uint8_t)(((T >> k) & 1ull) | (((M >> k) & 1ull) << 1) | CLS_LOCAL);
+        }
+        const uint64_t thresh = T & F;
+        uint64_t R = M & F;
+        while (true) {
+            const uint64_t n = R | (grow4(R) & thresh);
+            const bool changed = __ballot(n != R) != 0ull;
+            R = n;
+            if (!changed) break;
+        }
+        if (__ballot(R != F) == 0ull) {
+            window_component(o, F, b, lane, f, t);
+        } else {
             while (true) {
-                const unsigned long long rows = __ballot(todo != 0ull);
-                if (!rows) break;
-                const int sy = __builtin_ctzll(rows);
-                const int sx = __builtin_ctzll(lane_mask(todo, sy));
-                const uint64_t F = flood8(lane == sy ? (1ull << sx) : 0ull, A);
-                todo &= ~F;
-                const WindowBox b = box_of(F, lane);
-                const bool large = __ballot((F & ring) != 0ull) != 0ull || b.x1 - b.x0 >= WIN_MARGIN || b.y1 - b.y0 >= WIN_MARGIN;
-                if (large) {
-                    // residue: this core's pixels of F go on the list, each its own root for the union-find passes
-                    const uint64_t E = F & core_rows;
-                    const uint32_t cnt = (uint32_t)__popcll(E);
-                    uint32_t before = 0, total = 0;
-#pragma unroll
-                    for (int bit = 0; bit < 6; ++bit) {
-                        const unsigned long long m = __ballot((cnt >> bit) & 1u);
-                        before += (uint32_t)__popcll(m & below) << bit;
-                        total += (uint32_t)__popcll(m) << bit;
-                    }
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&pl.hdr->count[0], total);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    uint32_t slot = base + before;
-                    for (uint64_t rest = E; rest; rest &= rest - 1, ++slot) {
-                        const int k = __builtin_ctzll(rest);
-                        const uint32_t p = row + (uint32_t)k;
-                        if (slot < pl.cap) pl.idx[0][slot] = o.fbase + p;
-                        o.labels[p] = p + 1u;
-                        cf[p] = (uint8_t)(((T >> k) & 1ull) | (((M >> k) & 1ull) << 1));   // (drops stale flag bits of a caller-supplied map)
-                    }
-                    continue;
-                }
-                if (sy != b.y0 || sx != __builtin_ctzll(lane_mask(F, b.y0))) continue;   // first pixel in another core: not ours
-                // every pixel of the island: settled here
-                for (uint64_t rest = F; rest; rest &= rest - 1) {
-                    const int k = __builtin_ctzll(rest);
-                    cf[row + (uint32_t)k] = (uint8_t)(((T >> k) & 1ull) | (((M >> k) & 1ull) << 1) | CLS_LOCAL);
-                }
-                const uint64_t thresh = T & F;
-                uint64_t R = M & F;
-                while (true) {
-                    const uint64_t n = R | (grow4(R) & thresh);
-                    const bool changed = __ballot(n != R) != 0ull;
-                    R = n;
-                    if (!changed) break;
-                }
-                if (__ballot(R != F) == 0ull) {
-                    window_component(o, F, b, lane, f, t);
-                } else {
-                    while (true) {
-                        const unsigned long long rr = __ballot(R != 0ull);
-                        if (!rr) break;
-                        const int cy0 = __builtin_ctzll(rr);
-                        const int cx0 = __builtin_ctzll(lane_mask(R, cy0));
-                        const uint64_t C = flood8(lane == cy0 ? (1ull << cx0) : 0ull, R);
-                        R &= ~C;
-                        window_component(o, C, box_of(C, lane), lane, f, t);
-                    }
-                }
+                const unsigned long long rr = __ballot(R != 0ull);
+                if (!rr) break;
+                const int cy0 = __builtin_ctzll(rr);
+                const int cx0 = __builtin_ctzll(lane_mask(R, cy0));
+                const uint64_t C = flood8(lane == cy0 ? (1ull << cx0) : 0ull, R);
+                R &= ~C;
+                window_component(o, C, box_of(C, lane), lane, f, t);
             }
         }
     }
 }
 
-// Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
-__global__ __launch_bounds__(256) void k_union4(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
-                                                PixelList pl)
+// Work item of a wave: WIN_GROUP cores side by side = 64 rows x 160 columns of class bytes, turned into row masks
+// through the wave's own slice of LDS (adjacent lanes load adjacent 16-byte chunks of a row; lane = row reads the
+// words back): no block barrier, the waves of a block do not wait for each other.
+__global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint32_t *__restrict__ labels,
+                                                 uint8_t *__restrict__ mask, Geo g, int batch, PixelList pl, CompTables t)
 {
-    DET_RING(5);
+    DET_RING(4);
+    constexpr int CHUNKS = 64 * WIN_HALVES, ROUNDS = CHUNKS / 64;
+    __shared__ __attribute__((aligned(8))) uint16_t s_bits[4][2][CHUNKS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = g.H, W = g.W;
+    constexpr int SPAN = WIN_GROUP * WIN_CORE;   // 128
+    const int groups_x = (W + SPAN - 1) / SPAN, rows_y = (H + WIN_CORE - 1) / WIN_CORE;
+    const long long per_frame = (long long)groups_x * rows_y, items = per_frame * batch;
+    uint16_t *st = s_bits[wave][0], *sm = s_bits[wave][1];
+    // Workgroups b and b + 8 run on the same XCD (as in k_threshold_strip): every XCD works through whole frames
+    // -- the frames it thresholded, if the batch is a multiple of 8 -- or else through one contiguous eighth of the
+    // items, so that the rows an item shares with its neighbours (each class byte is read by 2.5 items) come out
+    // of the XCD's own L2.  (Items dealt round-robin over the chip: 93 us per batch for the loads alone.)
+    long long first = (long long)blockIdx.x * 4 + wave, step = (long long)gridDim.x * 4, count = items, offset = 0;
+    int f_mul = 1, f_add = 0;
+    if ((gridDim.x & 7u) == 0) {
+        first = (long long)(blockIdx.x >> 3) * 4 + wave; step = (long long)(gridDim.x >> 3) * 4;
+        if ((batch & 7) == 0) { count = (long long)(batch >> 3) * per_frame; f_mul = 8; f_add = (int)(blockIdx.x & 7u); }
+        else {
+            const long long share = (items + 7) / 8;
+            offset = share * (blockIdx.x & 7u);
+            count = max(0ll, min(share, items - offset));
+        }
+    }
+    for (long long j = first; j < count; j += step) {
+        const long long it = offset + j;
+        const int f = (int)(it / per_frame) * f_mul + f_add, rem = (int)(it % per_frame);
+        const int Y0 = rem / groups_x * WIN_CORE, X0 = rem % groups_x * SPAN;
+        uint8_t *cf = cls + (size_t)f * g.HW;
+        static_assert(ROUNDS % 2 == 0, "two half-batches of loads");
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {   // (all ten loads in flight at once cost 40 VGPRs and a wave per SIMD)
+        uint4 v[ROUNDS / 2];
+#pragma unroll
+        for (int jj = 0; jj < ROUNDS / 2; ++jj) {
+            const int j = jj + half * (ROUNDS / 2);
+            const int q = lane + 64 * j, r = q / WIN_HALVES, c = q - r * WIN_HALVES;
+            const int y = Y0 - WIN_MARGIN + r, xs = X0 - WIN_MARGIN + 16 * c;
+            uint4 &vj = v[jj];
+            vj = make_uint4(0, 0, 0, 0);
+            if (y >= 0 && y < H && xs < W && xs + 16 > 0) {
+                const uint8_t *src = cf + (size_t)y * W + xs;
+                if (xs >= 0 && xs + 16 <= W) {
+                    __builtin_memcpy(&vj, src, 16);   // (any alignment: W need not be a multiple of 4)
+                } else if (xs >= 0 && W >= 16) {
+                    // the chunk sticks out of the row on the right: the row's last 16 bytes, shifted down.  (A loop
+                    // of guarded byte loads here was a chain of round trips in every item of the last column group,
+                    // and those items were the kernel's duration.)
+                    uint4 l;
+                    __builtin_memcpy(&l, src - (xs + 16 - W), 16);
+                    const int drop = xs + 16 - W, a = drop >> 2, b = drop & 3;   // 1..15 bytes
+                    const uint32_t e0 = a == 0 ? l.x : a == 1 ? l.y : a == 2 ? l.z : l.w;
+                    const uint32_t e1 = a == 0 ? l.y : a == 1 ? l.z : a == 2 ? l.w : 0u;
+                    const uint32_t e2 = a == 0 ? l.z : a == 1 ? l.w : 0u;
+                    const uint32_t e3 = a == 0 ? l.w : 0u;
+                    vj = make_uint4(__builtin_amdgcn_alignbyte(e1, e0, b), __builtin_amdgcn_alignbyte(e2, e1, b),
+                                      __builtin_amdgcn_alignbyte(e3, e2, b), __builtin_amdgcn_alignbyte(0u, e3, b));
+                } else {   // frames narrower than 16 pixels
+                    uint32_t d[4] = {0, 0, 0, 0};
+                    for (int k = 0; k < 16; ++k)
+                        if (xs + k >= 0 && xs + k < W) d[k >> 2] |= (uint32_t)src[k] << (8 * (k & 3));
+                    vj = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < ROUNDS / 2; ++jj) {
+            const int j = jj + half * (ROUNDS / 2);
+            const uint4 &vj = v[jj];
+            const uint32_t m = 0x01010101u, lo = 0x08040201u, hi = 0x80402010u;   // v_dot4_u32_u8: 4 class bits -> a nibble
+            const uint32_t t0 = __builtin_amdgcn_udot4(vj.x & m, lo, __builtin_amdgcn_udot4(vj.y & m, hi, 0u, false), false);
+            const uint32_t t1 = __builtin_amdgcn_udot4(vj.z & m, lo, __builtin_amdgcn_udot4(vj.w & m, hi, 0u, false), false);
+            const uint32_t m0 = __builtin_amdgcn_udot4((vj.x >> 1) & m, lo, __builtin_amdgcn_udot4((vj.y >> 1) & m, hi, 0u, false), false);
+            const uint32_t m1 = __builtin_amdgcn_udot4((vj.z >> 1) & m, lo, __builtin_amdgcn_udot4((vj.w >> 1) & m, hi, 0u, false), false);
+            st[lane + 64 * j] = (uint16_t)(t0 | (t1 << 8));
+            sm[lane + 64 * j] = (uint16_t)(m0 | (m1 << 8));
+        }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's LDS writes before its LDS reads
+        __builtin_amdgcn_wave_barrier();
+        uint32_t tw[WIN_GROUP + 1], mw[WIN_GROUP + 1];
+#pragma unroll
+        for (int k = 0; k <= WIN_GROUP; ++k) {
+            tw[k] = reinterpret_cast<const uint32_t *>(st)[lane * (WIN_GROUP + 1) + k];
+            mw[k] = reinterpret_cast<const uint32_t *>(sm)[lane * (WIN_GROUP + 1) + k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... and the reads before the next item's writes
+        __builtin_amdgcn_wave_barrier();
+        WindowOut o;
+        o.cls = cf; o.labels = labels + (size_t)f * g.HW; o.mask = mask ? mask + (size_t)f * g.HW : nullptr;
+        o.W = W; o.H = H; o.wy0 = Y0 - WIN_MARGIN;
+        o.fbase = (uint32_t)((size_t)f * g.HW);
+        static_assert(WIN_GROUP == 4, "the word selection below is written out for four cores");
+#pragma unroll 1
+        for (int cx = 0; cx < WIN_GROUP; ++cx) {   // (one copy of the window code: the words are picked by selects)
+            if (X0 + cx * WIN_CORE >= W) break;   // core outside the frame
+            const uint32_t t_lo = cx == 0 ? tw[0] : cx == 1 ? tw[1] : cx == 2 ? tw[2] : tw[3];
+            const uint32_t t_hi = cx == 0 ? tw[1] : cx == 1 ? tw[2] : cx == 2 ? tw[3] : tw[4];
+            const uint32_t m_lo = cx == 0 ? mw[0] : cx == 1 ? mw[1] : cx == 2 ? mw[2] : mw[3];
+            const uint32_t m_hi = cx == 0 ? mw[1] : cx == 1 ? mw[2] : cx == 2 ? mw[3] : mw[4];
+            const uint64_t T = (uint64_t)t_lo | ((uint64_t)t_hi << 32), M = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
+            const uint64_t core_rows = (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) ? 0x0000FFFFFFFF0000ull : 0ull;
+            if (__ballot(((T | M) & core_rows) != 0ull) == 0ull) continue;
+            o.wx0 = X0 + cx * WIN_CORE - WIN_MARGIN;
+#ifdef WIN_DBG_STAGE_ONLY
+            if (T == 0x123456789ull) o.labels[0] = 1;
+#else
+            window_islands(T, M, o, lane, f, cf, pl, t);
+#endif
+        }
+    }
+}
+
+// Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
+__device__ __forceinline__ void pass_union4(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const PixelList &pl)
+{
     FOR_LISTED_PIXELS(pl, g, flat) {
         if (flat >= g.total || (cls[flat] & (1u | CLS_LOCAL)) != 1u) continue;
         uint32_t f, p; int y, x;
@@ -1136,9 +1204,8 @@ __device__ __forceinline__ void set_flag(uint8_t *cls, size_t flat)
 
 // Pass C: flag (bit2 on the root's class byte) every thresh-component that holds a marker pixel
 // or touches (4-neighbourhood) a marker pixel lying outside the mask.
-__global__ __launch_bounds__(256) void k_flag(uint8_t *cls, uint32_t *labels, Geo g, PixelList pl)
+__device__ __forceinline__ void pass_flag(uint8_t *cls, uint32_t *labels, const Geo &g, const PixelList &pl)
 {
-    DET_RING(6);
     FOR_LISTED_PIXELS(pl, g, flat) {
         {
             if (flat >= g.total) continue;
@@ -1174,10 +1241,8 @@ __device__ __forceinline__ bool in_result(const uint8_t *cls_frame, const uint32
 }
 
 // Pass D: 8-connected components of R (what cv2.findContours traces).
-__global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls, uint32_t *labels, Geo g,
-                                                PixelList pl)
+__device__ __forceinline__ void pass_union8(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const PixelList &pl)
 {
-    DET_RING(7);
     FOR_LISTED_PIXELS(pl, g, flat) {
     {
         if (flat >= g.total) continue;
@@ -1211,10 +1276,9 @@ __global__ __launch_bounds__(256) void k_union8(const uint8_t *__restrict__ cls,
 }
 
 // Pass E: final labels (root + 1), final mask (cleared by k_clear beforehand), roots per frame.
-__global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls, uint32_t *labels,
-                                                 uint8_t *__restrict__ mask, Geo g, PixelList pl, CompTables t)
+__device__ __forceinline__ void pass_flatten(const uint8_t *__restrict__ cls, uint32_t *labels, uint8_t *__restrict__ mask,
+                                             const Geo &g, const PixelList &pl, const CompTables &t)
 {
-    DET_RING(8);
     FOR_LISTED_PIXELS(pl, g, flat) {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
@@ -1248,14 +1312,14 @@ __global__ __launch_bounds__(256) void k_flatten(const uint8_t *__restrict__ cls
 // ------------------------------------------------------------------------------------------
 
 // Rank of every root among its frame's roots (descending pixel index = findContours order); four
-// lanes share a root and split the comparisons.  While k_bbox_euler runs, a ranked root's own label
-// holds RANK_TAG | rank instead of root + 1, so that every pixel finds its component's table row
-// with one dependent load; k_holes puts root + 1 back.
-constexpr uint32_t RANK_TAG = 0x80000000u;
+// lanes share a root and split the comparisons.  A component takes its box and Euler number along to its rank
+// (k_windows / pass_bbox_euler filed them under the slot the root was appended at), gets its root's label back
+// (pass_tag_roots), and is queued for k_nested if it has holes.
 constexpr int RANK_THREADS = 1024;
+constexpr int HOLED_CAP = 4096;
 
 __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *labels, uint32_t HW, int32_t *status,
-                                                       WsHeader *hdr)
+                                                       WsHeader *hdr, int32_t *n_holed, int2 *holed)
 {
     DET_RING(9);
     const int f = blockIdx.x;
@@ -1289,12 +1353,26 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *l
         if (i < n && sub == 0) {
             size_t o = (size_t)f * t.max_det + rank;
             t.order[o] = mine;
-            const size_t from = (size_t)f * t.max_det + i;   // k_windows' components bring their box and Euler number
+            const size_t from = (size_t)f * t.max_det + i;
+            int bb[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t.bbox[o * 4 + q] = t.bbox_tmp[from * 4 + q];
-            t.euler4[o] = t.euler_tmp[from];
+            for (int q = 0; q < 4; ++q) t.bbox[o * 4 + q] = bb[q] = t.bbox_tmp[from * 4 + q];
+            const int e4 = t.euler_tmp[from];
+            t.euler4[o] = e4;
             t.nested[o] = 0;
-            labels[(size_t)f * HW + (uint32_t)mine] = RANK_TAG | (uint32_t)rank;
+            labels[(size_t)f * HW + (uint32_t)mine] = (uint32_t)mine + 1u;
+            // components whose Euler number is not 1 have holes and may enclose other components (RETR_EXTERNAL
+            // skips those): queued for k_nested
+            if (e4 != 4) {
+                const int at = atomicAdd(n_holed, 1);
+                if (at < HOLED_CAP) holed[at] = make_int2(f, rank);
+                else atomicOr(&status[f], YSMR_DET_ARENA);
+            }
+            // large boxes are named in the header: the next call's k_clear has every block work on them
+            if ((bb[1] - bb[0] + 1) * (bb[3] - bb[2] + 1) >= WS_BIG_AREA) {
+                const uint32_t at = atomicAdd(&hdr->n_big, 1u);
+                if (at < (uint32_t)WS_BIG) { hdr->big[at][0] = f; hdr->big[at][1] = rank; }
+            }
         }
     }
 }
@@ -1310,12 +1388,16 @@ __device__ __forceinline__ int find_rank(const int32_t *order, int n, int32_t ro
     return (lo < n && order[lo] == root) ? lo : -1;
 }
 
+// While pass_bbox_euler runs, the label of a residue component's root holds SLOT_TAG | (slot the root was appended
+// at) instead of root + 1, so that every pixel finds its component's table row with one dependent load; k_rank
+// puts root + 1 back.
+constexpr uint32_t SLOT_TAG = 0x80000000u;
+
 // Per final-mask pixel: bounding box of its component; bit-quad counts for the Euler number
 // (E8 = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows, each window counted by its first set pixel).
-__global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ cls, const uint32_t *__restrict__ labels,
-                                                    Geo g, PixelList pl, CompTables t)
+__device__ __forceinline__ void pass_bbox_euler(const uint8_t *__restrict__ cls, const uint32_t *labels, const Geo &g,
+                                                const PixelList &pl, const CompTables &t)
 {
-    DET_RING(10);
     // The list keeps the pixels of a 16-pixel chunk on adjacent lanes, so a horizontal run of a
     // component sits on consecutive lanes: its lanes pool their y-extent candidates and quad counts
     // with ballots, and only the run's first lane issues those atomics.  (The loop is kept
@@ -1337,9 +1419,9 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ 
         uint32_t f = 0, p = 0; int y = 0, x = 0;
         if (valid) locate(g, flat, f, p, y, x);
         const uint32_t *L = labels + (size_t)f * g.HW;
-        if (valid && !(lab_i & RANK_TAG)) lab_i = L[lab_i - 1];   // the root's label carries the rank (k_rank)
-        valid = valid && (lab_i & RANK_TAG);   // else: component beyond max_det (overflow already flagged)
-        const uint32_t o = valid ? f * (uint32_t)t.max_det + (lab_i & ~RANK_TAG) : 0xFFFFFFFFu;
+        if (valid && !(lab_i & SLOT_TAG)) lab_i = L[lab_i - 1];   // the root's label carries its slot (pass_tag_roots)
+        valid = valid && (lab_i & SLOT_TAG);   // else: component beyond max_det (k_rank flags the overflow)
+        const uint32_t o = valid ? f * (uint32_t)t.max_det + (lab_i & ~SLOT_TAG) : 0xFFFFFFFFu;
         const int W = g.W, H = g.H;
         auto at = [&](int yy, int xx) -> int {
             return (valid && yy >= 0 && yy < H && xx >= 0 && xx < W && L[(size_t)yy * W + xx] != 0) ? 1 : 0;
@@ -1374,44 +1456,72 @@ __global__ __launch_bounds__(256) void k_bbox_euler(const uint8_t *__restrict__ 
 #pragma unroll
         for (int bit = 0; bit < 4; ++bit) run_q += (int)__popcll(__ballot((qb >> bit) & 1u) & run) << bit;
         if (valid) {   // bbox: only extreme candidates issue atomics
-            if (!ww) atomicMin(&t.bbox[(size_t)o * 4 + 0], x);
-            if (!ee) atomicMax(&t.bbox[(size_t)o * 4 + 1], x);
+            if (!ww) atomicMin(&t.bbox_tmp[(size_t)o * 4 + 0], x);
+            if (!ee) atomicMax(&t.bbox_tmp[(size_t)o * 4 + 1], x);
         }
         if (head) {
-            if (top & run) atomicMin(&t.bbox[(size_t)o * 4 + 2], y);
-            if (bottom & run) atomicMax(&t.bbox[(size_t)o * 4 + 3], y);
-            if (run_q) atomicAdd(&t.euler4[o], run_q);
+            if (top & run) atomicMin(&t.bbox_tmp[(size_t)o * 4 + 2], y);
+            if (bottom & run) atomicMax(&t.bbox_tmp[(size_t)o * 4 + 3], y);
+            if (run_q) atomicAdd(&t.euler_tmp[o], run_q);
         }
     }
 }
 
-// One thread per component: components whose Euler number is not 1 have holes and may enclose
-// other components (RETR_EXTERNAL skips those); queue them for k_nested.
-constexpr int HOLED_CAP = 4096;
-
-__global__ __launch_bounds__(256) void k_holes(CompTables t, int batch, uint32_t *labels, uint32_t HW, int32_t *n_holed,
-                                               int2 *holed, int32_t *status, WsHeader *hdr)
+// The union-find passes over the residue as ONE launch: usually there is no residue (every block returns at
+// once; five near-empty launches cost 25 us per batch), otherwise the passes are separated by a software grid
+// barrier (all RESIDUE_BLOCKS blocks are resident: 128 x 256 threads, no LDS to speak of).
+constexpr int RESIDUE_BLOCKS = 128;
+__device__ __forceinline__ bool grid_barrier(uint32_t *counter, uint32_t target)
 {
-    DET_RING(11);
-    int i = blockIdx.x * 256 + threadIdx.x;
-    int f = i / t.max_det, k = i - f * t.max_det;
-    if (f >= batch) return;
-    int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
-    if (k < n) {   // the root's label goes back from RANK_TAG | rank to root + 1
-        const uint32_t root = (uint32_t)t.order[(size_t)f * t.max_det + k];
-        labels[(size_t)f * HW + root] = root + 1u;
-        // large boxes are named in the header: the next call's k_clear has every block work on them
-        const int32_t *bb = t.bbox + ((size_t)f * t.max_det + k) * 4;
-        if ((bb[1] - bb[0] + 1) * (bb[3] - bb[2] + 1) >= WS_BIG_AREA) {
-            const uint32_t at = atomicAdd(&hdr->n_big, 1u);
-            if (at < (uint32_t)WS_BIG) { hdr->big[at][0] = f; hdr->big[at][1] = k; }
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(counter, 1u);
+        uint32_t spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > 20000000u) { ok = 0; break; }   // (a block that cannot become resident: give up rather than hang)
         }
+        __threadfence();
+        s_ok = ok;
     }
-    if (k < n && t.euler4[(size_t)f * t.max_det + k] != 4) {
-        int idx = atomicAdd(n_holed, 1);
-        if (idx < HOLED_CAP) holed[idx] = make_int2(f, k);
-        else atomicOr(&status[f], YSMR_DET_ARENA);
+    __syncthreads();
+    return s_ok != 0;
+}
+
+__device__ __forceinline__ void pass_tag_roots(uint32_t *labels, const Geo &g, const CompTables &t, int batch)
+{
+    // (roots appended by k_windows get the tag too -- none of their pixels is visited by pass_bbox_euler -- and
+    // k_rank writes root + 1 back over every one)
+    const size_t slots = (size_t)batch * t.max_det;
+    for (size_t s = (size_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (size_t)gridDim.x * 256) {
+        const int f = (int)(s / t.max_det), k = (int)(s - (size_t)f * t.max_det);
+        if (k < min(t.nroots[(size_t)f * NR_STRIDE], t.max_det))
+            labels[(size_t)f * g.HW + (uint32_t)t.roots[s]] = SLOT_TAG | (uint32_t)k;
     }
+}
+
+__global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels, uint8_t *mask, Geo g, int batch, PixelList pl,
+                                                 CompTables t, uint32_t *barrier, int32_t *status)
+{
+    DET_RING(5);
+    if (pl.hdr->count[0] == 0u) return;   // (written by k_windows, the previous launch: every block sees the same)
+    bool ok = true;
+    pass_union4(cls, labels, g, pl);
+    ok = ok && grid_barrier(barrier, 1u * gridDim.x);
+    if (ok) pass_flag(cls, labels, g, pl);
+    ok = ok && grid_barrier(barrier, 2u * gridDim.x);
+    if (ok) pass_union8(cls, labels, g, pl);
+    ok = ok && grid_barrier(barrier, 3u * gridDim.x);
+    if (ok) pass_flatten(cls, labels, mask, g, pl, t);
+    ok = ok && grid_barrier(barrier, 4u * gridDim.x);
+    if (ok) pass_tag_roots(labels, g, t, batch);
+    ok = ok && grid_barrier(barrier, 5u * gridDim.x);
+    if (ok) pass_bbox_euler(cls, labels, g, pl, t);
+    if (!ok && threadIdx.x == 0)
+        for (int f = 0; f < batch; ++f) atomicOr(&status[f], YSMR_DET_STALLED);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2060,22 +2170,18 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
                        g.total, batch * NR_STRIDE + 8, status_dev, batch, height, width);
     const dim3 sg(sparse_blocks), tb(256);
     {
-        constexpr int SPAN = WIN_MT * WIN_CORE;
-        const long long tiles = (long long)batch * ((height + SPAN - 1) / SPAN) * ((width + SPAN - 1) / SPAN);
-        hipLaunchKernelGGL(k_windows, dim3((unsigned)std::min<long long>(tiles, window_blocks)), tb, 0, st, cls_dev, labels, mask_dev, g,
+        constexpr int SPAN = WIN_GROUP * WIN_CORE;
+        const long long items = (long long)batch * ((height + WIN_CORE - 1) / WIN_CORE) * ((width + SPAN - 1) / SPAN);
+        long long wblocks = std::min<long long>((items + 3) / 4, window_blocks);
+        if (wblocks >= 8) wblocks &= ~7ll;   // (a multiple of 8: the kernel deals its items to the XCDs)
+        hipLaunchKernelGGL(k_windows, dim3((unsigned)wblocks), tb, 0, st, cls_dev, labels, mask_dev, g,
                            batch, w.pixels, t);
     }
-    hipLaunchKernelGGL(k_union4, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
-    hipLaunchKernelGGL(k_flag, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
-    hipLaunchKernelGGL(k_union8, sg, tb, 0, st, cls_dev, labels, g, w.pixels);
-    hipLaunchKernelGGL(k_flatten, sg, tb, 0, st, cls_dev, labels, mask_dev, g, w.pixels, t);
+    hipLaunchKernelGGL(k_residue, dim3(RESIDUE_BLOCKS), tb, 0, st, cls_dev, labels, mask_dev, g, batch, w.pixels, t, w.arena_used + 1,
+                       status_dev);
     YSMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rank, dim3(batch, (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) < 32 ? (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) : 32), dim3(RANK_THREADS), 0, st, t, labels, g.HW,
-                       status_dev, w.pixels.hdr);
-    hipLaunchKernelGGL(k_bbox_euler, sg, tb, 0, st, cls_dev, labels, g, w.pixels, t);
-    const unsigned comp_threads = (unsigned)((size_t)batch * max_det);
-    hipLaunchKernelGGL(k_holes, dim3((comp_threads + 255) / 256), dim3(256), 0, st, t, batch, labels, g.HW, w.n_holed, w.holed,
-                       status_dev, w.pixels.hdr);
+                       status_dev, w.pixels.hdr, w.n_holed, w.holed);
     hipLaunchKernelGGL(k_nested, dim3(NEST_BLOCKS), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
                        w.arena_floats, w.arena_used, status_dev);
     YSMR_LAUNCH_CHECK();
