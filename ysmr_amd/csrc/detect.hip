@@ -685,8 +685,8 @@ __device__ __forceinline__ uint32_t chunk_byte(const uint4 &v, int i)
 // settles every island whose bounding box is at most 16 x 16 pixels in registers; the pixels of larger ones
 // -- the RESIDUE -- are listed, one entry per pixel, and go through the union-find passes k_union4 ..
 // k_bbox_euler, one lane per listed pixel.  The list has room for 1/8 of the batch; a denser residue makes
-// the passes fall back to walking every pixel (`count` keeps counting past `cap`, which is how they know;
-// pixels settled by k_windows carry bit3 of their class byte and are skipped).
+// the passes fall back to walking every pixel (`count` keeps counting past `cap`, which is how they know), and
+// then everything k_windows settled is done again by them (k_residue).
 // The workspace remembers, across calls, the components of the previous call (first pixel and bounding box
 // of each): if the next call gets the same buffers and geometry, clearing the label map and the final mask
 // inside those boxes replaces a dense memset (362 MB per 64-frame batch at 1228x922 -- more HBM traffic
@@ -726,8 +726,6 @@ constexpr int SPARSE_BLOCKS = 768;  // resident grid of the list-driven passes (
              li_ < ln_; li_ += (size_t)gridDim.x * 256)                                                          \
             if (const size_t flat = dense_ ? li_ : (size_t)idx_[li_]; true)
 
-constexpr uint32_t CLS_LOCAL = 8u;   // bit3 of a class byte: the pixel's island was settled by k_windows
-
 struct CompTables {
     int32_t *nroots;   // [B * NR_STRIDE]: one counter per 128-byte line (same-line atomics serialise)
     int32_t *roots;    // [B][max_det] unordered
@@ -736,6 +734,7 @@ struct CompTables {
     int32_t *euler4;   // [B][max_det] 4 * Euler number (8-connectivity)
     int32_t *nested;   // [B][max_det] component lies in a hole of another one
     int32_t *max_roots; // largest per-frame component count of the batch (k_rank)
+    int32_t *prev_n;   // [B] component counts of the previous call (k_compact -> k_clear)
     int32_t *bbox_tmp; // [B][max_det][4], [B][max_det]: box and Euler number of the components k_windows
     int32_t *euler_tmp; //   settled, in the order of `roots` (k_rank moves them to their rank)
     int max_det;
@@ -745,10 +744,10 @@ struct CompTables {
 // boxes of the previous call's components if the header vouches for these buffers, everything otherwise.  A
 // resident grid instead of hipMemsetAsync: the runtime's fill kernels use grids far larger than the chip
 // holds, and such a grid starves every other stream (the link) until it has drained.
-// (also: the per-call counters and status words are zeroed here, by the block that finishes last -- the others
-// still read the previous call's counts -- which also marks the header invalid until k_compact, the last kernel
-// of the call, vouches for the buffers again)
-constexpr int CLEAR_BLOCKS = 128;
+// (The status words are zeroed here.  The per-call counters are left at zero by k_compact, the last kernel of a
+// call, which also keeps the component counts for this kernel (prev_n) and vouches for the buffers; k_windows,
+// the next launch, marks the header invalid until then, so a chain that was cut short is followed by a full clear.)
+constexpr int CLEAR_BLOCKS = 512;
 __device__ __forceinline__ void clear_box(uint32_t *__restrict__ lab, uint8_t *__restrict__ mask, int W, int x0, int x1, int y0,
                                           int y1, int first, int step)
 {
@@ -777,31 +776,31 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
     if (h.magic == WS_MAGIC && h.labels == (unsigned long long)labels && h.mask == (unsigned long long)mask &&
         h.total == total && h.batch == batch && h.H == H && h.W == W && h.max_det == t.max_det && !h.dense &&
         h.n_big <= (uint32_t)WS_BIG) {
-        // Work items are (64 consecutive ranks, frame), frame fastest: the populated ranks come first in every
-        // frame, so the live items are spread evenly over the waves.  Lane = component for the box loads (one
-        // coalesced 16-byte load each); then the wave zeroes the boxes one after the other, 4 x 16 cells a step, with
-        // blind stores (test-then-store is a dependent L2 round trip per cell: 92 us per batch that way)
+        // Work items are (16 consecutive ranks, frame), frame fastest: the populated ranks come first in every
+        // frame, so the live items are spread evenly over the waves.  16 lanes per component (one per column of
+        // its box), four components at a time, all box loads of an item first; blind stores (test-then-store is a
+        // dependent L2 round trip per cell: 92 us per batch that way)
         const int lane = threadIdx.x & 63;
-        const long long items = (long long)((t.max_det + 63) / 64) * batch, waves = (long long)(stride / 64);
+        const long long items = (long long)((t.max_det + 15) / 16) * batch, waves = (long long)(stride / 64);
         for (long long it = (long long)(tid / 64); it < items; it += waves) {
             const int kb = (int)(it / batch), f = (int)(it - (long long)kb * batch);
-            const int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
-            if (kb * 64 >= n) break;   // (items are rank-major: every later item of this wave is empty too)
+            const int n = t.prev_n[f];
+            if (kb * 16 >= n) break;   // (items are rank-major: every later item of this wave is empty too)
             uint32_t *lab = reinterpret_cast<uint32_t *>(labels) + (size_t)f * HW;
             uint8_t *msk = mask ? mask + (size_t)f * HW : nullptr;
-            const int k = kb * 64 + lane;
-            int4 box = make_int4(0, -1, 0, -1);
-            if (k < n) box = *reinterpret_cast<const int4 *>(t.bbox + ((size_t)f * t.max_det + k) * 4);
-            const int bw_l = box.y - box.x + 1, bh_l = box.w - box.z + 1;
-            unsigned long long live = __ballot(bw_l > 0 && bh_l > 0 && bw_l * bh_l < WS_BIG_AREA);   // (large ones are in h.big: every block helps below)
-            while (live) {
-                const int src = __builtin_ctzll(live);
-                live &= live - 1;
-                const int x0 = __builtin_amdgcn_readlane(box.x, src), y0 = __builtin_amdgcn_readlane(box.z, src);
-                const int bw = __builtin_amdgcn_readlane(bw_l, src), bh = __builtin_amdgcn_readlane(bh_l, src);
-                for (int r = lane >> 4; r < bh; r += 4)          // 4 rows x 16 columns of the box per step
+            int4 box[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kb * 16 + i * 4 + (lane >> 4);
+                box[i] = k < n ? *reinterpret_cast<const int4 *>(t.bbox + ((size_t)f * t.max_det + k) * 4) : make_int4(0, -1, 0, -1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int bw = box[i].y - box[i].x + 1, bh = box[i].w - box[i].z + 1;
+                if (bw <= 0 || bh <= 0 || bw * bh >= WS_BIG_AREA) continue;   // (large ones are in h.big: every block helps below)
+                for (int r = 0; r < bh; ++r)
                     for (int c = lane & 15; c < bw; c += 16) {
-                        const size_t at = (size_t)(y0 + r) * W + (x0 + c);
+                        const size_t at = (size_t)(box[i].z + r) * W + (box[i].x + c);
                         lab[at] = 0u;
                         if (msk) msk[at] = 0;
                     }
@@ -814,6 +813,12 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
                       t.bbox[s * 4 + 1], t.bbox[s * 4 + 2], t.bbox[s * 4 + 3], (int)tid, (int)stride);
         }
     } else {
+        // (nobody reads the counters on this path, and every block takes it -- the header is not written here)
+        if (blockIdx.x == 0) {
+            for (int i = threadIdx.x; i < n_counters; i += 256) t.nroots[i] = 0;
+            for (int i = threadIdx.x; i < batch; i += 256) t.prev_n[i] = 0;
+            if (threadIdx.x == 0) pl.hdr->count[0] = 0;
+        }
         const uint4 z = make_uint4(0, 0, 0, 0);
         for (int which = 0; which < 2; ++which) {
             uint8_t *p = which ? mask : labels;
@@ -823,26 +828,6 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
             const size_t n16 = bytes / 16;
             for (size_t i = tid; i < n16; i += stride) q[i] = z;
             for (size_t i = n16 * 16 + tid; i < bytes; i += stride) p[i] = 0;
-        }
-    }
-    // every block has read the header and the tables by now; the last one to get here resets them
-    __shared__ uint32_t s_ticket;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_ticket = atomicAdd(&pl.hdr->pad, 1u);
-    }
-    __syncthreads();
-    if (s_ticket == gridDim.x - 1) {
-        for (int i = threadIdx.x; i < n_counters; i += 256) t.nroots[i] = 0;
-        if (threadIdx.x == 0) {
-            WsHeader *hd = pl.hdr;
-            hd->magic = 0;
-            hd->cur = 0;
-            hd->count[0] = 0;
-            hd->dense = 0;
-            hd->n_big = 0;
-            hd->pad = 0;
         }
     }
 }
@@ -958,6 +943,8 @@ struct WindowOut {
 __device__ __forceinline__ void window_component(const WindowOut &o, uint64_t c, const WindowBox &b, int lane, int f,
                                                  const CompTables &t)
 {
+    int idx = 0;   // slot of the component in the frame's tables: requested first, needed last (the atomic's round trip
+    if (lane == 0) idx = atomicAdd(&t.nroots[(size_t)f * NR_STRIDE], 1);   // is the longest wait of an island)
     const int rx = __builtin_ctzll(lane_mask(c, b.y0));                     // first pixel: top row, leftmost column
     const uint32_t root = (uint32_t)(o.wy0 + b.y0) * (uint32_t)o.W + (uint32_t)(o.wx0 + rx);
     const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)o.W + (uint32_t)o.wx0;
@@ -974,7 +961,6 @@ __device__ __forceinline__ void window_component(const WindowOut &o, uint64_t c,
     int q = __popcll(odd & ~pair) - __popcll(odd & pair) - 2 * __popcll(diag);
     const int euler4 = WAVE_REDUCE(dpp_iadd, q);
     if (lane == 0) {
-        const int idx = atomicAdd(&t.nroots[(size_t)f * NR_STRIDE], 1);
         if (idx < t.max_det) {
             const size_t s = (size_t)f * t.max_det + idx;
             t.roots[s] = (int32_t)root;
@@ -1032,20 +1018,18 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
 #ifdef WIN_DBG_NO_FINAL
         if (F != 0x123456789ull) continue;
 #endif
-        // every pixel of the island: settled here
-        for (uint64_t rest = F; rest; rest &= rest - 1) {
-            const int k = __builtin_ctzll(rest);
-            cf[row + (uint32_t)k] = (uint8_t)(((T >> k) & 1ull) | (((M >> k) & 1ull) << 1) | CLS_LOCAL);
-        }
+        // the island is settled here
         const uint64_t thresh = T & F;
         uint64_t R = M & F;
+        bool whole = false;   // R is the whole island (the usual end: one step from the markers)
         while (true) {
             const uint64_t n = R | (grow4(R) & thresh);
             const bool changed = __ballot(n != R) != 0ull;
             R = n;
-            if (!changed) break;
+            whole = __ballot(R != F) == 0ull;
+            if (!changed || whole) break;
         }
-        if (__ballot(R != F) == 0ull) {
+        if (whole) {
             window_component(o, F, b, lane, f, t);
         } else {
             while (true) {
@@ -1068,6 +1052,11 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
                                                  uint8_t *__restrict__ mask, Geo g, int batch, PixelList pl, CompTables t)
 {
     DET_RING(4);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // (k_clear, the previous launch, was the last reader of these)
+        pl.hdr->magic = 0;
+        pl.hdr->dense = 0;
+        pl.hdr->n_big = 0;
+    }
     constexpr int CHUNKS = 64 * WIN_HALVES, ROUNDS = CHUNKS / 64;
     __shared__ __attribute__((aligned(8))) uint16_t s_bits[4][2][CHUNKS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1184,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
 __device__ __forceinline__ void pass_union4(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const PixelList &pl)
 {
     FOR_LISTED_PIXELS(pl, g, flat) {
-        if (flat >= g.total || (cls[flat] & (1u | CLS_LOCAL)) != 1u) continue;
+        if (flat >= g.total || !(cls[flat] & 1u)) continue;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
         uint32_t *L = labels + (size_t)f * g.HW;
@@ -1210,7 +1199,7 @@ __device__ __forceinline__ void pass_flag(uint8_t *cls, uint32_t *labels, const 
         {
             if (flat >= g.total) continue;
             uint32_t b = cls[flat];
-            if (!(b & 2u) || (b & CLS_LOCAL)) continue;
+            if (!(b & 2u)) continue;
             uint32_t f, p; int y, x;
             locate(g, flat, f, p, y, x);
             uint32_t *L = labels + (size_t)f * g.HW;
@@ -1247,7 +1236,7 @@ __device__ __forceinline__ void pass_union8(const uint8_t *__restrict__ cls, uin
     {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
-        if (!(b & 3u) || (b & CLS_LOCAL)) continue;
+        if (!(b & 3u)) continue;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
         uint32_t *L = labels + (size_t)f * g.HW;
@@ -1282,7 +1271,7 @@ __device__ __forceinline__ void pass_flatten(const uint8_t *__restrict__ cls, ui
     FOR_LISTED_PIXELS(pl, g, flat) {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
-        if (!(b & 3u) || (b & CLS_LOCAL)) continue;
+        if (!(b & 3u)) continue;
         uint32_t f = (uint32_t)(flat / g.HW);
         uint32_t p = (uint32_t)(flat - (size_t)f * g.HW);
         uint32_t *L = labels + (size_t)f * g.HW;
@@ -1316,9 +1305,11 @@ __device__ __forceinline__ void pass_flatten(const uint8_t *__restrict__ cls, ui
 // (k_windows / pass_bbox_euler filed them under the slot the root was appended at), gets its root's label back
 // (pass_tag_roots), and is queued for k_nested if it has holes.
 constexpr int RANK_THREADS = 1024;
+constexpr int RANK_BANDS = 2048;      // bands of image rows (LDS histogram)
+constexpr int RANK_BUCKET = 8192;     // roots of a frame the banded ranking holds in LDS
 constexpr int HOLED_CAP = 4096;
 
-__global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *labels, uint32_t HW, int32_t *status,
+__global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *labels, uint32_t HW, int W, int H, int32_t *status,
                                                        WsHeader *hdr, int32_t *n_holed, int2 *holed)
 {
     DET_RING(9);
@@ -1333,20 +1324,62 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *l
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) atomicMax(t.max_roots, n);
     const int32_t *roots = t.roots + (size_t)f * t.max_det;
-    __shared__ int32_t tile[1024];
+    // rank of a root = roots in the bands of image rows below its own + roots of its own band with a larger index:
+    // a histogram over the bands, a suffix sum, the roots bucketed by band in LDS, and each root compared with its
+    // own bucket only (all pairs were 25 M comparisons per 4K frame: 68 us per batch)
+    __shared__ int32_t s_hist[RANK_BANDS], s_start[RANK_BANDS], s_bucket[RANK_BUCKET], s_wave[RANK_THREADS / 64];
+    const bool banded = n <= RANK_BUCKET;
+    const int band_h = (H + RANK_BANDS - 1) / RANK_BANDS;
+    if (banded) {
+        for (int b = threadIdx.x; b < RANK_BANDS; b += RANK_THREADS) s_hist[b] = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += RANK_THREADS) atomicAdd(&s_hist[(roots[j] / W) / band_h], 1);
+        __syncthreads();
+        // s_start[b] = roots in bands > b: thread k owns bands RANK_BANDS-1-2k and RANK_BANDS-2-2k (scan from the bottom)
+        static_assert(RANK_BANDS == 2 * RANK_THREADS, "two bands per thread");
+        const int b0 = RANK_BANDS - 1 - 2 * (int)threadIdx.x, h0 = s_hist[b0], h1 = s_hist[b0 - 1];
+        int incl = h0 + h1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if ((int)(threadIdx.x & 63) >= d) incl += o;
+        }
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int before = incl - (h0 + h1);
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += s_wave[w];
+        s_start[b0] = before;
+        s_start[b0 - 1] = before + h0;
+        s_hist[b0] = 0;          // reused as the fill count of the bucket
+        s_hist[b0 - 1] = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += RANK_THREADS) {
+            const int32_t r = roots[j];
+            const int b = (r / W) / band_h;
+            s_bucket[s_start[b] + atomicAdd(&s_hist[b], 1)] = r;
+        }
+        __syncthreads();
+    }
+    int32_t *tile = s_bucket;   // (the all-pairs path for tables beyond RANK_BUCKET roots stages 1024 roots at a time)
     const int sub = threadIdx.x & 3;
-    // blockIdx.y splits a frame's roots: the comparison count is quadratic in the components of a frame
-    // (5000 at 4K: one block per frame took 715 us per batch)
     for (int i0 = (int)blockIdx.y * (RANK_THREADS / 4); i0 < n; i0 += (int)gridDim.y * (RANK_THREADS / 4)) {
         const int i = i0 + (threadIdx.x >> 2);
         const int32_t mine = i < n ? roots[i] : -1;
         int rank = 0;
-        for (int j0 = 0; j0 < n; j0 += 1024) {
-            __syncthreads();
-            for (int j = threadIdx.x; j < 1024 && j0 + j < n; j += RANK_THREADS) tile[j] = roots[j0 + j];
-            __syncthreads();
-            const int m = min(1024, n - j0);
-            for (int j = sub; j < m; j += 4) rank += tile[j] > mine;
+        if (banded) {
+            if (i < n) {
+                const int b = (mine / W) / band_h, first = s_start[b], cnt = s_hist[b];
+                for (int j = sub; j < cnt; j += 4) rank += s_bucket[first + j] > mine;
+                if (sub == 0) rank += first;
+            }
+        } else {
+            for (int j0 = 0; j0 < n; j0 += 1024) {
+                __syncthreads();
+                for (int j = threadIdx.x; j < 1024 && j0 + j < n; j += RANK_THREADS) tile[j] = roots[j0 + j];
+                __syncthreads();
+                const int m = min(1024, n - j0);
+                for (int j = sub; j < m; j += 4) rank += tile[j] > mine;
+            }
         }
         rank += __shfl_xor(rank, 1);
         rank += __shfl_xor(rank, 2);
@@ -1414,7 +1447,7 @@ __device__ __forceinline__ void pass_bbox_euler(const uint8_t *__restrict__ cls,
         size_t flat = 0;
         if (valid) flat = dense ? li : (size_t)idx[li];
         uint32_t lab_i = 0;
-        if (valid) { const uint32_t b = cls[flat]; valid = (b & 3u) != 0 && !(b & CLS_LOCAL); }
+        if (valid) valid = (cls[flat] & 3u) != 0;
         if (valid) { lab_i = labels[flat]; valid = lab_i != 0; }
         uint32_t f = 0, p = 0; int y = 0, x = 0;
         if (valid) locate(g, flat, f, p, y, x);
@@ -1507,18 +1540,35 @@ __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels,
                                                  CompTables t, uint32_t *barrier, int32_t *status)
 {
     DET_RING(5);
-    if (pl.hdr->count[0] == 0u) return;   // (written by k_windows, the previous launch: every block sees the same)
+    const uint32_t listed = pl.hdr->count[0];   // (written by k_windows, the previous launch: every block sees the same)
+    if (listed == 0u) return;
     bool ok = true;
-    pass_union4(cls, labels, g, pl);
-    ok = ok && grid_barrier(barrier, 1u * gridDim.x);
+    uint32_t phase = 0;
+    if (listed > pl.cap) {
+        // more residue than the list holds: the passes walk every pixel, so everything k_windows settled is done
+        // again here -- its components are dropped, every class pixel becomes its own root again.  (Its final mask
+        // stays: the same pixels get the same 255.)
+        for (size_t flat = (size_t)blockIdx.x * 256 + threadIdx.x; flat < g.total; flat += (size_t)gridDim.x * 256) {
+            const uint32_t b = cls[flat];
+            if (b & 3u) {
+                labels[flat] = (uint32_t)(flat % g.HW) + 1u;
+                if (b & ~3u) cls[flat] = (uint8_t)(b & 3u);
+            }
+        }
+        if (blockIdx.x == 0)
+            for (int f = threadIdx.x; f < batch; f += 256) t.nroots[(size_t)f * NR_STRIDE] = 0;
+        ok = grid_barrier(barrier, ++phase * gridDim.x);
+    }
+    if (ok) pass_union4(cls, labels, g, pl);
+    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
     if (ok) pass_flag(cls, labels, g, pl);
-    ok = ok && grid_barrier(barrier, 2u * gridDim.x);
+    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
     if (ok) pass_union8(cls, labels, g, pl);
-    ok = ok && grid_barrier(barrier, 3u * gridDim.x);
+    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
     if (ok) pass_flatten(cls, labels, mask, g, pl, t);
-    ok = ok && grid_barrier(barrier, 4u * gridDim.x);
+    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
     if (ok) pass_tag_roots(labels, g, t, batch);
-    ok = ok && grid_barrier(barrier, 5u * gridDim.x);
+    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
     if (ok) pass_bbox_euler(cls, labels, g, pl, t);
     if (!ok && threadIdx.x == 0)
         for (int f = 0; f < batch; ++f) atomicOr(&status[f], YSMR_DET_STALLED);
@@ -1924,7 +1974,8 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
 }
 
 // Drop nested components, write final detection list / count / anchors.
-__global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__restrict__ det_tmp, float *det,
+constexpr int COMPACT_THREADS = 1024;
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact(CompTables t, const float *__restrict__ det_tmp, float *det,
                                                  int32_t *det_count, int32_t *anchors, PixelList pl, const uint8_t *labels,
                                                  const uint8_t *mask, size_t total, int batch, int H, int W, bool angle_pre451)
 {
@@ -1935,32 +1986,48 @@ __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__re
         h->mask = (unsigned long long)mask;
         h->total = total;
         h->batch = batch; h->H = H; h->W = W; h->max_det = t.max_det;
+        h->count[0] = 0;
         __threadfence();
         h->magic = WS_MAGIC;
     }
     const int f = blockIdx.x;
-    int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
-    __shared__ int s_scan[256];
-    __shared__ int s_base;
-    if (threadIdx.x == 0) s_base = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        int i = i0 + threadIdx.x;
-        size_t o = (size_t)f * t.max_det + i;
-        int keep = (i < n && !t.nested[o]) ? 1 : 0;
-        s_scan[threadIdx.x] = keep;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
-            __syncthreads();
-            s_scan[threadIdx.x] += v;
-            __syncthreads();
-        }
-        int pos = s_base + s_scan[threadIdx.x] - keep;
+    const int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
+    __syncthreads();   // (every thread has its n)
+    if (threadIdx.x == 0) {
+        t.prev_n[f] = n;
+        t.nroots[(size_t)f * NR_STRIDE] = 0;
+        if (f == 0)
+            for (int i = 0; i < 8; ++i) t.nroots[(size_t)batch * NR_STRIDE + i] = 0;   // n_holed, arena_used, barrier, max_roots
+    }
+    // stable compaction: ranks of the kept components from a ballot per wave and the wave totals of a round in LDS
+    // (two buffers used alternately: one barrier per round of COMPACT_THREADS components)
+    __shared__ int s_cnt[2][COMPACT_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int i0 = 0, round = 0; i0 < n; i0 += COMPACT_THREADS, ++round) {
+        const int i = i0 + threadIdx.x;
+        const size_t o = (size_t)f * t.max_det + i;
+        const bool keep = i < n && !t.nested[o];
+        float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        int anchor = 0;
         if (keep) {
-            size_t q = (size_t)f * t.max_det + pos;
-            float r[5];
+#pragma unroll
             for (int j = 0; j < 5; ++j) r[j] = det_tmp[o * 5 + j];
+            anchor = t.order[o];
+        }
+        const unsigned long long kept = __ballot(keep);
+        int *cnt = s_cnt[round & 1];
+        if (lane == 0) cnt[wave] = __popcll(kept);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < COMPACT_THREADS / 64; ++w) {
+            const int c = cnt[w];
+            before += w < wave ? c : 0;
+            total += c;
+        }
+        if (keep) {
+            const size_t q = (size_t)f * t.max_det + base + before + __popcll(kept & ((1ull << lane) - 1ull));
             // k_geometry's hull order + rotating calipers give the angle in [0, 90], cv::minAreaRect's range from
             // OpenCV 4.5.1 on.  Earlier releases report the same rectangle with its angle in [-90, 0) and the
             // sides named the other way round (YSMR_CV_ANGLE_PRE451; only rectangles from the rotating
@@ -1969,14 +2036,13 @@ __global__ __launch_bounds__(256) void k_compact(CompTables t, const float *__re
                 if (r[4] == 90.f) r[4] = -90.f;
                 else { const float w = r[2]; r[2] = r[3]; r[3] = w; r[4] -= 90.f; }
             }
+#pragma unroll
             for (int j = 0; j < 5; ++j) det[q * 5 + j] = r[j];
-            if (anchors) anchors[q] = t.order[o];
+            if (anchors) anchors[q] = anchor;
         }
-        __syncthreads();
-        if (threadIdx.x == 255) s_base += s_scan[255];
-        __syncthreads();
+        base += total;
     }
-    if (threadIdx.x == 0) det_count[f] = s_base;
+    if (threadIdx.x == 0) det_count[f] = base;
 }
 
 Gauss11 make_gauss11()
@@ -1996,7 +2062,7 @@ Gauss11 make_gauss11()
 }
 
 struct Workspace {
-    int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed, *max_roots, *bbox_tmp, *euler_tmp;
+    int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed, *max_roots, *prev_n, *bbox_tmp, *euler_tmp;
     int2 *holed;
     PixelList pixels;
     uint32_t *arena_used;
@@ -2017,6 +2083,7 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     w.n_holed = w.nroots + (size_t)batch * NR_STRIDE;
     w.arena_used = (uint32_t *)(w.n_holed + 1);
     w.max_roots = w.n_holed + 3;
+    w.prev_n = (int32_t *)take(sizeof(int32_t) * (size_t)batch);
     w.pixels.cap = (uint32_t)(((size_t)batch * H * W + 7) / 8);
     w.pixels.idx[0] = (uint32_t *)take(sizeof(uint32_t) * w.pixels.cap);
     w.pixels.idx[1] = nullptr;
@@ -2165,7 +2232,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     const unsigned sparse_blocks = kn.sparse_blocks > 0 ? (unsigned)kn.sparse_blocks : (unsigned)SPARSE_BLOCKS;
     const unsigned clear_blocks = kn.clear_blocks > 0 ? (unsigned)kn.clear_blocks : (unsigned)CLEAR_BLOCKS;
     const unsigned geo_blocks = kn.geo_blocks > 0 ? (unsigned)kn.geo_blocks : (unsigned)GEO_BLOCKS;
-    CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, w.max_roots, w.bbox_tmp, w.euler_tmp, max_det};
+    CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, w.max_roots, w.prev_n, w.bbox_tmp, w.euler_tmp, max_det};
     hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, st, w.pixels, t, reinterpret_cast<uint8_t *>(labels), mask_dev,
                        g.total, batch * NR_STRIDE + 8, status_dev, batch, height, width);
     const dim3 sg(sparse_blocks), tb(256);
@@ -2181,13 +2248,13 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
                        status_dev);
     YSMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rank, dim3(batch, (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) < 32 ? (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) : 32), dim3(RANK_THREADS), 0, st, t, labels, g.HW,
-                       status_dev, w.pixels.hdr, w.n_holed, w.holed);
+                       width, height, status_dev, w.pixels.hdr, w.n_holed, w.holed);
     hipLaunchKernelGGL(k_nested, dim3(NEST_BLOCKS), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
                        w.arena_floats, w.arena_used, status_dev);
     YSMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_geometry, dim3(geo_blocks), dim3(GEO_THREADS), 0, st,
                        labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
-    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev, w.pixels,
+    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(COMPACT_THREADS), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev, w.pixels,
                        reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total, batch, height, width,
                        (cv_flavour & YSMR_CV_ANGLE_PRE451) != 0);
     YSMR_LAUNCH_CHECK();
