@@ -918,16 +918,36 @@ __device__ __forceinline__ int dpp_iadd(int v) { return v + __builtin_amdgcn_upd
      v = fn<0x143, 0xC>(v), __builtin_amdgcn_readlane(v, 63))
 
 struct WindowBox { int x0, x1, y0, y1; };   // window coordinates (column = bit, row = lane); wave-uniform
-__device__ __forceinline__ WindowBox box_of(uint64_t m, int lane)
+
+// ---- the same in 32 bits.  A small island lies within 15 columns of any of its pixels, so once a seed in column sx
+// is chosen the work moves to the 32-column SLICE [sx - 16, sx + 15] of the window (one funnel shift per row mask):
+// half the instructions of the 64-bit forms in every step below.
+__device__ __forceinline__ uint32_t grow8(uint32_t m)
+{
+    const uint32_t h = m | (m << 1) | (m >> 1);
+    return h | wave_shr1(h) | wave_shl1(h);
+}
+__device__ __forceinline__ uint32_t grow4(uint32_t m) { return m | (m << 1) | (m >> 1) | wave_shr1(m) | wave_shl1(m); }
+__device__ __forceinline__ uint32_t flood8(uint32_t seed, uint32_t within)
+{
+    uint32_t f = seed;
+    while (true) {
+        uint32_t n = grow8(f) & within;
+        n = grow8(n) & within;
+        const bool changed = __ballot(n != f) != 0ull;
+        f = n;
+        if (!changed) return f;
+    }
+}
+__device__ __forceinline__ WindowBox box_of(uint32_t m)
 {
     WindowBox b;
-    const unsigned long long rows = __ballot(m != 0ull);
+    const unsigned long long rows = __ballot(m != 0u);
     b.y0 = rows ? __builtin_ctzll(rows) : 64;
     b.y1 = rows ? 63 - __builtin_clzll(rows) : -1;
-    int lo = m ? __builtin_ctzll(m) : 64, hi = m ? 63 - __builtin_clzll(m) : -1;
+    int lo = m ? __builtin_ctz(m) : 32, hi = m ? 31 - __builtin_clz(m) : -1;
     b.x0 = WAVE_REDUCE(dpp_imin, lo);
     b.x1 = WAVE_REDUCE(dpp_imax, hi);
-    (void)lane;
     return b;
 }
 
@@ -939,32 +959,33 @@ struct WindowOut {
     uint32_t fbase;      // flat index of the frame's first pixel
 };
 
-// One component C of the final mask (rows in lanes, wave-uniform box): label map, mask, tables.
-__device__ __forceinline__ void window_component(const WindowOut &o, uint64_t c, const WindowBox &b, int lane, int f,
+// One component C of the final mask (rows in lanes, columns of the slice that starts at frame column sx0;
+// wave-uniform box in slice coordinates): label map, mask, tables.
+__device__ __forceinline__ void window_component(const WindowOut &o, uint32_t c, const WindowBox &b, int sx0, int lane, int f,
                                                  const CompTables &t)
 {
     int idx = 0;   // slot of the component in the frame's tables: requested first, needed last (the atomic's round trip
     if (lane == 0) idx = atomicAdd(&t.nroots[(size_t)f * NR_STRIDE], 1);   // is the longest wait of an island)
-    const int rx = __builtin_ctzll(lane_mask(c, b.y0));                     // first pixel: top row, leftmost column
-    const uint32_t root = (uint32_t)(o.wy0 + b.y0) * (uint32_t)o.W + (uint32_t)(o.wx0 + rx);
-    const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)o.W + (uint32_t)o.wx0;
-    for (uint64_t rest = c; rest; rest &= rest - 1) {
-        const uint32_t p = row + (uint32_t)__builtin_ctzll(rest);
+    const int rx = __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)c, b.y0));   // first pixel: top row, leftmost column
+    const uint32_t root = (uint32_t)(o.wy0 + b.y0) * (uint32_t)o.W + (uint32_t)(sx0 + rx);
+    const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)o.W + (uint32_t)sx0;
+    for (uint32_t rest = c; rest; rest &= rest - 1) {
+        const uint32_t p = row + (uint32_t)__builtin_ctz(rest);
         o.labels[p] = root + 1u;
         if (o.mask) o.mask[p] = 255;
     }
-    // bit quads: window (rows r, r+1; columns k, k+1) is counted at bit k of lane r.  C touches neither the
-    // ring nor, therefore, row 0 / column 0, so every window that meets C has its top-left cell inside
-    const uint64_t qa = c, qb = c >> 1, qc = row_below(c), qd = qc >> 1;
-    const uint64_t odd = qa ^ qb ^ qc ^ qd, pair = (qa & qb) | (qc & qd);
-    const uint64_t diag = (qa & qd & ~(qb | qc)) | (qb & qc & ~(qa | qd));
-    int q = __popcll(odd & ~pair) - __popcll(odd & pair) - 2 * __popcll(diag);
+    // bit quads: window (rows r, r+1; columns k, k+1) is counted at bit k of lane r.  C touches neither row 0 of
+    // the window nor column 0 / 31 of the slice, so every 2 x 2 window that meets C has its top-left cell inside
+    const uint32_t qa = c, qb = c >> 1, qc = wave_shl1(c), qd = qc >> 1;
+    const uint32_t odd = qa ^ qb ^ qc ^ qd, pair = (qa & qb) | (qc & qd);
+    const uint32_t diag = (qa & qd & ~(qb | qc)) | (qb & qc & ~(qa | qd));
+    int q = __popc(odd & ~pair) - __popc(odd & pair) - 2 * __popc(diag);
     const int euler4 = WAVE_REDUCE(dpp_iadd, q);
     if (lane == 0) {
         if (idx < t.max_det) {
             const size_t s = (size_t)f * t.max_det + idx;
             t.roots[s] = (int32_t)root;
-            t.bbox_tmp[s * 4 + 0] = o.wx0 + b.x0; t.bbox_tmp[s * 4 + 1] = o.wx0 + b.x1;
+            t.bbox_tmp[s * 4 + 0] = sx0 + b.x0; t.bbox_tmp[s * 4 + 1] = sx0 + b.x1;
             t.bbox_tmp[s * 4 + 2] = o.wy0 + b.y0; t.bbox_tmp[s * 4 + 3] = o.wy0 + b.y1;
             t.euler_tmp[s] = euler4;
         }
@@ -976,22 +997,30 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
                                                const PixelList &pl, const CompTables &t)
 {
     const uint64_t core_rows = (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) ? 0x0000FFFFFFFF0000ull : 0ull;
-    const uint64_t ring = (lane == 0 || lane == 63) ? ~0ull : 0x8000000000000001ull;
     const uint64_t A = T | M;
     uint64_t todo = A & core_rows;
-    const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)o.W + (uint32_t)o.wx0;   // (wraps for rows above the frame: never used there)
     while (true) {
         const unsigned long long rows = __ballot(todo != 0ull);
         if (!rows) break;
         const int sy = __builtin_ctzll(rows);
         const int sx = __builtin_ctzll(lane_mask(todo, sy));
-        const uint64_t F = flood8(lane == sy ? (1ull << sx) : 0ull, A);
-        todo &= ~F;
-        const WindowBox b = box_of(F, lane);
-        const bool large = __ballot((F & ring) != 0ull) != 0ull || b.x1 - b.x0 >= WIN_MARGIN || b.y1 - b.y0 >= WIN_MARGIN;
+        // the slice: window columns sx - 16 .. sx + 15 (sx is a core column, 16 .. 47: the slice lies inside the window)
+        const int sh = sx - WIN_MARGIN;
+        const uint32_t a32 = __builtin_amdgcn_alignbit((uint32_t)(A >> 32), (uint32_t)A, sh);
+        const uint32_t F = flood8(lane == sy ? (1u << WIN_MARGIN) : 0u, a32);
+        // LARGE (seen alike from every window): the island reaches the first or the last row of the window, column
+        // sx - 16, a class pixel in column sx + 16 next to its own in column sx + 15, or its box exceeds 16 x 16
+        const uint32_t beyond = (uint32_t)(A >> 32) >> sh & 1u;                     // class pixel in window column sx + 16
+        const uint32_t spill = (F >> 31) & (beyond | wave_shr1(beyond) | wave_shl1(beyond));
+        const WindowBox b = box_of(F);
+        const bool large = __ballot(((F & 1u) | spill) != 0u || ((lane == 0 || lane == 63) && F != 0u)) != 0ull ||
+                           b.x1 - b.x0 >= WIN_MARGIN || b.y1 - b.y0 >= WIN_MARGIN;
         if (large) {
-            // residue: this core's pixels of F go on the list, each its own root for the union-find passes
-            const uint64_t E = F & core_rows;
+            // residue: this core's pixels of the island (as far as the window shows it) go on the list, each its own
+            // root for the union-find passes
+            const uint64_t F64 = flood8(lane == sy ? (1ull << sx) : 0ull, A);
+            todo &= ~F64;
+            const uint64_t E = F64 & core_rows;
             const uint32_t cnt = (uint32_t)__popcll(E);
             const unsigned long long below = (1ull << lane) - 1ull;
             uint32_t before = 0, total = 0;
@@ -1005,6 +1034,7 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
             if (lane == 0) base = atomicAdd(&pl.hdr->count[0], total);
             base = __builtin_amdgcn_readfirstlane(base);
             uint32_t slot = base + before;
+            const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)o.W + (uint32_t)o.wx0;   // (wraps above the frame: never used there)
             for (uint64_t rest = E; rest; rest &= rest - 1, ++slot) {
                 const int k = __builtin_ctzll(rest);
                 const uint32_t p = row + (uint32_t)k;
@@ -1014,32 +1044,31 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
             }
             continue;
         }
-        if (sy != b.y0 || sx != __builtin_ctzll(lane_mask(F, b.y0))) continue;   // first pixel in another core: not ours
-#ifdef WIN_DBG_NO_FINAL
-        if (F != 0x123456789ull) continue;
-#endif
+        todo &= ~((uint64_t)F << sh);
+        if (sy != b.y0 || __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)F, b.y0)) != WIN_MARGIN) continue;   // first pixel in another core: not ours
         // the island is settled here
-        const uint64_t thresh = T & F;
-        uint64_t R = M & F;
+        const uint32_t thresh = __builtin_amdgcn_alignbit((uint32_t)(T >> 32), (uint32_t)T, sh) & F;
+        uint32_t R = __builtin_amdgcn_alignbit((uint32_t)(M >> 32), (uint32_t)M, sh) & F;
         bool whole = false;   // R is the whole island (the usual end: one step from the markers)
         while (true) {
-            const uint64_t n = R | (grow4(R) & thresh);
+            const uint32_t n = R | (grow4(R) & thresh);
             const bool changed = __ballot(n != R) != 0ull;
             R = n;
             whole = __ballot(R != F) == 0ull;
             if (!changed || whole) break;
         }
+        const int sx0 = o.wx0 + sh;   // frame column of the slice's column 0
         if (whole) {
-            window_component(o, F, b, lane, f, t);
+            window_component(o, F, b, sx0, lane, f, t);
         } else {
             while (true) {
-                const unsigned long long rr = __ballot(R != 0ull);
+                const unsigned long long rr = __ballot(R != 0u);
                 if (!rr) break;
                 const int cy0 = __builtin_ctzll(rr);
-                const int cx0 = __builtin_ctzll(lane_mask(R, cy0));
-                const uint64_t C = flood8(lane == cy0 ? (1ull << cx0) : 0ull, R);
+                const int cx0 = __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)R, cy0));
+                const uint32_t C = flood8(lane == cy0 ? (1u << cx0) : 0u, R);
                 R &= ~C;
-                window_component(o, C, box_of(C, lane), lane, f, t);
+                window_component(o, C, box_of(C), sx0, lane, f, t);
             }
         }
     }

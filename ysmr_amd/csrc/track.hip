@@ -739,6 +739,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
                                                const DetT *__restrict__ next_det, int next_m_host,
                                                const int32_t *next_m_dev, DetGrid next_grid)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) RING((4ull << 40) | (unsigned)frame);   // k_track entry
     const int n_live = *t.n_tracks;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_live) return;
@@ -883,6 +884,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     __shared__ int s_n_used, s_n_new, s_any_dead;
     const int tid = threadIdx.x;
     const int cap = t.capacity;
+    if (tid == 0) RING((9ull << 40) | (unsigned)frame);    // entry (before the first load)
     const int n = *t.n_tracks;
     const int m = det_count(m_host, m_dev, t.max_det, t.err);
     LRING(0);
