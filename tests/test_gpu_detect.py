@@ -387,10 +387,10 @@ def test_detect_extreme_aspect_ratios(torch_cuda, oracle):
 def test_detection_writes_stay_inside_their_buffers(torch_cuda, oracle):
     """Every output and the workspace carved out of ONE allocation with guard bands between them: no kernel
     of the chain may write outside the buffer it was given.  The geometries are the ones in which an index
-    can run past an end: more foreground than the pixel list holds (count > cap: the passes walk every
-    pixel), a batch whose size is neither a multiple of 16 (last class-map chunk) nor of 4 (dword-wide mask
-    clears at the tail), frames that are not a multiple of 16 pixels (chunks straddling two frames), a
-    second call on the same buffers (list-driven clearing), and max_det smaller than the component count.
+    can run past an end: more foreground than the residue list holds (count > cap: the passes walk every
+    pixel and redo what k_windows settled), a batch whose size is neither a multiple of 16 nor of 4, frames
+    smaller than one 64 x 64 window and rows that end inside a 16-byte chunk, repeated calls on the same buffers
+    (clearing by the previous call's component boxes), and max_det smaller than the component count.
     (Round 1 recorded one unexplained GPU memory fault in an uncommitted intermediate state of these passes,
     gpurun_out/prof_v17.log; this is the test that guards the candidates: DESIGN.md section 9.)"""
     import ctypes

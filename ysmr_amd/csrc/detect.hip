@@ -719,11 +719,12 @@ constexpr int SPARSE_BLOCKS = 768;  // resident grid of the list-driven passes (
 
 // The passes are bound by chains of dependent L2 round trips (union-find), so they want many
 // short threads: one lane per pixel, grid-stride.
-#define FOR_LISTED_PIXELS(pl, g, flat)                                                                           \
+// (nb: the number of blocks that take part, see k_residue)
+#define FOR_LISTED_PIXELS(pl, g, nb, flat)                                                                       \
     if (const uint32_t *idx_ = (pl).idx[0]; true)                                                                \
         for (size_t cnt_ = (pl).hdr->count[0], dense_ = cnt_ > (pl).cap, ln_ = dense_ ? (g).total : cnt_,        \
                     li_ = (size_t)blockIdx.x * 256 + threadIdx.x;                                                \
-             li_ < ln_; li_ += (size_t)gridDim.x * 256)                                                          \
+             li_ < ln_; li_ += (size_t)(nb) * 256)                                                               \
             if (const size_t flat = dense_ ? li_ : (size_t)idx_[li_]; true)
 
 struct CompTables {
@@ -1109,6 +1110,8 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
             count = max(0ll, min(share, items - offset));
         }
     }
+    // (static dealing: handing further items out by a ticket counter per group of blocks, requested an item ahead,
+    // was slower -- 61 against 55 us -- and 230 us with the eight counters on one cache line)
     for (long long j = first; j < count; j += step) {
         const long long it = offset + j;
         const int f = (int)(it / per_frame) * f_mul + f_add, rem = (int)(it % per_frame);
@@ -1199,9 +1202,10 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
 }
 
 // Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
-__device__ __forceinline__ void pass_union4(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const PixelList &pl)
+__device__ __forceinline__ void pass_union4(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const PixelList &pl,
+                                            unsigned nb)
 {
-    FOR_LISTED_PIXELS(pl, g, flat) {
+    FOR_LISTED_PIXELS(pl, g, nb, flat) {
         if (flat >= g.total || !(cls[flat] & 1u)) continue;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
@@ -1222,9 +1226,9 @@ __device__ __forceinline__ void set_flag(uint8_t *cls, size_t flat)
 
 // Pass C: flag (bit2 on the root's class byte) every thresh-component that holds a marker pixel
 // or touches (4-neighbourhood) a marker pixel lying outside the mask.
-__device__ __forceinline__ void pass_flag(uint8_t *cls, uint32_t *labels, const Geo &g, const PixelList &pl)
+__device__ __forceinline__ void pass_flag(uint8_t *cls, uint32_t *labels, const Geo &g, const PixelList &pl, unsigned nb)
 {
-    FOR_LISTED_PIXELS(pl, g, flat) {
+    FOR_LISTED_PIXELS(pl, g, nb, flat) {
         {
             if (flat >= g.total) continue;
             uint32_t b = cls[flat];
@@ -1259,9 +1263,10 @@ __device__ __forceinline__ bool in_result(const uint8_t *cls_frame, const uint32
 }
 
 // Pass D: 8-connected components of R (what cv2.findContours traces).
-__device__ __forceinline__ void pass_union8(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const PixelList &pl)
+__device__ __forceinline__ void pass_union8(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const PixelList &pl,
+                                            unsigned nb)
 {
-    FOR_LISTED_PIXELS(pl, g, flat) {
+    FOR_LISTED_PIXELS(pl, g, nb, flat) {
     {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
@@ -1295,9 +1300,9 @@ __device__ __forceinline__ void pass_union8(const uint8_t *__restrict__ cls, uin
 
 // Pass E: final labels (root + 1), final mask (cleared by k_clear beforehand), roots per frame.
 __device__ __forceinline__ void pass_flatten(const uint8_t *__restrict__ cls, uint32_t *labels, uint8_t *__restrict__ mask,
-                                             const Geo &g, const PixelList &pl, const CompTables &t)
+                                             const Geo &g, const PixelList &pl, const CompTables &t, unsigned nb)
 {
-    FOR_LISTED_PIXELS(pl, g, flat) {
+    FOR_LISTED_PIXELS(pl, g, nb, flat) {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
         if (!(b & 3u)) continue;
@@ -1458,7 +1463,7 @@ constexpr uint32_t SLOT_TAG = 0x80000000u;
 // Per final-mask pixel: bounding box of its component; bit-quad counts for the Euler number
 // (E8 = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows, each window counted by its first set pixel).
 __device__ __forceinline__ void pass_bbox_euler(const uint8_t *__restrict__ cls, const uint32_t *labels, const Geo &g,
-                                                const PixelList &pl, const CompTables &t)
+                                                const PixelList &pl, const CompTables &t, unsigned nb)
 {
     // The list keeps the pixels of a 16-pixel chunk on adjacent lanes, so a horizontal run of a
     // component sits on consecutive lanes: its lanes pool their y-extent candidates and quad counts
@@ -1469,7 +1474,7 @@ __device__ __forceinline__ void pass_bbox_euler(const uint8_t *__restrict__ cls,
     const bool dense = cnt > pl.cap;
     const size_t ln = dense ? g.total : cnt;
     const int lane = threadIdx.x & 63;
-    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t stride = (size_t)nb * 256;
     for (size_t base = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63); base < ln; base += stride) {
         const size_t li = base + lane;
         bool valid = li < ln;
@@ -1553,12 +1558,12 @@ __device__ __forceinline__ bool grid_barrier(uint32_t *counter, uint32_t target)
     return s_ok != 0;
 }
 
-__device__ __forceinline__ void pass_tag_roots(uint32_t *labels, const Geo &g, const CompTables &t, int batch)
+__device__ __forceinline__ void pass_tag_roots(uint32_t *labels, const Geo &g, const CompTables &t, int batch, unsigned nb)
 {
     // (roots appended by k_windows get the tag too -- none of their pixels is visited by pass_bbox_euler -- and
     // k_rank writes root + 1 back over every one)
     const size_t slots = (size_t)batch * t.max_det;
-    for (size_t s = (size_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (size_t)gridDim.x * 256) {
+    for (size_t s = (size_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (size_t)nb * 256) {
         const int f = (int)(s / t.max_det), k = (int)(s - (size_t)f * t.max_det);
         if (k < min(t.nroots[(size_t)f * NR_STRIDE], t.max_det))
             labels[(size_t)f * g.HW + (uint32_t)t.roots[s]] = SLOT_TAG | (uint32_t)k;
@@ -1571,13 +1576,18 @@ __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels,
     DET_RING(5);
     const uint32_t listed = pl.hdr->count[0];   // (written by k_windows, the previous launch: every block sees the same)
     if (listed == 0u) return;
+    // (a barrier among fewer blocks is cheaper -- 128 blocks: 2.7 us, 16: 1.2 us -- but letting only one block per 512
+    // listed pixels take part made the launch slower, 21 against 16 us: the passes are chains of round trips and
+    // want the threads)
+    const bool dense = listed > pl.cap;
+    const unsigned nb = gridDim.x;
     bool ok = true;
     uint32_t phase = 0;
-    if (listed > pl.cap) {
+    if (dense) {
         // more residue than the list holds: the passes walk every pixel, so everything k_windows settled is done
         // again here -- its components are dropped, every class pixel becomes its own root again.  (Its final mask
         // stays: the same pixels get the same 255.)
-        for (size_t flat = (size_t)blockIdx.x * 256 + threadIdx.x; flat < g.total; flat += (size_t)gridDim.x * 256) {
+        for (size_t flat = (size_t)blockIdx.x * 256 + threadIdx.x; flat < g.total; flat += (size_t)nb * 256) {
             const uint32_t b = cls[flat];
             if (b & 3u) {
                 labels[flat] = (uint32_t)(flat % g.HW) + 1u;
@@ -1586,19 +1596,19 @@ __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels,
         }
         if (blockIdx.x == 0)
             for (int f = threadIdx.x; f < batch; f += 256) t.nroots[(size_t)f * NR_STRIDE] = 0;
-        ok = grid_barrier(barrier, ++phase * gridDim.x);
+        ok = grid_barrier(barrier, ++phase * nb);
     }
-    if (ok) pass_union4(cls, labels, g, pl);
-    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
-    if (ok) pass_flag(cls, labels, g, pl);
-    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
-    if (ok) pass_union8(cls, labels, g, pl);
-    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
-    if (ok) pass_flatten(cls, labels, mask, g, pl, t);
-    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
-    if (ok) pass_tag_roots(labels, g, t, batch);
-    ok = ok && grid_barrier(barrier, ++phase * gridDim.x);
-    if (ok) pass_bbox_euler(cls, labels, g, pl, t);
+    if (ok) pass_union4(cls, labels, g, pl, nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb);
+    if (ok) pass_flag(cls, labels, g, pl, nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb);
+    if (ok) pass_union8(cls, labels, g, pl, nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb);
+    if (ok) pass_flatten(cls, labels, mask, g, pl, t, nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb);
+    if (ok) pass_tag_roots(labels, g, t, batch, nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb);
+    if (ok) pass_bbox_euler(cls, labels, g, pl, t, nb);
     if (!ok && threadIdx.x == 0)
         for (int f = 0; f < batch; ++f) atomicOr(&status[f], YSMR_DET_STALLED);
 }
@@ -1860,7 +1870,10 @@ extern "C" int ysmr_debug_read_geo_stamps(unsigned long long *out) { return (int
 // in flight: 8 lanes instead of 16 per component hold twice as many per resident wave (32 k at 4 blocks per
 // CU: the benchmark batch in one round instead of two).  Components wider than GEO_COLS columns take the
 // serial path with arena storage.
-constexpr int GEO_GROUP = 8;
+#ifndef GEO_GROUP_N
+#define GEO_GROUP_N 8
+#endif
+constexpr int GEO_GROUP = GEO_GROUP_N;
 constexpr int GEO_COLS = 16;
 constexpr int GEO_COMPS = GEO_THREADS / GEO_GROUP;          // components per block
 constexpr int GEO_LDS_STRIDE = LDS_POINTS * 5 + 2;          // 177 floats: the 8 active lanes of a wave start on 8 different banks
@@ -1922,17 +1935,20 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
     const int W = g.W;
     const bool narrow = live && bwid <= GEO_COLS;
     GEOSTAMP(1);
-    if (narrow && sub < bwid) {
-        if (sub + GEO_GROUP < bwid) {
-            int top[2], bot[2];
-            column_extent2(L, W, minx + sub, minx + sub + GEO_GROUP, miny, maxy, want, top, bot);
-            s_top[grp][sub] = top[0]; s_bot[grp][sub] = bot[0];
-            s_top[grp][sub + GEO_GROUP] = top[1]; s_bot[grp][sub + GEO_GROUP] = bot[1];
-        } else {
-            int top, bot;
-            column_extent(L, W, minx + sub, miny, maxy, want, top, bot);
-            s_top[grp][sub] = top;
-            s_bot[grp][sub] = bot;
+    if (narrow) {
+        // lane `sub` takes columns sub, sub + GEO_GROUP, ... of the box, two at a time
+        for (int c = sub; c < bwid; c += 2 * GEO_GROUP) {
+            if (c + GEO_GROUP < bwid) {
+                int top[2], bot[2];
+                column_extent2(L, W, minx + c, minx + c + GEO_GROUP, miny, maxy, want, top, bot);
+                s_top[grp][c] = top[0]; s_bot[grp][c] = bot[0];
+                s_top[grp][c + GEO_GROUP] = top[1]; s_bot[grp][c + GEO_GROUP] = bot[1];
+            } else {
+                int top, bot;
+                column_extent(L, W, minx + c, miny, maxy, want, top, bot);
+                s_top[grp][c] = top;
+                s_bot[grp][c] = bot;
+            }
         }
     }
     __syncthreads();
