@@ -8,6 +8,7 @@
  * (ysmr/track_eval.py:50-77, ysmr/main.py:92-95); ysmr_last_error() gives the message.
  *
  * Reference interfaces replaced (files under /root/reference):
+ *   ysmr_unpack_dib_batch cv2.VideoCapture.read (uncompressed AVI frames)   ysmr/track_eval.py:159
  *   ysmr_threshold_batch  cv2.cvtColor + cv2.GaussianBlur + 2 x cv2.adaptiveThreshold
  *                         ysmr/track_eval.py:180-208
  *   ysmr_mean_threshold_batch  cv2.cvtColor + cv2.GaussianBlur + cv2.meanStdDev + threshold_list
@@ -41,7 +42,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   6
+#define YSMR_ABI_VERSION   7
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -75,6 +76,18 @@ typedef struct ysmr_tracker ysmr_tracker; /* opaque; bound to one device + used 
 
 int         ysmr_abi_version(void);
 const char *ysmr_last_error(void);        /* message of the calling thread's last failing call */
+
+/* ---- frame ingest: f1 ------------------------------------------------------------------- */
+
+/* What cv2.VideoCapture.read() (ysmr/track_eval.py:159) does to a frame of an UNCOMPRESSED AVI once it has its bytes:
+ * DIB rows are stored bottom-up (bottom_up = 1) with a stride padded to 4 bytes; 8-bit frames with a palette that
+ * is not the gray ramp are expanded to BGR.  raw_dev: u8 [n_frames][raw_frame_bytes], the 'movi' chunk bodies as
+ * they are in the file; bytes_per_pixel 1 or 3; palette_dev: NULL, or u8 [256][3] (B, G, R) for 1-byte pixels.
+ * frames_dev: u8 [n_frames][height][width][channels], channels = 3 with a palette, else bytes_per_pixel -- the
+ * layout ysmr_threshold_batch / ysmr_detect_batch read; 4-byte aligned. */
+int ysmr_unpack_dib_batch(void *stream, const uint8_t *raw_dev, int n_frames, size_t raw_frame_bytes, int height,
+                          int width, int bytes_per_pixel, int row_stride, int bottom_up,
+                          const uint8_t *palette_dev, uint8_t *frames_dev);
 
 /* ---- detection: a1-a6 ------------------------------------------------------------------- */
 

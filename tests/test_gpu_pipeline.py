@@ -321,6 +321,44 @@ def test_device_frame_feed_order_and_reuse(tmp_path):
         video.close()
 
 
+def test_uncompressed_avi_is_unpacked_on_the_device(tmp_path):
+    """f1: DeviceFrameFeed uploads the stored DIB frames of an uncompressed AVI as they are (bottom-up or top-down,
+    rows padded to 4 bytes, 8-bit gray / palette indices / 24-bit BGR, dropped frames, an OpenDML continuation) and
+    ysmr_unpack_dib_batch turns them into frames on the device: the same bytes as the host reader delivers."""
+    import ctypes
+    import torch
+    from avi_tools import write_avi
+    from ysmr_amd import _lib
+    from ysmr_amd.frames import DeviceFrameFeed, open_video
+    rng = np.random.default_rng(21)
+    palette = rng.integers(0, 256, (256, 3), dtype=np.uint8)
+    cases = [dict(shape=(19, 33, 50), bits=8), dict(shape=(11, 20, 37), bits=8, top_down=True, dropped=(3, 4)),
+             dict(shape=(13, 18, 21, 3), bits=24, split=6), dict(shape=(9, 25, 31), bits=8, palette=palette),
+             dict(shape=(5, 1, 1), bits=8), dict(shape=(7, 9, 3, 3), bits=24, top_down=True)]
+    for i, c in enumerate(cases):
+        clip = rng.integers(0, 256, c.pop("shape"), dtype=np.uint8)
+        path = tmp_path / f"u{i}.avi"
+        write_avi(path, clip, c.pop("bits"), **c)
+        video = open_video(str(path))
+        assert video.raw_layout is not None
+        want = video.read(0, video.frame_count)                    # the host reader (tests/test_host.py pins it to the file)
+        feed = DeviceFrameFeed(video, 4, "cuda:0", depth=2, readers=2)
+        assert feed._raw is not None
+        got = []
+        for dev, f0, n, slot in feed:
+            got.append(dev.cpu().numpy().copy())
+            done = torch.cuda.Event(); done.record()
+            feed.release(slot, done)
+        feed.close(); video.close()
+        np.testing.assert_array_equal(np.concatenate(got), want)
+    # argument checks of the entry point
+    L = _lib.lib()
+    buf = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    for args in [(0, 16, 2, 2, 1, 4, 1), (1, 16, 2, 2, 2, 4, 1), (1, 16, 2, 5, 1, 4, 1), (1, 4, 2, 2, 1, 4, 1)]:
+        n, raw_bytes, h, w, bpp, stride, up = args
+        assert L.ysmr_unpack_dib_batch(None, buf.data_ptr(), n, raw_bytes, h, w, bpp, stride, up, None, buf.data_ptr()) == _lib.YSMR_ERR_ARG
+
+
 def test_ysmr_multiprocess_two_streams_per_gpu(tmp_path):
     """ysmr(multiprocess=True): single-use worker processes, two at a time on the one GPU of the box."""
     from ysmr_amd import ysmr
@@ -408,6 +446,45 @@ def test_bench_config_rows_hold_1e9_outside_the_oracles_ill_conditioned_set(tmp_
     assert lost > 5000                          # the clip does lose tracks (2 % dropout)
     assert n_loose < 0.03 * len(got), report
     assert report["worst_well_conditioned_relative"] <= 1e-9
+
+
+def test_config0_full_size_through_ysmr_with_the_default_settings(tmp_path, oracle):
+    """BASELINE configs[0] as it stands: one 1228x922 video at 30 fps, ~50 bacteria, through ysmr() with the
+    default tracking.ini (only the interactive switches off) -- so with the default 600-frame minimum, the default
+    selection and statistics stages -- and the table compared with the oracle row for row."""
+    import pandas as pd
+    from ysmr_amd import ysmr
+    from ysmr_amd.helper_file import default_settings, get_data
+    from ysmr_amd.synth import SyntheticVideo
+    frames = SyntheticVideo(922, 1228, 50, seed=4, fps=30.0).frames(630)
+    path = tmp_path / "config0.npy"
+    np.save(path, frames)
+    s = default_settings(**{"user input": False, "select files": False, "display video analysis": False, "log to file": False})
+    assert s["minimal frame count"] == 600
+    out = tmp_path / "res"
+    done = ysmr([str(path)], settings=s, result_folder=str(out))
+    assert done is not None and done[0][0] == str(path) and done[0][1] is True
+    table = get_data(str(out / "config0_list.csv"))
+    ref_rows, _ = oracle.track_frames(frames, fps=30.0, shadows=2)
+    n_loose, _ = compare_rows(_rows_from_df(table), ref_rows)
+    assert len(table) == len(ref_rows) > 25000 and n_loose < 0.01 * len(table)
+    # the later stages ran on it: the selection's and the statistics' files are the oracle's
+    selected, info = oracle.select_tracks_oracle(table, s, 30.0, 922, 1228)
+    assert selected is not None and info["good_tracks"] >= 5
+    # (the table was parsed back from its csv here, a second pass through pandas' float parser: same rows, values
+    # equal to the last digit or two -- the byte-for-byte comparison of this file is test_gpu_select.py's)
+    ours = pd.read_csv(out / "config0_selected_data.csv")
+    assert list(ours.columns) == list(selected.columns) and len(ours) == len(selected)
+    for c in ("index", "TRACK_ID", "POSITION_T"):
+        np.testing.assert_array_equal(ours[c].to_numpy(), selected[c].to_numpy())
+    for c in ("POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE"):
+        np.testing.assert_allclose(ours[c].to_numpy(), selected[c].to_numpy(), rtol=1e-12, atol=0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, ref_stats = oracle.evaluate_tracks_oracle(selected, s, 30.0)
+    stats = pd.read_csv(out / "config0_statistics.csv")
+    assert len(stats) == len(ref_stats) == info["good_tracks"]
 
 
 def test_video_denser_than_the_buffers_is_run_again_with_larger_ones(tmp_path, oracle, caplog):

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YSMR_HIP_LIB") or os.path.join(_HERE, "csrc", "libysmr_hip.so")  # env: tuning builds
 
 YSMR_OK = 0
+YSMR_ERR_ARG = 1
 DET_OVERFLOW = 1
 DET_ARENA = 2
 DET_STALLED = 4
@@ -46,7 +47,7 @@ EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
            "ysmr_rows_format_csv", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks",
-           "ysmr_evaluate_workspace_bytes", "ysmr_evaluate_tracks")
+           "ysmr_evaluate_workspace_bytes", "ysmr_evaluate_tracks", "ysmr_unpack_dib_batch")
 
 SELECT_OK, SELECT_TOO_SHORT, SELECT_TOO_SHORT_CLEANED, SELECT_NONE = 0, 1, 2, 3
 
@@ -134,6 +135,7 @@ def lib():
     L.ysmr_select_workspace_bytes.restype = ctypes.c_size_t
     L.ysmr_select_tracks.argtypes = [vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, ctypes.POINTER(SelectParams), vp,
                                      ctypes.c_size_t, vp, vp, ctypes.POINTER(SelectSummary)]
+    L.ysmr_unpack_dib_batch.argtypes = [vp, vp, ci, ctypes.c_size_t, ci, ci, ci, ci, ci, vp, vp]
     L.ysmr_evaluate_workspace_bytes.argtypes = [ctypes.c_longlong]
     L.ysmr_evaluate_workspace_bytes.restype = ctypes.c_size_t
     L.ysmr_evaluate_tracks.argtypes = [vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, ctypes.POINTER(EvaluateParams), vp,

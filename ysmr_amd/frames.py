@@ -8,8 +8,9 @@ it happens to be importable:
                ``<name>_meta.json`` side file (key ``fps``) or the tracking.ini value
 * ``.y4m``  -- YUV4MPEG2; the luma plane is used as the gray frame
 * ``.avi``  -- uncompressed AVI (what many microscope cameras write): 8-bit gray or 24-bit BGR DIB frames,
-               bottom-up or top-down, OpenDML ``AVIX`` extensions included; Motion-JPEG AVI if Pillow can
-               be imported (frames decoded on the reader threads); other compressed streams go to cv2
+               bottom-up or top-down, OpenDML ``AVIX`` extensions included -- ``DeviceFrameFeed`` uploads the stored
+               frames as they are and unpacks them on the device (``ysmr_unpack_dib_batch``); Motion-JPEG AVI if
+               Pillow can be imported (frames decoded on the reader threads); other compressed streams go to cv2
 * anything else -- ``cv2.VideoCapture`` if cv2 can be imported, otherwise an error
 
 Every source exposes ``frame_count``, ``fps``, ``height``, ``width``, ``channels`` and
@@ -286,6 +287,26 @@ class AviVideo:
                 out[i] = rows
         return n
 
+    # ---- frames as they are in the file, for unpacking on the device (DeviceFrameFeed, ysmr_unpack_dib_batch)
+    @property
+    def raw_layout(self):
+        """None, or what ``ysmr_unpack_dib_batch`` needs to turn the chunk bodies of this file into frames:
+        (bytes per stored frame, bytes per pixel, row stride, bottom-up, palette u8 [256, 3] or None)."""
+        if self._jpeg:
+            return None
+        return self._stride * self.height, self._bytes_pp, self._stride, bool(self._bottom_up), self._lut
+
+    def read_raw_into(self, start, count, out, pool=None):
+        """Chunk bodies of frames [start, start + count) into ``out[:n]`` (u8 [n, bytes per stored frame], e.g.
+        pinned memory): file reads only, no per-pixel work on the host."""
+        n = max(0, min(count, self.frame_count - start))
+        need = self._stride * self.height
+        for i in range(n):
+            self._fh.seek(self._frames[start + i][0])
+            if self._fh.readinto(memoryview(out[i]).cast("B")[:need]) != need:
+                raise ValueError(f"{self.path}: frame {start + i} is truncated")
+        return n
+
     def close(self):
         self._fh.close()
 
@@ -339,7 +360,16 @@ class DeviceFrameFeed:
         import torch
         self.video, self.B, self.device, self.depth = video, int(batch), torch.device(device), int(depth)
         shape = (self.B, video.height, video.width) + ((3,) if video.channels == 3 else ())
-        self._pinned = [torch.empty(shape, dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
+        # uncompressed AVI: the stored frames (bottom-up, padded rows, palette indices) go to the device as they are
+        # and are unpacked there; every other source delivers finished frames
+        self._raw = getattr(video, "raw_layout", None)
+        if self._raw is not None:
+            raw_bytes, _, _, _, palette = self._raw
+            self._pinned = [torch.empty((self.B, raw_bytes), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
+            self._raw_dev = [torch.empty((self.B, raw_bytes), dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
+            self._palette = None if palette is None else torch.from_numpy(np.ascontiguousarray(palette)).to(self.device)
+        else:
+            self._pinned = [torch.empty(shape, dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
         self._dev = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._uploaded = [None] * self.depth     # event: H2D copy out of pinned[slot] finished
@@ -369,7 +399,9 @@ class DeviceFrameFeed:
                 if self._uploaded[slot] is not None:
                     self._uploaded[slot].synchronize()          # staging buffer free again
                 host = self._pinned[slot].numpy()
-                if hasattr(self.video, "read_into"):
+                if self._raw is not None:
+                    n = self.video.read_raw_into(f0, self.B, host, self._pool)
+                elif hasattr(self.video, "read_into"):
                     n = self.video.read_into(f0, self.B, host, self._pool)
                 else:
                     got = self.video.read(f0, self.B)
@@ -380,7 +412,17 @@ class DeviceFrameFeed:
                 with torch.cuda.stream(self._copy_stream):
                     if released is not True:
                         self._copy_stream.wait_event(released)  # the kernels that read this device buffer are done
-                    self._dev[slot][:n].copy_(self._pinned[slot][:n], non_blocking=True)
+                    if self._raw is not None:
+                        from . import _lib
+                        raw_bytes, bpp, stride, bottom_up, _ = self._raw
+                        self._raw_dev[slot][:n].copy_(self._pinned[slot][:n], non_blocking=True)
+                        _lib.check(_lib.lib().ysmr_unpack_dib_batch(
+                            self._copy_stream.cuda_stream, self._raw_dev[slot].data_ptr(), n, raw_bytes, self.video.height,
+                            self.video.width, bpp, stride, int(bottom_up),
+                            None if self._palette is None else self._palette.data_ptr(), self._dev[slot].data_ptr()),
+                            "ysmr_unpack_dib_batch")
+                    else:
+                        self._dev[slot][:n].copy_(self._pinned[slot][:n], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self._copy_stream)
                 self._uploaded[slot] = ev
