@@ -298,13 +298,26 @@ class AviVideo:
 
     def read_raw_into(self, start, count, out, pool=None):
         """Chunk bodies of frames [start, start + count) into ``out[:n]`` (u8 [n, bytes per stored frame], e.g.
-        pinned memory): file reads only, no per-pixel work on the host."""
+        pinned memory): file reads only, no per-pixel work on the host; positional reads (``os.preadv``), spread
+        over the threads of ``pool`` if one is given."""
         n = max(0, min(count, self.frame_count - start))
         need = self._stride * self.height
-        for i in range(n):
-            self._fh.seek(self._frames[start + i][0])
-            if self._fh.readinto(memoryview(out[i]).cast("B")[:need]) != need:
-                raise ValueError(f"{self.path}: frame {start + i} is truncated")
+        fd = self._fh.fileno()
+
+        def one(i):
+            got, view = 0, memoryview(out[i]).cast("B")[:need]
+            while got < need:                                   # (a read may return short of a large request)
+                k = os.preadv(fd, [view[got:]], self._frames[start + i][0] + got)
+                if k <= 0:
+                    raise ValueError(f"{self.path}: frame {start + i} is truncated")
+                got += k
+
+        if pool is None or n < 2:
+            for i in range(n):
+                one(i)
+        else:
+            for job in [pool.submit(one, i) for i in range(n)]:
+                job.result()
         return n
 
     def close(self):
