@@ -861,8 +861,12 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
 constexpr int WIN_CORE = 32, WIN_MARGIN = 16;
 constexpr int WIN_GROUP = 4;                                     // cores per work item, side by side
 constexpr int WIN_HALVES = 2 * (WIN_GROUP + 1);                  // 16-pixel half-words per staged row (5 dwords, odd: lanes = rows hit 32 banks)
+// Resident grid: 4 blocks per CU.  The kernel's own time hardly depends on it (1536 .. 2560 blocks: 62 .. 66 us), but
+// every block holds 10 KB of LDS, and with 8 per CU only one of k_frame's 59 KB blocks fits next to them
+// (scripts/sweep_e2e_blocks.sh: end to end 83.7 k frames/s with 2048 blocks here and 1536 in k_geometry, 85.7 k
+// with 1024 and 512).
 #ifndef WINDOW_BLOCKS_N
-#define WINDOW_BLOCKS_N 2048
+#define WINDOW_BLOCKS_N 1024
 #endif
 constexpr int WINDOW_BLOCKS = WINDOW_BLOCKS_N;
 
@@ -2001,8 +2005,10 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
 
 // Resident grid.  Work items are (block of GEO_COMPS ranks, frame), frame fastest: the populated
 // ranks come first in every frame, so the live items are spread evenly over the blocks and the
-// loop stops at the largest component count of the batch (t.max_roots, from k_rank).
-constexpr int GEO_BLOCKS = 1536;
+// loop stops at the largest component count of the batch (t.max_roots, from k_rank).  2 blocks per CU: a block
+// holds 27 KB of LDS, and six of them per CU left no room for a k_frame block (see WINDOW_BLOCKS); the benchmark
+// batch takes two rounds this way (detection alone 229 k instead of 243 k frames/s, end to end +2 %).
+constexpr int GEO_BLOCKS = 512;
 __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__restrict__ labels, Geo g, CompTables t,
                                                           int batch, float *det_tmp, float *arena,
                                                           uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
