@@ -30,3 +30,9 @@ out.update({"threshold_" + k: v for k, v in mean(f"{O}/pmc_thr_SQ", "k_threshold
 json.dump(out, open(f"{O}/pmc_summary.json", "w"), indent=1)
 print(json.dumps(out))
 PY
+# the other single-GPU configurations of BASELINE.json as bench lines, and the k_windows counters
+for c in 0 1 4; do python $R/bench.py --config $c --cpu-sample 20 2>> $O/bench.err >> $O/bench_configs.jsonl; done
+cut -c1-150 $O/bench_configs.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_det -- python3 $R/bench.py --cpu-sample 0 --config 1 > $O/ktrace_det.log 2>&1
+python3 $R/scripts/kstats.py $O/ktrace 30 > $O/kernel_stats.txt; python3 $R/scripts/kstats.py $O/ktrace_det 20 > $O/kernel_stats_detect_only.txt
+cat $O/kernel_stats.txt | cut -c1-150
