@@ -184,6 +184,68 @@ def test_components_on_arbitrary_class_maps(torch_cuda, oracle):
             _assert_angle_close(res.det[f, :n, 4].cpu().numpy(), rects[:, 4])
 
 
+def test_islands_at_the_limits_of_a_window(torch_cuda, oracle):
+    """k_windows settles islands of up to 16 x 16 pixels in 64 x 64 bit windows around 32 x 32 cores and hands
+    larger ones to the union-find passes: shapes whose extent is 14 .. 18 and 31 .. 33 pixels, at offsets that put
+    them across core and window boundaries and against the frame's edges, with the marker patterns that matter to
+    the hysteresis (marker at one end of a diagonal chain, marker-only pixels next to / diagonal to a thresh
+    component, a ring with a dot in its hole, two components that touch only diagonally)."""
+    import torch
+    from scipy import ndimage
+    from ysmr_amd.detect import Detector
+    H, W = 330, 470
+    shapes = []
+    for L in (1, 2, 14, 15, 16, 17, 18, 31, 32, 33):
+        bar = np.ones((1, L), np.uint8)
+        shapes += [bar * 3, bar.T * 3, np.pad(bar, ((0, 0), (0, 0))) * 1 + np.eye(1, L, dtype=np.uint8) * 2]   # marker at one end
+        diag = np.eye(L, dtype=np.uint8)
+        shapes += [diag * 3, diag[::-1] * 3, diag + np.eye(L, dtype=np.uint8) * np.r_[2, np.zeros(L - 1, np.uint8)]]
+    for L in (15, 16, 17):
+        ell = np.zeros((L, L), np.uint8); ell[:, 0] = 3; ell[-1, :] = 3
+        box = np.full((L, L), 1, np.uint8); box[L // 2, L // 2] = 3
+        ring = np.zeros((L, L), np.uint8); ring[[0, -1], :] = 3; ring[:, [0, -1]] = 3; ring[L // 2, L // 2] = 3   # dot in the hole
+        shapes += [ell, ell[::-1, ::-1].copy(), box, ring]
+    blob = np.array([[0, 1, 1, 0], [1, 3, 3, 1], [0, 1, 1, 0]], np.uint8)
+    shapes += [blob, np.array([[2, 0, 0], [1, 1, 0], [0, 0, 0]], np.uint8),       # marker-only pixel 4-next to thresh
+               np.array([[2, 0, 0], [0, 1, 1], [0, 0, 0]], np.uint8),              # ... only diagonal to it: stays alone
+               np.array([[3, 3, 0, 0], [0, 0, 1, 1]], np.uint8),                   # R and a marker-less part touching diagonally
+               np.array([[3, 1, 0, 0], [0, 0, 3, 1]], np.uint8)]                   # two 4-components, one 8-component of R
+    rng = np.random.default_rng(3)
+    frames = []
+    for shift in range(6):                       # the same catalogue at six alignments to the 32-pixel cores
+        cls = np.zeros((H, W), np.uint8)
+        y, x, row_h = 1 + 5 * shift, 0 if shift % 2 else 2 + 7 * shift, 0
+        for sh in rng.permutation(len(shapes)):
+            a = shapes[sh]
+            if x + a.shape[1] > W:
+                y, x, row_h = y + row_h + 3, (3 * shift) % 11, 0
+            if y + a.shape[0] > H:
+                break
+            cls[y:y + a.shape[0], x:x + a.shape[1]] = a
+            x += a.shape[1] + 3
+            row_h = max(row_h, a.shape[0])
+        frames.append(cls)
+    edge = np.zeros((H, W), np.uint8)              # against the four edges and in the corners
+    edge[0, :16] = 3; edge[:16, W - 1] = 3; edge[H - 1, W - 17:] = 3; edge[H - 16:, 0] = 3; edge[40:57, 0] = 3; edge[0, 100:117] = 3
+    frames.append(edge)
+    cls = np.stack(frames)
+    b = cls.shape[0]
+    det = Detector(b, H, W, max_det=1024)
+    for rep in range(2):                           # (second call: cleared through the first call's boxes)
+        res = det.components(cls=torch.from_numpy(cls).cuda())
+        torch.cuda.synchronize()
+        for f in range(b):
+            ref_mask = ndimage.binary_propagation((cls[f] & 2) != 0, mask=(cls[f] & 1) != 0)
+            np.testing.assert_array_equal(res.mask[f].cpu().numpy() > 0, ref_mask, err_msg=f"frame {f}")
+            labels, rects, anchors, n = oracle.components(ref_mask.astype(np.uint8), max_det=1024)
+            assert int(res.status[f].item()) == 0 and n > (3 if f == b - 1 else 40)
+            np.testing.assert_array_equal(res.labels[f].cpu().numpy(), labels, err_msg=f"frame {f}")
+            assert int(res.det_count[f].item()) == n
+            np.testing.assert_array_equal(res.anchors[f, :n].cpu().numpy(), anchors)
+            np.testing.assert_array_equal(res.det[f, :n, :4].cpu().numpy(), rects[:, :4])
+            _assert_angle_close(res.det[f, :n, 4].cpu().numpy(), rects[:, 4])
+
+
 def test_detector_reuse_clears_what_the_previous_call_wrote(torch_cuda, oracle):
     """The workspace clears labels/mask sparsely from the previous call's pixel list (ysmr_hip.h:
     ysmr_detect_workspace_init).  Reusing one Detector for different clips, a shorter batch, a dense
