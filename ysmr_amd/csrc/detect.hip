@@ -2279,10 +2279,12 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     uint32_t *labels = reinterpret_cast<uint32_t *>(labels_dev);
 
     const Knobs &kn = knobs();
-    const unsigned window_blocks = kn.collect_blocks > 0 ? (unsigned)kn.collect_blocks : (unsigned)WINDOW_BLOCKS;
+    // (the LDS reserve matters to k_frame, the one-launch link, which tables of more than 2456 detections do not use)
+    const bool small_tables = max_det <= 2456;
+    const unsigned window_blocks = kn.collect_blocks > 0 ? (unsigned)kn.collect_blocks : (unsigned)(small_tables ? WINDOW_BLOCKS : 2 * WINDOW_BLOCKS);
     const unsigned sparse_blocks = kn.sparse_blocks > 0 ? (unsigned)kn.sparse_blocks : (unsigned)SPARSE_BLOCKS;
     const unsigned clear_blocks = kn.clear_blocks > 0 ? (unsigned)kn.clear_blocks : (unsigned)CLEAR_BLOCKS;
-    const unsigned geo_blocks = kn.geo_blocks > 0 ? (unsigned)kn.geo_blocks : (unsigned)GEO_BLOCKS;
+    const unsigned geo_blocks = kn.geo_blocks > 0 ? (unsigned)kn.geo_blocks : (unsigned)(small_tables ? GEO_BLOCKS : 3 * GEO_BLOCKS);
     CompTables t{w.nroots, w.roots, w.order, w.bbox, w.euler4, w.nested, w.max_roots, w.prev_n, w.bbox_tmp, w.euler_tmp, max_det};
     hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, st, w.pixels, t, reinterpret_cast<uint8_t *>(labels), mask_dev,
                        g.total, batch * NR_STRIDE + 8, status_dev, batch, height, width);
