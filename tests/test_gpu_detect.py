@@ -94,6 +94,26 @@ def test_detect_synthetic_video(torch_cuda, oracle):
     _compare(oracle, frames, _detect_gpu(torch_cuda, frames, p), p)
 
 
+def test_detect_bench_batch_frame_by_frame(torch_cuda, oracle):
+    """The detection half of BASELINE configs[1] / configs[2] exactly as bench.py launches it -- 64 frames of
+    1228x922 with ~500 blobs in ONE call (frames dealt to the XCDs by the threshold kernel and by k_windows, resident
+    grids striding over their work, a second call clearing through the first call's component boxes) -- compared
+    with the oracle on every frame: class map, mask, label map, anchors, rectangles."""
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    torch = torch_cuda
+    p = threshold_params(True, 5, 2.0)
+    video = SyntheticVideo(922, 1228, 500, seed=0)
+    det = Detector(64, 922, 1228, max_det=2048, params=p)
+    for call in range(2):
+        frames = video.frames(64)
+        res = det.detect(torch.from_numpy(frames).cuda())
+        torch.cuda.synchronize()
+        got = {k: getattr(res, k).cpu().numpy() for k in ("cls", "mask", "labels", "det_count", "det", "anchors", "status")}
+        assert got["det_count"].min() > 400
+        _compare(oracle, frames, got, p, max_det=2048)
+
+
 def test_detect_dense_noise_stresses_union_find(torch_cuda, oracle):
     """Uniform noise gives dense, convoluted masks: long union-find chains, holes, nesting."""
     from ysmr_amd.detect import threshold_params
