@@ -94,11 +94,12 @@ int ysmr_unpack_dib_batch(void *stream, const uint8_t *raw_dev, int n_frames, si
 /* Bytes of scratch ysmr_detect_batch needs for this geometry. */
 size_t ysmr_detect_workspace_bytes(int batch, int height, int width, int max_det);
 
-/* Call once after allocating a workspace (and again if the output buffers used with it were
- * written by anyone else).  The workspace remembers which pixels of labels_dev / mask_dev the
- * previous ysmr_components_batch / ysmr_detect_batch call made non-zero; when the next call gets
- * the same buffers and geometry it clears exactly those instead of the whole maps.  A workspace
- * whose first 256 bytes are zero (this call) makes the next call clear everything. */
+/* Call once after allocating a workspace, again if the output buffers used with it were written by anyone else,
+ * and after a detection call that returned an error.  The workspace keeps the component tables of the previous
+ * ysmr_components_batch / ysmr_detect_batch call (first pixel and bounding box of every component); when the next
+ * call gets the same labels_dev / mask_dev, batch, geometry and max_det it zeroes the label map and the mask
+ * inside those boxes instead of the whole maps.  A workspace whose first 256 bytes are zero (this call) makes the
+ * next call clear everything. */
 int ysmr_detect_workspace_init(void *stream, void *workspace_dev, size_t workspace_bytes);
 
 /* a1-a3 fused.  frames_dev: u8 [batch][height][width][channels], channels 1 (gray) or 3 (BGR).
