@@ -412,6 +412,38 @@ def test_track_bacteria_row_buffer_smaller_than_the_video(tmp_path, monkeypatch)
     assert open(whole[4], "rb").read() == open(pieces[4], "rb").read()
 
 
+def test_rows_can_be_persisted_while_the_video_runs(tmp_path, monkeypatch):
+    """'hip persist rows': full row buffers are appended to <name>_list.csv during the run, as the reference does every
+    'list save length interval' rows (an interrupted run leaves what was tracked so far); the final table and file
+    are those of the default run."""
+    from ysmr_amd import track_eval
+    from ysmr_amd.synth import SyntheticVideo
+    frames = SyntheticVideo(120, 160, 18, seed=12, dropout=0.02).frames(90)
+    np.save(tmp_path / "v.npy", frames)
+    os.makedirs(tmp_path / "whole"); os.makedirs(tmp_path / "kept")
+    kw = dict(batch=16, max_det=64, capacity=64)
+    whole = track_eval.track_bacteria(str(tmp_path / "v.npy"), settings=_settings(), result_folder=str(tmp_path / "whole"), **kw)
+    seen = []
+    original = track_eval._persist_chunk
+
+    def spy(list_name, rows, first):
+        original(list_name, rows, first)
+        text = open(list_name).read().splitlines()
+        seen.append((first, len(rows), len(text)))
+        assert text[0] == "TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE"
+        t = np.array([int(line.split(",")[1]) for line in text[1:]])
+        assert (np.diff(t) >= 0).all()                       # in the order they were tracked: by frame
+
+    monkeypatch.setattr(track_eval, "_persist_chunk", spy)
+    s = _settings(**{"hip persist rows": True, "list save length interval": 100})     # buffer = 2 batches x 64 rows per frame
+    kept = track_eval.track_bacteria(str(tmp_path / "v.npy"), settings=s, result_folder=str(tmp_path / "kept"), **kw)
+    assert whole is not None and kept is not None
+    assert len(seen) >= 2 and seen[0][0] and not seen[1][0]
+    assert all(lines == 1 + sum(n for _, n, _ in seen[:i + 1]) for i, (_, _, lines) in enumerate(seen))
+    assert whole[0].equals(kept[0])
+    assert open(whole[4], "rb").read() == open(kept[4], "rb").read()
+
+
 def test_bench_config_rows_hold_1e9_outside_the_oracles_ill_conditioned_set(tmp_path, oracle):
     """BASELINE configs[2] at full size (1228x922, ~500 blobs, 200 frames) through track_bacteria: every
     row the reference's arithmetic determines is within 1e-9 of the oracle; the rows it does not determine

@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from .detect import Detector, MeanGrayState, mean_gray_params, threshold_params
 from .frames import DeviceFrameFeed, open_video
-from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_file,
+from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes, rows_to_csv_file,
                           rows_to_dataframe, save_list)
 from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
@@ -171,6 +171,9 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
     tracks) size the device buffers; the reference has no such limits, so they may also be given as the
     optional settings keys 'hip frames per batch', 'hip max detections per frame', 'hip max tracks', and a
     video that overflows them is run again with both doubled (checked after the first batch and at the end).
+    Optional settings key 'hip persist rows' (default False): keep at most 'list save length interval' rows on the
+    device and append every full buffer to ``<name>_list.csv`` as the reference does (helper_file.py:1403-1478), so
+    that an interrupted run leaves the rows tracked so far; the file is rewritten in order at the end either way.
     """
     logger = logging.getLogger("ysmr").getChild(__name__)
     settings = get_configs(settings)
@@ -225,7 +228,7 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
     capacity = int(capacity or settings.get("hip max tracks") or DEFAULT_CAPACITY)
     while True:
         outcome = _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_det, capacity, device,
-                               settings, logger)
+                               settings, logger, list_name if settings.get("hip persist rows") else None)
         if outcome[0] == "overflow" and 2 * max(max_det, capacity) <= LIMIT_MAX:
             max_det, capacity = 2 * max_det, 2 * capacity
             logger.warning("More objects than the device buffers hold in file {}: running it again with "
@@ -241,8 +244,15 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
                    list_name, fps_of_file, frame_height, frame_width, t_start, t_frames)
 
 
+def _persist_chunk(list_name, rows, first):
+    """'hip persist rows': the rows of one full device buffer, in the order they were tracked, appended to the list
+    file -- what save_list (helper_file.py:1403-1478) does every 'list save length interval' rows."""
+    with open(list_name, "wb" if first else "ab") as fh:
+        fh.write(rows_to_csv_bytes(rows, header=first, via_pandas=False))
+
+
 def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_det, capacity, device, settings,
-                 logger):
+                 logger, persist_to=None):
     """The frame loop of one attempt.  Returns (verdict, sorted rows or None, frames done, error flag,
     start time, time when the last frame was linked); verdict 'overflow' asks for larger buffers."""
     frame_height, frame_width = video.height, video.width
@@ -258,6 +268,8 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
         # moved to the host in between.  ('list save length interval' bounded the reference's Python
         # list, helper_file.py:171; here it only sets the smallest buffer.)
         row_budget = min(max(frame_count, 1) * capacity, ROW_BUDGET_MAX)
+        if persist_to:      # as upstream: the rows leave for the file every 'list save length interval'
+            row_budget = 0
         row_budget = max(row_budget, 2 * batch * capacity, int(settings["list save length interval"]))
         pipe = TrackingPipeline(frame_height, frame_width, fps_of_file, local, batch=batch, max_det=max_det,
                                 capacity=capacity, device=device, rows_per_flush=row_budget)
@@ -277,6 +289,8 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
                     if res is not None:
                         pipe.check(res)
                     chunks.append(pipe.take_rows())
+                    if persist_to:
+                        _persist_chunk(persist_to, chunks[-1], len(chunks) == 1)
                     rows_upper = 0
                 res = pipe.link(slot, r, ready, p0)
                 rows_upper += cnt * pipe.capacity
@@ -291,6 +305,8 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
                 if res is not None:
                     pipe.check(res)
                 chunks.append(pipe.take_rows())
+                if persist_to:
+                    _persist_chunk(persist_to, chunks[-1], len(chunks) == 1)
             res = pipe.link(slot, r, ready, p0)
             frames_done = p0 + cnt
         if res is not None:
