@@ -266,6 +266,61 @@ def test_islands_at_the_limits_of_a_window(torch_cuda, oracle):
             _assert_angle_close(res.det[f, :n, 4].cpu().numpy(), rects[:, 4])
 
 
+def test_components_call_after_call_on_random_maps(torch_cuda, oracle):
+    """Differential run of the component path: random class maps of mixed character -- sparse small islands (settled by
+    k_windows), blobs of 10..40 pixels across (the residue passes), dense noise (the residue outgrows its list: the
+    passes walk every pixel and redo the batch) -- in arbitrary order through ONE detector per geometry, so that
+    every call also has to clear what the previous one left (component boxes, large boxes, overflowed tables)."""
+    import torch
+    from scipy import ndimage
+    from ysmr_amd.detect import Detector
+    rng = np.random.default_rng(99)
+
+    def sparse(b, h, w):
+        m = np.zeros((b, h, w), np.uint8)
+        for f in range(b):
+            for _ in range(max(1, h * w // 900)):
+                y, x = rng.integers(0, h), rng.integers(0, w)
+                hh, ww = rng.integers(1, 9), rng.integers(1, 9)
+                m[f, y:y + hh, x:x + ww] |= rng.choice(np.array([1, 1, 3], np.uint8), size=m[f, y:y + hh, x:x + ww].shape)
+        return m
+
+    def blobs(b, h, w):
+        m = np.zeros((b, h, w), np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        for f in range(b):
+            for _ in range(max(1, h * w // 6000)):
+                cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(5, 21)
+                ring = rng.random() < 0.3
+                d = np.hypot(yy - cy, xx - cx)
+                m[f][(d < r) & (~ring | (d > r - 2.5))] |= 1
+            m[f][(rng.random((h, w)) < 0.01) & (m[f] > 0)] |= 2
+            m[f][rng.random((h, w)) < 0.0005] |= 2                      # markers outside the mask
+        return m
+
+    def dense(b, h, w):
+        return rng.choice(np.array([0, 1, 2, 3], np.uint8), size=(b, h, w), p=[0.5, 0.3, 0.05, 0.15])
+
+    kinds = [sparse, blobs, dense]
+    for (b, h, w, max_det) in [(3, 97, 131, 512), (1, 64, 64, 64), (4, 150, 37, 256), (2, 33, 260, 24), (5, 70, 92, 1024)]:
+        det = Detector(b, h, w, max_det=max_det)
+        for call in range(6):
+            cls = kinds[rng.integers(0, 3)](b, h, w)
+            res = det.components(cls=torch.from_numpy(cls).cuda())
+            torch.cuda.synchronize()
+            for f in range(b):
+                ref_mask = ndimage.binary_propagation((cls[f] & 2) != 0, mask=(cls[f] & 1) != 0)
+                np.testing.assert_array_equal(res.mask[f].cpu().numpy() > 0, ref_mask, err_msg=f"{b}x{h}x{w} call {call} frame {f}")
+                labels, rects, anchors, n = oracle.components(ref_mask.astype(np.uint8), max_det=max_det)
+                np.testing.assert_array_equal(res.labels[f].cpu().numpy(), labels, err_msg=f"{b}x{h}x{w} call {call} frame {f}")
+                n_all = len(np.unique(labels)) - 1
+                assert (int(res.status[f].item()) & 1) == (1 if n_all > max_det else 0)
+                if n_all <= max_det:
+                    assert int(res.det_count[f].item()) == n
+                    np.testing.assert_array_equal(res.anchors[f, :n].cpu().numpy(), anchors)
+                    np.testing.assert_array_equal(res.det[f, :n, :4].cpu().numpy(), rects[:, :4])
+
+
 def test_detector_reuse_clears_what_the_previous_call_wrote(torch_cuda, oracle):
     """The workspace clears labels/mask sparsely from the previous call's pixel list (ysmr_hip.h:
     ysmr_detect_workspace_init).  Reusing one Detector for different clips, a shorter batch, a dense
