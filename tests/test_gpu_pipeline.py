@@ -321,6 +321,47 @@ def test_device_frame_feed_order_and_reuse(tmp_path):
         video.close()
 
 
+def test_ysmr_worker_processes_started_from_a_gpu_free_parent(tmp_path):
+    """The branch of ysmr(multiprocess=True) a multi-GPU node takes -- one spawned worker process per GPU, started by
+    a parent that has not touched the GPU -- run for real on this one-GPU box: a fresh interpreter is told there are
+    two devices, deals four videos to 'cuda:0' and 'cuda:1', and its two workers (which see one device and fold the
+    ordinal) analyse two videos each, two streams at a time."""
+    import subprocess
+    import sys
+    from ysmr_amd.synth import SyntheticVideo
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = []
+    for i in range(4):
+        p = tmp_path / f"w{i}.npy"
+        np.save(p, SyntheticVideo(96, 128, 6, seed=20 + i).frames(44))
+        paths.append(str(p))
+    out = tmp_path / "res"
+    script = f"""
+import sys, json
+sys.path.insert(0, {root!r})
+import torch
+torch.cuda.device_count = lambda: 2            # (device_count does not initialise the GPU; nothing else is touched)
+from ysmr_amd import ysmr
+from ysmr_amd.helper_file import default_settings
+from ysmr_amd.main import _OFFLINE_KEYS
+s = default_settings(**{{"user input": False, "select files": False, "display video analysis": False, "log to file": False,
+                        "minimal frame count": 40, **{{k: False for k in _OFFLINE_KEYS}}}})
+done = ysmr({paths!r}, settings=s, result_folder={str(out)!r}, multiprocess=True, streams_per_gpu=2)
+assert not torch.cuda.is_initialized()          # the parent never touched the GPU
+print("RESULT " + json.dumps([[p, r] for p, r in done]))
+"""
+    proc = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    import json
+    done = json.loads(line[len("RESULT "):])
+    assert [p for p, _ in done] == paths and all(r is True for _, r in done)
+    assert "running the" not in proc.stderr            # not the in-process fallback: real worker processes
+    for i in range(4):
+        text = (out / f"w{i}_list.csv").read_text().splitlines()
+        assert text[0] == "TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE" and len(text) > 100
+
+
 def test_uncompressed_avi_is_unpacked_on_the_device(tmp_path):
     """f1: DeviceFrameFeed uploads the stored DIB frames of an uncompressed AVI as they are (bottom-up or top-down,
     rows padded to 4 bytes, 8-bit gray / palette indices / 24-bit BGR, dropped frames, an OpenDML continuation) and

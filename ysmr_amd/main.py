@@ -102,12 +102,25 @@ def analyse(path, settings=None, result_folder=None, return_df=False, device="cu
     return value if return_df else True
 
 
+def _visible(device):
+    """A worker may see fewer devices than the process that dealt the jobs (HIP_VISIBLE_DEVICES per worker, a
+    scheduler's cgroup): fold the ordinal instead of failing the video."""
+    import torch
+    try:        # the HIP runtime's own count (device_count() may answer from the management library, which lists
+        seen = int(torch._C._cuda_getDeviceCount())      # every GPU of the host whatever this process may use)
+    except (AttributeError, RuntimeError):
+        seen = torch.cuda.device_count()
+    index = torch.device(device).index or 0
+    return "cuda:{}".format(index % seen) if seen and index >= seen else device
+
+
 def _worker(args):
     """One video on the GPU it was dealt to.  The device is made current here: a fresh worker's current
     device is cuda:0 whatever its job says (the entry points below it select their device themselves as
     well; this covers allocations made in between)."""
     path, settings, result_folder, device = args
     from . import _lib
+    device = _visible(device)
     with _lib.on(device):
         return path, analyse(path, settings=settings, result_folder=result_folder, device=device)
 
@@ -130,7 +143,7 @@ def _gpu_worker(args):
                 short_file_output=st["shorten logfile logging output"], log_to_file=st["log to file"], settings=st)
 
     def run(job):
-        device = torch.device(job[3])
+        device = torch.device(_visible(job[3]))
         with torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device=device)):
             return _worker(job)
     with ThreadPoolExecutor(max_workers=streams, thread_name_prefix="ysmr-stream") as pool:
