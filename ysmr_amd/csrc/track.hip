@@ -36,13 +36,16 @@ struct TrackerDev {
     // persistent state
     int *n_tracks, *next_id, *err, *n_free;
     int *order, *order_tmp, *free_slots;
-    int *id, *gone, *mode, *hist_len, *hist_head;
+    int *id, *gone;
     double *pos;      // [2][cap]
     float *info;      // [3][cap]
     double *hist;     // [cap][hist_cap][2]  (one contiguous ring per track slot)
-    double *weights;  // [n_f][cap]
-    double *liks;     // [n_f][cap]
-    double *xhat;     // [2][n_f][cap]
+    // the filter bank's scalars of a slot as ONE record of rec_stride doubles: [0] history length | head << 32,
+    // [1] mode, [2 + f] weight, [2 + n_f + f] / [2 + 2 n_f + f] x-hat of filter f (the likelihoods are recomputed in
+    // every step and not kept).  A wave fetches and stores it with one instruction, lane = field: 15 VGPRs fewer than
+    // separately addressed scalars in k_frame and 10 in k_track (more of its 5000 waves resident at 4K: +2.5 %)
+    double *rec;      // [cap][rec_stride]
+    int rec_stride;
     // per-frame scratch
     int *unused;                  // [max_det] unclaimed detection columns, ascending
     double *row_min;              // [cap]
@@ -564,6 +567,7 @@ struct GsffState {
     TrackRegs h;
     double w[NF], xh0[NF], xh1[NF];
     int len, head, mode;
+    double raw;          // this lane's field of the slot's record, as fetched (decoded by gsff_decode)
 };
 // Issue every load of a track's filter state; no load depends on another, so one round trip.
 template <int NF>
@@ -571,28 +575,40 @@ __device__ __forceinline__ void gsff_fetch(const TrackerDev &t, int slot, int la
 {
     const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
     const double *hist = t.hist + (size_t)slot * 2 * L;
-    // (an opaque per-lane zero keeps these three loads in vector registers: as uniform loads the
-    // compiler moves them to scalar registers on the spot, which waits for them on the spot)
-    int lane0;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
-    s.len = t.hist_len[slot + lane0]; s.head = t.hist_head[slot + lane0]; s.mode = t.mode[slot + lane0];
+    s.raw = lane < t.rec_stride ? t.rec[(size_t)slot * t.rec_stride + lane] : 0.0;
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) {
         const int e = hist_entry(lane, q);
         s.h.v[q] = (e < L) ? hist[2 * e + hist_comp(lane)] : 0.0;
     }
+    (void)cap; (void)nf;
+}
+// the fields of the fetched record, broadcast to the wave (v_readlane: the wait for the load lands here)
+template <int NF>
+__device__ __forceinline__ void gsff_decode(const TrackerDev &t, GsffState<NF> &s)
+{
+    const int nf = t.n_f;
+    const long long b = __double_as_longlong(s.raw);
+    const int lo = (int)(b & 0xFFFFFFFFll), hi = (int)(b >> 32);
+    auto field = [&](int k) {
+        return __longlong_as_double(((long long)__builtin_amdgcn_readlane(hi, k) << 32) | (unsigned int)__builtin_amdgcn_readlane(lo, k));
+    };
+    s.len = __builtin_amdgcn_readlane(lo, 0);
+    s.head = __builtin_amdgcn_readlane(hi, 0);
+    s.mode = __builtin_amdgcn_readlane(lo, 1);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const bool on = f < nf;   // entries >= mode hold stale values that nothing reads
-        s.w[f] = on ? t.weights[(size_t)f * cap + slot] : 0.0;
-        s.xh0[f] = on ? t.xhat[((size_t)0 * nf + f) * cap + slot] : 0.0;
-        s.xh1[f] = on ? t.xhat[((size_t)1 * nf + f) * cap + slot] : 0.0;
+        s.w[f] = on ? field(2 + f) : 0.0;
+        s.xh0[f] = on ? field(2 + nf + f) : 0.0;
+        s.xh1[f] = on ? field(2 + 2 * nf + f) : 0.0;
     }
 }
 template <int NF>
 __device__ __forceinline__ void gsff_blank(GsffState<NF> &s)
 {
     s.len = s.head = s.mode = 0;
+    s.raw = 0.0;         // (decodes to an empty bank)
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) s.h.v[q] = 0.0;
 #pragma unroll
@@ -606,8 +622,8 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
     GSTAMP(0);
     double *hist = t.hist + (size_t)slot * 2 * L;
-    int len = __builtin_amdgcn_readfirstlane(st.len), head = __builtin_amdgcn_readfirstlane(st.head);
-    int mode = __builtin_amdgcn_readfirstlane(st.mode);
+    gsff_decode(t, st);
+    int len = st.len, head = st.head, mode = st.mode;
     TrackRegs &h = st.h;
     double (&w)[NF] = st.w;
     double (&xh0)[NF] = st.xh0;
@@ -717,20 +733,20 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
         if (e < L && (fresh || e == at)) hist[2 * e + hist_comp(lane)] = h.v[q];
     }
     if (lane == 0) {
-        t.hist_len[slot] = len;
-        t.hist_head[slot] = head;
-        t.mode[slot] = mode;
         t.pos[slot] = p0;
         t.pos[cap + slot] = p1;
     }
+    {   // the record, one store: every lane picks its field
+        double val = __longlong_as_double(lane == 0 ? ((long long)head << 32) | (unsigned int)len : (long long)(unsigned int)mode);
 #pragma unroll
-    for (int f = 0; f < NF; ++f)
-        if (f < mode && lane == f) {
-            t.weights[(size_t)f * cap + slot] = w[f];
-            t.liks[(size_t)f * cap + slot] = lik[f];
-            t.xhat[((size_t)0 * nf + f) * cap + slot] = xh0[f];
-            t.xhat[((size_t)1 * nf + f) * cap + slot] = xh1[f];
-        }
+        for (int f = 0; f < NF; ++f)
+            if (f < nf) {
+                val = lane == 2 + f ? w[f] : val;
+                val = lane == 2 + nf + f ? xh0[f] : val;
+                val = lane == 2 + 2 * nf + f ? xh1[f] : val;
+            }
+        if (lane < t.rec_stride) t.rec[(size_t)slot * t.rec_stride + lane] = val;
+    }
     GSTAMP(6);
 }
 
@@ -1148,9 +1164,8 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             t.info[cap + slot] = (float)det[(size_t)c * 5 + 3];
             t.info[2 * cap + slot] = (float)det[(size_t)c * 5 + 4];
             t.gone[slot] = 0;
-            t.mode[slot] = 0;
-            t.hist_len[slot] = 0;
-            t.hist_head[slot] = 0;
+            t.rec[(size_t)slot * t.rec_stride + 0] = 0.0;   // history length, head
+            t.rec[(size_t)slot * t.rec_stride + 1] = 0.0;   // mode
             if (new_cols_out) new_cols_out[j] = c;
         }
         __syncthreads();
@@ -1764,12 +1779,11 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return o; };
     const size_t o_scal = take(sizeof(int) * 16);
     const size_t o_order = take(sizeof(int) * cap), o_order_tmp = take(sizeof(int) * cap), o_free = take(sizeof(int) * cap);
-    const size_t o_id = take(sizeof(int) * cap), o_gone = take(sizeof(int) * cap), o_mode = take(sizeof(int) * cap);
-    const size_t o_hlen = take(sizeof(int) * cap), o_hhead = take(sizeof(int) * cap);
+    const size_t o_id = take(sizeof(int) * cap), o_gone = take(sizeof(int) * cap);
     const size_t o_pos = take(sizeof(double) * 2 * cap), o_info = take(sizeof(float) * 3 * cap);
     const size_t o_hist = take(sizeof(double) * 2 * cap * d.hist_cap);
-    const size_t o_w = take(sizeof(double) * nf * cap), o_l = take(sizeof(double) * nf * cap);
-    const size_t o_x = take(sizeof(double) * 2 * nf * cap);
+    d.rec_stride = (2 + 3 * nf + 7) / 8 * 8;
+    const size_t o_rec = take(sizeof(double) * (size_t)d.rec_stride * cap);
     const size_t o_gain = take(sizeof(double) * (gain_doubles ? gain_doubles : 1));
     const size_t o_unused = take(sizeof(int) * max_det);
     const size_t o_rmin = take(sizeof(double) * cap), o_rarg = take(sizeof(int) * cap);
@@ -1791,10 +1805,9 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     d.n_tracks = scal; d.next_id = scal + 1; d.err = scal + 2; d.n_free = scal + 3;
     d.row_base = (long long *)(scal + 8);
     d.order = (int *)(b + o_order); d.order_tmp = (int *)(b + o_order_tmp); d.free_slots = (int *)(b + o_free);
-    d.id = (int *)(b + o_id); d.gone = (int *)(b + o_gone); d.mode = (int *)(b + o_mode);
-    d.hist_len = (int *)(b + o_hlen); d.hist_head = (int *)(b + o_hhead);
+    d.id = (int *)(b + o_id); d.gone = (int *)(b + o_gone);
     d.pos = (double *)(b + o_pos); d.info = (float *)(b + o_info); d.hist = (double *)(b + o_hist);
-    d.weights = (double *)(b + o_w); d.liks = (double *)(b + o_l); d.xhat = (double *)(b + o_x);
+    d.rec = (double *)(b + o_rec);
     d.gains = (const double *)(b + o_gain);
     d.unused = (int *)(b + o_unused);
     d.row_min = (double *)(b + o_rmin); d.row_arg = (int *)(b + o_rarg);
