@@ -433,6 +433,16 @@ def test_track_bacteria_reads_uncompressed_avi(tmp_path):
     assert ra is not None and rb is not None and rb[1:4] == (30.0, 118, 150)
     assert ra[0].equals(rb[0]) and len(ra[0]) > 200
     assert open(ra[4], "rb").read() == open(rb[4], "rb").read()
+    # 24-bit BGR frames (top-down here): unpacked on the device, a1 (BGR2GRAY) inside the threshold kernel
+    rng = np.random.default_rng(4)
+    tint = np.clip(frames[..., None] * rng.uniform(0.6, 1.0, (1, 1, 1, 3)), 0, 255).astype(np.uint8)
+    np.save(tmp_path / "c.npy", tint)
+    write_avi(tmp_path / "d.avi", tint, 24, fps=(30, 1), top_down=True)
+    os.makedirs(tmp_path / "rc"); os.makedirs(tmp_path / "rd")
+    rc = track_bacteria(str(tmp_path / "c.npy"), settings=_settings(), result_folder=str(tmp_path / "rc"), batch=16)
+    rd = track_bacteria(str(tmp_path / "d.avi"), settings=_settings(), result_folder=str(tmp_path / "rd"), batch=16)
+    assert rc is not None and rd is not None and rc[0].equals(rd[0]) and len(rc[0]) > 200
+    assert open(rc[4], "rb").read() == open(rd[4], "rb").read()
 
 
 def test_track_bacteria_row_buffer_smaller_than_the_video(tmp_path, monkeypatch):
