@@ -42,7 +42,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   7
+#define YSMR_ABI_VERSION   8
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -110,6 +110,19 @@ int ysmr_detect_workspace_init(void *stream, void *workspace_dev, size_t workspa
 int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
                          int channels, int inv, int t_low, int t_high, int use_high,
                          uint8_t *cls_dev, int cv_flavour);
+
+/* The same call with the kernel named (test and measurement aid; the results are the same bytes whichever is taken).
+ * Gray frames of at least 18 rows and 64 columns (width a multiple of 4) are served by a kernel that evaluates the
+ * Gaussian mean on the matrix pipe to within 1/128, decides every pixel that is farther than that from both levels
+ * and re-evaluates the rest with cv2's float32 arithmetic (csrc/thr_mfma.hip); everything else, and BGR input, by the
+ * kernels that run that arithmetic for every pixel (csrc/detect.hip: k_threshold_strip, k_threshold).
+ * variant 0: as ysmr_threshold_batch; 1: the float32-chain kernels only; 2: the matrix-pipe kernel deciding EVERY
+ * pixel that is not an exact tie (wrong bytes measure how far its mean is from cv2's: diagnostic); 3: the matrix-pipe
+ * kernel with every pixel sent through its exact path (diagnostic).  2 and 3 fail for geometries that kernel does
+ * not serve. */
+int ysmr_threshold_batch_variant(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
+                                 int channels, int inv, int t_low, int t_high, int use_high,
+                                 uint8_t *cls_dev, int cv_flavour, int variant);
 
 /* The mean-gray threshold branch, taken by the reference when 'adaptive double threshold' < 0
  * (ysmr/track_eval.py:219-253): replaces cv2.meanStdDev(gray), the 5 s moving average of

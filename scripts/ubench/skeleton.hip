@@ -1,0 +1,210 @@
+// Memory skeletons for the threshold kernel (VERDICT r02 task 2b): how fast can 64 frames of 922 x 1228 bytes be
+// read once and a class map of the same size be written once, by access shape.  No arithmetic beyond one xor.
+//   A  linear copy, 16 B per lane, grid-stride                                   (the chip's copy rate)
+//   B  wave-private strips of 112 output columns: 128-byte row pieces (8 lanes x 16 B, 8 rows per load), 16-row
+//      steps, two steps in flight, 112-byte row pieces stored (7 lanes x 16 B)
+//   C  as B, rows by LDS-DMA (global_load_lds_dwordx4) and ds_read_b128
+//   D  workgroup-wide row blocks: 16 whole rows (19 648 contiguous bytes) per step through LDS, one barrier per step
+//   E  the shipped kernel's shape: 4 B per lane, 64-lane strips of 52 output lanes, 8 rows in flight
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+constexpr int H = 922, W = 1228, B = 64, SETS = 8;
+constexpr size_t FRAME = (size_t)H * W, BATCH = FRAME * B;
+
+__global__ __launch_bounds__(256) void k_linear(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        uint4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        a.x ^= 1; b.x ^= 1; c.x ^= 1; d.x ^= 1;
+        out[i] = a; out[i + stride] = b; out[i + 2 * stride] = c; out[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) { uint4 a = in[i]; a.x ^= 1; out[i] = a; }
+}
+
+__device__ __forceinline__ uint4 ld16(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st16(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
+
+// B: items = (frame, strip, segment); a wave marches down its segment in steps of 16 rows
+template <bool DMA>
+__global__ __launch_bounds__(256) void k_strips(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int seg_h, int segs, int by_xcd)
+{
+    __shared__ uint4 s_q[4][4][64];   // [wave][slot of 8 rows][lane]
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int strips = (W + 111) / 112;   // 11
+    const int per_frame = strips * segs;
+    long long first, step, count; int f_mul, f_add;
+    if (by_xcd) { first = (long long)(blockIdx.x >> 3) * 4 + wv; step = (long long)(gridDim.x >> 3) * 4; count = (long long)(B >> 3) * per_frame; f_mul = 8; f_add = blockIdx.x & 7; }
+    else { first = (long long)blockIdx.x * 4 + wv; step = (long long)gridDim.x * 4; count = (long long)B * per_frame; f_mul = 1; f_add = 0; }
+    const int r8 = lane >> 3, c8 = lane & 7;
+    for (long long it = first; it < count; it += step) {
+        const int f = (int)(it / per_frame) * f_mul + f_add, rem = (int)(it % per_frame);
+        const int sx = rem % strips, sy = rem / strips;
+        const int x0 = sx * 112 - 8;                       // first loaded column (4-byte aligned)
+        const int y0 = sy * seg_h, y1 = min(y0 + seg_h, H);
+        const uint8_t *src = in + (size_t)f * FRAME;
+        uint8_t *dst = out + (size_t)f * FRAME;
+        int col = x0 + 16 * c8; col = col < 0 ? 0 : (col > W - 16 ? W - 16 : col);
+        const bool writes = c8 < 7 && (sx * 112 + 16 * c8 + 16 <= W);
+        const int ocol = sx * 112 + 16 * c8;
+        auto row_of = [&](int r) { return r < 0 ? 0 : (r > H - 1 ? H - 1 : r); };
+        auto request = [&](int y, int slot) -> uint4 {     // 8 rows y .. y + 7
+            const uint8_t *p = src + (size_t)row_of(y + r8) * W + col;
+            if (DMA) {
+                const uint32_t lds = (uint32_t)(uintptr_t)&s_q[wv][slot][0];
+                const uint32_t off = (uint32_t)(p - src);
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(off), "s"(src) : "memory");
+                return uint4{0, 0, 0, 0};
+            }
+            return ld16(p);
+        };
+        // two 16-row steps in flight: 4 loads (DMA: a ring of four 8-row slots)
+        uint4 q0 = request(y0 - 6, 0), q1 = request(y0 + 2, 1), q2 = request(y0 + 10, 2), q3 = request(y0 + 18, 3);
+        int slot = 0;
+        for (int y = y0; y < y1; y += 16) {
+            uint4 a, b;
+            if (DMA) {
+                // all but the two youngest operations done: this step's rows have landed (and the stores before them)
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                a = s_q[wv][slot][lane]; b = s_q[wv][slot + 1][lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else { a = q0; b = q1; }
+            a.x ^= b.y; b.x ^= a.y;
+            if (writes) {
+                if (y + r8 < y1) st16(dst + (size_t)(y + r8) * W + ocol, a);
+                if (y + 8 + r8 < y1) st16(dst + (size_t)(y + 8 + r8) * W + ocol, b);
+            }
+            if (DMA) {
+                request(y + 26, slot); request(y + 34, slot + 1);
+                slot ^= 2;
+            } else {
+                q0 = q2; q1 = q3;
+                q2 = request(y + 26, 2); q3 = request(y + 34, 3);
+            }
+        }
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// D: a 512-thread workgroup moves whole-row blocks through LDS
+__global__ __launch_bounds__(512) void k_rowblocks(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int band_h, int bands)
+{
+    __shared__ uint4 s_t[2][1232];   // 16 rows x 1228 B = 19 648 B = 1228 uint4
+    const int t = threadIdx.x;
+    const long long count = (long long)B * bands;
+    for (long long it = blockIdx.x; it < count; it += gridDim.x) {
+        const int f = (int)(it / bands), bd = (int)(it % bands);
+        const int y0 = bd * band_h, y1 = min(y0 + band_h, H);
+        const uint8_t *src = in + (size_t)f * FRAME;
+        uint8_t *dst = out + (size_t)f * FRAME;
+        int buf = 0;
+        auto fetch = [&](int y, uint4 *r) {
+            const size_t base = (size_t)y * W; const int n16 = (min(y + 16, y1) - y) * W / 16;
+            for (int k = 0; k < 3; ++k) { const int i = t + 512 * k; r[k] = i < n16 ? ld16(src + base + 16 * (size_t)i) : uint4{0, 0, 0, 0}; }
+        };
+        uint4 r[3]; fetch(y0, r);
+        for (int y = y0; y < y1; y += 16) {
+            for (int k = 0; k < 3; ++k) { const int i = t + 512 * k; if (i < 1228) s_t[buf][i] = r[k]; }
+            if (y + 16 < y1) fetch(y + 16, r);
+            __syncthreads();
+            const size_t base = (size_t)y * W; const int n16 = (min(y + 16, y1) - y) * W / 16;
+            for (int k = 0; k < 3; ++k) {
+                const int i = t + 512 * k;
+                if (i < n16) { uint4 v = s_t[buf][i]; uint4 u = s_t[buf][(i + 77) % 1228]; v.x ^= u.y; st16(dst + base + 16 * (size_t)i, v); }
+            }
+            buf ^= 1;
+        }
+        __syncthreads();
+    }
+}
+
+// E: 4 B per lane strips (the shipped shape), 8 rows in flight in registers
+__global__ __launch_bounds__(256) void k_strips4(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int seg_h, int segs)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int strips = 6, out_lanes = 52, per_frame = strips * segs;
+    const long long first = (long long)(blockIdx.x >> 3) * 4 + wv, step = (long long)(gridDim.x >> 3) * 4, count = (long long)(B >> 3) * per_frame;
+    for (long long it = first; it < count; it += step) {
+        const int f = (int)(it / per_frame) * 8 + (blockIdx.x & 7), rem = (int)(it % per_frame);
+        const int sx = rem % strips, sy = rem / strips;
+        const int c0 = sx * out_lanes * 4 - 12 + 4 * lane;
+        const int col = c0 < 0 ? 0 : (c0 > W - 4 ? W - 4 : c0);
+        const bool writes = lane >= 3 && lane < 3 + out_lanes && c0 < W;
+        const int y0 = sy * seg_h, y1 = min(y0 + seg_h, H);
+        const uint32_t *src = (const uint32_t *)(in + (size_t)f * FRAME + col);
+        uint32_t *dst = (uint32_t *)(out + (size_t)f * FRAME + c0);
+        uint32_t q[8];
+        auto row_of = [&](int r) { return r < 0 ? 0 : (r > H - 1 ? H - 1 : r); };
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = src[(size_t)row_of(y0 - 6 + k) * (W / 4)];
+        for (int y = y0; y < y1; y += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t v = q[k] ^ 1u;
+                q[k] = src[(size_t)row_of(y + 2 + k + 8) * (W / 4)];
+                if (writes && y + k < y1) dst[(size_t)(y + k) * (W / 4)] = v;
+            }
+        }
+    }
+}
+
+template <typename F> float time_sets(F launch)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int s = 0; s < SETS; ++s) launch(s);
+    hipDeviceSynchronize();
+    std::vector<float> t;
+    for (int rep = 0; rep < 3; ++rep)
+        for (int s = 0; s < SETS; ++s) {
+            hipEventRecord(e0); launch(s); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); t.push_back(ms * 1e3f);
+        }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
+
+int main()
+{
+    uint8_t *in, *out;
+    hipMalloc(&in, BATCH * SETS + 4096); hipMalloc(&out, BATCH * SETS + 4096);
+    hipMemset(in, 0x28, BATCH * SETS); hipMemset(out, 0, BATCH * SETS);
+    const double mb = 2.0 * BATCH / 1e6;
+    auto report = [&](const char *name, float us) { printf("%-64s %7.1f us  %6.0f GB/s  %.3f of 8 TB/s\n", name, us, mb / us * 1e3, mb / us * 1e3 / 8000.0); };
+    for (int blocks : {1024, 2048, 4096}) {
+        float us = time_sets([&](int s) { hipLaunchKernelGGL(k_linear, dim3(blocks), dim3(256), 0, 0, (const uint4 *)(in + BATCH * s), (uint4 *)(out + BATCH * s), BATCH / 16); });
+        char nm[96]; snprintf(nm, 96, "A linear copy 16 B/lane, %d blocks", blocks); report(nm, us);
+    }
+    for (int blocks : {768, 1024, 1536, 2048}) {
+        for (int xcd : {0, 1}) {
+            const int strips = 11;
+            long long segs = std::max<long long>(1, (long long)blocks * 4 / ((long long)B * strips));
+            int seg_h = (int)std::max<long long>(32, (H + segs - 1) / segs); seg_h = (seg_h + 15) / 16 * 16;
+            const int nsegs = (H + seg_h - 1) / seg_h;
+            float us = time_sets([&](int s) { hipLaunchKernelGGL(k_strips<false>, dim3(blocks), dim3(256), 0, 0, in + BATCH * s, out + BATCH * s, seg_h, nsegs, xcd); });
+            char nm[96]; snprintf(nm, 96, "B strips 112 cols, regs, %d blocks, seg %d rows, by_xcd %d", blocks, seg_h, xcd); report(nm, us);
+            us = time_sets([&](int s) { hipLaunchKernelGGL(k_strips<true>, dim3(blocks), dim3(256), 0, 0, in + BATCH * s, out + BATCH * s, seg_h, nsegs, xcd); });
+            snprintf(nm, 96, "C strips 112 cols, LDS-DMA, %d blocks, seg %d rows, by_xcd %d", blocks, seg_h, xcd); report(nm, us);
+        }
+    }
+    for (int blocks : {256, 512, 768}) {
+        for (int band_h : {64, 128, 240}) {
+            const int bands = (H + band_h - 1) / band_h;
+            float us = time_sets([&](int s) { hipLaunchKernelGGL(k_rowblocks, dim3(blocks), dim3(512), 0, 0, in + BATCH * s, out + BATCH * s, band_h, bands); });
+            char nm[96]; snprintf(nm, 96, "D row blocks through LDS, %d blocks x 512, band %d rows", blocks, band_h); report(nm, us);
+        }
+    }
+    for (int blocks : {768, 1024}) {
+        const int strips = 6;
+        long long segs = std::max<long long>(1, (long long)blocks * 4 / ((long long)B * strips));
+        int seg_h = (int)std::max<long long>(32, (H + segs - 1) / segs);
+        const int nsegs = (H + seg_h - 1) / seg_h;
+        float us = time_sets([&](int s) { hipLaunchKernelGGL(k_strips4, dim3(blocks), dim3(256), 0, 0, in + BATCH * s, out + BATCH * s, seg_h, nsegs); });
+        char nm[96]; snprintf(nm, 96, "E strips 4 B/lane (shipped shape), %d blocks, seg %d rows", blocks, seg_h); report(nm, us);
+    }
+    return 0;
+}

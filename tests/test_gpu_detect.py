@@ -66,6 +66,67 @@ def test_threshold_only_matches_oracle(torch_cuda, oracle):
                 np.testing.assert_array_equal(cls[f], ref, err_msg=f"{h}x{w} {args} frame {f}")
 
 
+def _threshold_reference(oracle, frames, p):
+    out = []
+    for f in range(frames.shape[0]):
+        blur = oracle.blur3(frames[f])
+        out.append(oracle.classify(blur, oracle.adaptive_mean(blur), p.inv, p.t_low, p.t_high, p.use_high))
+    return np.stack(out)
+
+
+def _mismatch_report(got, ref, limit=8):
+    bad = np.argwhere(got != ref)
+    return f"{len(bad)} bytes differ; first (frame, y, x): got/want " + ", ".join(
+        f"{tuple(int(v) for v in b)}: {int(got[tuple(b)])}/{int(ref[tuple(b)])}" for b in bad[:limit])
+
+
+@pytest.mark.parametrize("h,w", [(18, 64), (19, 68), (64, 64), (97, 132), (200, 260), (45, 1228), (40, 1232), (33, 1236),
+                                 (35, 2472), (130, 1228)])
+def test_threshold_matrix_pipe_kernel(torch_cuda, oracle, h, w):
+    """The matrix-pipe threshold kernel (csrc/thr_mfma.hip) on the geometries that exercise its edges: one tile and
+    many, widths that are / are not multiples of 16, one and several column panels (1236 splits into 2 x 624, 2472 into
+    3), bands that end inside a 16-row step, both polarities, one and two levels.  Variant 0 (shipped), 3 (every pixel
+    through its exact path) and 1 (the float32-chain kernels) must all give the oracle's bytes."""
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    torch = torch_cuda
+    rng = np.random.default_rng(h * 10007 + w)
+    frames = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
+    frames[1] = (rng.normal(40, 2, (h, w))).round().clip(0, 255).astype(np.uint8)
+    frames[1, ::9, ::11] = 200
+    if h >= 64 and w >= 64:
+        frames[2] = SyntheticVideo(h, w, max(4, h * w // 3000), seed=w).next_frame()
+    dev = torch.from_numpy(frames).cuda()
+    for args in [(True, 5, 2.0), (False, 5, 2.0), (True, 3, 0.0), (True, 5, 2.5)]:
+        p = threshold_params(*args)
+        ref = _threshold_reference(oracle, frames, p)
+        d = Detector(3, h, w, max_det=64, params=p)
+        for variant in (0, 3, 1):
+            got = d.threshold(dev, variant=variant).cpu().numpy()
+            assert np.array_equal(got, ref), f"{h}x{w} {args} variant {variant}: " + _mismatch_report(got, ref)
+
+
+def test_threshold_matrix_pipe_distance(torch_cuda, oracle):
+    """How far is the matrix pipe's mean from cv2's float32 chain?  Variant 2 decides EVERY pixel that is not an exact tie
+    on the matrix pipe alone, so each wrong byte is a pixel whose two means straddle a level.  On uniform noise the
+    difference s - mean is spread over +-128, about 1/100 of the pixels per unit at the levels: a distance d shows as
+    ~ 4 d / 100 wrong pixels per pixel.  The shipped kernel refines within EPS = 1/128; the test demands that the
+    measured rate stay below what a distance of EPS / 8 would give (and prints it)."""
+    from ysmr_amd.detect import Detector, threshold_params
+    torch = torch_cuda
+    rng = np.random.default_rng(7)
+    h, w = 400, 1228
+    frames = rng.integers(0, 256, (8, h, w), dtype=np.uint8)
+    p = threshold_params(True, 5, 2.0)
+    ref = _threshold_reference(oracle, frames, p)
+    d = Detector(8, h, w, max_det=64, params=p)
+    got = d.threshold(torch.from_numpy(frames).cuda(), variant=2).cpu().numpy()
+    rate = float((got != ref).mean())
+    print(f"matrix pipe alone: {int((got != ref).sum())} of {got.size} bytes differ ({rate:.2e})")
+    assert rate < 4 * (1.0 / 128 / 8) / 100, _mismatch_report(got, ref)
+    assert np.array_equal(d.threshold(torch.from_numpy(frames).cuda()).cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("h,w", [(70, 90), (70, 92), (130, 1228), (61, 16)])
 def test_threshold_bgr(torch_cuda, oracle, h, w):
     """a1: BGR input (what cv2.VideoCapture delivers).  W % 4 == 0 takes the strip kernel (several

@@ -41,8 +41,10 @@ def cv_flavour_of(version):
 ROW_DTYPE = np.dtype([("frame", "<i4"), ("track_id", "<i4"), ("x", "<f8"), ("y", "<f8"),
                       ("w", "<f4"), ("h", "<f4"), ("angle", "<f4"), ("disappeared", "<i4")])
 
+ABI_VERSION = 8   # YSMR_ABI_VERSION of include/ysmr_hip.h these argtypes were written against
+
 EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_detect_workspace_init",
-           "ysmr_threshold_batch", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
+           "ysmr_threshold_batch", "ysmr_threshold_batch_variant", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
@@ -104,11 +106,15 @@ def lib():
         raise YsmrLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
     vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     L.ysmr_abi_version.restype = ci
+    if L.ysmr_abi_version() != ABI_VERSION:
+        raise YsmrLibraryError(f"{LIB_PATH} has ABI version {L.ysmr_abi_version()}, this host code binds version "
+                               f"{ABI_VERSION} (include/ysmr_hip.h): rebuild the library (make -C ysmr_amd/csrc)")
     L.ysmr_last_error.restype = ctypes.c_char_p
     L.ysmr_detect_workspace_bytes.argtypes = [ci, ci, ci, ci]
     L.ysmr_detect_workspace_bytes.restype = ctypes.c_size_t
     L.ysmr_detect_workspace_init.argtypes = [vp, vp, ctypes.c_size_t]
     L.ysmr_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci]
+    L.ysmr_threshold_batch_variant.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci]
     L.ysmr_mean_threshold_state_bytes.argtypes = [ci]
     L.ysmr_mean_threshold_state_bytes.restype = ctypes.c_size_t
     L.ysmr_mean_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, vp, vp, vp, vp, ci]

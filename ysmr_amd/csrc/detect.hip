@@ -13,6 +13,7 @@
 //
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
 #include "common.h"
+#include "thr_mfma.h"
 #include <cfloat>
 #include <cmath>
 #include <algorithm>
@@ -2188,11 +2189,17 @@ const Knobs &knobs()
     return k;
 }
 
+// variant: 0 = the shipped choice of kernel; 1 = strip / tile kernels only (bit-exact float32 chain for every pixel);
+// 2, 3 = the matrix-pipe kernel's diagnostic builds (thr_mfma.h)
 int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, int W, int channels, int inv, int t_low,
-                     int t_high, int use_high, uint8_t *cls, int cv_flavour)
+                     int t_high, int use_high, uint8_t *cls, int cv_flavour, int variant = 0)
 {
     Gauss11 gk = make_gauss11();
     const ysmr::GrayCoef gc = ysmr::gray_coef(cv_flavour);
+    if (variant != 1 && ysmr_thr::supported(H, W, channels, t_low, t_high, use_high))
+        return ysmr_thr::launch(st, frames, cls, batch, H, W, inv, t_low, t_high, use_high, gk.k, knobs().thr_blocks,
+                                variant >= 2 ? variant - 1 : 0);
+    if (variant >= 2) return ysmr::fail(YSMR_ERR_ARG, "the matrix-pipe threshold kernel does not serve this geometry");
     const int t_gap = use_high ? (t_high > t_low ? t_high - t_low : t_low - t_high) : 0;
     if ((W & 3) == 0 && W >= 16 && H >= 2 && t_low > -100000 && t_low < 100000 && t_high > -100000 && t_high < 100000 && t_gap <= 127) {
         StripParams P;
@@ -2259,6 +2266,17 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
     if (cv_flavour & ~YSMR_CV_FLAVOUR_MASK) return ysmr::fail(YSMR_ERR_ARG, "unknown cv_flavour bits 0x%x", cv_flavour);
     return launch_threshold((hipStream_t)stream, frames_dev, batch, height, width, channels, inv, t_low, t_high,
                             use_high, cls_dev, cv_flavour);
+}
+
+int ysmr_threshold_batch_variant(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels,
+                                 int inv, int t_low, int t_high, int use_high, uint8_t *cls_dev, int cv_flavour, int variant)
+{
+    if (int rc = check_geometry(batch, height, width, channels, 1)) return rc;
+    if (!frames_dev || !cls_dev) return ysmr::fail(YSMR_ERR_ARG, "frames_dev and cls_dev must not be NULL");
+    if (cv_flavour & ~YSMR_CV_FLAVOUR_MASK) return ysmr::fail(YSMR_ERR_ARG, "unknown cv_flavour bits 0x%x", cv_flavour);
+    if (variant < 0 || variant > 3) return ysmr::fail(YSMR_ERR_ARG, "variant must be 0..3, got %d", variant);
+    return launch_threshold((hipStream_t)stream, frames_dev, batch, height, width, channels, inv, t_low, t_high,
+                            use_high, cls_dev, cv_flavour, variant);
 }
 
 int ysmr_components_batch(void *stream, int batch, int height, int width, void *workspace_dev, size_t workspace_bytes,

@@ -1,0 +1,27 @@
+// Interface between detect.hip's launcher and the matrix-pipe threshold kernel (thr_mfma.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace ysmr_thr {
+
+struct Params {
+    int H, W, batch;
+    int panels, panel_w;   // column panels of at most 1232 columns (a multiple of 16 wide, the last one may be narrower)
+    int bands, band_h;     // bands of rows (a multiple of 16 high)
+    int by_xcd;            // frames are dealt to the 8 XCDs
+    int inv, use_high, t_low, t_high;
+    // x = S * (theta - v) * sign + 127.5 saturates to byte 0 / 255 outside EPS of the level theta (v = mean - blurred)
+    float x_mul, lo_add, hi_add;
+    float kw[6];           // the Gaussian's distinct weights k[0..5] (k[i] == k[10 - i]), cv2's float32 values
+};
+
+// geometry / arguments the kernel serves (everything else stays on k_threshold_strip / k_threshold)
+bool supported(int H, int W, int channels, int t_low, int t_high, int use_high);
+
+// variant: 0 = shipped (EPS = 1/128), 1 = EPS -> 0 (diagnostic: every pixel decided by the matrix pipe alone, only exact
+// ties refined), 2 = every pixel through the exact path (diagnostic)
+int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H, int W, int inv, int t_low, int t_high,
+           int use_high, const float *gauss11, int blocks_wanted, int variant);
+
+}  // namespace ysmr_thr

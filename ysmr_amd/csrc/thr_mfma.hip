@@ -1,0 +1,488 @@
+// k_threshold_mfma: a1-a3 (gray input) as "decide on the matrix pipe, refine exactly".
+//
+// What the reference computes per pixel (track_eval.py:182-208):
+//   b   = GaussianBlur 3x3 of the gray frame (exact integers, REFLECT_101)
+//   acc = 11x11 Gaussian (sigma 2) of b in float32, cv2's evaluation order (row pass = ascending FMA chain,
+//         column pass = symmetric form), REPLICATE border
+//   m   = round-half-even(acc);  thresh = (b - m > t_low), markers = (b - m > t_high)   [INV: <=]
+// The two class bits only depend on where acc lies relative to b - t - 0.5.  This kernel evaluates
+//   v = mean - b   with |v - (acc - b)| < EPS   (a bound, below)
+// on the matrix pipe (v_mfma_f32_16x16x32_f16: the pixels are exact in f16, the weights and the row-filtered
+// values travel as f16 hi + lo pairs, products and sums are f32) and decides every pixel whose v is farther
+// than EPS from both levels; the few that are not (a few per 100 000 pixels) are listed and recomputed with cv2's
+// exact float32 chain at the end of the work item, from the frame in global memory.  Results are bit for bit those of
+// k_threshold / k_threshold_strip (detect.hip), which remain the path for BGR input and odd geometries.
+//
+// Memory skeleton (scripts/ubench/skeleton.hip): a 1024-thread workgroup owns a band of rows of one frame over a
+// column panel (the whole width up to 1232 columns) and walks down in steps of 16 rows: whole rows come in by
+// LDS-DMA (global_load_lds_dwordx4, no registers), the class map leaves as 16-byte stores.  Per step:
+//   DMA    raw rows of step s+2                                        -> s_raw[s & 1]
+//   filter output rows of step s-1 from the f16 tiles of steps s-1 and s (32 rows resident):
+//            column pass FIRST, transposed: A = the tile read column-major (ds_read_b64_tr_b16), B = the taps
+//            (hi, lo): 2 MFMA per 16-column block -> the accumulator has the output row on the lane and four
+//            columns in its registers, which is the k order of the next product -> f16 hi / lo split in registers
+//            row pass: A = the taps (hi, lo), B = two neighbouring blocks: 3 MFMA per 16x16 output tile,
+//            accumulator preset to -b (the tile's centre pixels, one ds_read_b64) = mean - b with four CONSECUTIVE
+//            columns of one row per lane -> classification, ambiguity test, one dword of the class map per lane
+//   barrier
+//   blur   step s+1: s_raw[(s+1) & 1] -> SWAR 3x3 blur -> f16 tile s_f16[(s+1) & 1]   (wave w = tile row w)
+//   barrier
+// Nothing is carried in registers from step to step.
+// Error bound (EPS = 1/128): the pixels are exact; each weight enters as hi + lo with a residual below 2^-11 |lo|
+// (< 3e-8, x 255 x 11 < 1e-4); a row-filtered value enters as rtz-f16 hi + f16 lo (residual < 2^-10 x 2^-3 = 1.3e-4,
+// the weights sum to 1); the dropped lo x lo product is below 2e-4 x 0.13 = 3e-5; float32 accumulation of at most
+// 32 + 32 products of magnitude <= 255 per chained MFMA, six MFMAs: < 6 x 64 x 2^-24 x 255 = 6e-3 if every partial sum
+// were rounded separately and all errors added up (the hardware does better); cv2's own chain is within 2e-4 of the
+// real mean.  Sum < 7e-3 < EPS = 7.8e-3.  tests/test_gpu_detect.py runs the kernel with EPS scaled to 0 in a tuning
+// build to MEASURE the distance (the count of wrong pixels is the test), and with EPS huge so that every pixel takes
+// the exact path.
+#include "common.h"
+#include "thr_mfma.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM_WAVES = 16, TM_THREADS = 64 * TM_WAVES;
+constexpr int TM_ROWS = 16;                       // rows per step (one MFMA tile row block)
+constexpr int TM_RAW_ROWS = 18;                   // gray rows a step's blur needs
+constexpr int TM_MAX_PANEL = 1232;                // columns per panel (77 tiles of 16)
+constexpr int TM_TILES_PER_WAVE = (TM_MAX_PANEL / 16 + TM_WAVES - 1) / TM_WAVES;   // 5
+constexpr int TM_PITCH = TM_MAX_PANEL + 16;       // f16 per tile row: position p = column - x0 + 8
+constexpr int TM_RAW_CHUNKS = (TM_MAX_PANEL + 32 + 15) / 16;   // 16-byte chunks per raw row: columns x0 - 16 ...
+constexpr int TM_RAW_PIECES = (TM_RAW_ROWS * TM_RAW_CHUNKS + 63) / 64;   // 1 KiB DMA pieces per step
+constexpr int TM_PIECES_PER_WAVE = (TM_RAW_PIECES + TM_WAVES - 1) / TM_WAVES;
+constexpr int TM_OUT_PITCH = 16 * TM_TILES_PER_WAVE;           // bytes per row of a wave's class-byte staging
+constexpr int TM_LIST_CAP = 2048;                 // ambiguous pixels a work item can list
+constexpr int TM_GROUP = 62;                      // blur: output dwords per 64-lane group (lanes 0 and 63 are halo)
+
+struct ThrItem {
+    int f, x0, x1, y0, y1;
+};
+
+__device__ __forceinline__ int reflect101(int i, int n) { if (i < 0) i = -i; if (i >= n) i = 2 * (n - 1) - i; return i; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t lane_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }
+
+// x - float(h) for the low / high half of a packed f16 pair, in one instruction
+__device__ __forceinline__ float sub_f16_lo(float x, uint32_t h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float x, uint32_t h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkrtz(float a, float b)
+{
+    auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ half8_t as_half8(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    u32x4 v = {a, b, c, d};
+    return __builtin_bit_cast(half8_t, v);
+}
+__device__ __forceinline__ uint32_t f16_bits(float x) { _Float16 h = (_Float16)x; unsigned short b; __builtin_memcpy(&b, &h, 2); return b; }
+__device__ __forceinline__ float f16_value(uint32_t bits) { unsigned short b = (unsigned short)bits; _Float16 h; __builtin_memcpy(&h, &b, 2); return (float)h; }
+
+// the eleven taps from the six distinct weights
+__device__ __forceinline__ float tap_weight(const ysmr_thr::Params &P, int tap) { return P.kw[tap <= 5 ? tap : 10 - tap]; }
+
+// ---- exact path: cv2's float32 arithmetic for one pixel, sixteen lanes per pixel (lane dy computes one row) -------
+__device__ __forceinline__ uint32_t blur_at(const uint8_t *frame, int H, int W, int y, int x)
+{
+    const int ym = reflect101(y - 1, H), yp = reflect101(y + 1, H), xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
+    const uint8_t *ru = frame + (size_t)ym * W, *rc = frame + (size_t)y * W, *rd = frame + (size_t)yp * W;
+    const uint32_t s = ru[xm] + 2u * ru[x] + ru[xp] + 2u * (rc[xm] + 2u * rc[x] + rc[xp]) + rd[xm] + 2u * rd[x] + rd[xp];
+    return (s + 8u) >> 4;
+}
+
+// every lane of a 16-lane group passes the same (y, x); returns the class byte in all of them
+__device__ __forceinline__ uint32_t exact_class(const uint8_t *frame, const ysmr_thr::Params &P, int y, int x, int lane)
+{
+    const int H = P.H, W = P.W, dy = lane & 15, base = lane & ~15;
+    const int yy = clampi(y - 5 + min(dy, 10), 0, H - 1);
+    float acc = 0.0f;
+    uint32_t centre = 0;
+    for (int i = 0; i < 11; ++i) {
+        const uint32_t b = blur_at(frame, H, W, yy, clampi(x - 5 + i, 0, W - 1));
+        if (i == 5) centre = b;
+        acc = __builtin_fmaf((float)b, tap_weight(P, i), acc);
+    }
+    float rv[11];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) rv[j] = __shfl(acc, base + j, 64);
+    const uint32_t s = (uint32_t)__shfl((int)centre, base + 5, 64);
+    float m = __builtin_fmaf(rv[5], P.kw[5], 0.0f);
+#pragma unroll
+    for (int j = 1; j <= 5; ++j) m = __builtin_fmaf(rv[5 + j] + rv[5 - j], P.kw[5 - j], m);
+    const int mi = clampi((int)__builtin_rintf(m), 0, 255);
+    const int d = (int)s - mi;
+    const int lo = P.inv ? (d <= P.t_low) : (d > P.t_low);
+    const int hi = P.use_high ? (P.inv ? (d <= P.t_high) : (d > P.t_high)) : lo;
+    return (uint32_t)(lo | (hi << 1));
+}
+
+struct Lds {
+    _Float16 f16[2][TM_ROWS][TM_PITCH];                  // blurred pixels of a step, quads stored as (0, 2, 1, 3)
+    uint8_t raw[2][TM_RAW_ROWS * TM_RAW_CHUNKS * 16];    // gray rows of a step, pitch 16 * chunks-per-row
+    uint32_t out[TM_WAVES][TM_ROWS * TM_OUT_PITCH / 4];  // a wave's class bytes of a step
+    uint32_t list[TM_LIST_CAP];                          // ambiguous pixels: y << 16 | x
+    uint32_t n_list;
+};
+static_assert(sizeof(Lds) <= 160 * 1024, "LDS of one CU");
+
+template <int EPS_MODE>
+__global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__restrict__ frames, uint8_t *__restrict__ cls,
+                                                               ysmr_thr::Params P)
+{
+    extern __shared__ __align__(16) uint8_t lds_bytes[];
+    Lds &L = *reinterpret_cast<Lds *>(lds_bytes);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = P.H, W = P.W;
+    const int l16 = lane & 15, q = lane >> 4;
+
+    // ---- constant MFMA operands of this lane ---------------------------------------------------------------------
+    // Column pass, B operand [k][n]: lane (n = l16, q) holds k = 8q + j = window row; output row n is window row n + 5,
+    // so the tap is k - n.
+    // Row pass, A operand [m][k]: lane (m = l16, q) holds k = 8q + j.  The B operand is two column blocks' accumulators
+    // kept in place: halves j = 0..3 / 4..7 hold tile positions 4q + (j & 3) of one 16-column block each; position i of a
+    // block is pixel column 16u - 8 + (i & ~3) + (0, 2, 1, 3)[i & 3] (the tile stores quads as 0, 2, 1, 3).  Variant v: the
+    // RIGHT block (u = t + 1) sits in half v.  Output m is column 16t + m, so the tap is column_in - m + 5.
+    uint32_t tbh[4], tbl[4], thh[2][4], thl[2][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        uint32_t bh = 0, bl = 0, hh[2] = {0, 0}, hl[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2 * jj + e, k = 8 * q + j;
+            const int p4 = ((j & 3) == 1) ? 2 : ((j & 3) == 2) ? 1 : (j & 3);
+            int taps[3] = {k - l16, -8 + 4 * q + p4 + ((j >> 2) == 0 ? 16 : 0) - l16 + 5, -8 + 4 * q + p4 + ((j >> 2) == 1 ? 16 : 0) - l16 + 5};
+            uint32_t hb[3], lb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bool ok = taps[c] >= 0 && taps[c] <= 10;
+                const float w = ok ? tap_weight(P, clampi(taps[c], 0, 10)) : 0.0f;
+                hb[c] = f16_bits(w);
+                lb[c] = f16_bits(w - f16_value(hb[c]));
+            }
+            bh |= hb[0] << (16 * e); bl |= lb[0] << (16 * e);
+            hh[0] |= hb[1] << (16 * e); hl[0] |= lb[1] << (16 * e);
+            hh[1] |= hb[2] << (16 * e); hl[1] |= lb[2] << (16 * e);
+        }
+        tbh[jj] = bh; tbl[jj] = bl;
+        thh[0][jj] = hh[0]; thl[0][jj] = hl[0]; thh[1][jj] = hh[1]; thl[1][jj] = hl[1];
+    }
+    const half8_t TBh = as_half8(tbh[0], tbh[1], tbh[2], tbh[3]), TBl = as_half8(tbl[0], tbl[1], tbl[2], tbl[3]);
+    const half8_t THh[2] = {as_half8(thh[0][0], thh[0][1], thh[0][2], thh[0][3]), as_half8(thh[1][0], thh[1][1], thh[1][2], thh[1][3])};
+    const half8_t THl[2] = {as_half8(thl[0][0], thl[0][1], thl[0][2], thl[0][3]), as_half8(thl[1][0], thl[1][1], thl[1][2], thl[1][3])};
+
+    // the tile rows beyond what the blur writes must hold finite numbers (they meet zero weights)
+    for (int i = tid; i < (int)(sizeof(L.f16) / 4); i += TM_THREADS) reinterpret_cast<uint32_t *>(L.f16)[i] = 0u;
+    if (tid == 0) L.n_list = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int per_frame = P.panels * P.bands;
+    long long first, stride, count;
+    int f_mul, f_add;
+    if (P.by_xcd) {
+        first = blockIdx.x >> 3; stride = gridDim.x >> 3; count = (long long)(P.batch >> 3) * per_frame; f_mul = 8; f_add = (int)(blockIdx.x & 7u);
+    } else {
+        first = blockIdx.x; stride = gridDim.x; count = (long long)P.batch * per_frame; f_mul = 1; f_add = 0;
+    }
+
+    for (long long item = first; item < count; item += stride) {
+        ThrItem it;
+        {
+            const int rem = (int)(item % per_frame);
+            it.f = (int)(item / per_frame) * f_mul + f_add;
+            const int panel = rem % P.panels, band = rem / P.panels;
+            it.x0 = panel * P.panel_w; it.x1 = min(it.x0 + P.panel_w, W);
+            it.y0 = band * P.band_h;   it.y1 = min(it.y0 + P.band_h, H);
+        }
+        const uint8_t *frame = frames + (size_t)it.f * H * W;
+        uint8_t *dst = cls + (size_t)it.f * H * W;
+        const int PW = it.x1 - it.x0;                       // a multiple of 4
+        const int ntiles = (PW + 15) >> 4;
+        const int nch = (PW + 32 + 15) >> 4;                // raw chunks per row
+        const int nblk = (it.y1 - it.y0 + TM_ROWS - 1) / TM_ROWS;
+        const bool edge_l = it.x0 == 0, edge_r = it.x1 == W;
+        const int dlo = edge_l ? 0 : -2, dhi = (PW >> 2) + (edge_r ? 0 : 2);   // blurred dwords [dlo, dhi)
+        const int groups = (dhi - dlo + TM_GROUP - 1) / TM_GROUP;
+        // the row tail: the last 16-byte chunk of an image row is fetched from column W - 16, i.e. shifted by `tail_shift`
+        const int tail_col = ((W - 1) & ~15) - (it.x0 - 16);          // panel-raw column where that chunk begins
+        const int tail_shift = ((W - 1) & ~15) + 16 - W;              // 0 when W is a multiple of 16
+
+        // ---- this thread's raw chunks (the same every step): piece = wave + TM_WAVES k, chunk = 64 piece + lane -----
+        uint32_t goff[TM_PIECES_PER_WAVE]; bool gok[TM_PIECES_PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < TM_PIECES_PER_WAVE; ++k) {
+            const int ci = (wave + TM_WAVES * k) * 64 + lane;
+            const int r = ci / nch, c = ci - r * nch;
+            gok[k] = r < TM_RAW_ROWS;
+            const int col = clampi(it.x0 - 16 + 16 * c, 0, W - 16);
+            goff[k] = (uint32_t)((gok[k] ? r : 0) * W + col);
+        }
+        const int npieces = (TM_RAW_ROWS * nch + 63) >> 6;
+        auto raw_base_row = [&](int s) { return clampi(it.y0 - 5 + TM_ROWS * s - 1, 0, H - TM_RAW_ROWS); };
+        auto request_raw = [&](int s) __attribute__((always_inline)) {
+            const uint32_t row_off = (uint32_t)raw_base_row(s) * (uint32_t)W;
+#pragma unroll
+            for (int k = 0; k < TM_PIECES_PER_WAVE; ++k) {
+                const int piece = wave + TM_WAVES * k;
+                if (piece < npieces) {   // wave-uniform
+                    const uint32_t lds = (uint32_t)(uintptr_t)&L.raw[s & 1][piece * 1024];
+                    const uint32_t off = row_off + goff[k];
+                    if (gok[k])
+                        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(off), "s"(frame) : "memory");
+                }
+            }
+        };
+
+        // ---- blur of step s: wave w computes tile rows w, w + TM_WAVES, ... ----------------------------------------
+        auto blur_step = [&](int s) __attribute__((always_inline)) {
+            const int a = raw_base_row(s);
+            const int RP = nch * 16;
+            const uint8_t *raw = L.raw[s & 1];
+            for (int tr = wave; tr < TM_ROWS; tr += TM_WAVES)
+            for (int g = 0; g < groups; ++g) {
+                const int yy = clampi(it.y0 - 5 + TM_ROWS * s + tr, 0, H - 1);
+                const uint8_t *ru = raw + (reflect101(yy - 1, H) - a) * RP, *rc = raw + (yy - a) * RP, *rd = raw + (reflect101(yy + 1, H) - a) * RP;
+                _Float16 *trow = L.f16[s & 1][tr];
+                const int d = dlo + TM_GROUP * g - 1 + lane;          // dword: columns x0 + 4d .. + 3
+                int off = 16 + 4 * clampi(d, -4, (PW >> 2) + 3);
+                if (tail_shift && off >= tail_col) off += tail_shift;
+                off = min(off, RP - 4);
+                const uint32_t gu = *reinterpret_cast<const uint32_t *>(ru + off), gc = *reinterpret_cast<const uint32_t *>(rc + off),
+                               gd = *reinterpret_cast<const uint32_t *>(rd + off);
+                const uint32_t M = 0x00FF00FFu;
+                const uint32_t ve = (gu & M) + ((gc & M) << 1) + (gd & M);
+                const uint32_t vo = ((gu >> 8) & M) + (((gc >> 8) & M) << 1) + ((gd >> 8) & M);
+                const uint32_t vop = lane_shr1(vo), ven = lane_shl1(ve);
+                uint32_t pm = __builtin_amdgcn_alignbit(vo, vop, 16);   // (V-1, V1)
+                uint32_t pp = __builtin_amdgcn_alignbit(ven, ve, 16);   // (V2, V4)
+                if (edge_l && d == 0) pm = (vo & 0xFFFFu) * 0x10001u;               // column -1 := column 1
+                if (edge_r && d == (PW >> 2) - 1) pp = (ve >> 16) * 0x10001u;       // column W := column W - 2
+                const uint32_t h02 = pm + (ve << 1) + vo + 0x00080008u, h13 = ve + (vo << 1) + pp + 0x00080008u;
+                // blurred pixels (0, 2) and (1, 3) as packed f16: 0x6400 | b is 1024 + b
+                const half2_t bias = {(_Float16)1024.0f, (_Float16)1024.0f};
+                const uint32_t m02 = ((h02 >> 4) & M) | 0x64006400u, m13 = ((h13 >> 4) & M) | 0x64006400u;
+                const uint32_t f02 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, m02) - bias);
+                const uint32_t f13 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, m13) - bias);
+                if (lane >= 1 && lane <= TM_GROUP && d < dhi) {
+                    uint2 *pos = reinterpret_cast<uint2 *>(trow + 4 * d + 8);
+                    *pos = make_uint2(f02, f13);
+                    if (edge_l && d == 0) {               // columns -8 .. -1 := column 0
+                        const uint32_t r = (f02 & 0xFFFFu) * 0x10001u;
+                        pos[-1] = make_uint2(r, r); pos[-2] = make_uint2(r, r);
+                    }
+                    if (edge_r && d == (PW >> 2) - 1) {   // columns W .. := column W - 1
+                        const uint32_t r = (f13 >> 16) * 0x10001u;
+                        for (int e = 1; 4 * (d + e) + 8 < 16 * ntiles + 16; ++e) pos[e] = make_uint2(r, r);
+                    }
+                }
+            }
+        };
+
+        // ---- filter: output rows of step s - 1 (window rows 0..15 = tile of step s - 1, 16..31 = tile of step s) ----
+        auto filter_step = [&](int s) __attribute__((always_inline)) {
+            const int oy = it.y0 + TM_ROWS * (s - 1);            // first output row
+            uint32_t *wout = L.out[wave];
+            const int t0 = wave * TM_TILES_PER_WAVE;
+            // column-major reads of the tile: lane 4qq + p of a 16-lane group supplies row qq, positions 4p .. 4p + 3 of a
+            // 4-row x 16-position block and receives position (lane & 15) of the four rows; group q reads window rows 8q .. 8q + 7
+            const int trow = 8 * q + (l16 >> 2);
+            const _Float16 *tr_lo = &L.f16[(trow >> 4) ? (s & 1) : ((s - 1) & 1)][trow & 15][4 * (l16 & 3)];
+            // the centre pixels of this lane's four output columns: window row l16 + 5
+            const int crow = l16 + 5;
+            const _Float16 *cpix = &L.f16[(crow >> 4) ? (s & 1) : ((s - 1) & 1)][crow & 15][8 + 4 * q];
+            uint32_t xh[4] = {0, 0, 0, 0}, xl[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int bi = 0; bi <= TM_TILES_PER_WAVE; ++bi) {
+                const int u = t0 + bi;                            // column block: positions 16u .. 16u + 15
+                const int hsel = bi & 1;
+                if (bi == 0 ? u < ntiles : u - 1 < ntiles) {      // some tile of this wave uses the block (wave-uniform)
+                    typedef short short4_t __attribute__((__vector_size__(4 * sizeof(short))));
+                    const short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t *)(tr_lo + 16 * u));
+                    const short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t *)(tr_lo + 16 * u + 4 * TM_PITCH));
+                    const uint2 a0u = __builtin_bit_cast(uint2, a0), a1u = __builtin_bit_cast(uint2, a1);
+                    const half8_t A = as_half8(a0u.x, a0u.y, a1u.x, a1u.y);
+                    f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+                    cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, TBh, cv, 0, 0, 0);
+                    cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, TBl, cv, 0, 0, 0);
+                    const uint32_t h01 = pkrtz(cv[0], cv[1]), h23 = pkrtz(cv[2], cv[3]);
+                    xh[2 * hsel] = h01; xh[2 * hsel + 1] = h23;
+                    xl[2 * hsel] = pkrtz(sub_f16_lo(cv[0], h01), sub_f16_hi(cv[1], h01));
+                    xl[2 * hsel + 1] = pkrtz(sub_f16_lo(cv[2], h23), sub_f16_hi(cv[3], h23));
+                }
+                if (bi >= 1) {
+                    const int t = u - 1, ti = bi - 1;
+                    if (t < ntiles) {   // wave-uniform
+                        const uint2 sc = *reinterpret_cast<const uint2 *>(cpix + 16 * t);   // positions (0, 2, 1, 3) of the quad
+                        const half2_t s02 = __builtin_bit_cast(half2_t, sc.x), s13 = __builtin_bit_cast(half2_t, sc.y);
+                        f32x4 c2 = {-(float)s02[0], -(float)s13[0], -(float)s02[1], -(float)s13[1]};
+                        const half8_t XH = as_half8(xh[0], xh[1], xh[2], xh[3]), XL = as_half8(xl[0], xl[1], xl[2], xl[3]);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THh[hsel], XH, c2, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THl[hsel], XH, c2, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THh[hsel], XL, c2, 0, 0, 0);
+                        // c2[r] = mean - b at output row l16, column 16t + 4q + r;
+                        // x saturates to byte 0 / 255 when v is farther than EPS from the level, on the side that clears / sets the bit
+                        uint32_t pk_lo = 0, pk_hi = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pk_lo = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(c2[r], P.x_mul, P.lo_add), r, pk_lo);
+                            pk_hi = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(c2[r], P.x_mul, P.hi_add), r, pk_hi);
+                        }
+                        const uint32_t b_lo = (pk_lo >> 7) & 0x01010101u, b_hi = (pk_hi >> 7) & 0x01010101u;
+                        uint32_t amb = (pk_lo ^ ((b_lo << 8) - b_lo)) | (pk_hi ^ ((b_hi << 8) - b_hi));   // bytes other than 0x00 / 0xFF
+                        const uint32_t cb = b_lo | (b_hi << 1);
+                        if (EPS_MODE == 2) amb = 0x01010101u;          // diagnostic build: every pixel takes the exact path
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(amb != 0u) != 0ull, 0)) {
+                            const int y = oy + l16;
+                            if (amb != 0u && y < it.y1) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int x = it.x0 + 16 * t + 4 * q + r;
+                                    if (((amb >> (8 * r)) & 0xFFu) && x < it.x1) {
+                                        const uint32_t slot = atomicAdd(&L.n_list, 1u);
+                                        if (slot < (uint32_t)TM_LIST_CAP) L.list[slot] = ((uint32_t)y << 16) | (uint32_t)x;
+                                    }
+                                }
+                            }
+                        }
+                        wout[l16 * (TM_OUT_PITCH / 4) + 4 * ti + q] = cb;
+                    }
+                }
+            }
+            // the wave's 16 rows x 80 bytes leave as 16-byte pieces: piece = (row, 16 columns)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int rows = min(TM_ROWS, it.y1 - oy);
+            const int xw = it.x0 + 16 * t0;                               // first column of this wave's tiles
+#pragma unroll
+            for (int k = 0; k < (TM_ROWS * TM_TILES_PER_WAVE + 63) / 64; ++k) {
+                const int pc = lane + 64 * k;
+                const int r = pc / TM_TILES_PER_WAVE, c = pc - r * TM_TILES_PER_WAVE;
+                const int x = xw + 16 * c;
+                if (pc < TM_ROWS * TM_TILES_PER_WAVE && r < rows && x < it.x1) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint8_t *>(wout) + r * TM_OUT_PITCH + 16 * c);
+                    uint8_t *g = dst + (size_t)(oy + r) * W + x;
+                    const int nb = it.x1 - x;                             // bytes left in the row: 4, 8, 12 or >= 16
+                    if (nb >= 16) __builtin_memcpy(g, &v, 16);
+                    else {
+                        uint32_t *g4 = reinterpret_cast<uint32_t *>(g);
+                        g4[0] = v[0];
+                        if (nb >= 8) g4[1] = v[1];
+                        if (nb >= 12) g4[2] = v[2];
+                    }
+                }
+            }
+        };
+
+        // ---- the walk ------------------------------------------------------------------------------------------------
+        request_raw(0);
+        if (nblk >= 1) request_raw(1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        blur_step(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int s = 0; s <= nblk; ++s) {
+            if (s + 2 <= nblk) request_raw(s + 2);               // into the buffer the blur of step s has finished with
+            if (s >= 1) filter_step(s);
+            // this step's DMA pieces are read after the NEXT barrier pair; the class-map stores stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s + 1 <= nblk) blur_step(s + 1);                 // overwrites the tile of step s - 1
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+
+        // ---- ambiguous pixels: cv2's own arithmetic, sixteen lanes per pixel -------------------------------------------
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");          // every provisional byte of the item is on its way
+        const uint32_t n_amb = L.n_list;
+        if (__builtin_expect(n_amb != 0u, 0)) {
+            if (n_amb <= (uint32_t)TM_LIST_CAP) {
+                for (uint32_t e0 = 0; e0 < n_amb; e0 += TM_THREADS / 16) {
+                    const uint32_t e = e0 + (uint32_t)(tid >> 4);
+                    const uint32_t ent = L.list[min(e, n_amb - 1)];
+                    const int y = (int)(ent >> 16), x = (int)(ent & 0xFFFFu);
+                    const uint32_t c = exact_class(frame, P, y, x, lane);
+                    if (e < n_amb && l16 == 0) dst[(size_t)y * W + x] = (uint8_t)c;
+                }
+            } else {
+                // more than the list holds (a frame made to sit on the levels): the whole item again, exactly
+                const int npx = PW * (it.y1 - it.y0);
+                for (int p0 = 0; p0 < npx; p0 += TM_THREADS / 16) {
+                    const int p = min(p0 + (tid >> 4), npx - 1);
+                    const int y = it.y0 + p / PW, x = it.x0 + p % PW;
+                    const uint32_t c = exact_class(frame, P, y, x, lane);
+                    if (p0 + (tid >> 4) < npx && l16 == 0) dst[(size_t)y * W + x] = (uint8_t)c;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tid == 0) L.n_list = 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+}  // namespace
+
+namespace ysmr_thr {
+
+bool supported(int H, int W, int channels, int t_low, int t_high, int use_high)
+{
+    const int gap = use_high ? (t_high > t_low ? t_high - t_low : t_low - t_high) : 1;
+    return channels == 1 && (W & 3) == 0 && W >= 64 && W <= 16384 && H >= TM_RAW_ROWS && H <= 16383 && gap >= 1 &&
+           t_low > -1000 && t_low < 1000 && t_high > -1000 && t_high < 1000;
+}
+
+int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H, int W, int inv, int t_low, int t_high,
+           int use_high, const float *gauss11, int blocks_wanted, int variant)
+{
+    Params P{};
+    P.H = H; P.W = W; P.batch = batch;
+    P.panels = (W + TM_MAX_PANEL - 1) / TM_MAX_PANEL;
+    P.panel_w = ((W + P.panels - 1) / P.panels + 15) & ~15;
+    P.panels = (W + P.panel_w - 1) / P.panel_w;
+    const int blocks = blocks_wanted > 0 ? blocks_wanted : 256;
+    // bands: as tall as they can be while every resident workgroup still has an item (an item re-filters 16 halo rows),
+    // a multiple of 16 rows, at least 32
+    {
+        const long long columns = (long long)batch * P.panels;
+        const long long per_col = std::max<long long>(1, blocks / std::max<long long>(1, columns));
+        int bh = (int)((H + per_col - 1) / per_col);
+        bh = std::max(32, (bh + 15) & ~15);
+        P.band_h = bh;
+        P.bands = (H + bh - 1) / bh;
+    }
+    P.inv = inv; P.use_high = use_high; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
+    for (int i = 0; i < 6; ++i) P.kw[i] = gauss11[i];
+    // v = mean - b.  BINARY: bit = (b - m > t) <=> v < -t - 0.5;  INV: bit = (b - m <= t) <=> v > -t - 0.5 (ties: exact path).
+    // x = sign * S * (theta - v) + 127.5 leaves [0, 255) exactly when v is EPS = 127.5 / S or more away from theta
+    const float eps = variant == 1 ? 1e-9f : 1.0f / 128.0f;
+    const float S = 127.5f / eps, sgn = inv ? -1.0f : 1.0f;
+    P.x_mul = -sgn * S;
+    P.lo_add = sgn * S * (-(float)t_low - 0.5f) + 127.5f;
+    P.hi_add = use_high ? sgn * S * (-(float)t_high - 0.5f) + 127.5f : P.lo_add;   // one level: both bits are the same
+    const long long items = (long long)batch * P.panels * P.bands;
+    long long grid = std::min<long long>(items, blocks);
+    P.by_xcd = (batch % 8 == 0 && grid % 8 == 0 && grid / 8 <= (long long)(batch / 8) * P.panels * P.bands) ? 1 : 0;
+    const size_t lds = sizeof(Lds);
+    auto kern = variant == 2 ? k_threshold_mfma<2> : k_threshold_mfma<0>;
+    YSMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TM_THREADS), lds, st, frames, cls, P);
+    YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+}  // namespace ysmr_thr

@@ -156,10 +156,11 @@ class Detector:
         return b, ch
 
     @_on_own_device
-    def threshold(self, frames: torch.Tensor) -> torch.Tensor:
+    def threshold(self, frames: torch.Tensor, variant: int = 0) -> torch.Tensor:
         """a1-a3 only: class map u8 [b,H,W] (bit0 thresh, bit1 markers).  In the mean-gray branch the
         call also advances the moving-average state by these frames; per-frame mean, stddev, level and
-        averaged level are left in ``mean_stats[:b]``, the integer levels in ``mean_levels[:b]``."""
+        averaged level are left in ``mean_stats[:b]``, the integer levels in ``mean_levels[:b]``.
+        ``variant``: which kernel (``ysmr_threshold_batch_variant`` in include/ysmr_hip.h; 0 = the shipped choice)."""
         b, ch = self._check_frames(frames)
         p = self.params
         if self.mean_state is not None:
@@ -168,6 +169,12 @@ class Detector:
                 self.mean_state.buf.data_ptr(), self.mean_stats.data_ptr(), self.mean_levels.data_ptr(),
                 self._cls.data_ptr(), self.cv_flavour)
             _lib.check(rc, "ysmr_mean_threshold_batch")
+            return self._view(self._cls, b)
+        if variant:
+            rc = _lib.lib().ysmr_threshold_batch_variant(_lib.stream_ptr(self.device), frames.data_ptr(), b, self.H, self.W,
+                                                         ch, p.inv, p.t_low, p.t_high, p.use_high, self._cls.data_ptr(),
+                                                         self.cv_flavour, int(variant))
+            _lib.check(rc, "ysmr_threshold_batch_variant")
             return self._view(self._cls, b)
         rc = _lib.lib().ysmr_threshold_batch(_lib.stream_ptr(self.device), frames.data_ptr(), b, self.H, self.W, ch,
                                              p.inv, p.t_low, p.t_high, p.use_high, self._cls.data_ptr(), self.cv_flavour)

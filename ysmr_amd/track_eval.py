@@ -92,10 +92,11 @@ class TrackingPipeline:
         self._k = 0
 
     @_on_own_device
-    def detect_async(self, frames_dev, threshold_events=None):
+    def detect_async(self, frames_dev, threshold_events=None, chain_events=None):
         """Issue detection of one batch on the side stream; returns (slot, result, ready_event).
         ``threshold_events``: list that receives a (start, stop) HIP event pair bracketing the fused
-        threshold kernel on the stream it is launched on (bench.py's roofline measurement)."""
+        threshold kernel on the stream it is launched on (bench.py's roofline measurement);
+        ``chain_events``: the same for the labelling / geometry chain behind it."""
         slot = self._k & 1
         self._k += 1
         cur = torch.cuda.current_stream(self.device)
@@ -113,6 +114,10 @@ class TrackingPipeline:
                 e1.record(self.side)
                 threshold_events.append((e0, e1, frames_dev.shape[0]))
                 res = det.components(frames_dev.shape[0])
+                if chain_events is not None:
+                    e2 = torch.cuda.Event(enable_timing=True)
+                    e2.record(self.side)
+                    chain_events.append((e1, e2, frames_dev.shape[0]))
             ready = torch.cuda.Event()
             ready.record(self.side)
         return slot, res, ready
@@ -123,11 +128,22 @@ class TrackingPipeline:
         self.row_count.zero_()
 
     @_on_own_device
-    def link(self, slot, res, ready, first_frame):
-        """Link one detected batch on the current stream; rows accumulate in self.rows."""
+    def link(self, slot, res, ready, first_frame, link_events=None):
+        """Link one detected batch on the current stream; rows accumulate in self.rows.
+        ``link_events``: list that receives a (start, stop, frames, host_seconds) record around the batch's
+        launches -- HIP events on the link stream, and how long the host took to issue them."""
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ready)
-        self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
+        if link_events is None:
+            self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            t0 = time.perf_counter()
+            self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
+            host = time.perf_counter() - t0
+            e1.record(cur)
+            link_events.append((e0, e1, int(res.det_count.shape[0]), host))
         done = torch.cuda.Event()
         done.record(cur)
         self._done[slot] = done
