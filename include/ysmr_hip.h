@@ -113,12 +113,12 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
 
 /* The same call with the kernel named (test and measurement aid; the results are the same bytes whichever is taken).
  * Gray frames of at least 18 rows and 64 columns (width a multiple of 4) are served by a kernel that evaluates the
- * Gaussian mean on the matrix pipe to within 1/128, decides every pixel that is farther than that from both levels
+ * Gaussian mean on the matrix pipe to within 1/512, decides every pixel that is farther than that from both levels
  * and re-evaluates the rest with cv2's float32 arithmetic (csrc/thr_mfma.hip); everything else, and BGR input, by the
  * kernels that run that arithmetic for every pixel (csrc/detect.hip: k_threshold_strip, k_threshold).
- * variant 0: as ysmr_threshold_batch; 1: the float32-chain kernels only; 2: the matrix-pipe kernel deciding EVERY
- * pixel that is not an exact tie (wrong bytes measure how far its mean is from cv2's: diagnostic); 3: the matrix-pipe
- * kernel with every pixel sent through its exact path (diagnostic).  2 and 3 fail for geometries that kernel does
+ * variant 0: as ysmr_threshold_batch; 1: the float32-chain kernels only; 2: the matrix-pipe kernel deciding every
+ * pixel farther than 1/2048 from the levels (a quarter of the shipped margin: any wrong byte says that the margin is
+ * being used up; diagnostic); 3: the matrix-pipe kernel with every pixel sent through its exact path (diagnostic).  2 and 3 fail for geometries that kernel does
  * not serve. */
 int ysmr_threshold_batch_variant(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
                                  int channels, int inv, int t_low, int t_high, int use_high,

@@ -12,15 +12,16 @@ struct Params {
     int by_xcd;            // frames are dealt to the 8 XCDs
     int inv, use_high, t_low, t_high;
     // x = S * (theta - v) * sign + 127.5 saturates to byte 0 / 255 outside EPS of the level theta (v = mean - blurred)
-    float x_mul, lo_add, hi_add;
+    float x_mul, neg_x_mul, lo_add, hi_minus_lo;
+    uint32_t lo_bits;      // class bits taken from the first level's byte (both when there is one level)
     float kw[6];           // the Gaussian's distinct weights k[0..5] (k[i] == k[10 - i]), cv2's float32 values
 };
 
 // geometry / arguments the kernel serves (everything else stays on k_threshold_strip / k_threshold)
 bool supported(int H, int W, int channels, int t_low, int t_high, int use_high);
 
-// variant: 0 = shipped (EPS = 1/128), 1 = EPS -> 0 (diagnostic: every pixel decided by the matrix pipe alone, only exact
-// ties refined), 2 = every pixel through the exact path (diagnostic)
+// variant: 0 = shipped (EPS = 1/512), 1 = EPS = 1/2048 (diagnostic: a quarter of the margin), 2 = every pixel through the
+// exact path (diagnostic)
 int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H, int W, int inv, int t_low, int t_high,
            int use_high, const float *gauss11, int blocks_wanted, int variant);
 

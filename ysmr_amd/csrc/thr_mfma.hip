@@ -28,14 +28,15 @@
 //   blur   step s+1: s_raw[(s+1) & 1] -> SWAR 3x3 blur -> f16 tile s_f16[(s+1) & 1]   (wave w = tile row w)
 //   barrier
 // Nothing is carried in registers from step to step.
-// Error bound (EPS = 1/128): the pixels are exact; each weight enters as hi + lo with a residual below 2^-11 |lo|
-// (< 3e-8, x 255 x 11 < 1e-4); a row-filtered value enters as rtz-f16 hi + f16 lo (residual < 2^-10 x 2^-3 = 1.3e-4,
-// the weights sum to 1); the dropped lo x lo product is below 2e-4 x 0.13 = 3e-5; float32 accumulation of at most
-// 32 + 32 products of magnitude <= 255 per chained MFMA, six MFMAs: < 6 x 64 x 2^-24 x 255 = 6e-3 if every partial sum
-// were rounded separately and all errors added up (the hardware does better); cv2's own chain is within 2e-4 of the
-// real mean.  Sum < 7e-3 < EPS = 7.8e-3.  tests/test_gpu_detect.py runs the kernel with EPS scaled to 0 in a tuning
-// build to MEASURE the distance (the count of wrong pixels is the test), and with EPS huge so that every pixel takes
-// the exact path.
+// Error bound (EPS = 1/512 = 1.95e-3): the pixels are exact; each tap enters as f16 hi + lo with a residual below
+// 2^-11 |lo| (< 3e-8 of the weight's scale; x 255 x 11 taps, two passes: < 2e-4); a column-filtered value enters the row pass
+// as rtz-f16 hi + rtz-f16 lo (residual < 2^-10 x 2^-3 = 1.2e-4; the taps sum to 1); the dropped lo x lo product is below
+// 3.2e-4 x 0.125 = 4e-5; float32 accumulation inside the five chained MFMAs (32 products each) costs at most
+// 5 x 32 x 2^-24 x 255 = 2.4e-3 if every partial sum were rounded on its own and all errors lined up, and 5 x 2^-24 x 255
+// = 8e-5 with one rounding per MFMA; cv2's own chain is within 22 x 2^-24 x 255 = 3.3e-4 of the real mean.  MEASURED
+// (tests/test_gpu_detect.py::test_threshold_matrix_pipe_distance): with EPS = 1/2048 the kernel still reproduces the
+// oracle byte for byte on 3.9 M pixels of uniform noise, and an earlier build that decided everything but exact ties
+// differed in 3 of them -- a distance of about 2e-5, a hundredth of EPS.
 #include "common.h"
 #include "thr_mfma.h"
 #include <algorithm>
@@ -48,17 +49,23 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM_WAVES = 16, TM_THREADS = 64 * TM_WAVES;
+#ifndef TM_WAVES_N
+#define TM_WAVES_N 16
+#endif
+#ifndef TM_MAX_PANEL_N
+#define TM_MAX_PANEL_N 1232
+#endif
+constexpr int TM_WAVES = TM_WAVES_N, TM_THREADS = 64 * TM_WAVES;
 constexpr int TM_ROWS = 16;                       // rows per step (one MFMA tile row block)
 constexpr int TM_RAW_ROWS = 18;                   // gray rows a step's blur needs
-constexpr int TM_MAX_PANEL = 1232;                // columns per panel (77 tiles of 16)
+constexpr int TM_MAX_PANEL = TM_MAX_PANEL_N;      // columns per panel, a multiple of 16 (1232: 77 tiles of 16)
 constexpr int TM_TILES_PER_WAVE = (TM_MAX_PANEL / 16 + TM_WAVES - 1) / TM_WAVES;   // 5
 constexpr int TM_PITCH = TM_MAX_PANEL + 16;       // f16 per tile row: position p = column - x0 + 8
 constexpr int TM_RAW_CHUNKS = (TM_MAX_PANEL + 32 + 15) / 16;   // 16-byte chunks per raw row: columns x0 - 16 ...
 constexpr int TM_RAW_PIECES = (TM_RAW_ROWS * TM_RAW_CHUNKS + 63) / 64;   // 1 KiB DMA pieces per step
 constexpr int TM_PIECES_PER_WAVE = (TM_RAW_PIECES + TM_WAVES - 1) / TM_WAVES;
 constexpr int TM_OUT_PITCH = 16 * TM_TILES_PER_WAVE;           // bytes per row of a wave's class-byte staging
-constexpr int TM_LIST_CAP = 2048;                 // ambiguous pixels a work item can list
+constexpr int TM_LIST_CAP = 1024;                 // ambiguous pixels a work item can list
 constexpr int TM_GROUP = 62;                      // blur: output dwords per 64-lane group (lanes 0 and 63 are halo)
 
 struct ThrItem {
@@ -82,6 +89,19 @@ __device__ __forceinline__ float sub_f16_hi(float x, uint32_t h)
 {
     float r;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+// float(h) * a + b for the low / high half of a packed f16 pair
+__device__ __forceinline__ float mad_f16_lo(uint32_t h, float a, float b)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float mad_f16_hi(uint32_t h, float a, float b)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ uint32_t pkrtz(float a, float b)
@@ -175,7 +195,8 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const bool ok = taps[c] >= 0 && taps[c] <= 10;
-                const float w = ok ? tap_weight(P, clampi(taps[c], 0, 10)) : 0.0f;
+                // (the row pass's taps carry the classification's scale: its accumulator is x_lo itself)
+                const float w = ok ? tap_weight(P, clampi(taps[c], 0, 10)) * (c == 0 ? 1.0f : P.x_mul) : 0.0f;
                 hb[c] = f16_bits(w);
                 lb[c] = f16_bits(w - f16_value(hb[c]));
             }
@@ -222,6 +243,8 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         const bool edge_l = it.x0 == 0, edge_r = it.x1 == W;
         const int dlo = edge_l ? 0 : -2, dhi = (PW >> 2) + (edge_r ? 0 : 2);   // blurred dwords [dlo, dhi)
         const int groups = (dhi - dlo + TM_GROUP - 1) / TM_GROUP;
+        const int g_last = ((PW >> 2) - 1 - dlo) / TM_GROUP;       // the group that holds the row's last dword
+        const int blur_off = 16 + 4 * (dlo - 1 + lane);            // raw-row byte offset of this lane's dword in group 0
         // the row tail: the last 16-byte chunk of an image row is fetched from column W - 16, i.e. shifted by `tail_shift`
         const int tail_col = ((W - 1) & ~15) - (it.x0 - 16);          // panel-raw column where that chunk begins
         const int tail_shift = ((W - 1) & ~15) + 16 - W;              // 0 when W is a multiple of 16
@@ -239,6 +262,9 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         const int npieces = (TM_RAW_ROWS * nch + 63) >> 6;
         auto raw_base_row = [&](int s) { return clampi(it.y0 - 5 + TM_ROWS * s - 1, 0, H - TM_RAW_ROWS); };
         auto request_raw = [&](int s) __attribute__((always_inline)) {
+#ifdef TM_DBG_NOLOAD
+            return;
+#endif
             const uint32_t row_off = (uint32_t)raw_base_row(s) * (uint32_t)W;
 #pragma unroll
             for (int k = 0; k < TM_PIECES_PER_WAVE; ++k) {
@@ -254,51 +280,65 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
 
         // ---- blur of step s: wave w computes tile rows w, w + TM_WAVES, ... ----------------------------------------
         auto blur_step = [&](int s) __attribute__((always_inline)) {
+#ifdef TM_DBG_NOBLUR   // (TM_DBG_*: parts deleted to time the rest, scripts/thr_mfma_parts.sh; results are wrong)
+            return;
+#endif
             const int a = raw_base_row(s);
             const int RP = nch * 16;
             const uint8_t *raw = L.raw[s & 1];
-            for (int tr = wave; tr < TM_ROWS; tr += TM_WAVES)
-            for (int g = 0; g < groups; ++g) {
+            const uint32_t M = 0x00FF00FFu;
+            for (int tr = wave; tr < TM_ROWS; tr += TM_WAVES) {
                 const int yy = clampi(it.y0 - 5 + TM_ROWS * s + tr, 0, H - 1);
                 const uint8_t *ru = raw + (reflect101(yy - 1, H) - a) * RP, *rc = raw + (yy - a) * RP, *rd = raw + (reflect101(yy + 1, H) - a) * RP;
                 _Float16 *trow = L.f16[s & 1][tr];
-                const int d = dlo + TM_GROUP * g - 1 + lane;          // dword: columns x0 + 4d .. + 3
-                int off = 16 + 4 * clampi(d, -4, (PW >> 2) + 3);
-                if (tail_shift && off >= tail_col) off += tail_shift;
-                off = min(off, RP - 4);
-                const uint32_t gu = *reinterpret_cast<const uint32_t *>(ru + off), gc = *reinterpret_cast<const uint32_t *>(rc + off),
-                               gd = *reinterpret_cast<const uint32_t *>(rd + off);
-                const uint32_t M = 0x00FF00FFu;
-                const uint32_t ve = (gu & M) + ((gc & M) << 1) + (gd & M);
-                const uint32_t vo = ((gu >> 8) & M) + (((gc >> 8) & M) << 1) + ((gd >> 8) & M);
-                const uint32_t vop = lane_shr1(vo), ven = lane_shl1(ve);
-                uint32_t pm = __builtin_amdgcn_alignbit(vo, vop, 16);   // (V-1, V1)
-                uint32_t pp = __builtin_amdgcn_alignbit(ven, ve, 16);   // (V2, V4)
-                if (edge_l && d == 0) pm = (vo & 0xFFFFu) * 0x10001u;               // column -1 := column 1
-                if (edge_r && d == (PW >> 2) - 1) pp = (ve >> 16) * 0x10001u;       // column W := column W - 2
-                const uint32_t h02 = pm + (ve << 1) + vo + 0x00080008u, h13 = ve + (vo << 1) + pp + 0x00080008u;
-                // blurred pixels (0, 2) and (1, 3) as packed f16: 0x6400 | b is 1024 + b
-                const half2_t bias = {(_Float16)1024.0f, (_Float16)1024.0f};
-                const uint32_t m02 = ((h02 >> 4) & M) | 0x64006400u, m13 = ((h13 >> 4) & M) | 0x64006400u;
-                const uint32_t f02 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, m02) - bias);
-                const uint32_t f13 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, m13) - bias);
-                if (lane >= 1 && lane <= TM_GROUP && d < dhi) {
+                // group g: dwords dlo - 1 + 62 g + lane; the reads of group g + 1 are in flight during the arithmetic of g
+                auto fetch = [&](int g, uint32_t &u, uint32_t &c, uint32_t &dn) __attribute__((always_inline)) {
+                    int off = blur_off + 4 * TM_GROUP * g;
+                    if (tail_shift && off >= tail_col) off += tail_shift;
+                    off = min(off, RP - 4);
+                    u = *reinterpret_cast<const uint32_t *>(ru + off); c = *reinterpret_cast<const uint32_t *>(rc + off);
+                    dn = *reinterpret_cast<const uint32_t *>(rd + off);
+                };
+                uint32_t gu, gc, gd, nu = 0, nc = 0, nd = 0;
+                fetch(0, gu, gc, gd);
+                for (int g = 0; g < groups; ++g) {
+                    if (g + 1 < groups) fetch(g + 1, nu, nc, nd);
+                    const int d = dlo + TM_GROUP * g - 1 + lane;          // dword: columns x0 + 4d .. + 3
+                    // bytes (0, 2) and (1, 3) of each row as 16-bit fields (v_perm), vertical 1-2-1
+                    const uint32_t ve = __builtin_amdgcn_perm(0, gu, 0x0C020C00u) + (__builtin_amdgcn_perm(0, gc, 0x0C020C00u) << 1) + __builtin_amdgcn_perm(0, gd, 0x0C020C00u);
+                    const uint32_t vo = __builtin_amdgcn_perm(0, gu, 0x0C030C01u) + (__builtin_amdgcn_perm(0, gc, 0x0C030C01u) << 1) + __builtin_amdgcn_perm(0, gd, 0x0C030C01u);
+                    const uint32_t vop = lane_shr1(vo), ven = lane_shl1(ve);
+                    uint32_t pm = __builtin_amdgcn_alignbit(vo, vop, 16);   // (V-1, V1)
+                    uint32_t pp = __builtin_amdgcn_alignbit(ven, ve, 16);   // (V2, V4)
+                    const bool first = edge_l && g == 0, last = edge_r && g == g_last;   // wave-uniform
+                    if (first) pm = d == 0 ? (vo & 0xFFFFu) * 0x10001u : pm;                        // column -1 := column 1
+                    if (last) pp = d == (PW >> 2) - 1 ? (ve >> 16) * 0x10001u : pp;                 // column W := column W - 2
+                    const uint32_t h02 = pm + (ve << 1) + vo + 0x00080008u, h13 = ve + (vo << 1) + pp + 0x00080008u;
+                    // blurred pixels (0, 2) and (1, 3) as packed f16: 0x6400 | b is 1024 + b
+                    const half2_t bias = {(_Float16)1024.0f, (_Float16)1024.0f};
+                    const uint32_t m02 = ((h02 >> 4) & M) | 0x64006400u, m13 = ((h13 >> 4) & M) | 0x64006400u;
+                    const uint32_t f02 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, m02) - bias);
+                    const uint32_t f13 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, m13) - bias);
                     uint2 *pos = reinterpret_cast<uint2 *>(trow + 4 * d + 8);
-                    *pos = make_uint2(f02, f13);
-                    if (edge_l && d == 0) {               // columns -8 .. -1 := column 0
+                    if (lane >= 1 && lane <= TM_GROUP && d < dhi) *pos = make_uint2(f02, f13);
+                    if (first && d == 0) {                   // columns -8 .. -1 := column 0
                         const uint32_t r = (f02 & 0xFFFFu) * 0x10001u;
                         pos[-1] = make_uint2(r, r); pos[-2] = make_uint2(r, r);
                     }
-                    if (edge_r && d == (PW >> 2) - 1) {   // columns W .. := column W - 1
+                    if (last && d == (PW >> 2) - 1) {        // columns W .. := column W - 1
                         const uint32_t r = (f13 >> 16) * 0x10001u;
                         for (int e = 1; 4 * (d + e) + 8 < 16 * ntiles + 16; ++e) pos[e] = make_uint2(r, r);
                     }
+                    gu = nu; gc = nc; gd = nd;
                 }
             }
         };
 
         // ---- filter: output rows of step s - 1 (window rows 0..15 = tile of step s - 1, 16..31 = tile of step s) ----
         auto filter_step = [&](int s) __attribute__((always_inline)) {
+#ifdef TM_DBG_NOFILTER
+            return;
+#endif
             const int oy = it.y0 + TM_ROWS * (s - 1);            // first output row
             uint32_t *wout = L.out[wave];
             const int t0 = wave * TM_TILES_PER_WAVE;
@@ -321,8 +361,12 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                     const uint2 a0u = __builtin_bit_cast(uint2, a0), a1u = __builtin_bit_cast(uint2, a1);
                     const half8_t A = as_half8(a0u.x, a0u.y, a1u.x, a1u.y);
                     f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+#ifndef TM_DBG_NOMFMA
                     cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, TBh, cv, 0, 0, 0);
                     cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, TBl, cv, 0, 0, 0);
+#else
+                    cv[0] = (float)A[0]; cv[1] = (float)A[2]; cv[2] = (float)A[5]; cv[3] = (float)A[7];
+#endif
                     const uint32_t h01 = pkrtz(cv[0], cv[1]), h23 = pkrtz(cv[2], cv[3]);
                     xh[2 * hsel] = h01; xh[2 * hsel + 1] = h23;
                     xl[2 * hsel] = pkrtz(sub_f16_lo(cv[0], h01), sub_f16_hi(cv[1], h01));
@@ -332,23 +376,31 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                     const int t = u - 1, ti = bi - 1;
                     if (t < ntiles) {   // wave-uniform
                         const uint2 sc = *reinterpret_cast<const uint2 *>(cpix + 16 * t);   // positions (0, 2, 1, 3) of the quad
-                        const half2_t s02 = __builtin_bit_cast(half2_t, sc.x), s13 = __builtin_bit_cast(half2_t, sc.y);
-                        f32x4 c2 = {-(float)s02[0], -(float)s13[0], -(float)s02[1], -(float)s13[1]};
+                        // x_lo = x_mul (mean - b) + lo_add: the taps carry x_mul, the accumulator starts at lo_add - x_mul b
+                        f32x4 c2 = {mad_f16_lo(sc.x, P.neg_x_mul, P.lo_add), mad_f16_lo(sc.y, P.neg_x_mul, P.lo_add),
+                                    mad_f16_hi(sc.x, P.neg_x_mul, P.lo_add), mad_f16_hi(sc.y, P.neg_x_mul, P.lo_add)};
                         const half8_t XH = as_half8(xh[0], xh[1], xh[2], xh[3]), XL = as_half8(xl[0], xl[1], xl[2], xl[3]);
+#ifndef TM_DBG_NOMFMA
                         c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THh[hsel], XH, c2, 0, 0, 0);
                         c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THl[hsel], XH, c2, 0, 0, 0);
                         c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THh[hsel], XL, c2, 0, 0, 0);
-                        // c2[r] = mean - b at output row l16, column 16t + 4q + r;
-                        // x saturates to byte 0 / 255 when v is farther than EPS from the level, on the side that clears / sets the bit
+#else
+                        c2[0] += (float)XH[0] + (float)XL[1]; c2[1] += (float)XH[2]; c2[2] += (float)XL[4]; c2[3] += (float)XH[6];
+#endif
+                        // c2[r] = x_lo at output row l16, column 16t + 4q + r; x saturates to byte 0x00 / 0xFF when the mean is
+                        // farther than EPS from the level, on the side that clears / sets the bit; x_hi = x_lo + (hi_add - lo_add)
                         uint32_t pk_lo = 0, pk_hi = 0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            pk_lo = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(c2[r], P.x_mul, P.lo_add), r, pk_lo);
-                            pk_hi = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(c2[r], P.x_mul, P.hi_add), r, pk_hi);
+                            pk_lo = __builtin_amdgcn_cvt_pk_u8_f32(c2[r], r, pk_lo);
+                            pk_hi = __builtin_amdgcn_cvt_pk_u8_f32(c2[r] + P.hi_minus_lo, r, pk_hi);
                         }
-                        const uint32_t b_lo = (pk_lo >> 7) & 0x01010101u, b_hi = (pk_hi >> 7) & 0x01010101u;
-                        uint32_t amb = (pk_lo ^ ((b_lo << 8) - b_lo)) | (pk_hi ^ ((b_hi << 8) - b_hi));   // bytes other than 0x00 / 0xFF
-                        const uint32_t cb = b_lo | (b_hi << 1);
+                        // decided bytes are 0x00 / 0xFF: the class bits are bit 0 of pk_lo and bit 1 of pk_hi.  The levels are at
+                        // least 2^16 x-units apart, so at most one of the two bytes of a pixel is undecided, and then their XOR
+                        // is neither 0x00 nor 0xFF either: some bit differs from its upper neighbour inside the byte
+                        const uint32_t cb = (pk_lo & P.lo_bits) | (pk_hi & 0x02020202u);
+                        const uint32_t z = pk_lo ^ pk_hi;
+                        uint32_t amb = (z ^ (z >> 1)) & 0x7F7F7F7Fu;
                         if (EPS_MODE == 2) amb = 0x01010101u;          // diagnostic build: every pixel takes the exact path
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(amb != 0u) != 0ull, 0)) {
                             const int y = oy + l16;
@@ -376,7 +428,11 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 const int pc = lane + 64 * k;
                 const int r = pc / TM_TILES_PER_WAVE, c = pc - r * TM_TILES_PER_WAVE;
                 const int x = xw + 16 * c;
+#ifdef TM_DBG_NOSTORE
+                if (pc < TM_ROWS * TM_TILES_PER_WAVE && r < rows && x < it.x1 && lane == 77) {
+#else
                 if (pc < TM_ROWS * TM_TILES_PER_WAVE && r < rows && x < it.x1) {
+#endif
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint8_t *>(wout) + r * TM_OUT_PITCH + 16 * c);
                     uint8_t *g = dst + (size_t)(oy + r) * W + x;
                     const int nb = it.x1 - x;                             // bytes left in the row: 4, 8, 12 or >= 16
@@ -454,7 +510,7 @@ int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H
     P.panels = (W + TM_MAX_PANEL - 1) / TM_MAX_PANEL;
     P.panel_w = ((W + P.panels - 1) / P.panels + 15) & ~15;
     P.panels = (W + P.panel_w - 1) / P.panel_w;
-    const int blocks = blocks_wanted > 0 ? blocks_wanted : 256;
+    const int blocks = blocks_wanted > 0 ? blocks_wanted : 256 * (int)((160 * 1024) / sizeof(Lds));   // every CU full
     // bands: as tall as they can be while every resident workgroup still has an item (an item re-filters 16 halo rows),
     // a multiple of 16 rows, at least 32
     {
@@ -469,11 +525,13 @@ int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H
     for (int i = 0; i < 6; ++i) P.kw[i] = gauss11[i];
     // v = mean - b.  BINARY: bit = (b - m > t) <=> v < -t - 0.5;  INV: bit = (b - m <= t) <=> v > -t - 0.5 (ties: exact path).
     // x = sign * S * (theta - v) + 127.5 leaves [0, 255) exactly when v is EPS = 127.5 / S or more away from theta
-    const float eps = variant == 1 ? 1e-9f : 1.0f / 128.0f;
+    const float eps = variant == 1 ? 1.0f / 2048.0f : 1.0f / 512.0f;   // (the row pass's f16 taps carry S: S < 65504 / 0.2006)
     const float S = 127.5f / eps, sgn = inv ? -1.0f : 1.0f;
-    P.x_mul = -sgn * S;
+    P.x_mul = -sgn * S; P.neg_x_mul = sgn * S;
     P.lo_add = sgn * S * (-(float)t_low - 0.5f) + 127.5f;
-    P.hi_add = use_high ? sgn * S * (-(float)t_high - 0.5f) + 127.5f : P.lo_add;   // one level: both bits are the same
+    // one level: the second byte is always 0x00 and both class bits come from the first
+    P.hi_minus_lo = use_high ? sgn * S * (float)(t_low - t_high) : -1e30f;
+    P.lo_bits = use_high ? 0x01010101u : 0x03030303u;
     const long long items = (long long)batch * P.panels * P.bands;
     long long grid = std::min<long long>(items, blocks);
     P.by_xcd = (batch % 8 == 0 && grid % 8 == 0 && grid / 8 <= (long long)(batch / 8) * P.panels * P.bands) ? 1 : 0;
