@@ -7,28 +7,36 @@
 //   m   = round-half-even(acc);  thresh = (b - m > t_low), markers = (b - m > t_high)   [INV: <=]
 // The two class bits only depend on where acc lies relative to b - t - 0.5.  This kernel evaluates
 //   v = mean - b   with |v - (acc - b)| < EPS   (a bound, below)
-// on the matrix pipe (v_mfma_f32_16x16x32_f16: the pixels are exact in f16, the weights and the row-filtered
-// values travel as f16 hi + lo pairs, products and sums are f32) and decides every pixel whose v is farther
-// than EPS from both levels; the few that are not (a few per 100 000 pixels) are listed and recomputed with cv2's
-// exact float32 chain at the end of the work item, from the frame in global memory.  Results are bit for bit those of
-// k_threshold / k_threshold_strip (detect.hip), which remain the path for BGR input and odd geometries.
+// on the matrix pipe and decides every pixel whose v is farther than EPS from both levels; the few that are not (a few
+// per 100 000 pixels) are listed and recomputed with cv2's exact float32 chain at the end of the work item, from the
+// frame in global memory.  Results are bit for bit those of k_threshold / k_threshold_strip (detect.hip), which remain
+// the path for BGR input and odd geometries.
+//
+// Why the matrix pipe: the float32-chain kernel is bound by vector-instruction issue (~34 instructions per pixel), and
+// so was a first version of this kernel that still did the 3x3 blur with SWAR integer arithmetic (profiles/
+// r03_thr_mfma_by_deletion.log: blur 31 us, filter 33 us of 92).  Here every multiply-add is an MFMA:
+//   blur, row direction     v_mfma_i32_16x16x64_i8: the gray BYTES as they lie in LDS (XOR 0x80 makes them signed) times
+//                           a banded (1, 2, 1) matrix; the accumulator starts at 0x6400 + 512, so a result IS the f16
+//                           bit pattern of 1024 + sum -- two results pack into an f16 pair with one v_lshl_or
+//   blur, column direction  v_mfma_f32_16x16x32_f16 over the previous and this 16-row block of those sums (kept in
+//                           registers: the accumulator layout is the next product's B operand); exact integers;
+//                           (sum + 8) >> 4 is one fma and a round-toward-zero conversion at 1024 + x
+//   Gaussian, columns       the blurred tile lives in LDS as [column][row] f16, so the operand is a 16-byte read;
+//                           taps as f16 hi + lo: 2 MFMA per 16-column block; result split into f16 hi + lo in registers
+//   Gaussian, rows          3 MFMA per 16x16 output tile over two neighbouring blocks; the taps carry the classification's
+//                           scale and the accumulator starts at lo_add - scale * b, so the result is the byte-range value x
+// which leaves about 50 vector instructions per 256 pixels: conversions, the hi/lo split, the classification.
 //
 // Memory skeleton (scripts/ubench/skeleton.hip): a 1024-thread workgroup owns a band of rows of one frame over a
 // column panel (the whole width up to 1232 columns) and walks down in steps of 16 rows: whole rows come in by
 // LDS-DMA (global_load_lds_dwordx4, no registers), the class map leaves as 16-byte stores.  Per step:
-//   DMA    raw rows of step s+2                                        -> s_raw[s & 1]
-//   filter output rows of step s-1 from the f16 tiles of steps s-1 and s (32 rows resident):
-//            column pass FIRST, transposed: A = the tile read column-major (ds_read_b64_tr_b16), B = the taps
-//            (hi, lo): 2 MFMA per 16-column block -> the accumulator has the output row on the lane and four
-//            columns in its registers, which is the k order of the next product -> f16 hi / lo split in registers
-//            row pass: A = the taps (hi, lo), B = two neighbouring blocks: 3 MFMA per 16x16 output tile,
-//            accumulator preset to -b (the tile's centre pixels, one ds_read_b64) = mean - b with four CONSECUTIVE
-//            columns of one row per lane -> classification, ambiguity test, one dword of the class map per lane
+//   DMA    gray rows of step s+2                                       -> s_raw[s & 1]
+//   filter output rows of step s-1 from the tile blocks of steps s-1 and s -> class bytes -> wave-private staging -> stores
 //   barrier
-//   blur   step s+1: s_raw[(s+1) & 1] -> SWAR 3x3 blur -> f16 tile s_f16[(s+1) & 1]   (wave w = tile row w)
+//   blur   step s+1: s_raw[(s+1) & 1] -> tile block (s+1) & 1
 //   barrier
-// Nothing is carried in registers from step to step.
-// Error bound (EPS = 1/512 = 1.95e-3): the pixels are exact; each tap enters as f16 hi + lo with a residual below
+//
+// Error bound (EPS = 1/512 = 1.95e-3): the blurred pixels are exact; each tap enters as f16 hi + lo with a residual below
 // 2^-11 |lo| (< 3e-8 of the weight's scale; x 255 x 11 taps, two passes: < 2e-4); a column-filtered value enters the row pass
 // as rtz-f16 hi + rtz-f16 lo (residual < 2^-10 x 2^-3 = 1.2e-4; the taps sum to 1); the dropped lo x lo product is below
 // 3.2e-4 x 0.125 = 4e-5; float32 accumulation inside the five chained MFMAs (32 products each) costs at most
@@ -47,6 +55,7 @@ namespace {
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef TM_WAVES_N
@@ -56,17 +65,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define TM_MAX_PANEL_N 1232
 #endif
 constexpr int TM_WAVES = TM_WAVES_N, TM_THREADS = 64 * TM_WAVES;
-constexpr int TM_ROWS = 16;                       // rows per step (one MFMA tile row block)
-constexpr int TM_RAW_ROWS = 18;                   // gray rows a step's blur needs
-constexpr int TM_MAX_PANEL = TM_MAX_PANEL_N;      // columns per panel, a multiple of 16 (1232: 77 tiles of 16)
-constexpr int TM_TILES_PER_WAVE = (TM_MAX_PANEL / 16 + TM_WAVES - 1) / TM_WAVES;   // 5
-constexpr int TM_PITCH = TM_MAX_PANEL + 16;       // f16 per tile row: position p = column - x0 + 8
-constexpr int TM_RAW_CHUNKS = (TM_MAX_PANEL + 32 + 15) / 16;   // 16-byte chunks per raw row: columns x0 - 16 ...
-constexpr int TM_RAW_PIECES = (TM_RAW_ROWS * TM_RAW_CHUNKS + 63) / 64;   // 1 KiB DMA pieces per step
+constexpr int TM_ROWS = 16;                                  // rows per step (one MFMA tile row block)
+constexpr int TM_MAX_PANEL = TM_MAX_PANEL_N;                 // columns per panel, a multiple of 16 (1232: 77 tiles of 16)
+constexpr int TM_MAX_TILES = TM_MAX_PANEL / 16;              // output tiles t: columns 16t .. 16t + 15 of the panel
+constexpr int TM_MAX_BLOCKS = TM_MAX_TILES + 1;              // tile column blocks u: columns 16u - 8 .. 16u + 7
+constexpr int TM_PER_WAVE = (TM_MAX_BLOCKS + TM_WAVES - 1) / TM_WAVES;   // blocks (and tiles) per wave: 5
+constexpr int TM_POS = 16 * TM_MAX_BLOCKS;                   // tile positions: p = column - x0 + 8
+constexpr int TM_COL_PITCH = 40;                             // f16 per tile column: 32 rows + 8 (80 bytes: 16 columns hit 16 x 4 banks)
+constexpr int TM_RAW_CHUNKS = TM_MAX_TILES + 4;              // 16-byte chunks per gray row: columns x0 - 24 ...
+constexpr int TM_RAW_PITCH = 16 * TM_RAW_CHUNKS;
+constexpr int TM_RAW_PIECES = (TM_ROWS * TM_RAW_CHUNKS + 63) / 64;       // 1 KiB DMA pieces per step
 constexpr int TM_PIECES_PER_WAVE = (TM_RAW_PIECES + TM_WAVES - 1) / TM_WAVES;
-constexpr int TM_OUT_PITCH = 16 * TM_TILES_PER_WAVE;           // bytes per row of a wave's class-byte staging
-constexpr int TM_LIST_CAP = 1024;                 // ambiguous pixels a work item can list
-constexpr int TM_GROUP = 62;                      // blur: output dwords per 64-lane group (lanes 0 and 63 are halo)
+constexpr int TM_OUT_PITCH = 16 * TM_PER_WAVE;               // bytes per row of a wave's class-byte staging
+constexpr int TM_LIST_CAP = 248;                             // ambiguous pixels a work item can list
 
 struct ThrItem {
     int f, x0, x1, y0, y1;
@@ -74,9 +85,6 @@ struct ThrItem {
 
 __device__ __forceinline__ int reflect101(int i, int n) { if (i < 0) i = -i; if (i >= n) i = 2 * (n - 1) - i; return i; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-__device__ __forceinline__ uint32_t lane_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }
-__device__ __forceinline__ uint32_t lane_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }
 
 // x - float(h) for the low / high half of a packed f16 pair, in one instruction
 __device__ __forceinline__ float sub_f16_lo(float x, uint32_t h)
@@ -156,13 +164,16 @@ __device__ __forceinline__ uint32_t exact_class(const uint8_t *frame, const ysmr
 }
 
 struct Lds {
-    _Float16 f16[2][TM_ROWS][TM_PITCH];                  // blurred pixels of a step, quads stored as (0, 2, 1, 3)
-    uint8_t raw[2][TM_RAW_ROWS * TM_RAW_CHUNKS * 16];    // gray rows of a step, pitch 16 * chunks-per-row
+    _Float16 tile[TM_POS][TM_COL_PITCH];                 // blurred pixels [column position][row of a 2 x 16-row ring]
+    uint8_t raw[2][TM_ROWS * TM_RAW_PITCH];              // gray rows of a step: row r, columns x0 - 24 ... at r * 16 * (chunks per row)
     uint32_t out[TM_WAVES][TM_ROWS * TM_OUT_PITCH / 4];  // a wave's class bytes of a step
     uint32_t list[TM_LIST_CAP];                          // ambiguous pixels: y << 16 | x
     uint32_t n_list;
 };
 static_assert(sizeof(Lds) <= 160 * 1024, "LDS of one CU");
+
+// f16 bit pattern of the small integers 0..4 (the blur's column taps)
+__device__ __forceinline__ uint32_t small_f16(int w) { return w == 0 ? 0u : w == 1 ? 0x3C00u : w == 2 ? 0x4000u : w == 3 ? 0x4200u : 0x4400u; }
 
 template <int EPS_MODE>
 __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__restrict__ frames, uint8_t *__restrict__ cls,
@@ -175,27 +186,43 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
     const int H = P.H, W = P.W;
     const int l16 = lane & 15, q = lane >> 4;
 
-    // ---- constant MFMA operands of this lane ---------------------------------------------------------------------
-    // Column pass, B operand [k][n]: lane (n = l16, q) holds k = 8q + j = window row; output row n is window row n + 5,
-    // so the tap is k - n.
-    // Row pass, A operand [m][k]: lane (m = l16, q) holds k = 8q + j.  The B operand is two column blocks' accumulators
-    // kept in place: halves j = 0..3 / 4..7 hold tile positions 4q + (j & 3) of one 16-column block each; position i of a
-    // block is pixel column 16u - 8 + (i & ~3) + (0, 2, 1, 3)[i & 3] (the tile stores quads as 0, 2, 1, 3).  Variant v: the
-    // RIGHT block (u = t + 1) sits in half v.  Output m is column 16t + m, so the tap is column_in - m + 5.
-    uint32_t tbh[4], tbl[4], thh[2][4], thl[2][4];
+    // ---- constant MFMA operands of this lane (all maps: lane (x = l16, q) holds k = (8 or 16) q + j) -------------------
+    // blur rows, B [k][n] (i8, K = 64): k is gray column 16u - 24 + k, n is tile position 16u + n = column 16u - 8 + n.
+    uint32_t thi[4];
+    // blur columns, A [m][k] (f16, K = 32): halves j = 0..3 / 4..7 of the other operand hold rows 4q + (j & 3) of one 16-row
+    // block of row sums each; variant v: the NEWER block sits in half v.  Window row w = 4q + (j & 3) (+ 16 for the newer
+    // block); output row m is centred on window row 15 + m.
+    uint32_t tv[2][4];
+    // Gaussian columns, B [k][n]: k = window row (0..15 the older tile block, 16..31 the newer), output row n is window
+    // row n + 8: tap k - n - 3.
+    uint32_t tbh[4], tbl[4];
+    // Gaussian rows, B [k][n]: the A operand is two column blocks' accumulators kept in place, halves j = 0..3 / 4..7 =
+    // positions 4q + (j & 3) of one block each; variant v: the RIGHT block (u = t + 1) sits in half v.  Position i of block u
+    // is column 16u - 8 + i, output n is column 16t + n: tap = column_in - n + 5.  These taps carry the classification's scale.
+    uint32_t thh[2][4], thl[2][4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        uint32_t bh = 0, bl = 0, hh[2] = {0, 0}, hl[2] = {0, 0};
+        uint32_t b1 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int d = 16 * q + 4 * jj + e - 16 - l16;        // gray column minus output column
+            b1 |= (uint32_t)(d == 0 ? 2 : (d == 1 || d == -1) ? 1 : 0) << (8 * e);
+        }
+        thi[jj] = b1;
+        uint32_t v0 = 0, v1 = 0, bh = 0, bl = 0, hh[2] = {0, 0}, hl[2] = {0, 0};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int j = 2 * jj + e, k = 8 * q + j;
-            const int p4 = ((j & 3) == 1) ? 2 : ((j & 3) == 2) ? 1 : (j & 3);
-            int taps[3] = {k - l16, -8 + 4 * q + p4 + ((j >> 2) == 0 ? 16 : 0) - l16 + 5, -8 + 4 * q + p4 + ((j >> 2) == 1 ? 16 : 0) - l16 + 5};
+            const int w0 = 4 * q + (j & 3) + ((j >> 2) == 0 ? 16 : 0), w1 = 4 * q + (j & 3) + ((j >> 2) == 1 ? 16 : 0);
+            const int d0 = w0 - 15 - l16, d1 = w1 - 15 - l16;
+            v0 |= small_f16(d0 == 0 ? 2 : (d0 == 1 || d0 == -1) ? 1 : 0) << (16 * e);
+            v1 |= small_f16(d1 == 0 ? 2 : (d1 == 1 || d1 == -1) ? 1 : 0) << (16 * e);
+            int taps[3] = {k - l16 - 3, -8 + 4 * q + (j & 3) + ((j >> 2) == 0 ? 16 : 0) - l16 + 5,
+                           -8 + 4 * q + (j & 3) + ((j >> 2) == 1 ? 16 : 0) - l16 + 5};
             uint32_t hb[3], lb[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const bool ok = taps[c] >= 0 && taps[c] <= 10;
-                // (the row pass's taps carry the classification's scale: its accumulator is x_lo itself)
                 const float w = ok ? tap_weight(P, clampi(taps[c], 0, 10)) * (c == 0 ? 1.0f : P.x_mul) : 0.0f;
                 hb[c] = f16_bits(w);
                 lb[c] = f16_bits(w - f16_value(hb[c]));
@@ -204,15 +231,17 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             hh[0] |= hb[1] << (16 * e); hl[0] |= lb[1] << (16 * e);
             hh[1] |= hb[2] << (16 * e); hl[1] |= lb[2] << (16 * e);
         }
+        tv[0][jj] = v0; tv[1][jj] = v1;
         tbh[jj] = bh; tbl[jj] = bl;
         thh[0][jj] = hh[0]; thl[0][jj] = hl[0]; thh[1][jj] = hh[1]; thl[1][jj] = hl[1];
     }
+    const i32x4 THI = {(int)thi[0], (int)thi[1], (int)thi[2], (int)thi[3]};
     const half8_t TBh = as_half8(tbh[0], tbh[1], tbh[2], tbh[3]), TBl = as_half8(tbl[0], tbl[1], tbl[2], tbl[3]);
     const half8_t THh[2] = {as_half8(thh[0][0], thh[0][1], thh[0][2], thh[0][3]), as_half8(thh[1][0], thh[1][1], thh[1][2], thh[1][3])};
     const half8_t THl[2] = {as_half8(thl[0][0], thl[0][1], thl[0][2], thl[0][3]), as_half8(thl[1][0], thl[1][1], thl[1][2], thl[1][3])};
 
-    // the tile rows beyond what the blur writes must hold finite numbers (they meet zero weights)
-    for (int i = tid; i < (int)(sizeof(L.f16) / 4); i += TM_THREADS) reinterpret_cast<uint32_t *>(L.f16)[i] = 0u;
+    // every tile entry and gray byte must be a finite number from the first read on (they meet zero taps)
+    for (int i = tid; i < (int)((sizeof(L.tile) + sizeof(L.raw)) / 4); i += TM_THREADS) reinterpret_cast<uint32_t *>(lds_bytes)[i] = 0u;
     if (tid == 0) L.n_list = 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -237,129 +266,148 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         const uint8_t *frame = frames + (size_t)it.f * H * W;
         uint8_t *dst = cls + (size_t)it.f * H * W;
         const int PW = it.x1 - it.x0;                       // a multiple of 4
-        const int ntiles = (PW + 15) >> 4;
-        const int nch = (PW + 32 + 15) >> 4;                // raw chunks per row
+        const int ntiles = (PW + 15) >> 4;                  // output tiles; column blocks u = 0 .. ntiles
+        const int nch = ntiles + 4;                         // gray chunks per row
         const int nblk = (it.y1 - it.y0 + TM_ROWS - 1) / TM_ROWS;
         const bool edge_l = it.x0 == 0, edge_r = it.x1 == W;
-        const int dlo = edge_l ? 0 : -2, dhi = (PW >> 2) + (edge_r ? 0 : 2);   // blurred dwords [dlo, dhi)
-        const int groups = (dhi - dlo + TM_GROUP - 1) / TM_GROUP;
-        const int g_last = ((PW >> 2) - 1 - dlo) / TM_GROUP;       // the group that holds the row's last dword
-        const int blur_off = 16 + 4 * (dlo - 1 + lane);            // raw-row byte offset of this lane's dword in group 0
-        // the row tail: the last 16-byte chunk of an image row is fetched from column W - 16, i.e. shifted by `tail_shift`
-        const int tail_col = ((W - 1) & ~15) - (it.x0 - 16);          // panel-raw column where that chunk begins
-        const int tail_shift = ((W - 1) & ~15) + 16 - W;              // 0 when W is a multiple of 16
+        const int u0 = wave * TM_PER_WAVE;                  // this wave's blocks u0 .. u0 + 4 and tiles t = u0 .. u0 + 4
+        // blurred block j holds rows yb(j) .. + 15; it is made of gray blocks j - 1 and j (rows yb(j) + 1 ...)
+        auto yb = [&](int j) { return it.y0 - 8 + TM_ROWS * j; };
 
-        // ---- this thread's raw chunks (the same every step): piece = wave + TM_WAVES k, chunk = 64 piece + lane -----
-        uint32_t goff[TM_PIECES_PER_WAVE]; bool gok[TM_PIECES_PER_WAVE];
-#pragma unroll
-        for (int k = 0; k < TM_PIECES_PER_WAVE; ++k) {
-            const int ci = (wave + TM_WAVES * k) * 64 + lane;
-            const int r = ci / nch, c = ci - r * nch;
-            gok[k] = r < TM_RAW_ROWS;
-            const int col = clampi(it.x0 - 16 + 16 * c, 0, W - 16);
-            goff[k] = (uint32_t)((gok[k] ? r : 0) * W + col);
-        }
-        const int npieces = (TM_RAW_ROWS * nch + 63) >> 6;
-        auto raw_base_row = [&](int s) { return clampi(it.y0 - 5 + TM_ROWS * s - 1, 0, H - TM_RAW_ROWS); };
-        auto request_raw = [&](int s) __attribute__((always_inline)) {
+        // ---- gray rows: whole 16-byte chunks by LDS-DMA; chunks that straddle the row's ends through registers ------------
+        const int npieces = (TM_ROWS * nch + 63) >> 6;
+        const uint32_t nch_recip = 65536u / (uint32_t)nch + 1u;          // chunk index / nch for indices < 2048
+        // Chunks that straddle an end of the image row go through registers (lanes 0..15 of the last wave: the chunk that
+        // holds columns -8 .. 7; lanes 16..31: the chunk that holds column W), and they carry the blur's REFLECT_101
+        // neighbours: column -1 := column 1, column W := column W - 2 -- the banded matrix of the row pass is the same everywhere.
+        const int part_c = lane < 16 ? 1 : (W - (it.x0 - 24)) >> 4;
+        const int part_col = it.x0 - 24 + 16 * part_c;
+        const bool part_on = wave == TM_WAVES - 1 && lane < 32 && part_c < nch && (lane < 16 ? edge_l : edge_r);
+        auto request_raw = [&](int j) __attribute__((always_inline)) {
 #ifdef TM_DBG_NOLOAD
             return;
 #endif
-            const uint32_t row_off = (uint32_t)raw_base_row(s) * (uint32_t)W;
+            const int r0 = yb(j) + 1;
 #pragma unroll
             for (int k = 0; k < TM_PIECES_PER_WAVE; ++k) {
                 const int piece = wave + TM_WAVES * k;
                 if (piece < npieces) {   // wave-uniform
-                    const uint32_t lds = (uint32_t)(uintptr_t)&L.raw[s & 1][piece * 1024];
-                    const uint32_t off = row_off + goff[k];
-                    if (gok[k])
+                    const uint32_t ci = (uint32_t)piece * 64u + (uint32_t)lane;
+                    const int r = (int)((ci * nch_recip) >> 16), c = (int)ci - r * nch;
+                    const int col = it.x0 - 24 + 16 * c;
+                    const uint32_t lds = (uint32_t)(uintptr_t)&L.raw[j & 1][piece * 1024];
+                    const uint32_t off = (uint32_t)clampi(r0 + r, 0, H - 1) * (uint32_t)W + (uint32_t)max(col, 0);
+                    if (r < TM_ROWS && col >= 0 && col + 16 <= W)
                         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(off), "s"(frame) : "memory");
                 }
             }
-        };
-
-        // ---- blur of step s: wave w computes tile rows w, w + TM_WAVES, ... ----------------------------------------
-        auto blur_step = [&](int s) __attribute__((always_inline)) {
-#ifdef TM_DBG_NOBLUR   // (TM_DBG_*: parts deleted to time the rest, scripts/thr_mfma_parts.sh; results are wrong)
-            return;
-#endif
-            const int a = raw_base_row(s);
-            const int RP = nch * 16;
-            const uint8_t *raw = L.raw[s & 1];
-            const uint32_t M = 0x00FF00FFu;
-            for (int tr = wave; tr < TM_ROWS; tr += TM_WAVES) {
-                const int yy = clampi(it.y0 - 5 + TM_ROWS * s + tr, 0, H - 1);
-                const uint8_t *ru = raw + (reflect101(yy - 1, H) - a) * RP, *rc = raw + (yy - a) * RP, *rd = raw + (reflect101(yy + 1, H) - a) * RP;
-                _Float16 *trow = L.f16[s & 1][tr];
-                // group g: dwords dlo - 1 + 62 g + lane; the reads of group g + 1 are in flight during the arithmetic of g
-                auto fetch = [&](int g, uint32_t &u, uint32_t &c, uint32_t &dn) __attribute__((always_inline)) {
-                    int off = blur_off + 4 * TM_GROUP * g;
-                    if (tail_shift && off >= tail_col) off += tail_shift;
-                    off = min(off, RP - 4);
-                    u = *reinterpret_cast<const uint32_t *>(ru + off); c = *reinterpret_cast<const uint32_t *>(rc + off);
-                    dn = *reinterpret_cast<const uint32_t *>(rd + off);
-                };
-                uint32_t gu, gc, gd, nu = 0, nc = 0, nd = 0;
-                fetch(0, gu, gc, gd);
-                for (int g = 0; g < groups; ++g) {
-                    if (g + 1 < groups) fetch(g + 1, nu, nc, nd);
-                    const int d = dlo + TM_GROUP * g - 1 + lane;          // dword: columns x0 + 4d .. + 3
-                    // bytes (0, 2) and (1, 3) of each row as 16-bit fields (v_perm), vertical 1-2-1
-                    const uint32_t ve = __builtin_amdgcn_perm(0, gu, 0x0C020C00u) + (__builtin_amdgcn_perm(0, gc, 0x0C020C00u) << 1) + __builtin_amdgcn_perm(0, gd, 0x0C020C00u);
-                    const uint32_t vo = __builtin_amdgcn_perm(0, gu, 0x0C030C01u) + (__builtin_amdgcn_perm(0, gc, 0x0C030C01u) << 1) + __builtin_amdgcn_perm(0, gd, 0x0C030C01u);
-                    const uint32_t vop = lane_shr1(vo), ven = lane_shl1(ve);
-                    uint32_t pm = __builtin_amdgcn_alignbit(vo, vop, 16);   // (V-1, V1)
-                    uint32_t pp = __builtin_amdgcn_alignbit(ven, ve, 16);   // (V2, V4)
-                    const bool first = edge_l && g == 0, last = edge_r && g == g_last;   // wave-uniform
-                    if (first) pm = d == 0 ? (vo & 0xFFFFu) * 0x10001u : pm;                        // column -1 := column 1
-                    if (last) pp = d == (PW >> 2) - 1 ? (ve >> 16) * 0x10001u : pp;                 // column W := column W - 2
-                    const uint32_t h02 = pm + (ve << 1) + vo + 0x00080008u, h13 = ve + (vo << 1) + pp + 0x00080008u;
-                    // blurred pixels (0, 2) and (1, 3) as packed f16: 0x6400 | b is 1024 + b
-                    const half2_t bias = {(_Float16)1024.0f, (_Float16)1024.0f};
-                    const uint32_t m02 = ((h02 >> 4) & M) | 0x64006400u, m13 = ((h13 >> 4) & M) | 0x64006400u;
-                    const uint32_t f02 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, m02) - bias);
-                    const uint32_t f13 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, m13) - bias);
-                    uint2 *pos = reinterpret_cast<uint2 *>(trow + 4 * d + 8);
-                    if (lane >= 1 && lane <= TM_GROUP && d < dhi) *pos = make_uint2(f02, f13);
-                    if (first && d == 0) {                   // columns -8 .. -1 := column 0
-                        const uint32_t r = (f02 & 0xFFFFu) * 0x10001u;
-                        pos[-1] = make_uint2(r, r); pos[-2] = make_uint2(r, r);
+            if (wave == TM_WAVES - 1) {   // the lightest wave waits for these sixteen-plus-sixteen chunks at once
+                if (part_on) {
+                    const uint8_t *row = frame + (size_t)clampi(r0 + (lane & 15), 0, H - 1) * W;
+                    u32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const uint32_t *>(row + clampi(part_col + 4 * i, 0, W - 4));
+                    if (lane < 16) {
+                        v[1] = (v[1] & 0x00FFFFFFu) | ((v[2] << 16) & 0xFF000000u);           // column -1 := column 1
+                    } else {
+                        const uint32_t last4 = *reinterpret_cast<const uint32_t *>(row + W - 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (part_col + 4 * i == W) v[i] = (v[i] & 0xFFFFFF00u) | ((last4 >> 16) & 0xFFu);   // column W := column W - 2
                     }
-                    if (last && d == (PW >> 2) - 1) {        // columns W .. := column W - 1
-                        const uint32_t r = (f13 >> 16) * 0x10001u;
-                        for (int e = 1; 4 * (d + e) + 8 < 16 * ntiles + 16; ++e) pos[e] = make_uint2(r, r);
-                    }
-                    gu = nu; gc = nc; gd = nd;
+                    *reinterpret_cast<u32x4 *>(&L.raw[j & 1][(lane & 15) * 16 * nch + 16 * part_c]) = v;   // (rows lie 16 nch bytes apart: the DMA's chunk order)
                 }
             }
         };
+        auto finish_raw = [&](int) __attribute__((always_inline)) {};
 
-        // ---- filter: output rows of step s - 1 (window rows 0..15 = tile of step s - 1, 16..31 = tile of step s) ----
+        // ---- blur: gray block j -> row sums (kept for two steps) -> tile block j ------------------------------------------
+        uint32_t hst[TM_PER_WAVE][4];
+#pragma unroll
+        for (int bi = 0; bi < TM_PER_WAVE; ++bi)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hst[bi][k] = 0x64006400u;
+        auto blur_step = [&](int j, auto par_tag, auto sums_tag) __attribute__((always_inline)) {
+#ifdef TM_DBG_NOBLUR
+            return;
+#endif
+            constexpr int PAR = decltype(par_tag)::value;    // j & 1: the half the new sums go to
+            constexpr bool SUMS_ONLY = decltype(sums_tag)::value;
+            const uint8_t *raw = L.raw[j & 1];
+            // column taps: the interior constant, or (blocks that touch the image's first / last row) built here: a row outside
+            // the image repeats the nearest inside, and that row's neighbours reflect
+            uint32_t tvv[4] = {tv[PAR][0], tv[PAR][1], tv[PAR][2], tv[PAR][3]};
+            if (!SUMS_ONLY && (yb(j) < 1 || yb(j) + TM_ROWS > H - 1)) {   // wave-uniform
+                const int yc = clampi(yb(j) + l16, 0, H - 1);
+                const int ra = reflect101(yc - 1, H), rc = reflect101(yc + 1, H);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int jx = 2 * jj + e;
+                        const int rho = yb(j) + 1 - TM_ROWS + 4 * q + (jx & 3) + ((jx >> 2) == PAR ? 16 : 0);   // gray row of the slot
+                        v |= small_f16((rho == ra) + 2 * (rho == yc) + (rho == rc)) << (16 * e);
+                    }
+                    tvv[jj] = v;
+                }
+            }
+            const half8_t TV = as_half8(tvv[0], tvv[1], tvv[2], tvv[3]);
+#pragma unroll
+            for (int bi = 0; bi < TM_PER_WAVE; ++bi) {
+                const int u = u0 + bi;
+                if (u <= ntiles) {   // wave-uniform
+                    u32x4 a = *reinterpret_cast<const u32x4 *>(raw + l16 * 16 * nch + 16 * u + 16 * q);
+                    a ^= 0x80808080u;
+                    // sum over (gray - 128) + 0x6400 + 512 = the f16 bit pattern of 1024 + row sum (0 .. 1020)
+                    i32x4 ch = {0x6600, 0x6600, 0x6600, 0x6600};
+                    ch = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), THI, ch, 0, 0, 0);
+                    hst[bi][2 * PAR] = ((uint32_t)ch[1] << 16) | (uint32_t)ch[0];
+                    hst[bi][2 * PAR + 1] = ((uint32_t)ch[3] << 16) | (uint32_t)ch[2];
+                    if (!SUMS_ONLY) {
+                        f32x4 y = {0.f, 0.f, 0.f, 0.f};
+                        y = __builtin_amdgcn_mfma_f32_16x16x32_f16(TV, as_half8(hst[bi][0], hst[bi][1], hst[bi][2], hst[bi][3]), y, 0, 0, 0);
+                        // y = 4096 + S; (S + 8) >> 4 = floor(y / 16 + 768.5 - 1024): round toward zero at 1024 + x, where f16 counts in ones
+                        const half2_t bias = {(_Float16)1024.0f, (_Float16)1024.0f};
+                        const uint32_t b01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(__builtin_fmaf(y[0], 0.0625f, 768.5f), __builtin_fmaf(y[1], 0.0625f, 768.5f))) - bias);
+                        const uint32_t b23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(__builtin_fmaf(y[2], 0.0625f, 768.5f), __builtin_fmaf(y[3], 0.0625f, 768.5f))) - bias);
+                        uint2 *cell = reinterpret_cast<uint2 *>(&L.tile[16 * u + l16][16 * PAR + 4 * q]);
+                        // (positions beyond column W - 1 belong to the lane that holds that column, below)
+                        if (!edge_r || 16 * u + l16 <= PW + 7) *cell = make_uint2(b01, b23);
+                        // the Gaussian's REPLICATE border: columns < 0 repeat column 0 (position 8), columns >= W column W - 1
+                        if (edge_l && u == 0) {                          // wave-uniform
+                            if (l16 == 8)
+#pragma unroll
+                                for (int e = 1; e <= 8; ++e) cell[-e * (TM_COL_PITCH / 4)] = make_uint2(b01, b23);
+                        }
+                        if (edge_r && u == (PW + 7) >> 4) {              // wave-uniform: the block of column W - 1
+                            if (l16 == ((PW + 7) & 15))
+                                for (int e = 1; PW + 7 + e < 16 * ntiles + 16; ++e) cell[e * (TM_COL_PITCH / 4)] = make_uint2(b01, b23);
+                        }
+                    }
+                }
+                if (bi & 1) __builtin_amdgcn_sched_barrier(0);   // (two blocks in flight are enough; all five cost registers)
+            }
+        };
+
+        // ---- filter: output rows of step s - 1 = window rows 8 .. 23 (window rows 0..15: tile block s - 1, 16..31: block s) ---
         auto filter_step = [&](int s) __attribute__((always_inline)) {
 #ifdef TM_DBG_NOFILTER
             return;
 #endif
             const int oy = it.y0 + TM_ROWS * (s - 1);            // first output row
-            uint32_t *wout = L.out[wave];
-            const int t0 = wave * TM_TILES_PER_WAVE;
-            // column-major reads of the tile: lane 4qq + p of a 16-lane group supplies row qq, positions 4p .. 4p + 3 of a
-            // 4-row x 16-position block and receives position (lane & 15) of the four rows; group q reads window rows 8q .. 8q + 7
-            const int trow = 8 * q + (l16 >> 2);
-            const _Float16 *tr_lo = &L.f16[(trow >> 4) ? (s & 1) : ((s - 1) & 1)][trow & 15][4 * (l16 & 3)];
-            // the centre pixels of this lane's four output columns: window row l16 + 5
-            const int crow = l16 + 5;
-            const _Float16 *cpix = &L.f16[(crow >> 4) ? (s & 1) : ((s - 1) & 1)][crow & 15][8 + 4 * q];
+            uint8_t *wout = reinterpret_cast<uint8_t *>(L.out[wave]);
+            // window rows 8q .. 8q + 7 of this lane's column (A operand of the column pass)
+            const _Float16 *colp = &L.tile[l16][(q >> 1 ? (s & 1) : ((s - 1) & 1)) * 16 + 8 * (q & 1)];
+            // the centre pixels of this lane's output column, rows 4q .. 4q + 3 = window rows 8 + 4q ...
+            const _Float16 *cpix = &L.tile[8 + l16][(q >> 1 ? (s & 1) * 16 : ((s - 1) & 1) * 16 + 8) + 4 * (q & 1)];
             uint32_t xh[4] = {0, 0, 0, 0}, xl[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int bi = 0; bi <= TM_TILES_PER_WAVE; ++bi) {
-                const int u = t0 + bi;                            // column block: positions 16u .. 16u + 15
+            for (int bi = 0; bi <= TM_PER_WAVE; ++bi) {
+                const int u = u0 + bi;                            // column block: positions 16u .. 16u + 15
                 const int hsel = bi & 1;
                 if (bi == 0 ? u < ntiles : u - 1 < ntiles) {      // some tile of this wave uses the block (wave-uniform)
-                    typedef short short4_t __attribute__((__vector_size__(4 * sizeof(short))));
-                    const short4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t *)(tr_lo + 16 * u));
-                    const short4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t *)(tr_lo + 16 * u + 4 * TM_PITCH));
-                    const uint2 a0u = __builtin_bit_cast(uint2, a0), a1u = __builtin_bit_cast(uint2, a1);
-                    const half8_t A = as_half8(a0u.x, a0u.y, a1u.x, a1u.y);
+                    const half8_t A = *reinterpret_cast<const half8_t *>(colp + 16 * u * TM_COL_PITCH);
                     f32x4 cv = {0.f, 0.f, 0.f, 0.f};
 #ifndef TM_DBG_NOMFMA
                     cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, TBh, cv, 0, 0, 0);
@@ -367,6 +415,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
 #else
                     cv[0] = (float)A[0]; cv[1] = (float)A[2]; cv[2] = (float)A[5]; cv[3] = (float)A[7];
 #endif
+                    // cv[r]: output row l16, position 4q + r of the block
                     const uint32_t h01 = pkrtz(cv[0], cv[1]), h23 = pkrtz(cv[2], cv[3]);
                     xh[2 * hsel] = h01; xh[2 * hsel + 1] = h23;
                     xl[2 * hsel] = pkrtz(sub_f16_lo(cv[0], h01), sub_f16_hi(cv[1], h01));
@@ -375,19 +424,19 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 if (bi >= 1) {
                     const int t = u - 1, ti = bi - 1;
                     if (t < ntiles) {   // wave-uniform
-                        const uint2 sc = *reinterpret_cast<const uint2 *>(cpix + 16 * t);   // positions (0, 2, 1, 3) of the quad
                         // x_lo = x_mul (mean - b) + lo_add: the taps carry x_mul, the accumulator starts at lo_add - x_mul b
-                        f32x4 c2 = {mad_f16_lo(sc.x, P.neg_x_mul, P.lo_add), mad_f16_lo(sc.y, P.neg_x_mul, P.lo_add),
-                                    mad_f16_hi(sc.x, P.neg_x_mul, P.lo_add), mad_f16_hi(sc.y, P.neg_x_mul, P.lo_add)};
+                        const uint2 sc = *reinterpret_cast<const uint2 *>(cpix + 16 * t * TM_COL_PITCH);
+                        f32x4 c2 = {mad_f16_lo(sc.x, P.neg_x_mul, P.lo_add), mad_f16_hi(sc.x, P.neg_x_mul, P.lo_add),
+                                    mad_f16_lo(sc.y, P.neg_x_mul, P.lo_add), mad_f16_hi(sc.y, P.neg_x_mul, P.lo_add)};
                         const half8_t XH = as_half8(xh[0], xh[1], xh[2], xh[3]), XL = as_half8(xl[0], xl[1], xl[2], xl[3]);
 #ifndef TM_DBG_NOMFMA
-                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THh[hsel], XH, c2, 0, 0, 0);
-                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THl[hsel], XH, c2, 0, 0, 0);
-                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THh[hsel], XL, c2, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(XH, THh[hsel], c2, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(XH, THl[hsel], c2, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(XL, THh[hsel], c2, 0, 0, 0);
 #else
                         c2[0] += (float)XH[0] + (float)XL[1]; c2[1] += (float)XH[2]; c2[2] += (float)XL[4]; c2[3] += (float)XH[6];
 #endif
-                        // c2[r] = x_lo at output row l16, column 16t + 4q + r; x saturates to byte 0x00 / 0xFF when the mean is
+                        // c2[r] = x_lo at output row 4q + r, column 16t + l16; x saturates to byte 0x00 / 0xFF when the mean is
                         // farther than EPS from the level, on the side that clears / sets the bit; x_hi = x_lo + (hi_add - lo_add)
                         uint32_t pk_lo = 0, pk_hi = 0;
 #pragma unroll
@@ -403,37 +452,41 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                         uint32_t amb = (z ^ (z >> 1)) & 0x7F7F7F7Fu;
                         if (EPS_MODE == 2) amb = 0x01010101u;          // diagnostic build: every pixel takes the exact path
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(amb != 0u) != 0ull, 0)) {
-                            const int y = oy + l16;
-                            if (amb != 0u && y < it.y1) {
+                            const int x = it.x0 + 16 * t + l16;
+                            if (amb != 0u && x < it.x1) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const int x = it.x0 + 16 * t + 4 * q + r;
-                                    if (((amb >> (8 * r)) & 0xFFu) && x < it.x1) {
+                                    const int y = oy + 4 * q + r;
+                                    if (((amb >> (8 * r)) & 0xFFu) && y < it.y1) {
                                         const uint32_t slot = atomicAdd(&L.n_list, 1u);
                                         if (slot < (uint32_t)TM_LIST_CAP) L.list[slot] = ((uint32_t)y << 16) | (uint32_t)x;
                                     }
                                 }
                             }
                         }
-                        wout[l16 * (TM_OUT_PITCH / 4) + 4 * ti + q] = cb;
+                        // 4 rows x 1 column per lane -> bytes of the wave's staging rows
+                        uint8_t *ob = wout + (4 * q) * TM_OUT_PITCH + 16 * ti + l16;
+                        ob[0] = (uint8_t)cb; ob[TM_OUT_PITCH] = (uint8_t)(cb >> 8); ob[2 * TM_OUT_PITCH] = (uint8_t)(cb >> 16);
+                        ob[3 * TM_OUT_PITCH] = (uint8_t)(cb >> 24);
                     }
                 }
+                if (bi & 1) __builtin_amdgcn_sched_barrier(0);
             }
             // the wave's 16 rows x 80 bytes leave as 16-byte pieces: piece = (row, 16 columns)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int rows = min(TM_ROWS, it.y1 - oy);
-            const int xw = it.x0 + 16 * t0;                               // first column of this wave's tiles
+            const int xw = it.x0 + 16 * u0;                               // first column of this wave's tiles
 #pragma unroll
-            for (int k = 0; k < (TM_ROWS * TM_TILES_PER_WAVE + 63) / 64; ++k) {
+            for (int k = 0; k < (TM_ROWS * TM_PER_WAVE + 63) / 64; ++k) {
                 const int pc = lane + 64 * k;
-                const int r = pc / TM_TILES_PER_WAVE, c = pc - r * TM_TILES_PER_WAVE;
+                const int r = pc / TM_PER_WAVE, c = pc - r * TM_PER_WAVE;
                 const int x = xw + 16 * c;
 #ifdef TM_DBG_NOSTORE
-                if (pc < TM_ROWS * TM_TILES_PER_WAVE && r < rows && x < it.x1 && lane == 77) {
+                if (pc < TM_ROWS * TM_PER_WAVE && r < rows && x < it.x1 && lane == 77) {
 #else
-                if (pc < TM_ROWS * TM_TILES_PER_WAVE && r < rows && x < it.x1) {
+                if (pc < TM_ROWS * TM_PER_WAVE && r < rows && x < it.x1) {
 #endif
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint8_t *>(wout) + r * TM_OUT_PITCH + 16 * c);
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(wout + r * TM_OUT_PITCH + 16 * c);
                     uint8_t *g = dst + (size_t)(oy + r) * W + x;
                     const int nb = it.x1 - x;                             // bytes left in the row: 4, 8, 12 or >= 16
                     if (nb >= 16) __builtin_memcpy(g, &v, 16);
@@ -446,24 +499,32 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 }
             }
         };
+        auto blur_any = [&](int j) __attribute__((always_inline)) {
+            if (j & 1) blur_step(j, std::integral_constant<int, 1>{}, std::false_type{});
+            else blur_step(j, std::integral_constant<int, 0>{}, std::false_type{});
+        };
 
         // ---- the walk ------------------------------------------------------------------------------------------------
-        request_raw(0);
-        if (nblk >= 1) request_raw(1);
+        request_raw(-1); finish_raw(-1);
+        request_raw(0); finish_raw(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        blur_step(0);
+        blur_step(-1, std::integral_constant<int, 1>{}, std::true_type{});                                       // row sums of the sixteen gray rows above the first block
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (nblk >= 1) request_raw(1);
+        blur_any(0);
+        if (nblk >= 1) finish_raw(1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int s = 0; s <= nblk; ++s) {
             if (s + 2 <= nblk) request_raw(s + 2);               // into the buffer the blur of step s has finished with
             if (s >= 1) filter_step(s);
-            // this step's DMA pieces are read after the NEXT barrier pair; the class-map stores stay in flight
+            if (s + 2 <= nblk) finish_raw(s + 2);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (s + 1 <= nblk) blur_step(s + 1);                 // overwrites the tile of step s - 1
+            if (s + 1 <= nblk) blur_any(s + 1);           // overwrites the tile block of step s - 1
+            // this step's DMA pieces are read after the NEXT barrier pair; the class-map stores are waited for with them
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
 
         // ---- ambiguous pixels: cv2's own arithmetic, sixteen lanes per pixel -------------------------------------------
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");          // every provisional byte of the item is on its way
         const uint32_t n_amb = L.n_list;
         if (__builtin_expect(n_amb != 0u, 0)) {
             if (n_amb <= (uint32_t)TM_LIST_CAP) {
@@ -498,7 +559,7 @@ namespace ysmr_thr {
 bool supported(int H, int W, int channels, int t_low, int t_high, int use_high)
 {
     const int gap = use_high ? (t_high > t_low ? t_high - t_low : t_low - t_high) : 1;
-    return channels == 1 && (W & 3) == 0 && W >= 64 && W <= 16384 && H >= TM_RAW_ROWS && H <= 16383 && gap >= 1 &&
+    return channels == 1 && (W & 3) == 0 && W >= 64 && W <= 16384 && H >= 18 && H <= 16383 && gap >= 1 &&
            t_low > -1000 && t_low < 1000 && t_high > -1000 && t_high < 1000;
 }
 
