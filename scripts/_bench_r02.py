@@ -25,7 +25,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -97,41 +97,8 @@ def cpu_baseline(frames_np, sample, fps, adt=2.0, detect_only=False):
                       f"single process; host has {os.cpu_count()} cpus"}
 
 
-def gpu_clocks(index):
-    """Current sclk / mclk / fclk of the device from sysfs (the level marked '*'); best effort, no subprocess."""
-    import glob
-    out = {}
-    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-    if not cards:
-        return None
-    base = os.path.dirname(cards[min(index, len(cards) - 1)])
-    for name in ("sclk", "mclk", "fclk"):
-        try:
-            with open(os.path.join(base, "pp_dpm_" + name)) as fh:
-                cur = [ln.split(":")[1].replace("*", "").strip() for ln in fh if "*" in ln]
-            out[name] = cur[0] if cur else None
-        except OSError:
-            out[name] = None
-    return out
-
-
-def stats_us(vals):
-    vals = sorted(vals)
-    if not vals:
-        return None
-    pick = lambda q: vals[min(len(vals) - 1, int(q * len(vals)))]
-    return {"avg": sum(vals) / len(vals), "min": vals[0], "p50": pick(0.5), "p99": pick(0.99), "max": vals[-1], "n": len(vals)}
-
-
 def main():
     args = parse()
-    # (re)build the library before anything touches the GPU: no child process is started from a process that
-    # holds a GPU context, and a failed build stops the run instead of benchmarking a stale binary
-    if int(os.environ.get("RANK", "0")) == 0 and not os.environ.get("YSMR_HIP_LIB"):
-        import subprocess
-        rc = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "ysmr_amd", "csrc")]).returncode
-        if rc:
-            raise SystemExit(f"bench.py: building libysmr_hip.so failed (make exit code {rc})")
     import torch
 
     from ysmr_amd import dist
@@ -145,7 +112,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist.init(info, backend=args.dist_backend, device=dev)   # barrier + max-over-ranks time only; no data-path collective
 
-    dist.barrier(info)   # (rank 0 built the library before any rank loads it)
+    from ysmr_amd import _lib
+    if rank == 0 and _lib.LIB_PATH.startswith(ROOT):   # no-op when the library is current (make checks the sources)
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.dirname(_lib.LIB_PATH)], check=not os.path.exists(_lib.LIB_PATH))
+    dist.barrier(info)
     from ysmr_amd.helper_file import default_settings
     from ysmr_amd.synth import SyntheticVideo
     from ysmr_amd.track_eval import TrackingPipeline
@@ -165,26 +136,15 @@ def main():
         clips_np.append(frames_np)
         clips.append(frames)
         pipes.append(TrackingPipeline(H, W, fps_video, settings, batch=B, max_det=args.max_det, capacity=args.capacity,
-                                      device=dev, rows_per_flush=F * args.capacity, link=not args.detect_only))
+                                      device=dev, rows_per_flush=F * args.capacity))
         link_streams.append(torch.cuda.current_stream(dev) if S == 1 else torch.cuda.Stream(device=dev))
     frames_np, pipe = clips_np[0], pipes[0]
-    thr_events, chain_events, link_events, enqueue_s = [], [], [], []
-    DIAG = int(os.environ.get('YSMR_BENCH_DIAG', '3'))
-    # timing events are created (first record) BEFORE the timed region and reused inside it: creating one costs the host
-    # tens of microseconds, and the host has only ~1.4x the time it needs to keep this pipeline fed
-    n_batches = (F + B - 1) // B
-    pool = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps * n_batches)]
-    for evs in pool:
-        for e in evs:
-            e.record(torch.cuda.current_stream(dev))
-    torch.cuda.synchronize()
-    pool_i = [0]
+    thr_events = []
 
     def step(timed):
         # one clip per stream, fresh trackers; detection of batch b+1 (side stream) overlaps the link of
         # batch b; with several streams per GPU their (serial) link chains interleave as well
         pending = [None] * S
-        t_host = time.perf_counter()
         for k in range(S):
             with torch.cuda.stream(link_streams[k]):
                 pipes[k].reset()
@@ -193,18 +153,11 @@ def main():
                 with torch.cuda.stream(link_streams[k]):
                     nxt = None
                     if f0 is not None:
-                        probe = timed and k == 0
-                        evs = None
-                        if probe:
-                            evs = pool[pool_i[0] % len(pool)]; pool_i[0] += 1
-                        nxt = (pipes[k].detect_async(clips[k][f0:f0 + B], thr_events if probe else None,
-                                                     chain_events if (probe and DIAG & 1) else None, events=evs), f0, evs)
+                        nxt = (pipes[k].detect_async(clips[k][f0:f0 + B], thr_events if (timed and k == 0) else None), f0)
                     if pending[k] is not None and not args.detect_only:
-                        (slot, res, ready), p0, pevs = pending[k]
-                        pipes[k].link(slot, res, ready, p0, link_events if (timed and k == 0 and DIAG & 2) else None, events=pevs)
+                        (slot, res, ready), p0 = pending[k]
+                        pipes[k].link(slot, res, ready, p0)
                     pending[k] = nxt
-        if timed:
-            enqueue_s.append(time.perf_counter() - t_host)
 
     for _ in range(args.warmup):
         step(False)
@@ -239,14 +192,13 @@ def main():
         alg_bytes = ((2.0 if mean_gray else 1.0) * args.channels + 1.0) * sum(px) / len(px)
         avg_ms = sum(ms) / len(ms)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic = None
         pmc = os.path.join(ROOT, "profiles", "threshold_pmc.json")
         if os.path.exists(pmc) and not mean_gray:
             try:
                 rec = json.load(open(pmc))
                 if rec.get("batch") == B and rec.get("height") == H and rec.get("width") == W:
                     traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/threshold_pmc.json (separate rocprofv3 --pmc run of this geometry, not this run)"
             except Exception:
                 traffic = None
         which = {(1228, 922, 500): "BASELINE configs[2], the configuration the metric is quoted on",
@@ -270,23 +222,11 @@ def main():
                                    + (" -- DETECTION ONLY (BASELINE configs[1]), not the metric's configuration" if args.detect_only else ""),
                        "frames_per_step": F, "detect_batch": B, "channels": args.channels, "streams": world * S, "parallelism": f"{S} stream{'s' if S > 1 else ''}/GPU x{world}",
                        "rows_per_step": n_rows, "tracks_alive": n_tracks, "ids_issued": next_id},
-            "roofline": {"kernel": "k_gray_sums+k_mean_levels+k_level_threshold" if mean_gray else
-                         ("k_threshold_strip" if pipe.det[0].threshold_variant == 1 else "k_threshold_mfma"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "roofline": {"kernel": "k_gray_sums+k_mean_levels+k_level_threshold" if mean_gray else "k_threshold", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "launches_timed": len(ms)},
         }
-        # what the headline is made of, so that one line says which part was slow on this box: the link is a chain
-        # of one launch per frame (k_frame), so `value` ~ 1e6 / link.us_per_frame.avg as long as the host keeps ahead
-        # (host_enqueue_ms_per_step well below ms_per_step) and detection (threshold + chain) hides behind it
-        diag = {"threshold_us_per_batch": stats_us([m * 1e3 for m in ms]),
-                "components_us_per_batch": stats_us([e0.elapsed_time(e1) * 1e3 for e0, e1, _ in chain_events]),
-                "link_us_per_frame": stats_us([e0.elapsed_time(e1) * 1e3 / n for e0, e1, n, _ in link_events]),
-                "link_host_issue_us_per_frame": stats_us([h * 1e6 / n for _, _, n, h in link_events]),
-                "host_enqueue_ms_per_step": sum(enqueue_s) / len(enqueue_s) * 1e3 if enqueue_s else None,
-                "clocks": gpu_clocks(local_rank), "host_cpus": os.cpu_count(),
-                "host_load_1m": os.getloadavg()[0]}
-        out["diagnostics"] = diag
         if world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_sample, fps_video, args.adt, args.detect_only)
         print(json.dumps(out), flush=True)

@@ -71,7 +71,10 @@ constexpr int TM_MAX_TILES = TM_MAX_PANEL / 16;              // output tiles t: 
 constexpr int TM_MAX_BLOCKS = TM_MAX_TILES + 1;              // tile column blocks u: columns 16u - 8 .. 16u + 7
 constexpr int TM_PER_WAVE = (TM_MAX_BLOCKS + TM_WAVES - 1) / TM_WAVES;   // blocks (and tiles) per wave: 5
 constexpr int TM_POS = 16 * TM_MAX_BLOCKS;                   // tile positions: p = column - x0 + 8
-constexpr int TM_COL_PITCH = 40;                             // f16 per tile column: 32 rows + 8 (80 bytes: 16 columns hit 16 x 4 banks)
+#ifndef TM_COL_PITCH_N
+#define TM_COL_PITCH_N 40
+#endif
+constexpr int TM_COL_PITCH = TM_COL_PITCH_N;                             // f16 per tile column: 32 rows + 8 (80 bytes: 16 columns hit 16 x 4 banks)
 constexpr int TM_RAW_CHUNKS = TM_MAX_TILES + 4;              // 16-byte chunks per gray row: columns x0 - 24 ...
 constexpr int TM_RAW_PITCH = 16 * TM_RAW_CHUNKS;
 constexpr int TM_RAW_PIECES = (TM_ROWS * TM_RAW_CHUNKS + 63) / 64;       // 1 KiB DMA pieces per step
@@ -129,33 +132,47 @@ __device__ __forceinline__ float f16_value(uint32_t bits) { unsigned short b = (
 __device__ __forceinline__ float tap_weight(const ysmr_thr::Params &P, int tap) { return P.kw[tap <= 5 ? tap : 10 - tap]; }
 
 // ---- exact path: cv2's float32 arithmetic for one pixel, sixteen lanes per pixel (lane dy computes one row) -------
-__device__ __forceinline__ uint32_t blur_at(const uint8_t *frame, int H, int W, int y, int x)
-{
-    const int ym = reflect101(y - 1, H), yp = reflect101(y + 1, H), xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
-    const uint8_t *ru = frame + (size_t)ym * W, *rc = frame + (size_t)y * W, *rd = frame + (size_t)yp * W;
-    const uint32_t s = ru[xm] + 2u * ru[x] + ru[xp] + 2u * (rc[xm] + 2u * rc[x] + rc[xp]) + rd[xm] + 2u * rd[x] + rd[xp];
-    return (s + 8u) >> 4;
-}
-
-// every lane of a 16-lane group passes the same (y, x); returns the class byte in all of them
-__device__ __forceinline__ uint32_t exact_class(const uint8_t *frame, const ysmr_thr::Params &P, int y, int x, int lane)
+// Kept SMALL on purpose: the code is cold when a workgroup first needs it, and every instruction-cache line it spans is a
+// round trip that the whole workgroup waits for (a fully unrolled version cost 20 us per launch).  The 13 x 13 gray pixels
+// around (y, x) -- rows and columns clamped to the image, which is where every reflected neighbour lies -- are staged in
+// LDS by one load per lane and row; the blur and the row filter then index that window.
+// Every lane of a 16-lane group passes the same (y, x) and a 256-byte scratch of its group; returns the class byte in all.
+__device__ __forceinline__ uint32_t exact_class(const uint8_t *frame, const ysmr_thr::Params &P, int y, int x, int lane, uint8_t *win)
 {
     const int H = P.H, W = P.W, dy = lane & 15, base = lane & ~15;
+    // window[a][b] = gray[clamp(y - 6 + a)][clamp(x - 6 + b)], a, b = 0..12 (pitch 16)
+    if (dy < 13) {
+        const uint8_t *row = frame + (size_t)clampi(y - 6 + dy, 0, H - 1) * W;
+        uint8_t v[13];
+#pragma unroll
+        for (int b = 0; b < 13; ++b) v[b] = row[clampi(x - 6 + b, 0, W - 1)];
+#pragma unroll
+        for (int b = 0; b < 13; ++b) win[16 * dy + b] = v[b];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lane dy: the Gaussian's row y - 5 + dy (REPLICATE: clamped), blurred pixels at columns clamp(x - 5 + i)
     const int yy = clampi(y - 5 + min(dy, 10), 0, H - 1);
+    const int ra = reflect101(yy - 1, H) - (y - 6), rb = yy - (y - 6), rc = reflect101(yy + 1, H) - (y - 6);
     float acc = 0.0f;
     uint32_t centre = 0;
+#pragma unroll 1
     for (int i = 0; i < 11; ++i) {
-        const uint32_t b = blur_at(frame, H, W, yy, clampi(x - 5 + i, 0, W - 1));
+        const int xx = clampi(x - 5 + i, 0, W - 1);
+        const int ca = reflect101(xx - 1, W) - (x - 6), cb = xx - (x - 6), cc = reflect101(xx + 1, W) - (x - 6);
+        const uint32_t s = win[16 * ra + ca] + 2u * win[16 * ra + cb] + win[16 * ra + cc] +
+                           2u * (win[16 * rb + ca] + 2u * win[16 * rb + cb] + win[16 * rb + cc]) +
+                           win[16 * rc + ca] + 2u * win[16 * rc + cb] + win[16 * rc + cc];
+        const uint32_t b = (s + 8u) >> 4;
         if (i == 5) centre = b;
         acc = __builtin_fmaf((float)b, tap_weight(P, i), acc);
     }
-    float rv[11];
-#pragma unroll
-    for (int j = 0; j < 11; ++j) rv[j] = __shfl(acc, base + j, 64);
+    // column filter, symmetric form, in every lane (the eleven row values by cross-lane reads)
+    float m = __builtin_fmaf(__shfl(acc, base + 5, 64), P.kw[5], 0.0f);
+#pragma unroll 1
+    for (int j = 1; j <= 5; ++j) m = __builtin_fmaf(__shfl(acc, base + 5 + j, 64) + __shfl(acc, base + 5 - j, 64), P.kw[5 - j], m);
     const uint32_t s = (uint32_t)__shfl((int)centre, base + 5, 64);
-    float m = __builtin_fmaf(rv[5], P.kw[5], 0.0f);
-#pragma unroll
-    for (int j = 1; j <= 5; ++j) m = __builtin_fmaf(rv[5 + j] + rv[5 - j], P.kw[5 - j], m);
     const int mi = clampi((int)__builtin_rintf(m), 0, 255);
     const int d = (int)s - mi;
     const int lo = P.inv ? (d <= P.t_low) : (d > P.t_low);
@@ -171,6 +188,7 @@ struct Lds {
     uint32_t n_list;
 };
 static_assert(sizeof(Lds) <= 160 * 1024, "LDS of one CU");
+static_assert(sizeof(Lds::out) >= 256 * (TM_THREADS / 16), "the exact path's windows live in the class-byte staging");
 
 // f16 bit pattern of the small integers 0..4 (the blur's column taps)
 __device__ __forceinline__ uint32_t small_f16(int w) { return w == 0 ? 0u : w == 1 ? 0x3C00u : w == 2 ? 0x4000u : w == 3 ? 0x4200u : 0x4400u; }
@@ -192,14 +210,14 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
     // blur columns, A [m][k] (f16, K = 32): halves j = 0..3 / 4..7 of the other operand hold rows 4q + (j & 3) of one 16-row
     // block of row sums each; variant v: the NEWER block sits in half v.  Window row w = 4q + (j & 3) (+ 16 for the newer
     // block); output row m is centred on window row 15 + m.
-    uint32_t tv[2][4];
+    uint32_t tv[4];                   // (variant 1 is variant 0 with its register pairs exchanged: built where it is used)
     // Gaussian columns, B [k][n]: k = window row (0..15 the older tile block, 16..31 the newer), output row n is window
     // row n + 8: tap k - n - 3.
     uint32_t tbh[4], tbl[4];
     // Gaussian rows, B [k][n]: the A operand is two column blocks' accumulators kept in place, halves j = 0..3 / 4..7 =
     // positions 4q + (j & 3) of one block each; variant v: the RIGHT block (u = t + 1) sits in half v.  Position i of block u
     // is column 16u - 8 + i, output n is column 16t + n: tap = column_in - n + 5.  These taps carry the classification's scale.
-    uint32_t thh[2][4], thl[2][4];
+    uint32_t thh[4], thl[4];          // (variant 0; variant 1 likewise)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         uint32_t b1 = 0;
@@ -209,36 +227,31 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             b1 |= (uint32_t)(d == 0 ? 2 : (d == 1 || d == -1) ? 1 : 0) << (8 * e);
         }
         thi[jj] = b1;
-        uint32_t v0 = 0, v1 = 0, bh = 0, bl = 0, hh[2] = {0, 0}, hl[2] = {0, 0};
+        uint32_t v0 = 0, bh = 0, bl = 0, hh = 0, hl = 0;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int j = 2 * jj + e, k = 8 * q + j;
-            const int w0 = 4 * q + (j & 3) + ((j >> 2) == 0 ? 16 : 0), w1 = 4 * q + (j & 3) + ((j >> 2) == 1 ? 16 : 0);
-            const int d0 = w0 - 15 - l16, d1 = w1 - 15 - l16;
+            const int w0 = 4 * q + (j & 3) + ((j >> 2) == 0 ? 16 : 0);
+            const int d0 = w0 - 15 - l16;
             v0 |= small_f16(d0 == 0 ? 2 : (d0 == 1 || d0 == -1) ? 1 : 0) << (16 * e);
-            v1 |= small_f16(d1 == 0 ? 2 : (d1 == 1 || d1 == -1) ? 1 : 0) << (16 * e);
-            int taps[3] = {k - l16 - 3, -8 + 4 * q + (j & 3) + ((j >> 2) == 0 ? 16 : 0) - l16 + 5,
-                           -8 + 4 * q + (j & 3) + ((j >> 2) == 1 ? 16 : 0) - l16 + 5};
-            uint32_t hb[3], lb[3];
+            int taps[2] = {k - l16 - 3, -8 + 4 * q + (j & 3) + ((j >> 2) == 0 ? 16 : 0) - l16 + 5};
+            uint32_t hb[2], lb[2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < 2; ++c) {
                 const bool ok = taps[c] >= 0 && taps[c] <= 10;
                 const float w = ok ? tap_weight(P, clampi(taps[c], 0, 10)) * (c == 0 ? 1.0f : P.x_mul) : 0.0f;
                 hb[c] = f16_bits(w);
                 lb[c] = f16_bits(w - f16_value(hb[c]));
             }
             bh |= hb[0] << (16 * e); bl |= lb[0] << (16 * e);
-            hh[0] |= hb[1] << (16 * e); hl[0] |= lb[1] << (16 * e);
-            hh[1] |= hb[2] << (16 * e); hl[1] |= lb[2] << (16 * e);
+            hh |= hb[1] << (16 * e); hl |= lb[1] << (16 * e);
         }
-        tv[0][jj] = v0; tv[1][jj] = v1;
+        tv[jj] = v0;
         tbh[jj] = bh; tbl[jj] = bl;
-        thh[0][jj] = hh[0]; thl[0][jj] = hl[0]; thh[1][jj] = hh[1]; thl[1][jj] = hl[1];
+        thh[jj] = hh; thl[jj] = hl;
     }
     const i32x4 THI = {(int)thi[0], (int)thi[1], (int)thi[2], (int)thi[3]};
     const half8_t TBh = as_half8(tbh[0], tbh[1], tbh[2], tbh[3]), TBl = as_half8(tbl[0], tbl[1], tbl[2], tbl[3]);
-    const half8_t THh[2] = {as_half8(thh[0][0], thh[0][1], thh[0][2], thh[0][3]), as_half8(thh[1][0], thh[1][1], thh[1][2], thh[1][3])};
-    const half8_t THl[2] = {as_half8(thl[0][0], thl[0][1], thl[0][2], thl[0][3]), as_half8(thl[1][0], thl[1][1], thl[1][2], thl[1][3])};
 
     // every tile entry and gray byte must be a finite number from the first read on (they meet zero taps)
     for (int i = tid; i < (int)((sizeof(L.tile) + sizeof(L.raw)) / 4); i += TM_THREADS) reinterpret_cast<uint32_t *>(lds_bytes)[i] = 0u;
@@ -336,7 +349,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             const uint8_t *raw = L.raw[j & 1];
             // column taps: the interior constant, or (blocks that touch the image's first / last row) built here: a row outside
             // the image repeats the nearest inside, and that row's neighbours reflect
-            uint32_t tvv[4] = {tv[PAR][0], tv[PAR][1], tv[PAR][2], tv[PAR][3]};
+            uint32_t tvv[4] = {tv[2 * PAR], tv[2 * PAR + 1], tv[2 - 2 * PAR], tv[3 - 2 * PAR]};
             if (!SUMS_ONLY && (yb(j) < 1 || yb(j) + TM_ROWS > H - 1)) {   // wave-uniform
                 const int yc = clampi(yb(j) + l16, 0, H - 1);
                 const int ra = reflect101(yc - 1, H), rc = reflect101(yc + 1, H);
@@ -402,6 +415,8 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             // the centre pixels of this lane's output column, rows 4q .. 4q + 3 = window rows 8 + 4q ...
             const _Float16 *cpix = &L.tile[8 + l16][(q >> 1 ? (s & 1) * 16 : ((s - 1) & 1) * 16 + 8) + 4 * (q & 1)];
             uint32_t xh[4] = {0, 0, 0, 0}, xl[4] = {0, 0, 0, 0};
+            const half8_t THh[2] = {as_half8(thh[0], thh[1], thh[2], thh[3]), as_half8(thh[2], thh[3], thh[0], thh[1])};
+            const half8_t THl[2] = {as_half8(thl[0], thl[1], thl[2], thl[3]), as_half8(thl[2], thl[3], thl[0], thl[1])};
 #pragma unroll
             for (int bi = 0; bi <= TM_PER_WAVE; ++bi) {
                 const int u = u0 + bi;                            // column block: positions 16u .. 16u + 15
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                     const uint32_t e = e0 + (uint32_t)(tid >> 4);
                     const uint32_t ent = L.list[min(e, n_amb - 1)];
                     const int y = (int)(ent >> 16), x = (int)(ent & 0xFFFFu);
-                    const uint32_t c = exact_class(frame, P, y, x, lane);
+                    const uint32_t c = exact_class(frame, P, y, x, lane, reinterpret_cast<uint8_t *>(L.out) + 256 * (tid >> 4));
                     if (e < n_amb && l16 == 0) dst[(size_t)y * W + x] = (uint8_t)c;
                 }
             } else {
@@ -541,7 +556,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 for (int p0 = 0; p0 < npx; p0 += TM_THREADS / 16) {
                     const int p = min(p0 + (tid >> 4), npx - 1);
                     const int y = it.y0 + p / PW, x = it.x0 + p % PW;
-                    const uint32_t c = exact_class(frame, P, y, x, lane);
+                    const uint32_t c = exact_class(frame, P, y, x, lane, reinterpret_cast<uint8_t *>(L.out) + 256 * (tid >> 4));
                     if (p0 + (tid >> 4) < npx && l16 == 0) dst[(size_t)y * W + x] = (uint8_t)c;
                 }
             }

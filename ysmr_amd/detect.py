@@ -110,8 +110,13 @@ class Detector:
     """Owns the output/scratch buffers for a fixed (batch, H, W, max_det) geometry."""
 
     def __init__(self, batch, height, width, max_det=2048, params: ThresholdParams | MeanGrayParams | None = None,
-                 device="cuda:0", want_mask=True, mean_state: MeanGrayState | None = None, cv_flavour=0):
+                 device="cuda:0", want_mask=True, mean_state: MeanGrayState | None = None, cv_flavour=0,
+                 threshold_variant=0):
         self.B, self.H, self.W, self.max_det = int(batch), int(height), int(width), int(max_det)
+        #: which threshold kernel ``detect`` / ``threshold`` take (``ysmr_threshold_batch_variant``): 0 = the library's choice
+        #: (the matrix-pipe kernel, which fills whole compute units); 1 = the float32-chain kernels, whose resident grid
+        #: leaves registers and LDS on every compute unit for a link kernel running beside it (``TrackingPipeline``)
+        self.threshold_variant = int(threshold_variant)
         self.cv_flavour = _lib.cv_flavour_of(cv_flavour)   # which OpenCV release a1 / a6 follow (_lib.CV_*)
         self.params = params or threshold_params(True, 5, 2.0)
         self.device = torch.device(device)
@@ -156,13 +161,14 @@ class Detector:
         return b, ch
 
     @_on_own_device
-    def threshold(self, frames: torch.Tensor, variant: int = 0) -> torch.Tensor:
+    def threshold(self, frames: torch.Tensor, variant: int | None = None) -> torch.Tensor:
         """a1-a3 only: class map u8 [b,H,W] (bit0 thresh, bit1 markers).  In the mean-gray branch the
         call also advances the moving-average state by these frames; per-frame mean, stddev, level and
         averaged level are left in ``mean_stats[:b]``, the integer levels in ``mean_levels[:b]``.
         ``variant``: which kernel (``ysmr_threshold_batch_variant`` in include/ysmr_hip.h; 0 = the shipped choice)."""
         b, ch = self._check_frames(frames)
         p = self.params
+        variant = self.threshold_variant if variant is None else variant
         if self.mean_state is not None:
             rc = _lib.lib().ysmr_mean_threshold_batch(
                 _lib.stream_ptr(self.device), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.offset, p.window,
@@ -207,7 +213,7 @@ class Detector:
         """a1-a6 for a batch of frames resident in HBM.  Asynchronous on the current stream."""
         b, ch = self._check_frames(frames)
         p = self.params
-        if self.mean_state is not None:
+        if self.mean_state is not None or self.threshold_variant:
             self.threshold(frames)
             return self.components(b)
         rc = _lib.lib().ysmr_detect_batch(

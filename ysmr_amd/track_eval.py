@@ -60,7 +60,7 @@ class TrackingPipeline:
     """Device-resident detect+link over consecutive batches of one video stream."""
 
     def __init__(self, height, width, fps, settings, batch=64, max_det=2048, capacity=2048, device="cuda:0",
-                 rows_per_flush=None):
+                 rows_per_flush=None, link=True):
         self.device = torch.device(device)
         self.B = int(batch)
         offset = settings["threshold offset for detection"]
@@ -76,8 +76,24 @@ class TrackingPipeline:
         # two detectors: batch b+1 is detected (stream 1) while batch b is linked (stream 0)
         # optional settings key 'opencv version' ('4.5.0', '4.10.0', '3.4.18', ...): which release the BGR2GRAY
         # coefficients and the minAreaRect angle convention follow (include/ysmr_hip.h: cv_flavour)
+        # Which threshold kernel: detection of batch b+1 runs BESIDE the link of batch b.  With tables small enough for
+        # the one-launch link (k_frame: two 59 KB workgroups on every compute unit, a chain of 10 us kernels) the
+        # float32-chain strip kernel is the better neighbour -- its resident grid leaves a wave slot, registers and LDS on
+        # every unit, while the matrix-pipe kernel takes whole units (160 KB of LDS) and the link waits for them:
+        # 66 k instead of 87 k frames/s end to end (profiles/r03_threshold_kernels_in_the_pipeline.log).  The two-launch
+        # link of larger tables time-slices the chip with detection anyway, and detection without a link has no
+        # neighbour: both take the faster matrix-pipe kernel.
+        beside_fused_link = bool(link) and max_det <= 2456
+        #: the threshold kernel is issued on the LINK stream, between two batches' link chains, where it has the chip to
+        #: itself (the labelling chain still runs beside the link, on the side stream)
+        self.exclusive_threshold = False
+        mode = os.environ.get("YSMR_THRESHOLD_MODE")   # (measurement aid: scripts/thr_kernels_in_pipeline.sh)
+        if mode in ("beside-strip", "beside-mfma", "exclusive-mfma", "exclusive-strip"):
+            beside_fused_link = mode.endswith("strip")
+            self.exclusive_threshold = mode.startswith("exclusive")
         self.det = [Detector(self.B, height, width, max_det=max_det, params=params, device=self.device,
-                             mean_state=mean_state, cv_flavour=settings.get("opencv version"))
+                             mean_state=mean_state, cv_flavour=settings.get("opencv version"),
+                             threshold_variant=1 if beside_fused_link else 0)
                     for _ in range(2)]
         self.trk = DeviceTracker(max_disappeared=fps, fps=fps, n_min=settings["minimum horizon size"],
                                  n_max=settings["maximum horizon size"], n_f=settings["number of LSFFs"],
@@ -92,30 +108,48 @@ class TrackingPipeline:
         self._k = 0
 
     @_on_own_device
-    def detect_async(self, frames_dev, threshold_events=None, chain_events=None):
+    def detect_async(self, frames_dev, threshold_events=None, chain_events=None, events=None):
         """Issue detection of one batch on the side stream; returns (slot, result, ready_event).
         ``threshold_events``: list that receives a (start, stop) HIP event pair bracketing the fused
         threshold kernel on the stream it is launched on (bench.py's roofline measurement);
-        ``chain_events``: the same for the labelling / geometry chain behind it."""
+        ``chain_events``: the same for the labelling / geometry chain behind it; ``events``: five ready-made timing
+        events to use for these records (the first three here, the last two in ``link``) instead of new ones."""
         slot = self._k & 1
         self._k += 1
         cur = torch.cuda.current_stream(self.device)
+        det = self.det[slot]
+        thresholded = None
+        if self.exclusive_threshold:
+            e0, e1 = (events[0], events[1]) if events else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            if threshold_events is not None:
+                e0.record(cur)
+            det.threshold(frames_dev)
+            if threshold_events is not None:
+                e1.record(cur)
+                threshold_events.append((e0, e1, frames_dev.shape[0]))
+            thresholded = torch.cuda.Event()
+            thresholded.record(cur)
         with torch.cuda.stream(self.side):
             self.side.wait_stream(cur)          # the frames were produced/uploaded on the caller's stream
             if self._done[slot] is not None:
                 self.side.wait_event(self._done[slot])
-            det = self.det[slot]
-            if threshold_events is None:
+            if thresholded is not None:
+                res = det.components(frames_dev.shape[0])
+                if chain_events is not None:
+                    e2 = events[2] if events else torch.cuda.Event(enable_timing=True)
+                    e2.record(self.side)
+                    chain_events.append((e1, e2, frames_dev.shape[0]))
+            elif threshold_events is None:
                 res = det.detect(frames_dev)
             else:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = (events[0], events[1]) if events else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 e0.record(self.side)
-                det.threshold(frames_dev)
+                det.threshold(frames_dev)      # (the detector's own choice of kernel)
                 e1.record(self.side)
                 threshold_events.append((e0, e1, frames_dev.shape[0]))
                 res = det.components(frames_dev.shape[0])
                 if chain_events is not None:
-                    e2 = torch.cuda.Event(enable_timing=True)
+                    e2 = events[2] if events else torch.cuda.Event(enable_timing=True)
                     e2.record(self.side)
                     chain_events.append((e1, e2, frames_dev.shape[0]))
             ready = torch.cuda.Event()
@@ -128,7 +162,7 @@ class TrackingPipeline:
         self.row_count.zero_()
 
     @_on_own_device
-    def link(self, slot, res, ready, first_frame, link_events=None):
+    def link(self, slot, res, ready, first_frame, link_events=None, events=None):
         """Link one detected batch on the current stream; rows accumulate in self.rows.
         ``link_events``: list that receives a (start, stop, frames, host_seconds) record around the batch's
         launches -- HIP events on the link stream, and how long the host took to issue them."""
@@ -137,7 +171,7 @@ class TrackingPipeline:
         if link_events is None:
             self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
         else:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = (events[3], events[4]) if events else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             e0.record(cur)
             t0 = time.perf_counter()
             self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
