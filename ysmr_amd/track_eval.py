@@ -76,14 +76,13 @@ class TrackingPipeline:
         # two detectors: batch b+1 is detected (stream 1) while batch b is linked (stream 0)
         # optional settings key 'opencv version' ('4.5.0', '4.10.0', '3.4.18', ...): which release the BGR2GRAY
         # coefficients and the minAreaRect angle convention follow (include/ysmr_hip.h: cv_flavour)
-        # Which threshold kernel: detection of batch b+1 runs BESIDE the link of batch b.  With tables small enough for
-        # the one-launch link (k_frame: two 59 KB workgroups on every compute unit, a chain of 10 us kernels) the
-        # float32-chain strip kernel is the better neighbour -- its resident grid leaves a wave slot, registers and LDS on
-        # every unit, while the matrix-pipe kernel takes whole units (160 KB of LDS) and the link waits for them:
-        # 66 k instead of 87 k frames/s end to end (profiles/r03_threshold_kernels_in_the_pipeline.log).  The two-launch
-        # link of larger tables time-slices the chip with detection anyway, and detection without a link has no
-        # neighbour: both take the faster matrix-pipe kernel.
-        beside_fused_link = bool(link) and max_det <= 2456
+        # Which threshold kernel: detection of batch b+1 runs BESIDE the link of batch b, and there the float32-chain strip
+        # kernel is the better neighbour -- its resident grid leaves a wave slot, registers and LDS on every compute unit
+        # for the link's chain of 10 us kernels, while the matrix-pipe kernel takes whole units (160 KB of LDS, every
+        # register) and the link waits for them: 80.7 k against 85.7 k frames/s end to end, and giving it the chip to itself
+        # between two batches' link chains costs more (77.8 k) than its 15 % buy (profiles/r03_threshold_kernels_in_the_pipeline.log;
+        # at 4K 14.8 k against 15.2 k).  Detection without a link has no neighbour and takes the matrix-pipe kernel.
+        beside_fused_link = bool(link)
         #: the threshold kernel is issued on the LINK stream, between two batches' link chains, where it has the chip to
         #: itself (the labelling chain still runs beside the link, on the side stream)
         self.exclusive_threshold = False
