@@ -47,7 +47,8 @@ extern "C" {
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
 #define YSMR_DET_ARENA     2   /* geometry scratch arena exhausted: some rectangles missing */
-#define YSMR_DET_STALLED   4   /* an internal grid barrier timed out: this batch has no valid result */
+#define YSMR_DET_STALLED   4   /* an internal grid barrier timed out: this call's outputs are undefined; the next call on
+                                 the same buffers clears everything and is valid again */
 
 /* cv_flavour: which OpenCV the a1 / a6 arithmetic follows.  opencv-contrib-python is an unpinned third-party
  * dependency of the reference (setup.py:29, "openCV v3 or v4"); two of its results changed between releases:
@@ -110,6 +111,12 @@ int ysmr_detect_workspace_init(void *stream, void *workspace_dev, size_t workspa
 int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int height, int width,
                          int channels, int inv, int t_low, int t_high, int use_high,
                          uint8_t *cls_dev, int cv_flavour);
+
+/* Fault injection for the library's own tests: YSMR_FAULT_RESIDUE_STALL makes the NEXT ysmr_components_batch /
+ * ysmr_detect_batch call of this process behave as if one workgroup of its barrier kernel never became resident -- the
+ * barrier times out (quickly), every frame's status gets YSMR_DET_STALLED and the call returns. */
+#define YSMR_FAULT_RESIDUE_STALL 1
+int ysmr_fault_inject(int what);
 
 /* The same call with the kernel named (test and measurement aid; the results are the same bytes whichever is taken).
  * Gray frames of at least 18 rows and 64 columns (width a multiple of 4) are served by a kernel that evaluates the

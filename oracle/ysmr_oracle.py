@@ -585,6 +585,43 @@ def track_frames(frames, fps=30.0, white_on_dark=True, offset=5, adt=2.0, use_gs
 
 
 # ------------------------------------------------------------------------------------------------
+# the frame source's protocol (f1): what track_bacteria does with the frame count a container REPORTS and the
+# frames cap.read() actually DELIVERS (ysmr/track_eval.py:73-93, 156-178, 368-405)
+# ------------------------------------------------------------------------------------------------
+def reader_protocol(reported_frames, delivered_frames, fps_of_container, settings):
+    """Restates the control flow around cv2.VideoCapture in track_bacteria for a container that reports
+    ``reported_frames`` (CAP_PROP_FRAME_COUNT) and whose cap.read() succeeds ``delivered_frames`` times.
+    Returns a dict: skipped (returned None before reading), frames_processed, read_error (the critical log of :176),
+    returns_none (the function's result is None), fps (what the tracker is built with, None when skipped)."""
+    out = {"skipped": False, "frames_processed": 0, "read_error": False, "returns_none": False, "fps": None}
+    if int(reported_frames) < settings["minimal frame count"]:                        # :73-77
+        out.update(skipped=True, returns_none=True)
+        return out
+    if not settings["force tracking.ini fps settings"]:                               # :78-93
+        fps = fps_of_container
+    else:
+        fps = settings["frames per second"]
+    out["fps"] = fps
+    curr, error_during_read = 0, False
+    while True:                                                                       # :156
+        ret = curr < delivered_frames                                                 # cap.read() :159
+        if not ret and (reported_frames == curr + 1 or reported_frames == curr) and \
+                reported_frames >= settings["minimal frame count"]:                   # :170-174
+            break
+        elif not ret:                                                                 # :175-178
+            out["read_error"] = True
+            error_during_read = settings["stop evaluation on error"]
+            break
+        curr += 1                                                                     # :348
+    out["frames_processed"] = curr
+    if curr == 0:
+        out["returns_none"] = True                                                    # no objects: :388-392
+    if error_during_read:                                                             # :402-404
+        out["returns_none"] = True
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # selection of good tracks: select_tracks / find_good_tracks (ysmr/track_eval.py:408-843)
 # ------------------------------------------------------------------------------------------------
 def select_tracks_oracle(df, settings, fps, frame_height, frame_width):

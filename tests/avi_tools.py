@@ -7,9 +7,10 @@ def _riff(fourcc, payload):
 
 
 def write_avi(path, frames, bits, fps=(30000, 1001), top_down=False, palette=None, split=None, jpeg=None, dropped=(),
-              truncated=None):
+              truncated=None, declared=None):
     """Minimal AVI (uncompressed DIB frames, or the given JPEG blobs as Motion-JPEG): hdrl (avih, strl(strh, strf)), movi with 00db chunks (+ an audio chunk that
-    must be skipped), optionally continued in a second RIFF AVIX."""
+    must be skipped), optionally continued in a second RIFF AVIX.  ``declared``: the frame count written into the stream
+    header when it is to differ from the frames stored."""
     import struct
     n, h, w = frames.shape[:3]
     stride = (w * bits // 8 + 3) & ~3
@@ -19,7 +20,7 @@ def write_avi(path, frames, bits, fps=(30000, 1001), top_down=False, palette=Non
         out = np.zeros((h, stride), np.uint8)
         out[:, :rows.shape[1]] = rows
         return out.tobytes()
-    strh = struct.pack("<4s4sIHHIIIIIIII4H", b"vids", b"DIB ", 0, 0, 0, 0, fps[1], fps[0], 0, n, stride * h, 0, 0, 0, 0, w, h)
+    strh = struct.pack("<4s4sIHHIIIIIIII4H", b"vids", b"DIB ", 0, 0, 0, 0, fps[1], fps[0], 0, n if declared is None else declared, stride * h, 0, 0, 0, 0, w, h)
     compression = int.from_bytes(b"MJPG", "little") if jpeg is not None else 0
     bih = struct.pack("<IiiHHIIiiII", 40, w, -h if top_down else h, 1, bits, compression, stride * h, 0, 0, 0, 0)
     if bits == 8 and jpeg is None:

@@ -175,6 +175,39 @@ def test_detect_bench_batch_frame_by_frame(torch_cuda, oracle):
         _compare(oracle, frames, got, p, max_det=2048)
 
 
+def test_stalled_barrier_is_reported_and_the_next_call_recovers(torch_cuda, oracle):
+    """k_residue's software grid barrier gives up when a workgroup never arrives (ysmr_fault_inject makes one stay away):
+    every frame of that call reports YSMR_DET_STALLED, the call returns, and the NEXT call on the same detector -- the same
+    label map, mask and workspace, which the stalled call left half written -- gives the oracle's result again."""
+    from ysmr_amd import _lib
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    torch = torch_cuda
+    p = threshold_params(True, 5, 2.0)
+    video = SyntheticVideo(300, 412, 60, seed=11)
+    det = Detector(3, 300, 412, max_det=512, params=p)
+
+    def run(frames):
+        res = det.detect(torch.from_numpy(frames).cuda())
+        torch.cuda.synchronize()
+        return {k: getattr(res, k).cpu().numpy() for k in ("cls", "mask", "labels", "det_count", "det", "anchors", "status")}
+
+    def big_blobs(frames):          # islands larger than a 16 x 16 window: residue for the barrier kernel
+        frames = frames.copy()
+        frames[:, 40:75, 50:95] = 200
+        frames[:, 150:170, 200:260] = 180
+        return frames
+
+    first = big_blobs(video.frames(3))
+    _compare(oracle, first, run(first), p, max_det=512)
+    assert _lib.lib().ysmr_fault_inject(1) == 0
+    stalled = run(big_blobs(video.frames(3)))
+    assert (stalled["status"] & _lib.DET_STALLED).all(), stalled["status"]
+    after = big_blobs(video.frames(3))
+    _compare(oracle, after, run(after), p, max_det=512)
+    assert _lib.lib().ysmr_fault_inject(99) != 0
+
+
 def test_detect_dense_noise_stresses_union_find(torch_cuda, oracle):
     """Uniform noise gives dense, convoluted masks: long union-find chains, holes, nesting."""
     from ysmr_amd.detect import threshold_params

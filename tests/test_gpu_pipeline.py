@@ -113,6 +113,84 @@ def test_4k_dense_field_config(oracle):
     compare_rows(rows_to_numpy(rows, int(count.item())), ref_rows)
 
 
+def test_4k_dense_field_through_every_filter_and_a_tracks_whole_life(oracle):
+    """BASELINE configs[4] in depth (the three-frame test above only sees the first filter): 3840x2160, ~5000 blobs,
+    32 frames through the two-launch link (k_link + k_track + the detection grid) in batches of 16, as bench.py --config 4
+    runs it, against the oracle's tracker with its conditioning probe.  fps = 10 keeps the oracle's Python loop to a
+    couple of minutes and still covers a track's whole life: the second and third filters switch on at frames 10 and 20,
+    dropped-out blobs (2 % per frame) are carried on their own predictions and deregistered after 10 lost frames, new ids
+    are issued throughout, and the ring search around a lost track's prediction falls back to wider rings."""
+    import torch
+    from ysmr_amd import _lib
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import S4K
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    n_frames, batch, fps = 32, 16, 10.0
+    frames = S4K(seed=2).frames(n_frames)
+    p = threshold_params(True, 5, 2.0)
+    det = Detector(batch, 2160, 3840, max_det=8192, params=p)
+    trk = DeviceTracker(max_disappeared=fps, fps=fps, n_min=0, n_max=30, n_f=3, capacity=8192, max_det=8192)
+    rows = torch.empty(n_frames * 8192 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for f0 in range(0, n_frames, batch):
+        res = det.detect(torch.from_numpy(frames[f0:f0 + batch]).cuda())
+        trk.run(res.det, res.det_count, f0, rows, count)
+        torch.cuda.synchronize()
+        assert int(res.status.max().item()) == 0
+    n_tracks, next_id, err = trk.info()
+    assert err == 0
+    got = rows_to_numpy(rows, int(count.item()))
+    ref_rows, ref_trk = oracle.track_frames(frames, fps=fps, max_det=8192, shadows=2)
+    ref = np.array([r[:7] for r in ref_rows])
+    # the clip does what the test is for: tracks lost and carried, tracks dropped, ids issued after the first frame
+    lost_rows = int((ref[:, 4] == 0).sum() - (ref[:, 4] == 0)[ref[:, 0] == 0].sum())
+    first_ids = set(ref[ref[:, 0] == 0][:, 1].astype(int))
+    last_ids = set(ref[ref[:, 0] == n_frames - 1][:, 1].astype(int))
+    assert lost_rows > 1000 and len(first_ids - last_ids) > 50 and next_id > len(first_ids) + 100, (lost_rows, len(first_ids - last_ids), next_id)
+    assert next_id == ref_trk.next_id and n_tracks == len(last_ids)
+    compare_rows(got, ref_rows)
+
+
+def test_reader_protocol_reported_against_delivered_frames(tmp_path, oracle):
+    """f1, the part of cv2.VideoCapture's contract that track_bacteria acts on (track_eval.py:73-93, 156-178, 402-404): the
+    container REPORTS a frame count, cap.read() DELIVERS frames until it fails, and the two may differ.  AVI files whose
+    stream header declares more / fewer frames than they store go through ``open_video`` + ``track_bacteria``; the outcome
+    -- skipped, how many frames were tracked, error or not, None or a result, which fps -- must be what the oracle's
+    restatement of the reference's control flow says for the same two numbers and settings."""
+    from avi_tools import write_avi
+    from ysmr_amd.frames import open_video
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    stored = 48
+    clip = SyntheticVideo(96, 128, 12, seed=5).frames(stored)
+    cases = [(stored, {}), (stored + 1, {}), (stored + 2, {}), (stored + 2, {"stop evaluation on error": False}),
+             (stored - 1, {}), (stored - 6, {"stop evaluation on error": False}), (30, {"minimal frame count": 40}),
+             (stored, {"force tracking.ini fps settings": True, "frames per second": 12.5}),
+             (stored + 1, {"minimal frame count": stored + 1})]
+    for k, (declared, extra) in enumerate(cases):
+        path = tmp_path / f"r{k}.avi"
+        write_avi(path, clip, 8, fps=(25, 1), declared=declared)
+        video = open_video(str(path))
+        assert (video.frame_count, video.frames_available, video.fps) == (declared, stored, 25.0)
+        video.close()
+        settings = _settings(**extra)
+        want = oracle.reader_protocol(declared, stored, 25.0, settings)
+        out = tmp_path / f"out{k}"
+        out.mkdir()
+        got = track_bacteria(str(path), settings=_settings(**extra), result_folder=str(out))
+        assert (got is None) == want["returns_none"], (declared, extra, want)
+        if want["skipped"]:
+            assert not list(out.iterdir())                  # returned before anything was written (:73-77)
+            continue
+        csv = out / f"r{k}_list.csv"
+        assert csv.exists()                                 # rows tracked before a read error stay on disk (:368-370)
+        frames_in_csv = int(np.loadtxt(csv, delimiter=",", skiprows=1, usecols=1).max()) + 1
+        assert frames_in_csv == want["frames_processed"] == stored
+        if got is not None:
+            df, fps, h, w, csv_path = got
+            assert fps == want["fps"] and (h, w) == (96, 128) and int(df["POSITION_T"].max()) + 1 == stored
+
+
 def test_rows_sort_on_device():
     """ysmr_rows_sort: (TRACK_ID, POSITION_T) order, the key of sort_list (helper_file.py:1538-1574)."""
     import torch
@@ -379,10 +457,18 @@ def test_uncompressed_avi_is_unpacked_on_the_device(tmp_path):
     for i, c in enumerate(cases):
         clip = rng.integers(0, 256, c.pop("shape"), dtype=np.uint8)
         path = tmp_path / f"u{i}.avi"
+        # what cap.read() owes for this clip, built from the clip itself and not by the product's host reader: a dropped
+        # (empty) chunk repeats the frame before it, palette indices become the palette's B, G, R, everything else is the
+        # array that went into the file
+        want = clip.copy()
+        for d in c.get("dropped", ()):
+            want[d] = want[d - 1]
+        if c.get("palette") is not None:
+            want = c["palette"][want]
         write_avi(path, clip, c.pop("bits"), **c)
         video = open_video(str(path))
         assert video.raw_layout is not None
-        want = video.read(0, video.frame_count)                    # the host reader (tests/test_host.py pins it to the file)
+        np.testing.assert_array_equal(video.read(0, video.frame_count), want)   # (the host reader owes the same)
         feed = DeviceFrameFeed(video, 4, "cuda:0", depth=2, readers=2)
         assert feed._raw is not None
         got = []

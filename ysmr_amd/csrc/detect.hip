@@ -14,6 +14,7 @@
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
 #include "common.h"
 #include "thr_mfma.h"
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <algorithm>
@@ -1543,7 +1544,10 @@ __device__ __forceinline__ void pass_bbox_euler(const uint8_t *__restrict__ cls,
 // once; five near-empty launches cost 25 us per batch), otherwise the passes are separated by a software grid
 // barrier (all RESIDUE_BLOCKS blocks are resident: 128 x 256 threads, no LDS to speak of).
 constexpr int RESIDUE_BLOCKS = 128;
-__device__ __forceinline__ bool grid_barrier(uint32_t *counter, uint32_t target)
+// (fault injection, ysmr_fault_inject: the library's own test of the bail-out below)
+static std::atomic<int> g_fault_residue_stall{0};
+
+__device__ __forceinline__ bool grid_barrier(uint32_t *counter, uint32_t target, uint32_t spin_limit = 20000000u)
 {
     __shared__ int s_ok;
     __syncthreads();
@@ -1554,7 +1558,7 @@ __device__ __forceinline__ bool grid_barrier(uint32_t *counter, uint32_t target)
         int ok = 1;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > 20000000u) { ok = 0; break; }   // (a block that cannot become resident: give up rather than hang)
+            if (++spins > spin_limit) { ok = 0; break; }   // (a block that cannot become resident: give up rather than hang)
         }
         __threadfence();
         s_ok = ok;
@@ -1576,11 +1580,14 @@ __device__ __forceinline__ void pass_tag_roots(uint32_t *labels, const Geo &g, c
 }
 
 __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels, uint8_t *mask, Geo g, int batch, PixelList pl,
-                                                 CompTables t, uint32_t *barrier, int32_t *status)
+                                                 CompTables t, uint32_t *barrier, int32_t *status, int fault)
 {
     DET_RING(5);
     const uint32_t listed = pl.hdr->count[0];   // (written by k_windows, the previous launch: every block sees the same)
-    if (listed == 0u) return;
+    if (listed == 0u && !fault) return;
+    // (fault injection: block 0 never arrives at the first barrier, as a workgroup that found no compute unit would not)
+    if (fault && blockIdx.x == 0) return;
+    const uint32_t spin_limit = fault ? 20000u : 20000000u;
     // (a barrier among fewer blocks is cheaper -- 128 blocks: 2.7 us, 16: 1.2 us -- but letting only one block per 512
     // listed pixels take part made the launch slower, 21 against 16 us: the passes are chains of round trips and
     // want the threads)
@@ -1601,21 +1608,27 @@ __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels,
         }
         if (blockIdx.x == 0)
             for (int f = threadIdx.x; f < batch; f += 256) t.nroots[(size_t)f * NR_STRIDE] = 0;
-        ok = grid_barrier(barrier, ++phase * nb);
+        ok = grid_barrier(barrier, ++phase * nb, spin_limit);
     }
     if (ok) pass_union4(cls, labels, g, pl, nb);
-    ok = ok && grid_barrier(barrier, ++phase * nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
     if (ok) pass_flag(cls, labels, g, pl, nb);
-    ok = ok && grid_barrier(barrier, ++phase * nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
     if (ok) pass_union8(cls, labels, g, pl, nb);
-    ok = ok && grid_barrier(barrier, ++phase * nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
     if (ok) pass_flatten(cls, labels, mask, g, pl, t, nb);
-    ok = ok && grid_barrier(barrier, ++phase * nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
     if (ok) pass_tag_roots(labels, g, t, batch, nb);
-    ok = ok && grid_barrier(barrier, ++phase * nb);
+    ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
     if (ok) pass_bbox_euler(cls, labels, g, pl, t, nb);
-    if (!ok && threadIdx.x == 0)
+    if (!ok && threadIdx.x == 0) {
+        // The passes stopped half way: labels hold union-find parents, tables do not cover what was written.  The call's
+        // results are void (status), and the header must not vouch for them either: dense = 1 makes the next call on
+        // these buffers clear everything -- label map, mask, counters and this barrier word -- instead of walking the
+        // component boxes (k_clear; k_compact keeps the flag).
+        pl.hdr->dense = 1u;
         for (int f = 0; f < batch; ++f) atomicOr(&status[f], YSMR_DET_STALLED);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2316,7 +2329,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
                            batch, w.pixels, t);
     }
     hipLaunchKernelGGL(k_residue, dim3(RESIDUE_BLOCKS), tb, 0, st, cls_dev, labels, mask_dev, g, batch, w.pixels, t, w.arena_used + 1,
-                       status_dev);
+                       status_dev, g_fault_residue_stall.exchange(0));
     YSMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rank, dim3(batch, (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) < 32 ? (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) : 32), dim3(RANK_THREADS), 0, st, t, labels, g.HW,
                        width, height, status_dev, w.pixels.hdr, w.n_holed, w.holed);
@@ -2329,6 +2342,13 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
                        reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total, batch, height, width,
                        (cv_flavour & YSMR_CV_ANGLE_PRE451) != 0);
     YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+int ysmr_fault_inject(int what)
+{
+    if (what != YSMR_FAULT_RESIDUE_STALL) return ysmr::fail(YSMR_ERR_ARG, "unknown fault %d", what);
+    g_fault_residue_stall.store(1);
     return YSMR_OK;
 }
 

@@ -2,40 +2,64 @@
 // of an uncompressed AVI after fetching them from the file -- DIB rows are stored bottom-up with a 4-byte padded
 // stride, 8-bit frames are palette indices -- done on the device, so that the host only moves file bytes into
 // pinned memory (ysmr_amd/frames.py: DeviceFrameFeed) and the frames the detection kernels read are unpacked
-// where they are used.  Pure byte shuffling: the result is identical to the host reader's (AviVideo.read).
+// where they are used.  Pure byte shuffling: the result is the frame sequence cap.read() owes (tests/test_gpu_pipeline.py
+// builds it from the clip that went into the file).
 #include "common.h"
 
 namespace {
 
 constexpr int UNPACK_BLOCKS = 1024;   // resident grid (see detect.hip: grids larger than the chip starve other streams)
 
-// One thread per aligned dword of the output (an output row need not start on a dword); every byte finds its
-// source on its own.  The kernel runs on the upload stream behind a PCIe copy ~50x its duration.
+__device__ __forceinline__ uint4 ld16(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st16(uint8_t *p, const uint4 &v) { __builtin_memcpy(p, &v, 16); }
+
+// A WAVE moves one row at a time: the (frame, row) of a work item costs one division per 64 lanes, each lane moves 16
+// bytes per step (the frame rows are W * channels bytes apart, so neither end need be aligned; gfx950 takes unaligned
+// 16-byte accesses), the last few bytes of a row go one by one.  With a palette a lane expands four stored indices
+// (one dword: DIB rows start on 4-byte boundaries) into their twelve B, G, R bytes from a copy of the palette in LDS.
+// The kernel runs on the upload stream behind a PCIe copy ~50x its duration.
 template <bool PALETTE>
 __global__ __launch_bounds__(256) void k_unpack_dib(const uint8_t *__restrict__ raw, size_t raw_frame_bytes, int n, int H, int W,
                                                     int bpp, int row_stride, int bottom_up, const uint8_t *__restrict__ palette,
                                                     uint8_t *__restrict__ out)
 {
-    const int ch = PALETTE ? 3 : bpp;
-    const size_t row_bytes = (size_t)W * ch, frame_bytes = row_bytes * H, total = frame_bytes * n;
-    const size_t dwords = (total + 3) / 4;
-    for (size_t d = (size_t)blockIdx.x * 256 + threadIdx.x; d < dwords; d += (size_t)gridDim.x * 256) {
-        uint32_t v = 0;
+    __shared__ uint8_t s_pal[PALETTE ? 768 : 4];
+    if (PALETTE) {
+        for (int i = threadIdx.x; i < 768; i += 256) s_pal[i] = palette[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const long long rows = (long long)n * H, wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const size_t row_bytes = (size_t)W * (PALETTE ? 3 : bpp);
+    for (long long item = wave0; item < rows; item += nwaves) {
+        const long long f = item / H;
+        const int y = (int)(item - f * H);
+        const uint8_t *src = raw + (size_t)f * raw_frame_bytes + (size_t)(bottom_up ? H - 1 - y : y) * row_stride;
+        uint8_t *dst = out + (size_t)item * row_bytes;
+        if (!PALETTE) {
+            const size_t whole = row_bytes & ~(size_t)15;
+            for (size_t b = (size_t)lane * 16; b < whole; b += 64 * 16) st16(dst + b, ld16(src + b));
+            if (whole + lane < row_bytes) dst[whole + lane] = src[whole + lane];
+        } else {
+            for (int x = 4 * lane; x < W; x += 4 * 64) {
+                if (x + 4 <= W) {
+                    uint32_t idx;
+                    __builtin_memcpy(&idx, src + x, 4);
+                    uint8_t o[12];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const size_t at = d * 4 + k;
-            if (at >= total) break;
-            const size_t f = at / frame_bytes, in_frame = at - f * frame_bytes;
-            const int y = (int)(in_frame / row_bytes), b = (int)(in_frame - (size_t)y * row_bytes);
-            const uint8_t *src_row = raw + f * raw_frame_bytes + (size_t)(bottom_up ? H - 1 - y : y) * row_stride;
-            uint32_t byte;
-            if (PALETTE) byte = palette[3 * src_row[b / 3] + b % 3];
-            else byte = src_row[b];
-            v |= byte << (8 * k);
+                    for (int k = 0; k < 4; ++k) {
+                        const uint8_t *c = s_pal + 3 * ((idx >> (8 * k)) & 0xFFu);
+                        o[3 * k] = c[0]; o[3 * k + 1] = c[1]; o[3 * k + 2] = c[2];
+                    }
+                    __builtin_memcpy(dst + 3 * (size_t)x, o, 12);
+                } else {
+                    for (int xx = x; xx < W; ++xx) {
+                        const uint8_t *c = s_pal + 3 * src[xx];
+                        dst[3 * (size_t)xx] = c[0]; dst[3 * (size_t)xx + 1] = c[1]; dst[3 * (size_t)xx + 2] = c[2];
+                    }
+                }
+            }
         }
-        if (d * 4 + 4 <= total) reinterpret_cast<uint32_t *>(out)[d] = v;
-        else
-            for (size_t at = d * 4; at < total; ++at) out[at] = (uint8_t)(v >> (8 * (at - d * 4)));
     }
 }
 
@@ -56,7 +80,8 @@ extern "C" int ysmr_unpack_dib_batch(void *stream, const uint8_t *raw_dev, int n
     if (!raw_dev || !frames_dev) return ysmr::fail(YSMR_ERR_ARG, "raw_dev and frames_dev must not be NULL");
     if ((uintptr_t)frames_dev & 3) return ysmr::fail(YSMR_ERR_ARG, "frames_dev must be 4-byte aligned");
     const size_t total = (size_t)n_frames * height * width * (palette_dev ? 3 : bytes_per_pixel);
-    const size_t blocks = std::min<size_t>((total / 4 + 255) / 256 + 1, UNPACK_BLOCKS);
+    (void)total;
+    const size_t blocks = std::min<size_t>(((size_t)n_frames * height + 3) / 4, UNPACK_BLOCKS);   // four rows (waves) per block
     hipStream_t st = (hipStream_t)stream;
     if (palette_dev)
         hipLaunchKernelGGL(k_unpack_dib<true>, dim3((unsigned)blocks), dim3(256), 0, st, raw_dev, raw_frame_bytes, n_frames, height,

@@ -13,7 +13,8 @@ it happens to be importable:
                Pillow can be imported (frames decoded on the reader threads); other compressed streams go to cv2
 * anything else -- ``cv2.VideoCapture`` if cv2 can be imported, otherwise an error
 
-Every source exposes ``frame_count``, ``fps``, ``height``, ``width``, ``channels`` and
+Every source exposes ``frame_count`` (what the container reports: cv2's CAP_PROP_FRAME_COUNT), optionally
+``frames_available`` (what it holds, when that can differ), ``fps``, ``height``, ``width``, ``channels`` and
 ``read(start, count) -> uint8 ndarray [n, H, W(, 3)]`` (fewer than ``count`` frames at the end).
 """
 from __future__ import annotations
@@ -151,6 +152,7 @@ class AviVideo:
         size = os.path.getsize(path)
         self.fps = float(default_fps)
         self._frames = []          # (offset, size) of every video chunk of stream 0
+        declared = [0]
         bih = palette = None
         first_stream = True
 
@@ -173,6 +175,8 @@ class AviVideo:
                         scale, rate = struct.unpack("<II", data[20:28])
                         if scale and rate:
                             self.fps = rate / scale
+                        if len(data) >= 36:
+                            declared[0] = struct.unpack("<I", data[32:36])[0]     # dwLength: the stream's frames
                 elif cid == b"strf" and first_stream:
                     data = fh.read(csz)
                     if len(data) >= 40:
@@ -214,8 +218,9 @@ class AviVideo:
                 raise ValueError(f"{path}: Motion-JPEG AVI needs Pillow ({exc})") from exc
             self._Image = Image
             self.width, self.height = int(width), abs(int(height))
-            self.frame_count = len(self._frames)
-            if not self.frame_count:
+            self.frames_available = len(self._frames)
+            self.frame_count = declared[0] or self.frames_available
+            if not self.frames_available:
                 raise ValueError(f"{path}: no frames")
             with Image.open(self._chunk(0)) as first:
                 self.channels = 1 if first.mode == "L" else 3
@@ -240,10 +245,14 @@ class AviVideo:
         short = [i for i, f in enumerate(self._frames) if f[1] < need]
         if short:      # dropping them silently would shift every later frame number
             raise ValueError(f"{path}: video chunk {short[0]} holds {self._frames[short[0]][1]} bytes, a frame needs {need}")
-        self.frame_count = len(self._frames)
+        # what the container REPORTS (the stream header's length, cv2's CAP_PROP_FRAME_COUNT) and what it HOLDS: the
+        # reference tolerates a report one above the frames it gets and treats anything else as a read error
+        # (track_eval.py:170-178); track_bacteria applies that rule to these two numbers
+        self.frames_available = len(self._frames)
+        self.frame_count = declared[0] or self.frames_available
 
     def read(self, start, count):
-        n = max(0, min(count, self.frame_count - start))
+        n = max(0, min(count, self.frames_available - start))
         out = np.empty((n, self.height, self.width) + ((3,) if self.channels == 3 else ()), np.uint8)
         self.read_into(start, n, out)
         return out
@@ -262,7 +271,7 @@ class AviVideo:
                 dst[...] = np.asarray(im.convert("RGB"))[:, :, ::-1]     # BGR, what cv2.VideoCapture delivers
 
     def read_into(self, start, count, out, pool=None):
-        n = max(0, min(count, self.frame_count - start))
+        n = max(0, min(count, self.frames_available - start))
         if self._jpeg:
             blobs = [self._chunk(start + i) for i in range(n)]           # file access stays on this thread
             if pool is None:
@@ -300,7 +309,7 @@ class AviVideo:
         """Chunk bodies of frames [start, start + count) into ``out[:n]`` (u8 [n, bytes per stored frame], e.g.
         pinned memory): file reads only, no per-pixel work on the host; positional reads (``os.preadv``), spread
         over the threads of ``pool`` if one is given."""
-        n = max(0, min(count, self.frame_count - start))
+        n = max(0, min(count, self.frames_available - start))
         need = self._stride * self.height
         fd = self._fh.fileno()
 
@@ -331,7 +340,8 @@ class Cv2Video:
         import cv2  # noqa: F401  (optional dependency)
         self._cv2 = cv2
         self._cap = cv2.VideoCapture(path)
-        self.frame_count = int(self._cap.get(cv2.CAP_PROP_FRAME_COUNT))
+        self.frame_count = int(self._cap.get(cv2.CAP_PROP_FRAME_COUNT))   # what the container reports ...
+        self.frames_available = 1 << 62                                    # ... read() tells where it really ends
         self.fps = float(self._cap.get(cv2.CAP_PROP_FPS) or default_fps)
         self.height, self.width = int(self._cap.get(4)), int(self._cap.get(3))
         self.channels = 3
@@ -401,7 +411,9 @@ class DeviceFrameFeed:
         try:
             torch.cuda.set_device(self.device)
             i = 0
-            for f0 in range(0, self.video.frame_count, self.B):
+            # (every frame the source HOLDS, which need not be the number it reports: track_bacteria applies the
+            # reference's rule to the difference)
+            for f0 in range(0, getattr(self.video, "frames_available", self.video.frame_count), self.B):
                 slot = i % self.depth
                 with self._cv:
                     while self._released[slot] is None and not self._stop:

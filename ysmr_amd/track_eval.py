@@ -104,6 +104,9 @@ class TrackingPipeline:
         self.row_count = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.side = torch.cuda.Stream(device=self.device)
         self._done = [None, None]   # event: detector i's outputs consumed by the tracker
+        # (events are made once and recorded again every batch: creating one costs the host tens of microseconds, and the
+        # host has little slack next to a link that wants a launch every ~11 us)
+        self._ev = [{k: torch.cuda.Event() for k in ("ready", "done", "thresholded")} for _ in range(2)]
         self._k = 0
 
     @_on_own_device
@@ -126,7 +129,7 @@ class TrackingPipeline:
             if threshold_events is not None:
                 e1.record(cur)
                 threshold_events.append((e0, e1, frames_dev.shape[0]))
-            thresholded = torch.cuda.Event()
+            thresholded = self._ev[slot]["thresholded"]
             thresholded.record(cur)
         with torch.cuda.stream(self.side):
             self.side.wait_stream(cur)          # the frames were produced/uploaded on the caller's stream
@@ -151,7 +154,7 @@ class TrackingPipeline:
                     e2 = events[2] if events else torch.cuda.Event(enable_timing=True)
                     e2.record(self.side)
                     chain_events.append((e1, e2, frames_dev.shape[0]))
-            ready = torch.cuda.Event()
+            ready = self._ev[slot]["ready"]
             ready.record(self.side)
         return slot, res, ready
 
@@ -177,7 +180,7 @@ class TrackingPipeline:
             host = time.perf_counter() - t0
             e1.record(cur)
             link_events.append((e0, e1, int(res.det_count.shape[0]), host))
-        done = torch.cuda.Event()
+        done = self._ev[slot]["done"]
         done.record(cur)
         self._done[slot] = done
         return res
@@ -369,7 +372,10 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
                 sorted_rows = rows_to_numpy(sort_rows(on_dev, len(everything)), len(everything))
             else:
                 sorted_rows = pipe.take_rows(sort=True)
-        if frames_done < frame_count - 1:   # some containers over-report by one frame (track_eval.py:170-171)
+        # the reference reads until cap.read() fails and accepts that only where the container said it would end, or
+        # one frame earlier ("some file formats skip one frame", track_eval.py:170-174); anything else -- frames missing
+        # OR frames beyond the reported count -- is its read error (:175-178)
+        if frames_done not in (frame_count, frame_count - 1):
             logger.critical("Error during read with file {}".format(video_path))
             error_during_read = settings["stop evaluation on error"]
     except _lib.YsmrCapacityError as exc:
