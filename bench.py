@@ -143,6 +143,9 @@ def main():
         local_rank = args.device_index
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # every rank runs on the CPUs next to its GPU (ysmr_amd/dist.py: sysfs local_cpulist of the device's PCI address): the
+    # link wants a launch every ~11 us from this process, and N ranks' threads left to the scheduler share cores
+    pinned = dist.pin_to_gpu(local_rank) if world > 1 or os.environ.get("YSMR_BENCH_PIN") == "1" else None
     dist.init(info, backend=args.dist_backend, device=dev)   # barrier + max-over-ranks time only; no data-path collective
 
     dist.barrier(info)   # (rank 0 built the library before any rank loads it)
@@ -285,6 +288,7 @@ def main():
                 "link_host_issue_us_per_frame": stats_us([h * 1e6 / n for _, _, n, h in link_events]),
                 "host_enqueue_ms_per_step": sum(enqueue_s) / len(enqueue_s) * 1e3 if enqueue_s else None,
                 "clocks": gpu_clocks(local_rank), "host_cpus": os.cpu_count(),
+                "cpus_usable": len(os.sched_getaffinity(0)), "pinned_to_gpu_numa_node": bool(pinned),
                 "host_load_1m": os.getloadavg()[0]}
         out["diagnostics"] = diag
         if world == 1:

@@ -5,6 +5,6 @@ import threading
 
 
 def fake_gpu_worker(args):
-    jobs, streams = args
+    jobs, streams, physical = args
     return [(path, {"device": device, "pid": os.getpid(), "thread": threading.current_thread().name,
-                    "streams": streams}) for path, _settings, _folder, device in jobs]
+                    "streams": streams, "physical": physical}) for path, _settings, _folder, device in jobs]

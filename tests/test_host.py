@@ -403,13 +403,64 @@ def test_ysmr_multiprocess_one_worker_process_per_gpu(tmp_path, monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: False)
     monkeypatch.setattr(main, "_gpu_worker", mgpu_stub.fake_gpu_worker)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,6")        # this process's cuda:0 / cuda:1 are the host's GPUs 4 and 6
     paths = [str(tmp_path / f"v{i}.npy") for i in range(5)]
+    paths[3] = paths[1]                                     # a path given twice is analysed twice, results by position
     done = main.ysmr(paths, settings=_mgpu_settings(), result_folder=str(tmp_path), multiprocess=True, streams_per_gpu=3)
     assert [p for p, _ in done] == paths
     assert [r["device"] for _, r in done] == ["cuda:0", "cuda:1", "cuda:0", "cuda:1", "cuda:0"]
     pids = {r["device"]: r["pid"] for _, r in done}
     assert len(set(pids.values())) == 2 and os.getpid() not in pids.values()     # two workers, neither is this process
     assert all(r["pid"] == pids[r["device"]] and r["streams"] == 3 for _, r in done)
+    # every worker process is told which GPU of the HOST is its own (it makes that its HIP_VISIBLE_DEVICES)
+    assert {r["device"]: r["physical"] for _, r in done} == {"cuda:0": "4", "cuda:1": "6"}
+
+
+def test_gpu_worker_sees_only_its_gpu_and_sits_next_to_it(tmp_path, monkeypatch):
+    """The placement a per-GPU worker process gives itself (ysmr_amd/dist.py): HIP_VISIBLE_DEVICES = its GPU, its jobs
+    renamed to cuda:0, CPU affinity = the GPU's NUMA-local CPUs that the process may use -- against a made-up sysfs tree;
+    nothing is pinned when sysfs does not know, when too few CPUs would be left, or when the GPU cannot be opened."""
+    from ysmr_amd import dist, main
+    sys_root = tmp_path / "sys"
+    dev = sys_root / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "local_cpulist").write_text("48-55,144-147\n")
+    want = set(range(48, 56)) | set(range(144, 148))
+    assert dist.local_cpus("0000:c1:00.0", str(sys_root)) == want
+    other = sys_root / "bus" / "pci" / "devices" / "0000:05:00.0"
+    other.mkdir(parents=True)
+    (other / "numa_node").write_text("1\n")
+    node = sys_root / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("64-127\n")
+    assert dist.local_cpus("0000:05:00.0", str(sys_root)) == set(range(64, 128))
+    (other / "numa_node").write_text("-1\n")
+    assert dist.local_cpus("0000:05:00.0", str(sys_root)) is None and dist.local_cpus(None, str(sys_root)) is None
+    pinned = []
+    assert dist.pin_to_gpu(0, str(sys_root), bus_id="0000:c1:00.0", allowed=range(0, 100), setter=pinned.append) == set(range(48, 56))
+    assert pinned == [set(range(48, 56))]
+    assert dist.pin_to_gpu(0, str(sys_root), bus_id="0000:c1:00.0", allowed=range(53, 60), setter=pinned.append) is None   # 3 CPUs: too few
+    assert dist.pin_to_gpu(0, str(sys_root), bus_id="0000:ff:00.0", allowed=range(0, 100), setter=pinned.append) is None
+    assert len(pinned) == 1
+    assert dist.physical_device(1, {"HIP_VISIBLE_DEVICES": "2, 5"}) == "5" and dist.physical_device(3, {}) == "3"
+    # the worker itself: environment, job names, and the fold when the parent counted a GPU this process cannot open
+    calls = []
+    monkeypatch.setattr(main, "_worker", lambda job: calls.append(job[3]) or (job[0], True))
+    monkeypatch.setattr(dist, "pin_to_gpu", lambda index=0, **kw: {1, 2, 3, 4})
+    monkeypatch.setattr(dist, "usable_gpus", lambda dev_root="/dev/dri": 8)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    jobs = [("a.npy", {}, "out", "cuda:5"), ("b.npy", {}, "out", "cuda:5")]
+    assert main._gpu_worker((jobs, 1, "5")) == [("a.npy", True), ("b.npy", True)]
+    assert os.environ["HIP_VISIBLE_DEVICES"] == "5" and calls == ["cuda:0", "cuda:0"]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.setattr(dist, "usable_gpus", lambda dev_root="/dev/dri": 1)
+    calls.clear()
+    main._gpu_worker((jobs, 1, "5"))
+    assert "HIP_VISIBLE_DEVICES" not in os.environ and calls == ["cuda:5", "cuda:5"]
+    # (in-process workers -- the parent holds a GPU context -- change neither the environment nor the names)
+    calls.clear()
+    main._gpu_worker((jobs, 1, None))
+    assert "HIP_VISIBLE_DEVICES" not in os.environ and calls == ["cuda:5", "cuda:5"]
 
 
 def test_ysmr_multiprocess_stays_in_process_once_the_gpu_is_initialised(tmp_path, monkeypatch, caplog):

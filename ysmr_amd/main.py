@@ -103,22 +103,29 @@ def analyse(path, settings=None, result_folder=None, return_df=False, device="cu
 
 
 def _visible(device):
-    """A worker may see fewer devices than the process that dealt the jobs (HIP_VISIBLE_DEVICES per worker, a
-    scheduler's cgroup): fold the ordinal instead of failing the video."""
+    """A worker may see fewer devices than the process that dealt the jobs (a scheduler's cgroup, a HIP_VISIBLE_DEVICES
+    this library did not set): fold the ordinal instead of failing the video -- and say so, because two GPUs' videos then
+    share one device.  (The worker processes ``ysmr`` starts itself see exactly one GPU and get their jobs renamed to
+    cuda:0 before they arrive here.)"""
     import torch
     try:        # the HIP runtime's own count (device_count() may answer from the management library, which lists
         seen = int(torch._C._cuda_getDeviceCount())      # every GPU of the host whatever this process may use)
     except (AttributeError, RuntimeError):
         seen = torch.cuda.device_count()
     index = torch.device(device).index or 0
-    return "cuda:{}".format(index % seen) if seen and index >= seen else device
+    if seen and index >= seen:
+        folded = "cuda:{}".format(index % seen)
+        logging.getLogger("ysmr").getChild(__name__).warning(
+            "a video dealt to {} runs on {}: this process sees {} device(s)".format(device, folded, seen))
+        return folded
+    return device
 
 
 def _worker(args):
     """One video on the GPU it was dealt to.  The device is made current here: a fresh worker's current
     device is cuda:0 whatever its job says (the entry points below it select their device themselves as
     well; this covers allocations made in between)."""
-    path, settings, result_folder, device = args
+    path, settings, result_folder, device = args[:4]
     from . import _lib
     device = _visible(device)
     with _lib.on(device):
@@ -128,7 +135,22 @@ def _worker(args):
 def _gpu_worker(args):
     """All videos dealt to one GPU: ``streams`` of them at a time, each on a thread with its own HIP
     stream (two streams inside one process overlap far better than two processes on one device)."""
-    jobs, streams = args
+    jobs, streams = args[:2]
+    own_process = len(args) > 2 and args[2] is not None
+    if own_process:
+        # A worker process of its own GPU: it must SEE only that GPU -- set before anything here initialises HIP -- so that
+        # no stray context, allocation or default-device call lands on another worker's device, and it runs on the CPUs
+        # of that GPU's NUMA node.
+        from . import dist
+        usable = dist.usable_gpus()
+        if args[2].isdigit() and usable and int(args[2]) >= usable:
+            pass    # the parent counted GPUs this process cannot open (a device cgroup): _visible() folds and says so
+        else:
+            os.environ["HIP_VISIBLE_DEVICES"] = args[2]
+            jobs = [(j[0], j[1], j[2], "cuda:0") + tuple(j[4:]) for j in jobs]
+        pinned = dist.pin_to_gpu(0)
+        logging.getLogger("ysmr").getChild(__name__).debug(
+            "worker {} for GPU {}: cpus {}".format(os.getpid(), args[2], sorted(pinned) if pinned else "unpinned"))
     if streams <= 1 or len(jobs) <= 1:
         return [_worker(j) for j in jobs]
     from concurrent.futures import ThreadPoolExecutor
@@ -189,7 +211,8 @@ def ysmr(paths=None, settings=None, result_folder=None, multiprocess=False, stre
     finished, failed = [], []
     if multiprocess and len(jobs) > 1:
         streams = max(1, int(streams_per_gpu))
-        per_gpu = [([j for j in jobs if j[3] == "cuda:{}".format(g)], streams) for g in range(n_gpu)]
+        from . import dist
+        per_gpu = [([j for j in jobs if j[3] == "cuda:{}".format(g)], streams, g) for g in range(n_gpu)]
         per_gpu = [a for a in per_gpu if a[0]]
         if len(per_gpu) > 1 and torch.cuda.is_initialized():
             # This process already holds a GPU context (a notebook, a test runner, an earlier call): starting
@@ -199,16 +222,18 @@ def ysmr(paths=None, settings=None, result_folder=None, multiprocess=False, stre
                            "running the {} per-GPU workers as threads of this process".format(len(per_gpu)))
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=len(per_gpu), thread_name_prefix="ysmr-gpu") as pool:
-                parts = list(pool.map(_gpu_worker, per_gpu))
+                parts = list(pool.map(_gpu_worker, [(a[0], a[1], None) for a in per_gpu]))
         elif len(per_gpu) > 1:                     # one worker process per GPU, as many as there are GPUs with work
             import multiprocessing as mp           # (started before anything here has touched the GPU)
             ctx = mp.get_context("spawn")
             with ctx.Pool(processes=len(per_gpu), maxtasksperchild=1) as pool:
-                parts = pool.map(_gpu_worker, per_gpu, chunksize=1)
+                parts = pool.map(_gpu_worker, [(a[0], a[1], dist.physical_device(a[2])) for a in per_gpu], chunksize=1)
         else:
-            parts = [_gpu_worker(per_gpu[0])]
-        by_path = {p: r for part in parts for p, r in part}
-        results = [(j[0], by_path.get(j[0])) for j in jobs]
+            parts = [_gpu_worker((per_gpu[0][0], per_gpu[0][1], None))]
+        # (a path given twice is analysed twice, as upstream's pool would: results go back by position, not by path)
+        order = [i for a in per_gpu for i, j in enumerate(jobs) if j in a[0]]
+        by_index = dict(zip(order, (r for part in parts for _, r in part)))
+        results = [(j[0], by_index.get(i)) for i, j in enumerate(jobs)]
     else:
         results = [_worker(j) for j in jobs]
     for path, res in results:
