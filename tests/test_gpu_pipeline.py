@@ -210,10 +210,16 @@ def test_rows_sort_on_device():
     # The tracker's own table needs no sort (row (id, f) belongs at offset[id] + f - first_frame[id]); tables
     # of any other shape are recognised on the device and go through the stable radix sort instead:
     # ids beyond the row count, tracks with gaps in their frames, and equal keys (input order kept)
-    for n, shape in ((9000, "sparse ids"), (9000, "gaps"), (70001, "duplicates")):
+    for n, shape in ((9000, "sparse ids"), (9000, "gaps"), (70001, "duplicates"), (4000, "a duplicate and a gap that cancel")):
         rows = np.zeros(n, _lib.ROW_DTYPE)
         perm = rng.permutation(n)
-        if shape == "sparse ids":
+        if shape == "a duplicate and a gap that cancel":
+            # every track's frames are gapless and unique except one: 0, 1, 1, 3 -- as many rows as last - first + 1
+            rows["track_id"], rows["frame"] = perm % 40, perm // 40
+            pick = np.nonzero(rows["track_id"] == 7)[0]
+            pick = pick[np.argsort(rows["frame"][pick])]
+            rows["frame"][pick[2]] = rows["frame"][pick[1]]
+        elif shape == "sparse ids":
             rows["track_id"], rows["frame"] = (perm % 31) * 1_000_003 + 17, perm // 31
         elif shape == "gaps":
             rows["track_id"], rows["frame"] = perm % 31, (perm // 31) * 3 + (perm % 2)

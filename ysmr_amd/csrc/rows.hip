@@ -29,14 +29,16 @@ namespace {
 // One pass gathers rows per track and first/last frame (atomics on 12 bytes per track), a prefix sum turns the
 // counts into offsets, one pass checks that every track's frames are gapless and scatters.  A table that does
 // not have this shape (ids beyond the row count, gaps, duplicates -- e.g. rows assembled by a caller) is
-// reported by the check and goes through the stable radix sort of prim.h instead.
+// reported by the checks (per track: span = rows; per place: taken exactly once) and goes through the stable radix
+// sort of prim.h instead.
 struct TrackSpan { uint32_t rows, first, last; };
 
-__global__ __launch_bounds__(256) void k_span_clear(TrackSpan *span, uint32_t *counts, long long n, uint32_t *bad)
+__global__ __launch_bounds__(256) void k_span_clear(TrackSpan *span, uint32_t *counts, uint32_t *written, long long n, uint32_t *bad)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         span[i] = TrackSpan{0u, 0xFFFFFFFFu, 0u};
         counts[i] = 0u;
+        written[i] = 0u;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *bad = 0u;
 }
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void k_span_gather(const ysmr_row *__restrict_
 // counts_incl: inclusive prefix sum of the rows per track
 __global__ __launch_bounds__(256) void k_span_scatter(const ysmr_row *__restrict__ rows, long long n, const TrackSpan *span,
                                                       const uint32_t *__restrict__ counts_incl, uint32_t *bad,
-                                                      ysmr_row *__restrict__ out)
+                                                      uint32_t *written, ysmr_row *__restrict__ out)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const ysmr_row r = rows[i];
@@ -65,7 +67,11 @@ __global__ __launch_bounds__(256) void k_span_scatter(const ysmr_row *__restrict
         const uint32_t end = counts_incl[id], begin = id ? counts_incl[id - 1] : 0u;
         const TrackSpan s = span[id];
         if (s.last - s.first + 1u != end - begin) { *bad = 1u; continue; }   // a gap or a duplicate (frame, id) pair
-        out[begin + ((uint32_t)r.frame - s.first)] = r;
+        // (a duplicate AND a gap in one track cancel in that count -- frames 0, 1, 1, 3 -- but then two rows want one
+        // place and another stays empty: every place must be taken exactly once)
+        const uint32_t place = begin + ((uint32_t)r.frame - s.first);
+        if (atomicAdd(&written[place], 1u)) { *bad = 1u; continue; }
+        out[place] = r;
     }
 }
 
@@ -288,10 +294,11 @@ int ysmr_rows_sort(void *stream, const ysmr_row *rows_dev, long long n_rows, voi
     // the tracker's table: no sort needed
     TrackSpan *span = (TrackSpan *)(w + L.span);
     uint32_t *counts = (uint32_t *)(w + L.counts), *bad = (uint32_t *)(w + L.bad);
-    hipLaunchKernelGGL(k_span_clear, dim3(grid), dim3(256), 0, st, span, counts, n_rows, bad);
+    uint32_t *written = (uint32_t *)(w + L.idx_a);   // (the fallback's buffer: not in use yet)
+    hipLaunchKernelGGL(k_span_clear, dim3(grid), dim3(256), 0, st, span, counts, written, n_rows, bad);
     hipLaunchKernelGGL(k_span_gather, dim3(grid), dim3(256), 0, st, rows_dev, n_rows, span, counts, bad);
     ysmr::prim::inclusive_scan_u32(st, counts, counts, (size_t)n_rows, (uint32_t *)(w + L.temp));
-    hipLaunchKernelGGL(k_span_scatter, dim3(grid), dim3(256), 0, st, rows_dev, n_rows, span, counts, bad, sorted_dev);
+    hipLaunchKernelGGL(k_span_scatter, dim3(grid), dim3(256), 0, st, rows_dev, n_rows, span, counts, bad, written, sorted_dev);
     YSMR_LAUNCH_CHECK();
     uint32_t irregular = 0;
     YSMR_HIP_CHECK(hipMemcpyAsync(&irregular, bad, sizeof(irregular), hipMemcpyDeviceToHost, st));
