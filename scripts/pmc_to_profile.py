@@ -21,4 +21,13 @@ out = {"kernel": "k_threshold_strip", "batch": B, "height": H, "width": W,
        "sq": {k[len("threshold_"):]: v for k, v in s.items() if k.startswith("threshold_SQ_")},
        "note": sys.argv[2] if len(sys.argv) > 2 else ""}
 json.dump(out, open(os.path.join(root, "profiles", "threshold_pmc.json"), "w"), indent=1)
-print(f"read {rd / 1e6:.1f} MB + written {wr / 1e6:.1f} MB = {(rd + wr) / (2 * B * H * W):.2f} x algorithmic")
+print(f"k_threshold_strip: read {rd / 1e6:.1f} MB + written {wr / 1e6:.1f} MB = {(rd + wr) / (2 * B * H * W):.2f} x algorithmic")
+if s.get("mfma_FETCH_SIZE") is not None:
+    rd, wr = s["mfma_FETCH_SIZE"] * 1024 / rf, s["mfma_WRITE_SIZE"] * 1024 / wf
+    out = {"kernel": "k_threshold_mfma", "batch": B, "height": H, "width": W, "FETCH_SIZE_KB_raw": s["mfma_FETCH_SIZE"],
+           "WRITE_SIZE_KB_raw": s["mfma_WRITE_SIZE"], "calibration": out["calibration"],
+           "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+           "algorithmic_bytes_per_launch": 2 * B * H * W,
+           "sq": {k[len("mfma_"):]: v for k, v in s.items() if k.startswith("mfma_SQ_")}, "note": sys.argv[2] if len(sys.argv) > 2 else ""}
+    json.dump(out, open(os.path.join(root, "profiles", "threshold_mfma_pmc.json"), "w"), indent=1)
+    print(f"k_threshold_mfma:  read {rd / 1e6:.1f} MB + written {wr / 1e6:.1f} MB = {(rd + wr) / (2 * B * H * W):.2f} x algorithmic")

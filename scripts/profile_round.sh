@@ -4,14 +4,18 @@
 # plus the FETCH/WRITE calibration copy.  Everything lands in gpurun_out/round/.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
 [ -x $R/scripts/ubench/copy_calib ] || make -C $R/scripts/ubench copy_calib >/dev/null
-python $R/bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
+python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python3 $R/bench.py --cpu-sample 0 > $O/ktrace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 > $O/ktrace.log 2>&1
+# (variant 1 = k_threshold_strip, the kernel of the pipeline and of the bench line; variant 0 = k_threshold_mfma)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_thr_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real > $O/pmc_thr_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_thr_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 1 > $O/pmc_thr_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_mfma_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 > $O/pmc_mfma_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_cal_$c -- $R/scripts/ubench/copy_calib > $O/pmc_cal_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_thr_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real > $O/pmc_thr_SQ.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_thr_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 1 > $O/pmc_thr_SQ.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_mfma_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 > $O/pmc_mfma_SQ.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_mfma_SQ2 -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 > $O/pmc_mfma_SQ2.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 O = "$O"
@@ -25,13 +29,16 @@ def mean(path, kernel):
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     out["threshold_" + c] = mean(f"{O}/pmc_thr_{c}", "k_threshold").get(c)
+    out["mfma_" + c] = mean(f"{O}/pmc_mfma_{c}", "k_threshold").get(c)
     out["calib_" + c] = mean(f"{O}/pmc_cal_{c}", "copy_dword").get(c)
 out.update({"threshold_" + k: v for k, v in mean(f"{O}/pmc_thr_SQ", "k_threshold").items()})
+out.update({"mfma_" + k: v for k, v in mean(f"{O}/pmc_mfma_SQ", "k_threshold").items()})
+out.update({"mfma_" + k: v for k, v in mean(f"{O}/pmc_mfma_SQ2", "k_threshold").items()})
 json.dump(out, open(f"{O}/pmc_summary.json", "w"), indent=1)
 print(json.dumps(out))
 PY
 # the other single-GPU configurations of BASELINE.json as bench lines, and the k_windows counters
-for c in 0 1 4; do python $R/bench.py --config $c --cpu-sample 20 2>> $O/bench.err >> $O/bench_configs.jsonl; done
+for c in 0 1 4; do python3 $R/bench.py --config $c --cpu-sample 20 2>> $O/bench.err >> $O/bench_configs.jsonl; done
 cut -c1-150 $O/bench_configs.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_det -- python3 $R/bench.py --cpu-sample 0 --config 1 > $O/ktrace_det.log 2>&1
 python3 $R/scripts/kstats.py $O/ktrace 30 > $O/kernel_stats.txt; python3 $R/scripts/kstats.py $O/ktrace_det 20 > $O/kernel_stats_detect_only.txt
