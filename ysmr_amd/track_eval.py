@@ -57,7 +57,12 @@ def _on_own_device(method):
 
 
 class TrackingPipeline:
-    """Device-resident detect+link over consecutive batches of one video stream."""
+    """Device-resident detect+link over consecutive batches of one video stream: ``detect_async`` issues a batch's detection
+    on a side stream (two detectors ping-pong), ``link`` its 64 link launches on the caller's stream, ``take_rows`` hands
+    the rows over (ordered on the device with ``sort=True``).  Rows accumulate in ``self.rows`` (``rows_per_flush`` of
+    them); ``track_bacteria`` empties the buffer when it fills and -- with the optional settings key 'hip persist rows' --
+    appends every full buffer to ``<name>_list.csv`` as the reference does, so that an interrupted run keeps what was
+    tracked.  ``link=False``: detection only (no tracker neighbour: the matrix-pipe threshold kernel is used)."""
 
     def __init__(self, height, width, fps, settings, batch=64, max_det=2048, capacity=2048, device="cuda:0",
                  rows_per_flush=None, link=True):
