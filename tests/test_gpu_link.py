@@ -68,16 +68,24 @@ def test_gsff_class_matches_reference_fixture(torch_cuda, name, fps, n_min, n_ma
         np.testing.assert_allclose(p, g["predict"][k], rtol=RTOL, atol=ATOL, err_msg=f"predict step {k}")
 
 
-def test_new_ids_follow_cpython_set_order(torch_cuda, oracle):
+@pytest.mark.parametrize("cap,trials,n0_max,extra_max", [
+    (1024, 25, 120, 200),      # k_frame: the model in its 16-bit LDS tables
+    (4096, 10, 1500, 2500),    # k_link, tables in LDS: the model takes over the dead claim tables (up to 16384 slots)
+    (8192, 6, 3000, 5100),     # ... up to 32768 slots (the 4K configuration's capacity)
+    (16384, 3, 1500, 2500),    # k_link, tables in HBM: the one-thread model
+])
+def test_new_ids_follow_cpython_set_order(torch_cuda, oracle, cap, trials, n0_max, extra_max):
     """tracker.py:216 iterates a set: ids of tracks born in one frame follow CPython's hash-table
     order.  The device model must reproduce it for every mix of claimed/unclaimed columns."""
     from ysmr_amd.tracker import CentroidTracker
     rng = np.random.default_rng(11)
-    for trial in range(25):
-        n0 = int(rng.integers(1, 120))
-        extra = int(rng.integers(1, 200))
+    for trial in range(trials):
+        n0 = int(rng.integers(1, n0_max))
+        extra = int(rng.integers(1, extra_max))
+        if trial == 0:
+            n0, extra = n0_max - 1, extra_max - 1          # the largest tables of the case
         base = rng.uniform(0, 5000, (n0, 2))
-        ct = CentroidTracker(max_disappeared=30, fps=30.0, use_gsff=False, capacity=1024, max_det=1024)
+        ct = CentroidTracker(max_disappeared=30, fps=30.0, use_gsff=False, capacity=cap, max_det=cap)
         ot = oracle.OracleTracker(max_disappeared=30, fps=30.0, use_gsff=False)
         info = np.zeros((n0, 3))
         ct.update(rects_of(base, info)); ot.update(rects_of(base, info))

@@ -873,6 +873,95 @@ __device__ int block_exclusive_scan(int v, int *s_scan, int *total)
     return before + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
+// The same model with its tables in LDS, for k_link once its claim tables are dead (all LINK_THREADS threads call it).
+// What is order-dependent -- the insertions -- stays on one lane but costs LDS round trips instead of HBM ones (a frame
+// with 300 unregistered columns spent 575 us in cpython_unused_order, 700 dependent insertions and a 2048-slot walk from
+// one thread); clearing a table and the final walk in slot order are done by the whole block, and at a resize wave 0
+// reads the old table 64 slots at a time.  Table sizes alternate 8, 32, 128, ... between `tab_a` and `tab_b`; 16-bit
+// slots (keys < 65535).  Returns the number of keys, or -1 when a table does not fit (the caller falls back).
+constexpr unsigned short SET_EMPTY16 = 0xFFFFu;
+__device__ __forceinline__ void set_insert_clean_u16(unsigned short *table, unsigned mask, unsigned key)
+{
+    unsigned long long perturb = (unsigned long long)key;
+    unsigned i = key & mask;
+    while (true) {
+        const int probes = (i + 9u <= mask) ? 9 : 0;
+        for (int j = 0; j <= probes; ++j)
+            if (table[i + j] == SET_EMPTY16) { table[i + j] = (unsigned short)key; return; }
+        perturb >>= 5;
+        i = (unsigned)(((unsigned long long)i * 5ull + 1ull + perturb) & mask);
+    }
+}
+
+__device__ int cpython_order_block(const int *unused, int n_unused, int m, int n_used, int *out, unsigned short *tab_a,
+                                   int cap_a, unsigned short *tab_b, int cap_b, unsigned short *stage, int *s_scan,
+                                   int *s_state)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((m >> 2) > n_used) {       // set_copy_and_difference: a copy of set(range(m)) iterates ascending
+        for (int k = tid; k < n_unused; k += LINK_THREADS) out[k] = unused[k];
+        return n_unused;
+    }
+    for (int k = tid; k < n_unused; k += LINK_THREADS) stage[k] = (unsigned short)unused[k];
+    if (tid < 8) tab_a[tid] = SET_EMPTY16;
+    __syncthreads();
+    unsigned short *table = tab_a, *other = tab_b;
+    int cap_other = cap_b, cap_table = cap_a;
+    unsigned mask = 7;
+    int next = 0;
+    while (true) {
+        if (tid == 0) {   // insert until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
+            int k = next;
+            bool grow = false;
+            while (k < n_unused && !grow) {
+                set_insert_clean_u16(table, mask, stage[k]);
+                ++k;
+                grow = (unsigned long long)k * 5ull >= (unsigned long long)mask * 3ull;   // fill == k: nothing is ever removed
+            }
+            s_state[0] = k;
+            s_state[1] = grow ? 1 : 0;
+        }
+        __syncthreads();
+        next = s_state[0];
+        const bool grow = s_state[1] != 0;
+        __syncthreads();
+        if (!grow) break;
+        const unsigned fill = (unsigned)next;
+        const unsigned minused = fill > 50000u ? fill * 2u : fill * 4u;
+        unsigned newsize = 8;
+        while (newsize <= minused) newsize <<= 1;
+        if ((int)newsize > cap_other) return -1;                      // (uniform)
+        for (unsigned i = tid; i < newsize; i += LINK_THREADS) other[i] = SET_EMPTY16;
+        __syncthreads();
+        if (tid < 64) {   // wave 0: the old table in slot order, 64 slots per read; lane 0 re-inserts
+            for (unsigned i0 = 0; i0 <= mask; i0 += 64) {
+                const unsigned key = i0 + lane <= mask ? table[i0 + lane] : SET_EMPTY16;
+                unsigned long long bal = __ballot(key != SET_EMPTY16);
+                while (bal) {
+                    const int j = __builtin_ctzll(bal);
+                    const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
+                    if (lane == 0) set_insert_clean_u16(other, newsize - 1, kj);
+                    bal &= bal - 1;
+                }
+            }
+        }
+        unsigned short *tp = table; table = other; other = tp;
+        const int tc = cap_table; cap_table = cap_other; cap_other = tc;
+        mask = newsize - 1;
+        __syncthreads();
+    }
+    int base = 0;
+    for (unsigned i0 = 0; i0 <= mask; i0 += LINK_THREADS) {
+        const unsigned i = i0 + tid;
+        const unsigned key = i <= mask ? table[i] : SET_EMPTY16;
+        int total;
+        const int ex = block_exclusive_scan(key != SET_EMPTY16 ? 1 : 0, s_scan, &total);
+        if (key != SET_EMPTY16) out[base + ex] = (int)key;
+        base += total;
+    }
+    return base;
+}
+
 // LDS_TABLES: the per-column winner tables and per-row claims fit in LDS (12 B per detection column + 4 B per track
 // row <= 140 KiB, e.g. 8192 / 8192): the claim rounds cost LDS atomics.  Otherwise they live in HBM (three rounds of
 // device-scope atomics, ~6 us more at 5000 rows) and capacity / max_det are only bounded by 65536.
@@ -897,7 +986,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         else return __hip_atomic_load(&s_col_row[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     __shared__ int s_scan[LINK_THREADS];
-    __shared__ int s_n_used, s_n_new, s_any_dead;
+    __shared__ int s_n_used, s_n_new, s_any_dead, s_set_state[2];
     const int tid = threadIdx.x;
     const int cap = t.capacity;
     if (tid == 0) RING((9ull << 40) | (unsigned)frame);    // entry (before the first load)
@@ -1138,8 +1227,19 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             }
             __threadfence_block();
             __syncthreads();
-            if (tid == 0) {
-                int cnt = cpython_unused_order(t, m, s_n_used, base, t.new_cols);
+            int cnt = -1;
+            if constexpr (LDS_TABLES) {
+                // (the claim tables are dead from here on: 8 B + 4 B per column hold the two set tables and the staged list)
+                unsigned short *tab_a = reinterpret_cast<unsigned short *>(s_dyn);                       // 4 * max_det slots
+                unsigned short *tab_b = reinterpret_cast<unsigned short *>(s_dyn + t.max_det);           // max_det slots
+                if (t.max_det < 65535)
+                    cnt = cpython_order_block(t.unused, base, m, s_n_used, t.new_cols, tab_a, 4 * t.max_det, tab_b, t.max_det,
+                                              tab_b + t.max_det, s_scan, s_set_state);
+            }
+            if (cnt >= 0) {
+                if (tid == 0) s_n_new = cnt;
+            } else if (tid == 0) {
+                cnt = cpython_unused_order(t, m, s_n_used, base, t.new_cols);
                 if (cnt < 0) { atomicOr(t.err, ERR_TRACK_CAPACITY); cnt = 0; }
                 s_n_new = cnt;
             }
@@ -1686,7 +1786,12 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
         const TrackerDev &d = t->d;
         if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, d, det, m, m_dev, 0, nullptr, grid);
         const size_t link_lds = 12 * (size_t)d.max_det + 4 * (size_t)d.capacity;
-        if (link_lds <= 140 * 1024)
+#ifdef YSMR_TUNING
+        static const bool hbm_tables = getenv("YSMR_LINK_TABLES") && !strcmp(getenv("YSMR_LINK_TABLES"), "hbm");
+#else
+        const bool hbm_tables = false;
+#endif
+        if (link_lds <= 140 * 1024 && !hbm_tables)
             hipLaunchKernelGGL((k_link<DetT, true>), dim3(1), dim3(LINK_THREADS), link_lds, st, d, det, m, m_dev, frame, rows,
                                rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
         else
