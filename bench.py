@@ -201,7 +201,8 @@ def main():
                         if probe:
                             evs = pool[pool_i[0] % len(pool)]; pool_i[0] += 1
                         nxt = (pipes[k].detect_async(clips[k][f0:f0 + B], thr_events if probe else None,
-                                                     chain_events if (probe and DIAG & 1) else None, events=evs), f0, evs)
+                                                     chain_events if (probe and DIAG & 1) else None, events=evs,
+                                                     frames_ready=False), f0, evs)   # (the clip is resident in HBM)
                     if pending[k] is not None and not args.detect_only:
                         (slot, res, ready), p0, pevs = pending[k]
                         pipes[k].link(slot, res, ready, p0, link_events if (timed and k == 0 and DIAG & 2) else None, events=pevs)

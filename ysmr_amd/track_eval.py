@@ -115,8 +115,13 @@ class TrackingPipeline:
         self._k = 0
 
     @_on_own_device
-    def detect_async(self, frames_dev, threshold_events=None, chain_events=None, events=None):
+    def detect_async(self, frames_dev, threshold_events=None, chain_events=None, events=None, frames_ready=None):
         """Issue detection of one batch on the side stream; returns (slot, result, ready_event).
+        ``frames_ready``: what the side stream has to wait for before it reads ``frames_dev`` -- None: everything issued
+        on the caller's stream so far (the frames were produced or uploaded there); an event: that event only; False:
+        nothing, the frames have been resident since before the caller's stream was given its pending work (a clip in
+        HBM).  The blanket wait also holds the batch back behind every link launch already issued, which drains the
+        pipeline wherever one clip ends and the next begins.
         ``threshold_events``: list that receives a (start, stop) HIP event pair bracketing the fused
         threshold kernel on the stream it is launched on (bench.py's roofline measurement);
         ``chain_events``: the same for the labelling / geometry chain behind it; ``events``: five ready-made timing
@@ -137,7 +142,10 @@ class TrackingPipeline:
             thresholded = self._ev[slot]["thresholded"]
             thresholded.record(cur)
         with torch.cuda.stream(self.side):
-            self.side.wait_stream(cur)          # the frames were produced/uploaded on the caller's stream
+            if frames_ready is None:
+                self.side.wait_stream(cur)      # the frames were produced/uploaded on the caller's stream
+            elif frames_ready is not False:
+                self.side.wait_event(frames_ready)
             if self._done[slot] is not None:
                 self.side.wait_event(self._done[slot])
             if thresholded is not None:
