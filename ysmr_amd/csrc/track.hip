@@ -58,6 +58,10 @@ struct TrackerDev {
     unsigned long long *link_key; // [max_det]
     int *link_row;                // [max_det]
     int *link_claim;              // [capacity]
+    // split path: the detection column the track in a slot claimed in the current frame (-1: none).  k_link only decides;
+    // the winner's detection is fetched, and position / box are stored, by the track's own wave in k_track (5000 waves
+    // instead of one workgroup's two rounds of dependent gathers: 5 us of k_link's 12.6 at 4K)
+    int *claim_slot;              // [capacity]
 };
 
 // Uniform grid over one frame's detections (split path): the nearest detection of a track is looked for in the
@@ -752,8 +756,8 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
 
 template <typename DetT, int NF>
 __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row *rows, long long rows_capacity,
-                                               const DetT *__restrict__ next_det, int next_m_host,
-                                               const int32_t *next_m_dev, DetGrid next_grid)
+                                               const DetT *__restrict__ det, const DetT *__restrict__ next_det,
+                                               int next_m_host, const int32_t *next_m_dev, DetGrid next_grid)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) RING((4ull << 40) | (unsigned)frame);   // k_track entry
     const int n_live = *t.n_tracks;
@@ -766,13 +770,29 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     DetChunk<DetT> first;
     if (m_next > 0 && !next_grid.start) load_chunk(first, next_det, m_next, 0, lane);
     const int slot = __builtin_amdgcn_readfirstlane(t.order[i]);
-    const double z0 = t.pos[slot], z1 = t.pos[cap + slot];
-    double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
-    if (t.use_gsff) {
-        GsffState<NF> st;
-        gsff_fetch(t, slot, lane, st);
-        gsff_wave(t, t.gains, slot, lane, z0, z1, false, st, o0, o1, p0, p1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) RING((5ull << 40) | (unsigned)frame);   // slot known
+    // the measurement: the detection k_link let this track claim (tracker.py:186-196 -- position and box are
+    // stored here, by the track's own wave), or the position it already has
+    GsffState<NF> st;
+    if (t.use_gsff) gsff_fetch(t, slot, lane, st);
+    const int c = __builtin_amdgcn_readfirstlane(t.claim_slot[slot]);
+    double z0, z1;
+    float bw, bh, ba;
+    if (c >= 0) {
+        const DetT *d = det + (size_t)c * 5;
+        z0 = (double)d[0]; z1 = (double)d[1];
+        bw = (float)d[2]; bh = (float)d[3]; ba = (float)d[4];
+        if (lane == 0) {
+            t.pos[slot] = z0; t.pos[cap + slot] = z1;
+            t.info[slot] = bw; t.info[cap + slot] = bh; t.info[2 * cap + slot] = ba;
+        }
+    } else {
+        z0 = t.pos[slot]; z1 = t.pos[cap + slot];
+        bw = t.info[slot]; bh = t.info[cap + slot]; ba = t.info[2 * cap + slot];
     }
+    double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
+    if (t.use_gsff) gsff_wave(t, t.gains, slot, lane, z0, z1, false, st, o0, o1, p0, p1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) RING((6ull << 40) | (unsigned)frame);   // filter bank done
     if (lane == 0) {
         const long long base = t.row_base[0];
         if (rows && base + i < rows_capacity) {
@@ -780,7 +800,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
             r.frame = frame;
             r.track_id = t.id[slot];
             r.x = o0; r.y = o1;
-            r.w = t.info[slot]; r.h = t.info[cap + slot]; r.angle = t.info[2 * cap + slot];
+            r.w = bw; r.h = bh; r.angle = ba;
             r.disappeared = t.gone[slot];
             rows[base + i] = r;
         }
@@ -788,7 +808,10 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     // ---- nearest detection of the NEXT frame for this track (tracker.py:151-163)
     if (m_next > 0) {
         if (next_grid.start) {
-            if (rowmin_grid(t, i, p0, p1, next_det, next_grid, lane)) return;
+            if (rowmin_grid(t, i, p0, p1, next_det, next_grid, lane)) {
+                if (blockIdx.x == 0 && threadIdx.x == 0) RING((7ull << 40) | (unsigned)frame);   // next row minimum known
+                return;
+            }
             load_chunk(first, next_det, m_next, 0, lane);
         }
         rowmin_wave(t, i, p0, p1, next_det, m_next, lane, first);
@@ -1017,13 +1040,10 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         const int r = tid;
         int c = 0, slot = 0;
         unsigned long long key = ~0ull;
-        DetT d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
         if (r < n) {
             c = t.row_arg[r];
             key = (unsigned long long)__double_as_longlong(t.row_min[r]);
             slot = t.order[r];
-            d0 = det[(size_t)c * 5 + 0]; d1 = det[(size_t)c * 5 + 1]; d2 = det[(size_t)c * 5 + 2];
-            d3 = det[(size_t)c * 5 + 3]; d4 = det[(size_t)c * 5 + 4];
             atomicMin(&s_col_key[c], key);
         }
         __syncthreads();
@@ -1032,12 +1052,8 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         if (r < n) {
             const bool mine = (row_of(c) == r);
             s_claim[r] = mine ? c : -1;
+            t.claim_slot[slot] = mine ? c : -1;
             if (mine) {
-                t.pos[slot] = (double)d0;
-                t.pos[cap + slot] = (double)d1;
-                t.info[slot] = (float)d2;
-                t.info[cap + slot] = (float)d3;
-                t.info[2 * cap + slot] = (float)d4;
                 t.gone[slot] = 0;
                 atomicAdd(&s_n_used, 1);
             }
@@ -1070,33 +1086,16 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         __syncthreads();
         int used = 0;
 #pragma unroll
-        for (int half = 0; half < LINK_ROWS; half += 4) {   // winners' detections: four rows' loads in flight
-            DetT dv[4][5];
-            bool mine[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = half + j, r = tid + k * LINK_THREADS;
-                mine[j] = r < n && row_of(pa[k]) == r;
-                if (r < n) s_claim[r] = mine[j] ? pa[k] : -1;
-                if (mine[j]) {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) dv[j][q] = det[(size_t)pa[k] * 5 + q];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = half + j;
-                if (mine[j]) {
-                    const int slot = po[k];
-                    t.pos[slot] = (double)dv[j][0];
-                    t.pos[cap + slot] = (double)dv[j][1];
-                    t.info[slot] = (float)dv[j][2];
-                    t.info[cap + slot] = (float)dv[j][3];
-                    t.info[2 * cap + slot] = (float)dv[j][4];
-                    t.gone[slot] = 0;
-                    pg[k] = -1;          // claimed (ageing below skips it)
-                    ++used;
-                }
+        for (int k = 0; k < LINK_ROWS; ++k) {
+            const int r = tid + k * LINK_THREADS;
+            if (r >= n) continue;
+            const bool mine = row_of(pa[k]) == r;
+            s_claim[r] = mine ? pa[k] : -1;
+            t.claim_slot[po[k]] = mine ? pa[k] : -1;
+            if (mine) {
+                t.gone[po[k]] = 0;
+                pg[k] = -1;          // claimed (ageing below skips it)
+                ++used;
             }
         }
         if (used) atomicAdd(&s_n_used, used);
@@ -1113,21 +1112,17 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         for (int r = tid; r < n; r += LINK_THREADS) {
             int c = t.row_arg[r];
             int mine = (row_of(c) == r) ? c : -1;
+            const int slot = t.order[r];
             s_claim[r] = mine;
+            t.claim_slot[slot] = mine;
             if (mine >= 0) {
-                int slot = t.order[r];
-                t.pos[slot] = (double)det[(size_t)mine * 5 + 0];
-                t.pos[cap + slot] = (double)det[(size_t)mine * 5 + 1];
-                t.info[slot] = (float)det[(size_t)mine * 5 + 2];
-                t.info[cap + slot] = (float)det[(size_t)mine * 5 + 3];
-                t.info[2 * cap + slot] = (float)det[(size_t)mine * 5 + 4];
                 t.gone[slot] = 0;
                 ++used;
             }
         }
         if (used) atomicAdd(&s_n_used, used);
     } else {
-        for (int r = tid; r < n; r += LINK_THREADS) s_claim[r] = -1;
+        for (int r = tid; r < n; r += LINK_THREADS) { s_claim[r] = -1; t.claim_slot[t.order[r]] = -1; }
     }
     __syncthreads();
 
@@ -1175,7 +1170,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             const int keep = (r < n && !pd[k]) ? 1 : 0;
             int total;
             const int ex = block_exclusive_scan(keep, s_scan, &total);
-            if (keep) t.order_tmp[base + ex] = po[k];
+            if (keep) t.order[base + ex] = po[k];     // in place: every row's slot has been in registers since the start
             if (r < n && !keep) {
                 const int q = atomicAdd(t.n_free, 1);
                 t.free_slots[q] = po[k];
@@ -1185,26 +1180,23 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         n_live = base;
         __threadfence_block();
         __syncthreads();
-        for (int r = tid; r < n_live; r += LINK_THREADS) t.order[r] = t.order_tmp[r];
-        __syncthreads();
     } else if (s_any_dead) {
         int base = 0;
         for (int r0 = 0; r0 < n; r0 += LINK_THREADS) {
             int r = r0 + tid;
             int keep = (r < n && !t.dead[r]) ? 1 : 0;
-            int total;
+            const int slot_r = r < n ? t.order[r] : 0;   // read before the scan's barriers: the writes below go to rows
+            int total;                                   // at or before this chunk's, all of them read by then
             int ex = block_exclusive_scan(keep, s_scan, &total);
-            if (keep) t.order_tmp[base + ex] = t.order[r];
+            if (keep) t.order[base + ex] = slot_r;
             if (r < n && !keep) {
                 int k = atomicAdd(t.n_free, 1);
-                t.free_slots[k] = t.order[r];
+                t.free_slots[k] = slot_r;
             }
             base += total;
         }
         n_live = base;
         __threadfence_block();
-        __syncthreads();
-        for (int r = tid; r < n_live; r += LINK_THREADS) t.order[r] = t.order_tmp[r];
         __syncthreads();
     }
 
@@ -1264,6 +1256,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             t.info[cap + slot] = (float)det[(size_t)c * 5 + 3];
             t.info[2 * cap + slot] = (float)det[(size_t)c * 5 + 4];
             t.gone[slot] = 0;
+            t.claim_slot[slot] = -1;                        // (k_track reads the position stored here)
             t.rec[(size_t)slot * t.rec_stride + 0] = 0.0;   // history length, head
             t.rec[(size_t)slot * t.rec_stride + 1] = 0.0;   // mode
             if (new_cols_out) new_cols_out[j] = c;
@@ -1798,11 +1791,11 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
             hipLaunchKernelGGL((k_link<DetT, false>), dim3(1), dim3(LINK_THREADS), 0, st, d, det, m, m_dev, frame, rows,
                                rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
         if (d.n_f <= 3)
-            hipLaunchKernelGGL((k_track<DetT, 3>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det, -1, next_m_dev,
-                               next_grid);
+            hipLaunchKernelGGL((k_track<DetT, 3>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, det, next_det, -1,
+                               next_m_dev, next_grid);
         else
-            hipLaunchKernelGGL((k_track<DetT, YSMR_MAX_FILTERS>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, next_det,
-                               -1, next_m_dev, next_grid);
+            hipLaunchKernelGGL((k_track<DetT, YSMR_MAX_FILTERS>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, det,
+                               next_det, -1, next_m_dev, next_grid);
     }
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
@@ -1895,7 +1888,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const size_t o_dead = take(sizeof(int) * cap);
     const size_t o_new = take(sizeof(int) * max_det), o_table = take(sizeof(int) * 2 * (size_t)d.table_cap);
     const size_t o_lkey = take(sizeof(unsigned long long) * max_det), o_lrow = take(sizeof(int) * max_det);
-    const size_t o_lclaim = take(sizeof(int) * cap);
+    const size_t o_lclaim = take(sizeof(int) * cap), o_cslot = take(sizeof(int) * cap);
     // parity-1 copies of the arrays k_frame double-buffers
     const size_t o_scal1 = take(sizeof(int) * 16), o_order1 = take(sizeof(int) * cap), o_gone1 = take(sizeof(int) * cap);
     const size_t o_rmin1 = take(sizeof(double) * cap), o_rarg1 = take(sizeof(int) * cap);
@@ -1919,6 +1912,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     d.dead = (int *)(b + o_dead);
     d.new_cols = (int *)(b + o_new); d.set_table = (int *)(b + o_table);
     d.link_key = (unsigned long long *)(b + o_lkey); d.link_row = (int *)(b + o_lrow); d.link_claim = (int *)(b + o_lclaim);
+    d.claim_slot = (int *)(b + o_cslot);
     t->d1 = d;
     {
         TrackerDev &q = t->d1;
