@@ -14,9 +14,9 @@ F = NB * B
 frames = torch.from_numpy(SyntheticVideo(H, W, 5000, seed=0).frames(F)).cuda()
 pipe = TrackingPipeline(H, W, 30.0, default_settings(), batch=B, max_det=8192, capacity=8192, rows_per_flush=4 * F * 8192)
 L = _lib.lib()
-PH = {9: "link entry", 10: "counters", 11: "tables cleared", 12: "claims", 13: "ageing", 14: "compaction", 15: "registration", 16: "link end",
+PH = {9: "link entry", 10: "counters", 11: "tables cleared", 17: "rows loaded", 18: "column minima", 19: "column winners", 12: "claims", 13: "ageing", 14: "compaction", 15: "registration", 16: "link end",
       4: "track entry", 5: "track slot known", 6: "track filters done", 7: "track next minimum"}
-ORDER = [9, 10, 11, 12, 13, 14, 15, 16, 4, 5, 6, 7]
+ORDER = [9, 10, 11, 17, 18, 19, 12, 13, 14, 15, 16, 4, 5, 6, 7]
 
 
 def read_ring():

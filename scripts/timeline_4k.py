@@ -67,6 +67,18 @@ def main():
     for k, g in gaps.items():
         g.sort()
         print(f"  gap {k:32s} n {len(g):4d}  p50 {g[len(g) // 2] / 1e3:6.2f}  mean {sum(g) / len(g) / 1e3:6.2f}  max {g[-1] / 1e3:7.2f} us")
+    # link kernels by the detection kernel that was running when they started
+    dk = sorted((s, e, n) for s, e, n, q in win if not n.startswith(LINK) and n.startswith("k_"))
+    by = collections.defaultdict(list)
+    for s, e, n, q in win:
+        if n in ("k_link", "k_track"):
+            co = [d[2] for d in dk if d[0] <= s < d[1]]
+            by[(n, co[0] if co else "-")].append(e - s)
+    print("  link kernel beside ...: calls, median, mean, max us, share of the link chain's time")
+    tot = sum(sum(v) for v in by.values())
+    for (n, co), v in sorted(by.items()):
+        v.sort()
+        print(f"    {n:8s} {co:20s} {len(v):4d} {v[len(v) // 2] / 1e3:7.2f} {sum(v) / len(v) / 1e3:7.2f} {v[-1] / 1e3:8.2f}  {100 * sum(v) / tot:5.1f} %")
     base = win[0][0]
     for s, e, n, q in win[:lines]:
         print(f"{(s - base) / 1e3:9.2f} +{(e - s) / 1e3:7.2f}  q{q}  {n}")

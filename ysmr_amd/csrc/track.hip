@@ -50,6 +50,8 @@ struct TrackerDev {
     int *unused;                  // [max_det] unclaimed detection columns, ascending
     double *row_min;              // [cap]
     int *row_arg;                 // [cap]
+    int *row_gone;                // [cap] split path: `gone` of the track in a row, written with the row minimum (k_link then
+                                  // has everything a row's claim and ageing need from ONE round of loads by row)
     int *dead;                    // [cap]
     int *new_cols;                // [max_det]
     int *set_table;               // [2][table_cap] CPython set model
@@ -418,6 +420,7 @@ __global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__rest
     if (row >= n || m == 0) return;
     const int slot = t.order[row];
     const int lane = threadIdx.x & 63;
+    if (lane == 0 && !t.gone_by_row) t.row_gone[row] = t.gone[slot];
     if (grid.start && rowmin_grid(t, row, t.pos[slot], t.pos[t.capacity + slot], det, grid, lane)) return;
     DetChunk<DetT> first;
     load_chunk(first, det, m, 0, lane);
@@ -760,6 +763,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
                                                int next_m_host, const int32_t *next_m_dev, DetGrid next_grid)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) RING((4ull << 40) | (unsigned)frame);   // k_track entry
+    BSTAMP(0);
     const int n_live = *t.n_tracks;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_live) return;
@@ -771,6 +775,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     if (m_next > 0 && !next_grid.start) load_chunk(first, next_det, m_next, 0, lane);
     const int slot = __builtin_amdgcn_readfirstlane(t.order[i]);
     if (blockIdx.x == 0 && threadIdx.x == 0) RING((5ull << 40) | (unsigned)frame);   // slot known
+    BSTAMP(1);
     // the measurement: the detection k_link let this track claim (tracker.py:186-196 -- position and box are
     // stored here, by the track's own wave), or the position it already has
     GsffState<NF> st;
@@ -793,15 +798,18 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
     if (t.use_gsff) gsff_wave(t, t.gains, slot, lane, z0, z1, false, st, o0, o1, p0, p1);
     if (blockIdx.x == 0 && threadIdx.x == 0) RING((6ull << 40) | (unsigned)frame);   // filter bank done
+    BSTAMP(2);
     if (lane == 0) {
         const long long base = t.row_base[0];
+        const int gone = t.gone[slot];
+        t.row_gone[i] = gone;
         if (rows && base + i < rows_capacity) {
             ysmr_row r;
             r.frame = frame;
             r.track_id = t.id[slot];
             r.x = o0; r.y = o1;
             r.w = bw; r.h = bh; r.angle = ba;
-            r.disappeared = t.gone[slot];
+            r.disappeared = gone;
             rows[base + i] = r;
         }
     }
@@ -810,6 +818,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
         if (next_grid.start) {
             if (rowmin_grid(t, i, p0, p1, next_det, next_grid, lane)) {
                 if (blockIdx.x == 0 && threadIdx.x == 0) RING((7ull << 40) | (unsigned)frame);   // next row minimum known
+                BSTAMP(3);
                 return;
             }
             load_chunk(first, next_det, m_next, 0, lane);
@@ -876,6 +885,17 @@ __device__ int cpython_unused_order(const TrackerDev &t, int m, int n_used, int 
 constexpr int LINK_THREADS = 1024;
 constexpr int LINK_ROWS = 8;       // rows per thread k_link keeps in registers for tables of more than 1024 rows
 
+// LDS_ONLY: the two barriers wait for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier) -- __syncthreads also waits
+// for every global load and store the wave has in flight, a round trip to HBM each time; only for callers that order
+// nothing in global memory through these barriers.
+template <bool LDS_ONLY>
+__device__ __forceinline__ void block_sync()
+{
+    if constexpr (LDS_ONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
+
+template <bool LDS_ONLY = false>
 __device__ int block_exclusive_scan(int v, int *s_scan, int *total)
 {
     // exclusive rank of a 0/1 flag among the block's 1024 flags: a ballot per wave, the sixteen wave
@@ -883,7 +903,7 @@ __device__ int block_exclusive_scan(int v, int *s_scan, int *total)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long bal = __ballot(v != 0);
     if (lane == 0) s_scan[w] = __popcll(bal);
-    __syncthreads();
+    block_sync<LDS_ONLY>();
     int before = 0, all = 0;
 #pragma unroll
     for (int k = 0; k < LINK_THREADS / 64; ++k) {
@@ -892,7 +912,7 @@ __device__ int block_exclusive_scan(int v, int *s_scan, int *total)
         all += c;
     }
     *total = all;
-    __syncthreads();      // (s_scan is reused by the caller's next chunk)
+    block_sync<LDS_ONLY>();      // (s_scan is reused by the caller's next chunk)
     return before + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
@@ -1010,6 +1030,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     };
     __shared__ int s_scan[LINK_THREADS];
     __shared__ int s_n_used, s_n_new, s_any_dead, s_set_state[2];
+    __shared__ int s_keep[LINK_ROWS][LINK_THREADS / 64];
     const int tid = threadIdx.x;
     const int cap = t.capacity;
     if (tid == 0) RING((9ull << 40) | (unsigned)frame);    // entry (before the first load)
@@ -1024,7 +1045,9 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             __hip_atomic_store(&s_col_row[c], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __syncthreads();
+    // (with the tables in LDS the barriers of the claim rounds order LDS traffic only: the rows' loads and the stores of
+    // the decisions stay in flight across them)
+    block_sync<LDS_TABLES>();
     LRING(1);
     // rows of a large table held per thread (see the `big` branch below)
     const bool big = n > LINK_THREADS && n <= LINK_ROWS * LINK_THREADS && m > 0;
@@ -1049,15 +1072,16 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         __syncthreads();
         if (r < n && key == key_of(c)) atomicMin(&s_col_row[c], r);
         __syncthreads();
+        bool won = false;
         if (r < n) {
             const bool mine = (row_of(c) == r);
             s_claim[r] = mine ? c : -1;
             t.claim_slot[slot] = mine ? c : -1;
-            if (mine) {
-                t.gone[slot] = 0;
-                atomicAdd(&s_n_used, 1);
-            }
+            if (mine) t.gone[slot] = 0;
+            won = mine;
         }
+        const int used = __popcll(__ballot(won));          // one LDS atomic per wave, not per thread
+        if ((tid & 63) == 0 && used) atomicAdd(&s_n_used, used);
     } else if (big) {
         // large tables (the 4K configuration: ~5000 rows): thread tid owns rows tid + LINK_THREADS * k.  Everything
         // the LDS rounds, the ageing and the compaction below need is requested up front and kept in
@@ -1069,36 +1093,40 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
                 pa[k] = t.row_arg[r];
                 pk[k] = (unsigned long long)__double_as_longlong(t.row_min[r]);
                 po[k] = t.order[r];
+                pg[k] = t.row_gone[r];
             }
         }
-#pragma unroll
-        for (int k = 0; k < LINK_ROWS; ++k)
-            if (tid + k * LINK_THREADS < n) pg[k] = t.gone[po[k]];      // (arrives during the rounds below)
+#ifdef YSMR_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LRING(7);          // the rows' loads have landed
+#endif
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k)
             if (tid + k * LINK_THREADS < n) atomicMin(&s_col_key[pa[k]], pk[k]);
-        __syncthreads();
+        block_sync<LDS_TABLES>();
+        LRING(8);
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k) {
             const int r = tid + k * LINK_THREADS;
             if (r < n && pk[k] == key_of(pa[k])) atomicMin(&s_col_row[pa[k]], r);
         }
-        __syncthreads();
+        block_sync<LDS_TABLES>();
+        LRING(9);
         int used = 0;
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k) {
             const int r = tid + k * LINK_THREADS;
+            const bool mine = r < n && row_of(pa[k]) == r;
+            used += __popcll(__ballot(mine));
             if (r >= n) continue;
-            const bool mine = row_of(pa[k]) == r;
             s_claim[r] = mine ? pa[k] : -1;
             t.claim_slot[po[k]] = mine ? pa[k] : -1;
             if (mine) {
                 t.gone[po[k]] = 0;
                 pg[k] = -1;          // claimed (ageing below skips it)
-                ++used;
             }
         }
-        if (used) atomicAdd(&s_n_used, used);
+        if ((tid & 63) == 0 && used) atomicAdd(&s_n_used, used);   // one LDS atomic per wave (1024 on one address: 3 us)
     } else if (n > 0 && m > 0) {
         for (int r = tid; r < n; r += LINK_THREADS)
             atomicMin(&s_col_key[t.row_arg[r]], (unsigned long long)__double_as_longlong(t.row_min[r]));
@@ -1124,7 +1152,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     } else {
         for (int r = tid; r < n; r += LINK_THREADS) { s_claim[r] = -1; t.claim_slot[t.order[r]] = -1; }
     }
-    __syncthreads();
+    block_sync<LDS_TABLES>();      // (s_n_used; what the paths above stored in global memory is read back by no other thread)
 
     LRING(2);
     // ---- ageing (tracker.py:95-107, 198-211): only when there are no detections or N >= M
@@ -1156,30 +1184,44 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             t.dead[r] = d;
         }
     }
-    __syncthreads();
+    block_sync<true>();            // (s_any_dead; a row's `dead` flag is read back by the thread that wrote it)
 
     LRING(3);
     // ---- stable compaction of the ordered track table
     int n_live = n;
     if (s_any_dead && big) {
+        // one pass: every wave counts its survivors chunk by chunk (a ballot each), ONE barrier, every thread adds up the
+        // counts in front of its rows (the chunk-by-chunk scan took two barriers per 1024 rows).  In place: every row's
+        // slot has been in registers since the start
+        const int lane = tid & 63, w = tid >> 6;
+        unsigned long long bal[LINK_ROWS];
+#pragma unroll
+        for (int k = 0; k < LINK_ROWS; ++k) {
+            const int r = tid + k * LINK_THREADS;
+            bal[k] = __ballot(r < n && !pd[k]);
+            if (lane == 0) s_keep[k][w] = __popcll(bal[k]);
+        }
+        block_sync<true>();
         int base = 0;
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k) {
-            if (k * LINK_THREADS >= n) break;            // (uniform)
             const int r = tid + k * LINK_THREADS;
-            const int keep = (r < n && !pd[k]) ? 1 : 0;
-            int total;
-            const int ex = block_exclusive_scan(keep, s_scan, &total);
-            if (keep) t.order[base + ex] = po[k];     // in place: every row's slot has been in registers since the start
-            if (r < n && !keep) {
-                const int q = atomicAdd(t.n_free, 1);
-                t.free_slots[q] = po[k];
+            int before = 0, all = 0;
+#pragma unroll
+            for (int q = 0; q < LINK_THREADS / 64; ++q) {
+                const int c = s_keep[k][q];
+                before += q < w ? c : 0;
+                all += c;
             }
-            base += total;
+            if (r < n) {
+                if (!pd[k]) t.order[base + before + __popcll(bal[k] & ((1ull << lane) - 1ull))] = po[k];
+                else t.free_slots[atomicAdd(t.n_free, 1)] = po[k];
+            }
+            base += all;
         }
         n_live = base;
         __threadfence_block();
-        __syncthreads();
+        __syncthreads();           // (the free slots are read by other threads at a registration below)
     } else if (s_any_dead) {
         int base = 0;
         for (int r0 = 0; r0 < n; r0 += LINK_THREADS) {
@@ -1884,7 +1926,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const size_t o_rec = take(sizeof(double) * (size_t)d.rec_stride * cap);
     const size_t o_gain = take(sizeof(double) * (gain_doubles ? gain_doubles : 1));
     const size_t o_unused = take(sizeof(int) * max_det);
-    const size_t o_rmin = take(sizeof(double) * cap), o_rarg = take(sizeof(int) * cap);
+    const size_t o_rmin = take(sizeof(double) * cap), o_rarg = take(sizeof(int) * cap), o_rgone = take(sizeof(int) * cap);
     const size_t o_dead = take(sizeof(int) * cap);
     const size_t o_new = take(sizeof(int) * max_det), o_table = take(sizeof(int) * 2 * (size_t)d.table_cap);
     const size_t o_lkey = take(sizeof(unsigned long long) * max_det), o_lrow = take(sizeof(int) * max_det);
@@ -1908,7 +1950,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     d.rec = (double *)(b + o_rec);
     d.gains = (const double *)(b + o_gain);
     d.unused = (int *)(b + o_unused);
-    d.row_min = (double *)(b + o_rmin); d.row_arg = (int *)(b + o_rarg);
+    d.row_min = (double *)(b + o_rmin); d.row_arg = (int *)(b + o_rarg); d.row_gone = (int *)(b + o_rgone);
     d.dead = (int *)(b + o_dead);
     d.new_cols = (int *)(b + o_new); d.set_table = (int *)(b + o_table);
     d.link_key = (unsigned long long *)(b + o_lkey); d.link_row = (int *)(b + o_lrow); d.link_claim = (int *)(b + o_lclaim);
