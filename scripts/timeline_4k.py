@@ -1,4 +1,4 @@
-"""Who runs when at BASELINE configs[4]: from a rocprofv3 --kernel-trace csv, the kernels of the last step as one
+"""Who runs when (written for BASELINE configs[4], works for any bench.py run): from a rocprofv3 --kernel-trace csv, the kernels of the last step as one
 timeline (start, duration, queue), the busy time of the link kernels, of the detection kernels, and of both at once.
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py --config 4 --steps 3 --cpu-sample 0
@@ -45,7 +45,7 @@ def main():
              r.get("Queue_Id", "?")) for r in csv.DictReader(open(f))]
     rows.sort()
     # the last 40 % of the run (steady state, no warm-up)
-    lk_all = [r for r in rows if r[2].startswith("k_link")]
+    lk_all = [r for r in rows if r[2].startswith(("k_link", "k_frame"))]
     t0, t1 = lk_all[0][0], lk_all[-1][1]
     lo, hi = t0 + (t1 - t0) * 5 // 10, t0 + (t1 - t0) * 9 // 10
     win = [r for r in rows if lo <= r[0] <= hi]
@@ -71,7 +71,7 @@ def main():
     dk = sorted((s, e, n) for s, e, n, q in win if not n.startswith(LINK) and n.startswith("k_"))
     by = collections.defaultdict(list)
     for s, e, n, q in win:
-        if n in ("k_link", "k_track"):
+        if n in ("k_link", "k_track", "k_frame", "k_rowmin"):
             co = [d[2] for d in dk if d[0] <= s < d[1]]
             by[(n, co[0] if co else "-")].append(e - s)
     print("  link kernel beside ...: calls, median, mean, max us, share of the link chain's time")

@@ -923,19 +923,26 @@ __device__ int block_exclusive_scan(int v, int *s_scan, int *total)
 // reads the old table 64 slots at a time.  Table sizes alternate 8, 32, 128, ... between `tab_a` and `tab_b`; 16-bit
 // slots (keys < 65535).  Returns the number of keys, or -1 when a table does not fit (the caller falls back).
 constexpr unsigned short SET_EMPTY16 = 0xFFFFu;
-__device__ __forceinline__ void set_insert_clean_u16(unsigned short *table, unsigned mask, unsigned key)
+// One insertion by a whole wave (every lane calls it with the same key): the up to ten slots of a linear-probe run are
+// read by ten lanes at once and the first empty one is found with a ballot -- one LDS round trip per run instead of one
+// per probe (small tables of large keys collide a lot: 19 keys < 500 in 32 slots averaged 4 probes each).
+template <typename SlotT>
+__device__ __forceinline__ void set_insert_wave(SlotT *table, unsigned mask, unsigned key, SlotT empty, int lane)
 {
     unsigned long long perturb = (unsigned long long)key;
     unsigned i = key & mask;
     while (true) {
         const int probes = (i + 9u <= mask) ? 9 : 0;
-        for (int j = 0; j <= probes; ++j)
-            if (table[i + j] == SET_EMPTY16) { table[i + j] = (unsigned short)key; return; }
+        const bool free_here = lane <= probes && table[i + (lane <= probes ? lane : 0)] == empty;
+        const unsigned long long e = __ballot(free_here);
+        if (e) {
+            if (lane == __builtin_ctzll(e)) table[i + lane] = (SlotT)key;
+            return;
+        }
         perturb >>= 5;
         i = (unsigned)(((unsigned long long)i * 5ull + 1ull + perturb) & mask);
     }
 }
-
 __device__ int cpython_order_block(const int *unused, int n_unused, int m, int n_used, int *out, unsigned short *tab_a,
                                    int cap_a, unsigned short *tab_b, int cap_b, unsigned short *stage, int *s_scan,
                                    int *s_state)
@@ -953,16 +960,15 @@ __device__ int cpython_order_block(const int *unused, int n_unused, int m, int n
     unsigned mask = 7;
     int next = 0;
     while (true) {
-        if (tid == 0) {   // insert until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
+        if (tid < 64) {   // wave 0 inserts until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
             int k = next;
             bool grow = false;
             while (k < n_unused && !grow) {
-                set_insert_clean_u16(table, mask, stage[k]);
+                set_insert_wave<unsigned short>(table, mask, stage[k], SET_EMPTY16, lane);
                 ++k;
                 grow = (unsigned long long)k * 5ull >= (unsigned long long)mask * 3ull;   // fill == k: nothing is ever removed
             }
-            s_state[0] = k;
-            s_state[1] = grow ? 1 : 0;
+            if (tid == 0) { s_state[0] = k; s_state[1] = grow ? 1 : 0; }
         }
         __syncthreads();
         next = s_state[0];
@@ -983,7 +989,7 @@ __device__ int cpython_order_block(const int *unused, int n_unused, int m, int n
                 while (bal) {
                     const int j = __builtin_ctzll(bal);
                     const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
-                    if (lane == 0) set_insert_clean_u16(other, newsize - 1, kj);
+                    set_insert_wave<unsigned short>(other, newsize - 1, kj, SET_EMPTY16, lane);
                     bal &= bal - 1;
                 }
             }
@@ -1379,25 +1385,14 @@ __device__ __forceinline__ int block_flag_rank(bool f, int *s_cnt, int *total)
     return before + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
-// CPython order of the ascending list `unused` (see cpython_unused_order), 16-bit tables in LDS
-__device__ void set_insert_clean16(short *table, unsigned mask, int key)
-{
-    unsigned long long perturb = (unsigned long long)key;
-    unsigned i = (unsigned)key & mask;
-    while (true) {
-        int probes = (i + 9u <= mask) ? 9 : 0;
-        for (int j = 0; j <= probes; ++j)
-            if (table[i + j] < 0) { table[i + j] = (short)key; return; }
-        perturb >>= 5;
-        i = (unsigned)(((unsigned long long)i * 5ull + 1ull + perturb) & mask);
-    }
-}
-// Block-cooperative form (all FRAME_THREADS threads call it): only the insertions themselves are
-// order-dependent and stay on thread 0; clearing a table, collecting the occupied slots of a table in
-// slot order (before a resize and for the final iteration order) are done by the whole block.  The
-// one-thread version spent 25 us of a registration frame walking a 512-slot table.
-// `out` doubles as the list of keys to re-insert at a resize.  Returns the number of keys, or -1 if
-// the model would need a table larger than FRAME_TABLE.
+// CPython order of the ascending list `unused` (see cpython_unused_order), 16-bit tables in LDS.
+// All FRAME_THREADS threads call it; the model itself runs on wave 0 alone, without a block barrier inside: lane 0 does
+// the insertions (the only order-dependent part), the wave clears a new table, reads the old one 64 slots at a time at a
+// resize (ballot, lane 0 re-inserts the occupied slots in slot order) and writes the final iteration order with a ballot
+// prefix.  LDS operations of one wave execute in order, so nothing but program order is needed between these steps.
+// (The block-wide version -- one barrier pair per scan chunk and per stage -- spent 15 us of a registration frame with
+// ~30 unclaimed columns; before that, one thread walking a 512-slot table 25 us.)
+// Returns the number of keys, or -1 if the model would need a table larger than FRAME_TABLE.
 __device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_used, int *out, short *tables, int *s_scan,
                                  int *s_state)
 {
@@ -1407,56 +1402,53 @@ __device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_u
         __syncthreads();
         return n_unused;
     }
-    // occupied slots of tab[0..size) in slot order -> out[0..count)
-    auto collect = [&](const short *tab, int size) {
-        int base = 0;
-        for (int i0 = 0; i0 < size; i0 += FRAME_THREADS) {
-            const int i = i0 + tid;
-            const int key = i < size ? tab[i] : -1;
-            int total;
-            const int ex = block_flag_rank(key >= 0, s_scan + ((i0 / FRAME_THREADS) & 1) * 4, &total);
-            if (key >= 0) out[base + ex] = key;
-            base += total;
-        }
-        __syncthreads();
-        return base;
-    };
-    short *table = tables, *other = tables + FRAME_TABLE;
-    unsigned mask = 7;
-    int next = 0;      // next element of `unused` to insert
-    if (tid < 8) table[tid] = -1;
-    __syncthreads();
-    while (true) {
-        if (tid == 0) {   // insert until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
-            int k = next;
+    if (tid < 64) {
+        const int lane = tid;
+        short *table = tables, *other = tables + FRAME_TABLE;
+        unsigned mask = 7;
+        int k = 0, result = 0;
+        if (lane < 8) table[lane] = -1;
+        while (true) {
             bool grow = false;
-            while (k < n_unused && !grow) {
-                set_insert_clean16(table, mask, unused[k]);
+            while (k < n_unused && !grow) {   // insert until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
+                set_insert_wave<short>(table, mask, (unsigned)unused[k], (short)-1, lane);
                 ++k;
                 grow = (unsigned long long)k * 5ull >= (unsigned long long)mask * 3ull;   // fill == k: nothing is ever removed
             }
-            s_state[0] = k;
-            s_state[1] = grow ? 1 : 0;
+            if (!grow) break;
+            const unsigned fill = (unsigned)k;
+            const unsigned minused = fill > 50000u ? fill * 2u : fill * 4u;
+            unsigned newsize = 8;
+            while (newsize <= minused) newsize <<= 1;
+            if ((int)newsize > FRAME_TABLE) { result = -1; break; }
+            for (unsigned i = lane; i < newsize; i += 64) other[i] = -1;
+            for (unsigned i0 = 0; i0 <= mask; i0 += 64) {
+                const int key = i0 + lane <= mask ? (int)table[i0 + lane] : -1;
+                unsigned long long bal = __ballot(key >= 0);
+                while (bal) {
+                    const int j = __builtin_ctzll(bal);
+                    const int kj = __builtin_amdgcn_readlane(key, j);
+                    set_insert_wave<short>(other, newsize - 1, (unsigned)kj, (short)-1, lane);
+                    bal &= bal - 1;
+                }
+            }
+            short *tmp = table; table = other; other = tmp;
+            mask = newsize - 1;
         }
-        __syncthreads();
-        next = s_state[0];
-        const bool grow = s_state[1] != 0;
-        __syncthreads();
-        if (!grow) break;
-        const unsigned fill = (unsigned)next;
-        const unsigned minused = fill > 50000u ? fill * 2u : fill * 4u;
-        unsigned newsize = 8;
-        while (newsize <= minused) newsize <<= 1;
-        if ((int)newsize > FRAME_TABLE) return -1;
-        for (unsigned i = tid; i < newsize; i += FRAME_THREADS) other[i] = -1;
-        const int cnt = collect(table, (int)mask + 1);      // (ends with a barrier: `other` is cleared, `out` is complete)
-        if (tid == 0)
-            for (int j = 0; j < cnt; ++j) set_insert_clean16(other, newsize - 1, out[j]);
-        short *tmp = table; table = other; other = tmp;
-        mask = newsize - 1;
-        __syncthreads();
+        if (result == 0) {
+            for (unsigned i0 = 0; i0 <= mask; i0 += 64) {
+                const int key = i0 + lane <= mask ? (int)table[i0 + lane] : -1;
+                const unsigned long long bal = __ballot(key >= 0);
+                if (key >= 0) out[result + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+                result += __popcll(bal);
+            }
+        }
+        if (lane == 0) s_state[0] = result;
     }
-    return collect(table, (int)mask + 1);
+    __syncthreads();
+    const int r = s_state[0];
+    __syncthreads();          // (s_state may be written again by the caller's next use)
+    return r;
 }
 
 #ifdef YSMR_STAMPS
