@@ -278,7 +278,10 @@ def main():
                          ("k_threshold_strip" if pipe.det[0].threshold_variant == 1 else "k_threshold_mfma"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "launches_timed": len(ms)},
+                         "launches_timed": len(ms),
+                         "timed_with": ("HIP events recorded on the kernels' stream around the three launches" if mean_gray else
+                                        "HIP events set by the kernel's own dispatch (hipExtLaunchKernel start/stop): the duration "
+                                        "a kernel trace reports, inside the timed region")},
         }
         # what the headline is made of, so that one line says which part was slow on this box: the link is a chain
         # of one launch per frame (k_frame), so `value` ~ 1e6 / link.us_per_frame.avg as long as the host keeps ahead

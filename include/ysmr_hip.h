@@ -42,7 +42,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   8
+#define YSMR_ABI_VERSION   9
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -117,6 +117,13 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
  * barrier times out (quickly), every frame's status gets YSMR_DET_STALLED and the call returns. */
 #define YSMR_FAULT_RESIDUE_STALL 1
 int ysmr_fault_inject(int what);
+
+/* Measurement aid: the NEXT ysmr_threshold_batch / _variant call of this host thread hands the two HIP events (hipEvent_t
+ * created with timing enabled; either may be NULL) to its kernel dispatch (hipExtLaunchKernel), which sets them to the
+ * kernel's own start and end on the device -- hipEventElapsedTime between them is the duration a kernel trace reports.
+ * Events recorded on the stream before and after the call also count the dispatch gaps on both sides (~10 us of a
+ * 100 us kernel).  Not used by the mean-gray call. */
+int ysmr_threshold_timing(void *start_event, void *stop_event);
 
 /* The same call with the kernel named (test and measurement aid; the results are the same bytes whichever is taken).
  * Gray frames of at least 18 rows and 64 columns (width a multiple of 4) are served by a kernel that evaluates the

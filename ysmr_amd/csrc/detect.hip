@@ -14,6 +14,7 @@
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
 #include "common.h"
 #include "thr_mfma.h"
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <cfloat>
 #include <cmath>
@@ -2202,6 +2203,8 @@ const Knobs &knobs()
     return k;
 }
 
+thread_local hipEvent_t t_thr_events[2] = {nullptr, nullptr};   // ysmr_threshold_timing -> the next launch_threshold of this thread
+
 // variant: 0 = the shipped choice of kernel; 1 = strip / tile kernels only (bit-exact float32 chain for every pixel);
 // 2, 3 = the matrix-pipe kernel's diagnostic builds (thr_mfma.h)
 int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, int W, int channels, int inv, int t_low,
@@ -2209,9 +2212,13 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
 {
     Gauss11 gk = make_gauss11();
     const ysmr::GrayCoef gc = ysmr::gray_coef(cv_flavour);
+    // (ysmr_threshold_timing: this call's kernel dispatch updates the caller's two events)
+    const hipEvent_t ev0 = t_thr_events[0], ev1 = t_thr_events[1];
+    t_thr_events[0] = t_thr_events[1] = nullptr;
+    const bool timed = ev0 || ev1;
     if (variant != 1 && ysmr_thr::supported(H, W, channels, t_low, t_high, use_high))
         return ysmr_thr::launch(st, frames, cls, batch, H, W, inv, t_low, t_high, use_high, gk.k, knobs().thr_blocks,
-                                variant >= 2 ? variant - 1 : 0);
+                                variant >= 2 ? variant - 1 : 0, ev0, ev1);
     if (variant >= 2) return ysmr::fail(YSMR_ERR_ARG, "the matrix-pipe threshold kernel does not serve this geometry");
     const int t_gap = use_high ? (t_high > t_low ? t_high - t_low : t_low - t_high) : 0;
     if ((W & 3) == 0 && W >= 16 && H >= 2 && t_low > -100000 && t_low < 100000 && t_high > -100000 && t_high < 100000 && t_gap <= 127) {
@@ -2241,11 +2248,19 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
         P.by_xcd = (batch % 8 == 0 && blocks % 8 == 0) ? 1 : 0;
         if (P.by_xcd && blocks / 8 * 4 > (long long)(batch / 8) * P.strips_x * P.segs_y)    // (no more waves than an XCD has items)
             blocks = (((long long)(batch / 8) * P.strips_x * P.segs_y + 3) / 4) * 8;
-        if (channels == 1) hipLaunchKernelGGL(k_threshold_strip<1>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
+        if (timed) {
+            if (channels == 1) hipExtLaunchKernelGGL(k_threshold_strip<1>, dim3((unsigned)blocks), dim3(256), 0u, st, ev0, ev1, 0u, frames, cls, P, gk);
+            else hipExtLaunchKernelGGL(k_threshold_strip<3>, dim3((unsigned)blocks), dim3(256), 0u, st, ev0, ev1, 0u, frames, cls, P, gk);
+        } else if (channels == 1) hipLaunchKernelGGL(k_threshold_strip<1>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
         else hipLaunchKernelGGL(k_threshold_strip<3>, dim3((unsigned)blocks), dim3(256), 0, st, frames, cls, P, gk);
     } else {
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, batch);
-        if (channels == 1)
+        if (timed) {
+            if (channels == 1)
+                hipExtLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0u, st, ev0, ev1, 0u, frames, cls, H, W, gk, inv, t_low, t_high, use_high, gc);
+            else
+                hipExtLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0u, st, ev0, ev1, 0u, frames, cls, H, W, gk, inv, t_low, t_high, use_high, gc);
+        } else if (channels == 1)
             hipLaunchKernelGGL(k_threshold<1>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high, gc);
         else
             hipLaunchKernelGGL(k_threshold<3>, grid, dim3(256), 0, st, frames, cls, H, W, gk, inv, t_low, t_high, use_high, gc);
@@ -2279,6 +2294,13 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
     if (cv_flavour & ~YSMR_CV_FLAVOUR_MASK) return ysmr::fail(YSMR_ERR_ARG, "unknown cv_flavour bits 0x%x", cv_flavour);
     return launch_threshold((hipStream_t)stream, frames_dev, batch, height, width, channels, inv, t_low, t_high,
                             use_high, cls_dev, cv_flavour);
+}
+
+int ysmr_threshold_timing(void *start_event, void *stop_event)
+{
+    t_thr_events[0] = (hipEvent_t)start_event;
+    t_thr_events[1] = (hipEvent_t)stop_event;
+    return YSMR_OK;
 }
 
 int ysmr_threshold_batch_variant(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels,

@@ -47,6 +47,7 @@
 // differed in 3 of them -- a distance of about 2e-5, a hundredth of EPS.
 #include "common.h"
 #include "thr_mfma.h"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <type_traits>
 
@@ -579,7 +580,7 @@ bool supported(int H, int W, int channels, int t_low, int t_high, int use_high)
 }
 
 int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H, int W, int inv, int t_low, int t_high,
-           int use_high, const float *gauss11, int blocks_wanted, int variant)
+           int use_high, const float *gauss11, int blocks_wanted, int variant, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     Params P{};
     P.H = H; P.W = W; P.batch = batch;
@@ -614,7 +615,10 @@ int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H
     const size_t lds = sizeof(Lds);
     auto kern = variant == 2 ? k_threshold_mfma<2> : k_threshold_mfma<0>;
     YSMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TM_THREADS), lds, st, frames, cls, P);
+    if (ev_start || ev_stop)
+        hipExtLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TM_THREADS), (uint32_t)lds, st, ev_start, ev_stop, 0u, frames, cls, P);
+    else
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TM_THREADS), lds, st, frames, cls, P);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }

@@ -161,14 +161,18 @@ class Detector:
         return b, ch
 
     @_on_own_device
-    def threshold(self, frames: torch.Tensor, variant: int | None = None) -> torch.Tensor:
+    def threshold(self, frames: torch.Tensor, variant: int | None = None, timing=None) -> torch.Tensor:
         """a1-a3 only: class map u8 [b,H,W] (bit0 thresh, bit1 markers).  In the mean-gray branch the
         call also advances the moving-average state by these frames; per-frame mean, stddev, level and
         averaged level are left in ``mean_stats[:b]``, the integer levels in ``mean_levels[:b]``.
-        ``variant``: which kernel (``ysmr_threshold_batch_variant`` in include/ysmr_hip.h; 0 = the shipped choice)."""
+        ``variant``: which kernel (``ysmr_threshold_batch_variant`` in include/ysmr_hip.h; 0 = the shipped choice).
+        ``timing``: a pair of ``torch.cuda.Event(enable_timing=True)`` that have been recorded before (so that they
+        exist); the kernel's dispatch sets them to its own start and end (``ysmr_threshold_timing``)."""
         b, ch = self._check_frames(frames)
         p = self.params
         variant = self.threshold_variant if variant is None else variant
+        if timing is not None and self.mean_state is None:
+            _lib.check(_lib.lib().ysmr_threshold_timing(timing[0].cuda_event, timing[1].cuda_event), "ysmr_threshold_timing")
         if self.mean_state is not None:
             rc = _lib.lib().ysmr_mean_threshold_batch(
                 _lib.stream_ptr(self.device), frames.data_ptr(), b, self.H, self.W, ch, p.inv, p.offset, p.window,

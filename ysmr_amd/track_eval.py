@@ -122,8 +122,8 @@ class TrackingPipeline:
         nothing, the frames have been resident since before the caller's stream was given its pending work (a clip in
         HBM).  The blanket wait also holds the batch back behind every link launch already issued, which drains the
         pipeline wherever one clip ends and the next begins.
-        ``threshold_events``: list that receives a (start, stop) HIP event pair bracketing the fused
-        threshold kernel on the stream it is launched on (bench.py's roofline measurement);
+        ``threshold_events``: list that receives a (start, stop) HIP event pair that the threshold kernel's own dispatch
+        sets to its start and end on the device (bench.py's roofline measurement; ``Detector.threshold(timing=...)``);
         ``chain_events``: the same for the labelling / geometry chain behind it; ``events``: five ready-made timing
         events to use for these records (the first three here, the last two in ``link``) instead of new ones."""
         slot = self._k & 1
@@ -133,11 +133,8 @@ class TrackingPipeline:
         thresholded = None
         if self.exclusive_threshold:
             e0, e1 = (events[0], events[1]) if events else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._timed_threshold(det, frames_dev, cur, e0, e1, threshold_events is not None, bool(events))
             if threshold_events is not None:
-                e0.record(cur)
-            det.threshold(frames_dev)
-            if threshold_events is not None:
-                e1.record(cur)
                 threshold_events.append((e0, e1, frames_dev.shape[0]))
             thresholded = self._ev[slot]["thresholded"]
             thresholded.record(cur)
@@ -158,9 +155,7 @@ class TrackingPipeline:
                 res = det.detect(frames_dev)
             else:
                 e0, e1 = (events[0], events[1]) if events else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                e0.record(self.side)
-                det.threshold(frames_dev)      # (the detector's own choice of kernel)
-                e1.record(self.side)
+                self._timed_threshold(det, frames_dev, self.side, e0, e1, True, bool(events))   # (the detector's own choice of kernel)
                 threshold_events.append((e0, e1, frames_dev.shape[0]))
                 res = det.components(frames_dev.shape[0])
                 if chain_events is not None:
@@ -170,6 +165,21 @@ class TrackingPipeline:
             ready = self._ev[slot]["ready"]
             ready.record(self.side)
         return slot, res, ready
+
+    @staticmethod
+    def _timed_threshold(det, frames_dev, stream, e0, e1, timed, events_exist):
+        """The batch's threshold launch with its duration between e0 and e1: set by the kernel's own dispatch (one
+        kernel), or recorded on the stream around the call (the mean-gray branch: three kernels)."""
+        if not timed:
+            det.threshold(frames_dev)
+        elif det.mean_state is not None:
+            e0.record(stream)
+            det.threshold(frames_dev)
+            e1.record(stream)
+        else:
+            if not events_exist:
+                e0.record(stream); e1.record(stream)     # (creates them; the dispatch sets them again)
+            det.threshold(frames_dev, timing=(e0, e1))
 
     @_on_own_device
     def reset(self):
