@@ -127,6 +127,30 @@ def test_threshold_matrix_pipe_distance(torch_cuda, oracle):
             assert np.array_equal(got, ref), f"{args} variant {variant}: " + _mismatch_report(got, ref)
 
 
+def test_threshold_dispatch_sets_the_callers_events(torch_cuda, oracle):
+    """ysmr_threshold_timing: the kernel's own dispatch sets the two events (what bench.py's roofline divides by); the
+    class map is the one an untimed call writes, for every kernel a geometry can take, and the hook is used up by one
+    call."""
+    from ysmr_amd.detect import Detector, threshold_params
+    torch = torch_cuda
+    rng = np.random.default_rng(3)
+    for (h, w, ch), variants in (((200, 1228, 1), (0, 1)), ((64, 90, 3), (0,)), ((64, 92, 3), (0,))):
+        shape = (4, h, w) if ch == 1 else (4, h, w, 3)
+        dev = torch.from_numpy(rng.integers(0, 256, shape, dtype=np.uint8)).cuda()
+        d = Detector(4, h, w, max_det=64, params=threshold_params(True, 5, 2.0))
+        for variant in variants:
+            plain = d.threshold(dev, variant=variant).clone()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()
+            torch.cuda.synchronize()
+            timed = d.threshold(dev, variant=variant, timing=(e0, e1)).clone()
+            again = d.threshold(dev, variant=variant).clone()       # (no events pending any more)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            assert 0.001 < ms < 50.0, ms
+            assert torch.equal(plain, timed) and torch.equal(plain, again)
+
+
 @pytest.mark.parametrize("h,w", [(70, 90), (70, 92), (130, 1228), (61, 16)])
 def test_threshold_bgr(torch_cuda, oracle, h, w):
     """a1: BGR input (what cv2.VideoCapture delivers).  W % 4 == 0 takes the strip kernel (several

@@ -191,6 +191,49 @@ def test_reader_protocol_reported_against_delivered_frames(tmp_path, oracle):
             assert fps == want["fps"] and (h, w) == (96, 128) and int(df["POSITION_T"].max()) + 1 == stored
 
 
+def test_resident_clip_needs_no_wait_behind_the_link():
+    """TrackingPipeline.detect_async(frames_ready=...): a clip that is already in HBM does not wait for the link launches
+    pending on the caller's stream (bench.py), an upload is waited for through its event alone; the rows are those of the
+    blanket wait."""
+    import torch
+    from ysmr_amd.helper_file import default_settings
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import TrackingPipeline
+    from ysmr_amd.tracker import rows_to_numpy
+    n, b, h, w = 48, 8, 240, 320
+    host = torch.from_numpy(SyntheticVideo(h, w, 30, seed=5).frames(n))
+    resident = host.cuda()
+    torch.cuda.synchronize()
+    up = torch.cuda.Stream()
+
+    def run(mode):
+        pipe = TrackingPipeline(h, w, 30.0, default_settings(), batch=b, max_det=256, capacity=256, rows_per_flush=n * 256)
+        pipe.reset()
+        pending = None
+        for f0 in list(range(0, n, b)) + [None]:
+            nxt = None
+            if f0 is not None:
+                if mode == "event":
+                    with torch.cuda.stream(up):
+                        dev = host[f0:f0 + b].pin_memory().to("cuda", non_blocking=True)
+                        ev = torch.cuda.Event(); ev.record(up)
+                    dev.record_stream(pipe.side)
+                    nxt = (pipe.detect_async(dev, frames_ready=ev), f0)
+                else:
+                    nxt = (pipe.detect_async(resident[f0:f0 + b], frames_ready=False if mode == "resident" else None), f0)
+            if pending is not None:
+                (slot, res, ready), p0 = pending
+                pipe.link(slot, res, ready, p0)
+            pending = nxt
+        return pipe.take_rows()
+
+    ref = run("blanket")
+    assert len(ref) > 1000
+    for mode in ("resident", "event"):
+        got = run(mode)
+        assert got.tobytes() == ref.tobytes(), mode
+
+
 def test_rows_sort_on_device():
     """ysmr_rows_sort: (TRACK_ID, POSITION_T) order, the key of sort_list (helper_file.py:1538-1574)."""
     import torch
