@@ -61,7 +61,13 @@ extern "C" {
  * (upstream-recollection, like the rest of the cv2 restatement: the image half is parity-unpinned) */
 #define YSMR_CV_ANGLE_PRE451 1
 #define YSMR_CV_GRAY_3X      2
-#define YSMR_CV_FLAVOUR_MASK 3
+/* A scheduling hint carried in the same argument (results are the same bytes with or without it): the caller runs the
+ * one-launch link (ysmr_tracker_run with capacity and max_det <= 2048 or so) on another stream while this call's kernels
+ * execute.  ysmr_threshold_batch then takes the float32-chain kernel, whose resident grid leaves registers and LDS on
+ * every compute unit, and ysmr_components_batch launches k_windows / k_geometry with the smaller resident grids that
+ * leave the link's workgroups their 59 KB of LDS per unit (detection alone is ~8 % slower that way). */
+#define YSMR_BESIDE_LINK     4
+#define YSMR_CV_FLAVOUR_MASK 7
 
 /* One output row: a live track in one frame (ysmr/track_eval.py:313-316,
  * CSV columns TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE). */

@@ -127,6 +127,27 @@ def test_threshold_matrix_pipe_distance(torch_cuda, oracle):
             assert np.array_equal(got, ref), f"{args} variant {variant}: " + _mismatch_report(got, ref)
 
 
+def test_beside_link_hint_changes_no_byte(torch_cuda):
+    """YSMR_BESIDE_LINK (Detector(threshold_variant=1), what TrackingPipeline passes next to the one-launch link) only
+    picks kernels and resident grids: class map, labels, detections and counts are the same bytes as without it."""
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd import _lib
+    torch = torch_cuda
+    h, w = 922, 1228
+    dev = torch.from_numpy(SyntheticVideo(h, w, 500, seed=2).frames(8)).cuda()
+    out = []
+    for variant in (0, 1):
+        d = Detector(8, h, w, max_det=2048, params=threshold_params(True, 5, 2.0), threshold_variant=variant)
+        assert bool(d.cv_flavour & _lib.BESIDE_LINK) == (variant == 1)
+        r = d.detect(dev)
+        torch.cuda.synchronize()
+        out.append([t.clone() for t in (r.cls, r.labels, r.det_count, r.det, r.status)])
+    assert int(out[0][2].min()) > 300 and int(out[0][4].max()) == 0
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
 def test_threshold_dispatch_sets_the_callers_events(torch_cuda, oracle):
     """ysmr_threshold_timing: the kernel's own dispatch sets the two events (what bench.py's roofline divides by); the
     class map is the one an untimed call writes, for every kernel a geometry can take, and the hook is used up by one

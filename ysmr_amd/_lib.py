@@ -21,6 +21,8 @@ DET_ARENA = 2
 DET_STALLED = 4
 #: ``cv_flavour`` bits (include/ysmr_hip.h): which OpenCV release the a1 / a6 arithmetic follows
 CV_DEFAULT, CV_ANGLE_PRE451, CV_GRAY_3X = 0, 1, 2
+#: scheduling hint in the same argument: the one-launch link runs on another stream beside the call (YSMR_BESIDE_LINK)
+BESIDE_LINK = 4
 
 
 def cv_flavour_of(version):

@@ -2293,7 +2293,7 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
     if (!frames_dev || !cls_dev) return ysmr::fail(YSMR_ERR_ARG, "frames_dev and cls_dev must not be NULL");
     if (cv_flavour & ~YSMR_CV_FLAVOUR_MASK) return ysmr::fail(YSMR_ERR_ARG, "unknown cv_flavour bits 0x%x", cv_flavour);
     return launch_threshold((hipStream_t)stream, frames_dev, batch, height, width, channels, inv, t_low, t_high,
-                            use_high, cls_dev, cv_flavour);
+                            use_high, cls_dev, cv_flavour, (cv_flavour & YSMR_BESIDE_LINK) ? 1 : 0);
 }
 
 int ysmr_threshold_timing(void *start_event, void *stop_event)
@@ -2310,6 +2310,7 @@ int ysmr_threshold_batch_variant(void *stream, const uint8_t *frames_dev, int ba
     if (!frames_dev || !cls_dev) return ysmr::fail(YSMR_ERR_ARG, "frames_dev and cls_dev must not be NULL");
     if (cv_flavour & ~YSMR_CV_FLAVOUR_MASK) return ysmr::fail(YSMR_ERR_ARG, "unknown cv_flavour bits 0x%x", cv_flavour);
     if (variant < 0 || variant > 3) return ysmr::fail(YSMR_ERR_ARG, "variant must be 0..3, got %d", variant);
+    if (variant == 0 && (cv_flavour & YSMR_BESIDE_LINK)) variant = 1;
     return launch_threshold((hipStream_t)stream, frames_dev, batch, height, width, channels, inv, t_low, t_high,
                             use_high, cls_dev, cv_flavour, variant);
 }
@@ -2332,8 +2333,9 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     uint32_t *labels = reinterpret_cast<uint32_t *>(labels_dev);
 
     const Knobs &kn = knobs();
-    // (the LDS reserve matters to k_frame, the one-launch link, which tables of more than 2456 detections do not use)
-    const bool small_tables = max_det <= 2456;
+    // (the LDS reserve matters to k_frame, the one-launch link, which tables of more than 2456 detections do not use
+    // and which the caller announces with YSMR_BESIDE_LINK)
+    const bool small_tables = max_det <= 2456 && (cv_flavour & YSMR_BESIDE_LINK);
     const unsigned window_blocks = kn.collect_blocks > 0 ? (unsigned)kn.collect_blocks : (unsigned)(small_tables ? WINDOW_BLOCKS : 2 * WINDOW_BLOCKS);
     const unsigned sparse_blocks = kn.sparse_blocks > 0 ? (unsigned)kn.sparse_blocks : (unsigned)SPARSE_BLOCKS;
     const unsigned clear_blocks = kn.clear_blocks > 0 ? (unsigned)kn.clear_blocks : (unsigned)CLEAR_BLOCKS;

@@ -117,7 +117,9 @@ class Detector:
         #: (the matrix-pipe kernel, which fills whole compute units); 1 = the float32-chain kernels, whose resident grid
         #: leaves registers and LDS on every compute unit for a link kernel running beside it (``TrackingPipeline``)
         self.threshold_variant = int(threshold_variant)
-        self.cv_flavour = _lib.cv_flavour_of(cv_flavour)   # which OpenCV release a1 / a6 follow (_lib.CV_*)
+        # which OpenCV release a1 / a6 follow (_lib.CV_*), plus the hint that a link runs beside: the labelling / geometry
+        # kernels then keep to the resident grids that leave its workgroups their LDS
+        self.cv_flavour = _lib.cv_flavour_of(cv_flavour) | (_lib.BESIDE_LINK if self.threshold_variant == 1 else 0)
         self.params = params or threshold_params(True, 5, 2.0)
         self.device = torch.device(device)
         L = _lib.lib()
