@@ -27,6 +27,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # (before torch loads the HIP runtime; see ysmr_amd/__init__.py)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -291,7 +292,8 @@ def main():
                 "link_us_per_frame": stats_us([e0.elapsed_time(e1) * 1e3 / n for e0, e1, n, _ in link_events]),
                 "link_host_issue_us_per_frame": stats_us([h * 1e6 / n for _, _, n, h in link_events]),
                 "host_enqueue_ms_per_step": sum(enqueue_s) / len(enqueue_s) * 1e3 if enqueue_s else None,
-                "clocks": gpu_clocks(local_rank), "host_cpus": os.cpu_count(),
+                "clocks": gpu_clocks(local_rank), "kernargs_in_device_memory": os.environ.get("HIP_FORCE_DEV_KERNARG") == "1",
+                "host_cpus": os.cpu_count(),
                 "cpus_usable": len(os.sched_getaffinity(0)), "pinned_to_gpu_numa_node": bool(pinned),
                 "host_load_1m": os.getloadavg()[0]}
         out["diagnostics"] = diag
