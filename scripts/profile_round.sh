@@ -7,6 +7,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 > $O/ktrace.log 2>&1
+if [ -z "$SKIP_PMC" ]; then   # (SKIP_PMC=1: the threshold kernels have not changed since the committed counters)
 # (variant 1 = k_threshold_strip, the kernel of the pipeline and of the bench line; variant 0 = k_threshold_mfma)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_thr_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 1 > $O/pmc_thr_$c.log 2>&1
@@ -37,9 +38,15 @@ out.update({"mfma_" + k: v for k, v in mean(f"{O}/pmc_mfma_SQ2", "k_threshold").
 json.dump(out, open(f"{O}/pmc_summary.json", "w"), indent=1)
 print(json.dumps(out))
 PY
+fi
 # the other single-GPU configurations of BASELINE.json as bench lines, and the k_windows counters
 for c in 0 1 4; do python3 $R/bench.py --config $c --cpu-sample 20 2>> $O/bench.err >> $O/bench_configs.jsonl; done
 cut -c1-150 $O/bench_configs.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_det -- python3 $R/bench.py --cpu-sample 0 --config 1 > $O/ktrace_det.log 2>&1
 python3 $R/scripts/kstats.py $O/ktrace 30 > $O/kernel_stats.txt; python3 $R/scripts/kstats.py $O/ktrace_det 20 > $O/kernel_stats_detect_only.txt
 cat $O/kernel_stats.txt | cut -c1-150
+# configs[4]: who runs beside whom (kernel trace), and the link's phases alone / beside detection (device stamps; needs
+# scripts/var_stamps.so from scripts/build_stamps.sh)
+rocprofv3 --kernel-trace --output-format csv -d $O/kt4k -- python3 $R/bench.py --config 4 --steps 6 --cpu-sample 0 > $O/kt4k.log 2>&1
+python3 $R/scripts/timeline_4k.py $O/kt4k 60 > $O/timeline_4k.txt; rm -rf $O/kt4k; head -45 $O/timeline_4k.txt | cut -c1-150
+[ -f $R/scripts/var_stamps.so ] && YSMR_HIP_LIB=$R/scripts/var_stamps.so python3 $R/scripts/link_timeline.py > $O/link_timeline_4k.log 2>&1; cat $O/link_timeline_4k.log | grep -v amdgpu
