@@ -35,7 +35,7 @@ struct TrackerDev {
     const double *gains;
     // persistent state
     int *n_tracks, *next_id, *err, *n_free;
-    int *order, *order_tmp, *free_slots;
+    int *order, *free_slots;
     int *id, *gone;
     double *pos;      // [2][cap]
     float *info;      // [3][cap]
@@ -1910,7 +1910,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = ysmr::align_up(off + bytes, 256); return o; };
     const size_t o_scal = take(sizeof(int) * 16);
-    const size_t o_order = take(sizeof(int) * cap), o_order_tmp = take(sizeof(int) * cap), o_free = take(sizeof(int) * cap);
+    const size_t o_order = take(sizeof(int) * cap), o_free = take(sizeof(int) * cap);
     const size_t o_id = take(sizeof(int) * cap), o_gone = take(sizeof(int) * cap);
     const size_t o_pos = take(sizeof(double) * 2 * cap), o_info = take(sizeof(float) * 3 * cap);
     const size_t o_hist = take(sizeof(double) * 2 * cap * d.hist_cap);
@@ -1936,7 +1936,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     int *scal = (int *)(b + o_scal);
     d.n_tracks = scal; d.next_id = scal + 1; d.err = scal + 2; d.n_free = scal + 3;
     d.row_base = (long long *)(scal + 8);
-    d.order = (int *)(b + o_order); d.order_tmp = (int *)(b + o_order_tmp); d.free_slots = (int *)(b + o_free);
+    d.order = (int *)(b + o_order); d.free_slots = (int *)(b + o_free);
     d.id = (int *)(b + o_id); d.gone = (int *)(b + o_gone);
     d.pos = (double *)(b + o_pos); d.info = (float *)(b + o_info); d.hist = (double *)(b + o_hist);
     d.rec = (double *)(b + o_rec);
