@@ -64,6 +64,10 @@ struct TrackerDev {
     // the winner's detection is fetched, and position / box are stored, by the track's own wave in k_track (5000 waves
     // instead of one workgroup's two rounds of dependent gathers: 5 us of k_link's 12.6 at 4K)
     int *claim_slot;              // [capacity]
+    // ... and by ROW of the table k_track sees (after compaction and registration), valid when n_tracks[4] != 0 (k_link's
+    // register-resident path, the 4K configuration): the wave then knows its detection one round of loads earlier -- with
+    // its slot instead of after it
+    int *claim_row;               // [capacity]
 };
 
 // Uniform grid over one frame's detections (split path): the nearest detection of a track is looked for in the
@@ -74,6 +78,8 @@ struct DetGrid {
     const int *start;     // [GRID_CELLS + 1] first item of each cell (cells row-major: cy * GRID_N + cx)
     const int *items;     // [max_det] detection columns, cell by cell (any order inside a cell)
     const float *hdr;     // x0, y0, cell size, 1 / cell size
+    const float2 *xy;     // [max_det] the centres of `items`, in the same order: a cell's candidates arrive with one round
+                          // of loads instead of column numbers first and the detections they name after them
 };
 
 struct ysmr_tracker {
@@ -93,12 +99,13 @@ struct ysmr_tracker {
     {
         char *b = (char *)grid_block;
         const size_t per = grid_bytes_per_frame(d.max_det);
-        return DetGrid{(const int *)(b + per * f), (const int *)(b + per * f + sizeof(int) * (GRID_CELLS + 64)),
-                       (const float *)(b + per * f + sizeof(int) * (GRID_CELLS + 64) + sizeof(int) * (size_t)d.max_det)};
+        const size_t o_items = sizeof(int) * (GRID_CELLS + 64), o_hdr = o_items + sizeof(int) * (size_t)d.max_det;
+        return DetGrid{(const int *)(b + per * f), (const int *)(b + per * f + o_items), (const float *)(b + per * f + o_hdr),
+                       (const float2 *)(b + per * f + o_hdr + 64)};
     }
     static size_t grid_bytes_per_frame(int max_det)
     {
-        return ysmr::align_up(sizeof(int) * (GRID_CELLS + 64) + sizeof(int) * (size_t)max_det + 64, 256);
+        return ysmr::align_up(sizeof(int) * (GRID_CELLS + 64) + sizeof(int) * (size_t)max_det + 64 + sizeof(float2) * (size_t)max_det, 256);
     }
     const TrackerDev &cur() const { return par ? d1 : d; }
     const TrackerDev &nxt() const { return par ? d : d1; }
@@ -276,6 +283,7 @@ __global__ __launch_bounds__(1024) void k_grid_build(const DetT *__restrict__ de
     int *start = (int *)(grid_block + per_frame * f);
     int *items = start + GRID_CELLS + 64;
     float *hdr = (float *)(items + max_det);
+    float2 *xy = (float2 *)(hdr + 16);
     for (int c = tid; c < GRID_CELLS; c += 1024) s_cnt[c] = 0;
     float lo_x = 3.0e38f, lo_y = 3.0e38f, hi_x = -3.0e38f, hi_y = -3.0e38f;
     for (int j = tid; j < m; j += 1024) {
@@ -325,7 +333,11 @@ __global__ __launch_bounds__(1024) void k_grid_build(const DetT *__restrict__ de
     }
     if (tid == 1023) start[GRID_CELLS] = before + sum;
     __syncthreads();
-    for (int j = tid; j < m; j += 1024) items[atomicAdd(&s_cnt[cell_of(j)], 1)] = j;
+    for (int j = tid; j < m; j += 1024) {
+        const int at = atomicAdd(&s_cnt[cell_of(j)], 1);
+        items[at] = j;
+        xy[at] = make_float2((float)det[(size_t)j * 5], (float)det[(size_t)j * 5 + 1]);
+    }
 }
 
 // Row minimum through the grid: rings of cells around the track until no unseen detection can be as near as the
@@ -333,11 +345,16 @@ __global__ __launch_bounds__(1024) void k_grid_build(const DetT *__restrict__ de
 // rule as rowmin_wave on the detections of that block -- lowest column among the equal rounded distances.
 // Returns false when four rings were not enough (a track far from every detection): the caller falls back to
 // all pairs.
+struct GridHdr { float x0, y0, cell, inv; };
+__device__ __forceinline__ GridHdr grid_hdr(const DetGrid &g)   // (fetched by the caller ahead of everything the search waits for)
+{
+    return g.start ? GridHdr{g.hdr[0], g.hdr[1], g.hdr[2], g.hdr[3]} : GridHdr{0.f, 0.f, 1.f, 1.f};
+}
 template <typename DetT>
 __device__ __forceinline__ bool rowmin_grid(const TrackerDev &t, int row, double px, double py, const DetT *__restrict__ det,
-                                            const DetGrid &g, int lane)
+                                            const DetGrid &g, int lane, const GridHdr &gh)
 {
-    const double x0 = (double)g.hdr[0], y0 = (double)g.hdr[1], cell = (double)g.hdr[2], inv = (double)g.hdr[3];
+    const double x0 = (double)gh.x0, y0 = (double)gh.y0, cell = (double)gh.cell, inv = (double)gh.inv;
     int cx = (int)floor((px - x0) * inv), cy = (int)floor((py - y0) * inv);
     cx = cx < 0 ? 0 : (cx > GRID_N - 1 ? GRID_N - 1 : cx);
     cy = cy < 0 ? 0 : (cy > GRID_N - 1 ? GRID_N - 1 : cy);
@@ -350,9 +367,9 @@ __device__ __forceinline__ bool rowmin_grid(const TrackerDev &t, int row, double
         if (have) { a = g.start[iy * GRID_N + ix]; b = g.start[iy * GRID_N + ix + 1]; }
         double lane_min = inf;
         for (int q = a; q < b; ++q) {
-            const int j = g.items[q];
-            const double dx = px - (double)det[(size_t)j * 5 + 0];
-            const double dy = py - (double)det[(size_t)j * 5 + 1];
+            const float2 c = g.xy[q];
+            const double dx = px - (double)c.x;
+            const double dy = py - (double)c.y;
             double s = dx * dx;
             s = s + dy * dy;
             lane_min = s < lane_min ? s : lane_min;
@@ -375,8 +392,9 @@ __device__ __forceinline__ bool rowmin_grid(const TrackerDev &t, int row, double
         bool inexact = false;
         for (int q = a; q < b; ++q) {
             const int j = g.items[q];
-            const double dx = px - (double)det[(size_t)j * 5 + 0];
-            const double dy = py - (double)det[(size_t)j * 5 + 1];
+            const float2 c = g.xy[q];
+            const double dx = px - (double)c.x;
+            const double dy = py - (double)c.y;
             double s = dx * dx;
             s = s + dy * dy;
             const bool near = s <= near_limit;
@@ -387,8 +405,9 @@ __device__ __forceinline__ bool rowmin_grid(const TrackerDev &t, int row, double
             cand = 0x7FFFFFFF;
             for (int q = a; q < b; ++q) {
                 const int j = g.items[q];
-                const double dx = px - (double)det[(size_t)j * 5 + 0];
-                const double dy = py - (double)det[(size_t)j * 5 + 1];
+                const float2 c = g.xy[q];
+                const double dx = px - (double)c.x;
+                const double dy = py - (double)c.y;
                 double s = dx * dx;
                 s = s + dy * dy;
                 if (s <= near_limit && sqrt(s) == d_min) cand = min(cand, j);
@@ -421,7 +440,8 @@ __global__ __launch_bounds__(256) void k_rowmin(TrackerDev t, const DetT *__rest
     const int slot = t.order[row];
     const int lane = threadIdx.x & 63;
     if (lane == 0 && !t.gone_by_row) t.row_gone[row] = t.gone[slot];
-    if (grid.start && rowmin_grid(t, row, t.pos[slot], t.pos[t.capacity + slot], det, grid, lane)) return;
+    const GridHdr gh = grid_hdr(grid);
+    if (grid.start && rowmin_grid(t, row, t.pos[slot], t.pos[t.capacity + slot], det, grid, lane, gh)) return;
     DetChunk<DetT> first;
     load_chunk(first, det, m, 0, lane);
     rowmin_wave(t, row, t.pos[slot], t.pos[t.capacity + slot], det, m, lane, first);
@@ -764,23 +784,28 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) RING((4ull << 40) | (unsigned)frame);   // k_track entry
     BSTAMP(0);
-    const int n_live = *t.n_tracks;
+    // one round trip: the table size, this wave's slot (row i of a table of `capacity` rows: valid memory whatever n is)
+    // and the next frame's grid header are requested together
+    const int cap = t.capacity;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot_spec = t.order[min(i, cap - 1)];
+    const int claim_spec = t.claim_row[min(i, cap - 1)];
+    const GridHdr gh = grid_hdr(next_grid);
+    const int n_live = *t.n_tracks, claims_by_row = t.n_tracks[4];
     if (i >= n_live) return;
     const int lane = threadIdx.x & 63;
-    const int cap = t.capacity;
     // the next frame's detections do not depend on this frame's state: fetch them first
     const int m_next = next_det ? det_count(next_m_host, next_m_dev, t.max_det, nullptr) : 0;
     DetChunk<DetT> first;
     if (m_next > 0 && !next_grid.start) load_chunk(first, next_det, m_next, 0, lane);
-    const int slot = __builtin_amdgcn_readfirstlane(t.order[i]);
+    const int slot = __builtin_amdgcn_readfirstlane(slot_spec);
     if (blockIdx.x == 0 && threadIdx.x == 0) RING((5ull << 40) | (unsigned)frame);   // slot known
     BSTAMP(1);
     // the measurement: the detection k_link let this track claim (tracker.py:186-196 -- position and box are
     // stored here, by the track's own wave), or the position it already has
     GsffState<NF> st;
     if (t.use_gsff) gsff_fetch(t, slot, lane, st);
-    const int c = __builtin_amdgcn_readfirstlane(t.claim_slot[slot]);
+    const int c = __builtin_amdgcn_readfirstlane(claims_by_row ? claim_spec : t.claim_slot[slot]);
     double z0, z1;
     float bw, bh, ba;
     if (c >= 0) {
@@ -816,7 +841,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     // ---- nearest detection of the NEXT frame for this track (tracker.py:151-163)
     if (m_next > 0) {
         if (next_grid.start) {
-            if (rowmin_grid(t, i, p0, p1, next_det, next_grid, lane)) {
+            if (rowmin_grid(t, i, p0, p1, next_det, next_grid, lane, gh)) {
                 if (blockIdx.x == 0 && threadIdx.x == 0) RING((7ull << 40) | (unsigned)frame);   // next row minimum known
                 BSTAMP(3);
                 return;
@@ -1092,6 +1117,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         // large tables (the 4K configuration: ~5000 rows): thread tid owns rows tid + LINK_THREADS * k.  Everything
         // the LDS rounds, the ageing and the compaction below need is requested up front and kept in
         // registers, so that a pass costs one round of loads or atomics instead of a global round trip per row chunk
+        // (requesting the rows before n is known, 8192 instead of ~5000, was slower: one unit's load path is the limit)
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k) {
             const int r = tid + k * LINK_THREADS;
@@ -1126,10 +1152,9 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             used += __popcll(__ballot(mine));
             if (r >= n) continue;
             s_claim[r] = mine ? pa[k] : -1;
-            t.claim_slot[po[k]] = mine ? pa[k] : -1;
             if (mine) {
                 t.gone[po[k]] = 0;
-                pg[k] = -1;          // claimed (ageing below skips it)
+                pg[k] = -1;          // claimed (ageing below skips it; claim_row below)
             }
         }
         if ((tid & 63) == 0 && used) atomicAdd(&s_n_used, used);   // one LDS atomic per wave (1024 on one address: 3 us)
@@ -1220,14 +1245,23 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
                 all += c;
             }
             if (r < n) {
-                if (!pd[k]) t.order[base + before + __popcll(bal[k] & ((1ull << lane) - 1ull))] = po[k];
-                else t.free_slots[atomicAdd(t.n_free, 1)] = po[k];
+                if (!pd[k]) {
+                    const int at = base + before + __popcll(bal[k] & ((1ull << lane) - 1ull));
+                    t.order[at] = po[k];
+                    t.claim_row[at] = pg[k] == -1 ? pa[k] : -1;
+                } else t.free_slots[atomicAdd(t.n_free, 1)] = po[k];
             }
             base += all;
         }
         n_live = base;
         __threadfence_block();
         __syncthreads();           // (the free slots are read by other threads at a registration below)
+    } else if (big) {              // nobody died: the rows stay where they are
+#pragma unroll
+        for (int k = 0; k < LINK_ROWS; ++k) {
+            const int r = tid + k * LINK_THREADS;
+            if (r < n) t.claim_row[r] = pg[k] == -1 ? pa[k] : -1;
+        }
     } else if (s_any_dead) {
         int base = 0;
         for (int r0 = 0; r0 < n; r0 += LINK_THREADS) {
@@ -1305,6 +1339,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             t.info[2 * cap + slot] = (float)det[(size_t)c * 5 + 4];
             t.gone[slot] = 0;
             t.claim_slot[slot] = -1;                        // (k_track reads the position stored here)
+            t.claim_row[n_live + j] = -1;
             t.rec[(size_t)slot * t.rec_stride + 0] = 0.0;   // history length, head
             t.rec[(size_t)slot * t.rec_stride + 1] = 0.0;   // mode
             if (new_cols_out) new_cols_out[j] = c;
@@ -1326,6 +1361,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     if (tid == 0) {
         long long base = row_count ? *row_count : 0;
         *t.n_tracks = n_live;
+        t.n_tracks[4] = big ? 1 : 0;      // claim_row is valid for this frame
         t.row_base[0] = base;
         if (rows && base + n_live > rows_capacity) atomicOr(t.err, ERR_ROWS_CAPACITY);
         if (row_count) *row_count = base + n_live;
@@ -1789,10 +1825,10 @@ template <typename DetT>
 int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, const int32_t *m_dev, int frame,
                     ysmr_row *rows, long long rows_capacity, long long *row_count, int32_t *n_rows, int32_t *claim,
                     int32_t *n_before, int32_t *new_cols, int32_t *n_new, bool rowmin_done, const DetT *next_det,
-                    const int32_t *next_m_dev, DetGrid grid = DetGrid{nullptr, nullptr, nullptr},
-                    DetGrid next_grid = DetGrid{nullptr, nullptr, nullptr})
+                    const int32_t *next_m_dev, DetGrid grid = DetGrid{nullptr, nullptr, nullptr, nullptr},
+                    DetGrid next_grid = DetGrid{nullptr, nullptr, nullptr, nullptr})
 {
-    const DetGrid no_grid{nullptr, nullptr, nullptr};
+    const DetGrid no_grid{nullptr, nullptr, nullptr, nullptr};
     const dim3 wgrid((t->d.capacity + 3) / 4);
     if (t->fused) {
         const TrackerDev &a = t->cur(), &b = t->nxt();
@@ -1922,7 +1958,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const size_t o_dead = take(sizeof(int) * cap);
     const size_t o_new = take(sizeof(int) * max_det), o_table = take(sizeof(int) * 2 * (size_t)d.table_cap);
     const size_t o_lkey = take(sizeof(unsigned long long) * max_det), o_lrow = take(sizeof(int) * max_det);
-    const size_t o_lclaim = take(sizeof(int) * cap), o_cslot = take(sizeof(int) * cap);
+    const size_t o_lclaim = take(sizeof(int) * cap), o_cslot = take(sizeof(int) * cap), o_crow = take(sizeof(int) * cap);
     // parity-1 copies of the arrays k_frame double-buffers
     const size_t o_scal1 = take(sizeof(int) * 16), o_order1 = take(sizeof(int) * cap), o_gone1 = take(sizeof(int) * cap);
     const size_t o_rmin1 = take(sizeof(double) * cap), o_rarg1 = take(sizeof(int) * cap);
@@ -1947,6 +1983,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     d.new_cols = (int *)(b + o_new); d.set_table = (int *)(b + o_table);
     d.link_key = (unsigned long long *)(b + o_lkey); d.link_row = (int *)(b + o_lrow); d.link_claim = (int *)(b + o_lclaim);
     d.claim_slot = (int *)(b + o_cslot);
+    d.claim_row = (int *)(b + o_crow);
     t->d1 = d;
     {
         TrackerDev &q = t->d1;
@@ -2034,7 +2071,7 @@ int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const 
     if (!det_dev || !det_count_dev || !rows_dev || !row_count_dev || batch <= 0)
         return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev, rows_dev, row_count_dev must be set and batch > 0");
     if (t->fused) { t->set_base = true; t->base_ptr = (const long long *)row_count_dev; }
-    const DetGrid no_grid{nullptr, nullptr, nullptr};
+    const DetGrid no_grid{nullptr, nullptr, nullptr, nullptr};
     bool grids = false;
     if (!t->fused) {
         // large tables: a uniform grid over every frame's detections, built for the whole batch in one launch
