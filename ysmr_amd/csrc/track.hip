@@ -941,36 +941,48 @@ __device__ int block_exclusive_scan(int v, int *s_scan, int *total)
     return before + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
-// The same model with its tables in LDS, for k_link once its claim tables are dead (all LINK_THREADS threads call it).
-// What is order-dependent -- the insertions -- stays on one lane but costs LDS round trips instead of HBM ones (a frame
-// with 300 unregistered columns spent 575 us in cpython_unused_order, 700 dependent insertions and a 2048-slot walk from
-// one thread); clearing a table and the final walk in slot order are done by the whole block, and at a resize wave 0
-// reads the old table 64 slots at a time.  Table sizes alternate 8, 32, 128, ... between `tab_a` and `tab_b`; 16-bit
-// slots (keys < 65535).  Returns the number of keys, or -1 when a table does not fit (the caller falls back).
-constexpr unsigned short SET_EMPTY16 = 0xFFFFu;
-// One insertion by a whole wave (every lane calls it with the same key): the up to ten slots of a linear-probe run are
-// read by ten lanes at once and the first empty one is found with a ballot -- one LDS round trip per run instead of one
-// per probe (small tables of large keys collide a lot: 19 keys < 500 in 32 slots averaged 4 probes each).
-template <typename SlotT>
-__device__ __forceinline__ void set_insert_wave(SlotT *table, unsigned mask, unsigned key, SlotT empty, int lane)
+// Up to 64 insertions at once, with the result of doing them one after the other in lane order.  A slot holds
+// (sequence number << 16 | key); every lane walks its key's probe sequence and takes a slot with an atomic minimum, so
+// a slot ends up with the EARLIEST key that ever asked for it; a lane whose entry was displaced by an earlier key (or
+// that found an earlier key there) moves on along its sequence.  The fixed point -- every key in the first slot of its
+// sequence that no earlier key holds -- is exactly what sequential insertion produces (an earlier key's place never
+// depends on a later one), and it is reached in as many rounds as the longest displacement chain instead of one LDS
+// round trip per probe per key (36 keys, with the re-insertions of two resizes: 14 us one key at a time).
+// Entries of earlier batches carry smaller sequence numbers and never move.  seq + 63 < 65535, key < 65536.
+constexpr uint32_t SET_EMPTY32 = 0xFFFFFFFFu;
+__device__ __forceinline__ void set_insert_batch(uint32_t *table, unsigned mask, bool active, unsigned key, unsigned seq)
 {
+    const uint32_t mine = (seq << 16) | key;
     unsigned long long perturb = (unsigned long long)key;
     unsigned i = key & mask;
-    while (true) {
+    int j = 0;                       // offset inside the linear run that starts at i
+    unsigned at = 0;
+    bool need = active;              // has to propose its next candidate
+    auto advance = [&]() {           // setobject.c set_insert_clean: i .. i + 9, then the perturbed jump
         const int probes = (i + 9u <= mask) ? 9 : 0;
-        const bool free_here = lane <= probes && table[i + (lane <= probes ? lane : 0)] == empty;
-        const unsigned long long e = __ballot(free_here);
-        if (e) {
-            if (lane == __builtin_ctzll(e)) table[i + lane] = (SlotT)key;
-            return;
+        if (j < probes) ++j;
+        else { perturb >>= 5; i = (unsigned)(((unsigned long long)i * 5ull + 1ull + perturb) & mask); j = 0; }
+    };
+    while (true) {
+        if (need) {
+            at = i + (unsigned)j;
+            const uint32_t old = atomicMin(&table[at], mine);
+            if (old > mine) need = false;      // ours for now (a displaced later entry's lane notices below)
+            else advance();                    // an earlier key holds it
         }
-        perturb >>= 5;
-        i = (unsigned)(((unsigned long long)i * 5ull + 1ull + perturb) & mask);
+        if (active && !need && table[at] != mine) { need = true; advance(); }   // displaced by an earlier key
+        if (__ballot(need) == 0ull) return;
     }
 }
-__device__ int cpython_order_block(const int *unused, int n_unused, int m, int n_used, int *out, unsigned short *tab_a,
-                                   int cap_a, unsigned short *tab_b, int cap_b, unsigned short *stage, int *s_scan,
-                                   int *s_state)
+
+// The model for k_link, in the LDS its claim tables no longer need (all LINK_THREADS threads call it): one table of
+// 32-bit slots (set_insert_batch), a list for the resizes and the staged list of unclaimed columns.  Wave 0 inserts, 64
+// keys at a time; clearing the table, collecting it in slot order at a resize and the final walk are done by the whole
+// block.  (One thread over tables in HBM, cpython_unused_order, spent 575 us on 300 unregistered columns: 700 dependent
+// insertions and a 2048-slot walk.)  Returns the number of keys, or -1 when the table would outgrow `cap_table` slots
+// (the caller falls back to cpython_unused_order).
+__device__ int cpython_order_block(const int *unused, int n_unused, int m, int n_used, int *out, uint32_t *table,
+                                   int cap_table, uint32_t *list, unsigned short *stage, int *s_scan, int *s_state)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     if ((m >> 2) > n_used) {       // set_copy_and_difference: a copy of set(range(m)) iterates ascending
@@ -978,62 +990,55 @@ __device__ int cpython_order_block(const int *unused, int n_unused, int m, int n
         return n_unused;
     }
     for (int k = tid; k < n_unused; k += LINK_THREADS) stage[k] = (unsigned short)unused[k];
-    if (tid < 8) tab_a[tid] = SET_EMPTY16;
+    if (tid < 8) table[tid] = SET_EMPTY32;
     __syncthreads();
-    unsigned short *table = tab_a, *other = tab_b;
-    int cap_other = cap_b, cap_table = cap_a;
-    unsigned mask = 7;
-    int next = 0;
-    while (true) {
-        if (tid < 64) {   // wave 0 inserts until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
-            int k = next;
-            bool grow = false;
-            while (k < n_unused && !grow) {
-                set_insert_wave<unsigned short>(table, mask, stage[k], SET_EMPTY16, lane);
-                ++k;
-                grow = (unsigned long long)k * 5ull >= (unsigned long long)mask * 3ull;   // fill == k: nothing is ever removed
-            }
-            if (tid == 0) { s_state[0] = k; s_state[1] = grow ? 1 : 0; }
+    unsigned mask = 7, seq = 0;
+    int k = 0, fill = 0;
+    // occupied slots of the table in slot order: keys -> dst (LDS list or the global result)
+    auto collect = [&](auto *dst) {
+        int base = 0;
+        for (unsigned i0 = 0; i0 <= mask; i0 += LINK_THREADS) {
+            const unsigned i = i0 + tid;
+            const uint32_t e = i <= mask ? table[i] : SET_EMPTY32;
+            int total;
+            const int ex = block_exclusive_scan<true>(e != SET_EMPTY32 ? 1 : 0, s_scan, &total);
+            if (e != SET_EMPTY32) dst[base + ex] = e & 0xFFFFu;
+            base += total;
         }
+        return base;
+    };
+    while (true) {
+        // wave 0: keys go in until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
+        const int thresh = (int)((3u * mask + 4u) / 5u);
+        const int upto = min(n_unused, k + (thresh - fill));
+        if (tid < 64) {
+            for (int k0 = k; k0 < upto; k0 += 64) {
+                const int b = min(64, upto - k0);
+                set_insert_batch(table, mask, lane < b, lane < b ? (unsigned)stage[k0 + lane] : 0u, seq + (unsigned)(k0 - k) + lane);
+            }
+        }
+        seq += (unsigned)(upto - k); fill += upto - k; k = upto;
         __syncthreads();
-        next = s_state[0];
-        const bool grow = s_state[1] != 0;
-        __syncthreads();
-        if (!grow) break;
-        const unsigned fill = (unsigned)next;
-        const unsigned minused = fill > 50000u ? fill * 2u : fill * 4u;
+        if (fill < thresh) break;
+        const unsigned minused = (unsigned)fill > 50000u ? (unsigned)fill * 2u : (unsigned)fill * 4u;
         unsigned newsize = 8;
         while (newsize <= minused) newsize <<= 1;
-        if ((int)newsize > cap_other) return -1;                      // (uniform)
-        for (unsigned i = tid; i < newsize; i += LINK_THREADS) other[i] = SET_EMPTY16;
+        if ((int)newsize > cap_table) return -1;                      // (uniform)
+        const int cnt = collect(list);
         __syncthreads();
-        if (tid < 64) {   // wave 0: the old table in slot order, 64 slots per read; lane 0 re-inserts
-            for (unsigned i0 = 0; i0 <= mask; i0 += 64) {
-                const unsigned key = i0 + lane <= mask ? table[i0 + lane] : SET_EMPTY16;
-                unsigned long long bal = __ballot(key != SET_EMPTY16);
-                while (bal) {
-                    const int j = __builtin_ctzll(bal);
-                    const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
-                    set_insert_wave<unsigned short>(other, newsize - 1, kj, SET_EMPTY16, lane);
-                    bal &= bal - 1;
-                }
-            }
-        }
-        unsigned short *tp = table; table = other; other = tp;
-        const int tc = cap_table; cap_table = cap_other; cap_other = tc;
+        for (unsigned i = tid; i < newsize; i += LINK_THREADS) table[i] = SET_EMPTY32;
         mask = newsize - 1;
         __syncthreads();
+        if (tid < 64) {
+            for (int j0 = 0; j0 < cnt; j0 += 64) {
+                const int b = min(64, cnt - j0);
+                set_insert_batch(table, mask, lane < b, lane < b ? list[j0 + lane] : 0u, seq + (unsigned)j0 + lane);
+            }
+        }
+        seq += (unsigned)cnt;
+        __syncthreads();
     }
-    int base = 0;
-    for (unsigned i0 = 0; i0 <= mask; i0 += LINK_THREADS) {
-        const unsigned i = i0 + tid;
-        const unsigned key = i <= mask ? table[i] : SET_EMPTY16;
-        int total;
-        const int ex = block_exclusive_scan(key != SET_EMPTY16 ? 1 : 0, s_scan, &total);
-        if (key != SET_EMPTY16) out[base + ex] = (int)key;
-        base += total;
-    }
-    return base;
+    return collect(out);
 }
 
 // LDS_TABLES: the per-column winner tables and per-row claims fit in LDS (12 B per detection column + 4 B per track
@@ -1303,12 +1308,14 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             __syncthreads();
             int cnt = -1;
             if constexpr (LDS_TABLES) {
-                // (the claim tables are dead from here on: 8 B + 4 B per column hold the two set tables and the staged list)
-                unsigned short *tab_a = reinterpret_cast<unsigned short *>(s_dyn);                       // 4 * max_det slots
-                unsigned short *tab_b = reinterpret_cast<unsigned short *>(s_dyn + t.max_det);           // max_det slots
+                // (the claim tables are dead from here on: of the 8 B per column of the key table, 4 hold the set model's
+                // table of max_det slots and 2 the staged list; the 4 B per column of the row table hold its resize list)
+                uint32_t *tab = reinterpret_cast<uint32_t *>(s_dyn);
+                unsigned short *stage = reinterpret_cast<unsigned short *>(tab + t.max_det);
+                uint32_t *list = reinterpret_cast<uint32_t *>(s_dyn + t.max_det);
                 if (t.max_det < 65535)
-                    cnt = cpython_order_block(t.unused, base, m, s_n_used, t.new_cols, tab_a, 4 * t.max_det, tab_b, t.max_det,
-                                              tab_b + t.max_det, s_scan, s_set_state);
+                    cnt = cpython_order_block(t.unused, base, m, s_n_used, t.new_cols, tab, t.max_det, list, stage, s_scan,
+                                              s_set_state);
             }
             if (cnt >= 0) {
                 if (tid == 0) s_n_new = cnt;
@@ -1398,7 +1405,7 @@ struct FrameLds {
     int *cg;                       // [capacity] (claimed column + 1) | new `gone` << 16, per old row
     int *inv;                      // [capacity] new row -> old row
     int *scan;                     // [16]
-    short *table;                  // [2 * FRAME_TABLE]
+    short *table;                  // 4 * FRAME_TABLE bytes: the set model's table of 32-bit slots
 };
 
 __host__ __device__ inline size_t frame_lds_bytes(int cap, int max_det, int gain_total)
@@ -1422,15 +1429,14 @@ __device__ __forceinline__ int block_flag_rank(bool f, int *s_cnt, int *total)
 }
 
 // CPython order of the ascending list `unused` (see cpython_unused_order), 16-bit tables in LDS.
-// All FRAME_THREADS threads call it; the model itself runs on wave 0 alone, without a block barrier inside: lane 0 does
-// the insertions (the only order-dependent part), the wave clears a new table, reads the old one 64 slots at a time at a
-// resize (ballot, lane 0 re-inserts the occupied slots in slot order) and writes the final iteration order with a ballot
-// prefix.  LDS operations of one wave execute in order, so nothing but program order is needed between these steps.
-// (The block-wide version -- one barrier pair per scan chunk and per stage -- spent 15 us of a registration frame with
-// ~30 unclaimed columns; before that, one thread walking a 512-slot table 25 us.)
+// All FRAME_THREADS threads call it; the model itself runs on wave 0 alone, without a block barrier inside.  One table
+// of 32-bit slots (set_insert_batch) and a list: the keys of a stage go in 64 at a time; at a resize the wave writes the
+// occupied slots in slot order to `list` (ballot prefix), clears the table at its new size and re-inserts the list, 64
+// at a time; the final walk writes the iteration order the same way.  LDS operations of one wave execute in order, so
+// nothing but program order is needed between these steps.
 // Returns the number of keys, or -1 if the model would need a table larger than FRAME_TABLE.
-__device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_used, int *out, short *tables, int *s_scan,
-                                 int *s_state)
+__device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_used, int *out, uint32_t *table,
+                                 uint32_t *list, int *s_state)
 {
     const int tid = threadIdx.x;
     if ((m >> 2) > n_used) {
@@ -1440,42 +1446,42 @@ __device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_u
     }
     if (tid < 64) {
         const int lane = tid;
-        short *table = tables, *other = tables + FRAME_TABLE;
-        unsigned mask = 7;
-        int k = 0, result = 0;
-        if (lane < 8) table[lane] = -1;
+        unsigned mask = 7, seq = 0;
+        int k = 0, fill = 0, result = 0;
+        if (lane < 8) table[lane] = SET_EMPTY32;
         while (true) {
-            bool grow = false;
-            while (k < n_unused && !grow) {   // insert until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
-                set_insert_wave<short>(table, mask, (unsigned)unused[k], (short)-1, lane);
-                ++k;
-                grow = (unsigned long long)k * 5ull >= (unsigned long long)mask * 3ull;   // fill == k: nothing is ever removed
+            // keys go in until the table wants to grow (setobject.c: fill*5 >= mask*3 after an add)
+            const int thresh = (int)((3u * mask + 4u) / 5u);
+            while (k < n_unused && fill < thresh) {
+                const int b = min(64, min(n_unused - k, thresh - fill));
+                set_insert_batch(table, mask, lane < b, lane < b ? (unsigned)unused[k + lane] : 0u, seq + lane);
+                k += b; fill += b; seq += b;
             }
-            if (!grow) break;
-            const unsigned fill = (unsigned)k;
-            const unsigned minused = fill > 50000u ? fill * 2u : fill * 4u;
+            if (fill < thresh) break;
+            const unsigned minused = (unsigned)fill > 50000u ? (unsigned)fill * 2u : (unsigned)fill * 4u;
             unsigned newsize = 8;
             while (newsize <= minused) newsize <<= 1;
             if ((int)newsize > FRAME_TABLE) { result = -1; break; }
-            for (unsigned i = lane; i < newsize; i += 64) other[i] = -1;
-            for (unsigned i0 = 0; i0 <= mask; i0 += 64) {
-                const int key = i0 + lane <= mask ? (int)table[i0 + lane] : -1;
-                unsigned long long bal = __ballot(key >= 0);
-                while (bal) {
-                    const int j = __builtin_ctzll(bal);
-                    const int kj = __builtin_amdgcn_readlane(key, j);
-                    set_insert_wave<short>(other, newsize - 1, (unsigned)kj, (short)-1, lane);
-                    bal &= bal - 1;
-                }
+            int cnt = 0;
+            for (unsigned i0 = 0; i0 <= mask; i0 += 64) {   // the old table in slot order -> list
+                const uint32_t e = i0 + lane <= mask ? table[i0 + lane] : SET_EMPTY32;
+                const unsigned long long bal = __ballot(e != SET_EMPTY32);
+                if (e != SET_EMPTY32) list[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = e & 0xFFFFu;
+                cnt += __popcll(bal);
             }
-            short *tmp = table; table = other; other = tmp;
+            for (unsigned i = lane; i < newsize; i += 64) table[i] = SET_EMPTY32;
             mask = newsize - 1;
+            for (int j0 = 0; j0 < cnt; j0 += 64) {
+                const int b = min(64, cnt - j0);
+                set_insert_batch(table, mask, lane < b, lane < b ? list[j0 + lane] : 0u, seq + lane);
+                seq += b;
+            }
         }
         if (result == 0) {
             for (unsigned i0 = 0; i0 <= mask; i0 += 64) {
-                const int key = i0 + lane <= mask ? (int)table[i0 + lane] : -1;
-                const unsigned long long bal = __ballot(key >= 0);
-                if (key >= 0) out[result + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+                const uint32_t e = i0 + lane <= mask ? table[i0 + lane] : SET_EMPTY32;
+                const unsigned long long bal = __ballot(e != SET_EMPTY32);
+                if (e != SET_EMPTY32) out[result + __popcll(bal & ((1ull << lane) - 1ull))] = (int)(e & 0xFFFFu);
                 result += __popcll(bal);
             }
         }
@@ -1669,7 +1675,9 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
             __syncthreads();
             STAMP(12);
             {
-                int cnt = cpython_order_lds(L.unused, base, m, s_n_used, L.newcols, L.table, L.scan, s_set_state);
+                // (col_row is dead once the unclaimed columns are listed: it holds the model's list)
+                int cnt = cpython_order_lds(L.unused, base, m, s_n_used, L.newcols, reinterpret_cast<uint32_t *>(L.table),
+                                            reinterpret_cast<uint32_t *>(L.col_row), s_set_state);
                 if (cnt < 0) { if (blockIdx.x == 0 && tid == 0) atomicOr(a.err, ERR_TRACK_CAPACITY); cnt = 0; }
                 n_new = cnt;
             }
