@@ -98,6 +98,37 @@ def test_new_ids_follow_cpython_set_order(torch_cuda, oracle, cap, trials, n0_ma
         np.testing.assert_array_equal(np.array(list(objs.values())), xy, err_msg=f"trial {trial}")
 
 
+@pytest.mark.parametrize("cap", [1024, 4096, 16384])
+def test_set_order_when_the_unclaimed_columns_collide(torch_cuda, oracle, cap):
+    """The set model inserts 64 keys at a time (set_insert_batch): the unclaimed columns are chosen so that their hash
+    slots collide as badly as they can -- one residue class of the small tables, a dense run that overflows the linear
+    probe window, both mixed -- and so that displacement chains cross the 64-key batches."""
+    from ysmr_amd.tracker import CentroidTracker
+    rng = np.random.default_rng(5)
+    total = 900
+    patterns = [np.arange(0, total, 128), np.arange(0, total, 32), np.arange(7, total, 8)[:90], np.arange(100, 190),
+                np.r_[np.arange(0, total, 64), np.arange(300, 345), np.arange(513, 530)],
+                np.r_[np.arange(3, total, 16), np.arange(640, 700)], np.arange(total - 70, total)]
+    for cols in patterns:
+        cols = np.unique(cols)
+        n0 = total - len(cols)
+        assert n0 >= total // 4          # (otherwise the reference iterates a plain copy: ascending)
+        base = rng.uniform(0, 5000, (n0, 2))
+        ct = CentroidTracker(max_disappeared=30, fps=30.0, use_gsff=False, capacity=cap, max_det=cap)
+        ot = oracle.OracleTracker(max_disappeared=30, fps=30.0, use_gsff=False)
+        info = np.zeros((n0, 3))
+        ct.update(rects_of(base, info)); ot.update(rects_of(base, info))
+        pts = np.empty((total, 2))
+        old = np.setdiff1d(np.arange(total), cols)
+        pts[old] = base + rng.normal(0, 0.01, base.shape)
+        pts[cols] = rng.uniform(6000, 9000, (len(cols), 2))
+        info = np.zeros((total, 3))
+        objs, _ = ct.update(rects_of(pts, info))
+        ids, xy, _, _ = ot.update(rects_of(pts, info))
+        assert list(objs.keys()) == ids
+        np.testing.assert_array_equal(np.array(list(objs.values())), xy)
+
+
 def test_distance_ties_take_lowest_column_and_row(torch_cuda, oracle):
     from ysmr_amd.tracker import CentroidTracker
     ct = CentroidTracker(max_disappeared=30, fps=30.0, use_gsff=False, capacity=64, max_det=64)
