@@ -1066,11 +1066,12 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     };
     __shared__ int s_scan[LINK_THREADS];
     __shared__ int s_n_used, s_n_new, s_any_dead, s_set_state[2];
-    __shared__ int s_keep[LINK_ROWS][LINK_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) int s_keep[LINK_ROWS][LINK_THREADS / 64];
     const int tid = threadIdx.x;
     const int cap = t.capacity;
     if (tid == 0) RING((9ull << 40) | (unsigned)frame);    // entry (before the first load)
-    const int n = *t.n_tracks;
+    const int n = *t.n_tracks, nfree0 = *t.n_free;
+    int nfree_now = nfree0;        // (the register-resident path keeps the height of the free stack here)
     const int m = det_count(m_host, m_dev, t.max_det, t.err);
     LRING(0);
     if (tid == 0) { s_n_used = 0; s_n_new = 0; s_any_dead = 0; }
@@ -1229,38 +1230,49 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         // one pass: every wave counts its survivors chunk by chunk (a ballot each), ONE barrier, every thread adds up the
         // counts in front of its rows (the chunk-by-chunk scan took two barriers per 1024 rows).  In place: every row's
         // slot has been in registers since the start
+        // The slots of the dead go on the free stack in row order, ranked the same way (a returning global atomic per
+        // dead row was a round trip to HBM inside this phase).  Nothing written here is read again in this launch: ageing
+        // happens when n >= m, registration -- the reader of the free stack -- when n < m.
         const int lane = tid & 63, w = tid >> 6;
-        unsigned long long bal[LINK_ROWS];
+        const unsigned long long below = (1ull << lane) - 1ull;
+        unsigned long long bal[LINK_ROWS], dbal[LINK_ROWS];
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k) {
             const int r = tid + k * LINK_THREADS;
             bal[k] = __ballot(r < n && !pd[k]);
-            if (lane == 0) s_keep[k][w] = __popcll(bal[k]);
+            dbal[k] = __ballot(r < n && pd[k]);
+            if (lane == 0) s_keep[k][w] = __popcll(bal[k]) | (__popcll(dbal[k]) << 16);
         }
         block_sync<true>();
-        int base = 0;
+        int base = 0, dbase = 0;
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k) {
             const int r = tid + k * LINK_THREADS;
             int before = 0, all = 0;
+            static_assert(LINK_THREADS / 64 == 16, "four 16-byte reads per chunk");
 #pragma unroll
-            for (int q = 0; q < LINK_THREADS / 64; ++q) {
-                const int c = s_keep[k][q];
-                before += q < w ? c : 0;
-                all += c;
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int4 c = reinterpret_cast<const int4 *>(s_keep[k])[q4];
+                const int cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    before += 4 * q4 + e < w ? cs[e] : 0;
+                    all += cs[e];
+                }
             }
             if (r < n) {
                 if (!pd[k]) {
-                    const int at = base + before + __popcll(bal[k] & ((1ull << lane) - 1ull));
+                    const int at = base + (before & 0xFFFF) + __popcll(bal[k] & below);
                     t.order[at] = po[k];
                     t.claim_row[at] = pg[k] == -1 ? pa[k] : -1;
-                } else t.free_slots[atomicAdd(t.n_free, 1)] = po[k];
+                } else t.free_slots[nfree0 + dbase + (before >> 16) + __popcll(dbal[k] & below)] = po[k];
             }
-            base += all;
+            base += all & 0xFFFF;
+            dbase += all >> 16;
         }
         n_live = base;
-        __threadfence_block();
-        __syncthreads();           // (the free slots are read by other threads at a registration below)
+        nfree_now = nfree0 + dbase;
+        if (tid == 0) *t.n_free = nfree_now;
     } else if (big) {              // nobody died: the rows stay where they are
 #pragma unroll
         for (int k = 0; k < LINK_ROWS; ++k) {
@@ -1332,7 +1344,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             if (tid == 0) atomicOr(t.err, ERR_TRACK_CAPACITY);
             n_new = cap - n_live;
         }
-        const int nfree = *t.n_free;
+        const int nfree = big ? nfree_now : *t.n_free;     // (the other paths push the dead with global atomics)
         const int id0 = *t.next_id;
         for (int j = tid; j < n_new; j += LINK_THREADS) {
             int c = t.new_cols[j];
