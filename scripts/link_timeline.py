@@ -15,8 +15,8 @@ frames = torch.from_numpy(SyntheticVideo(H, W, 5000, seed=0).frames(F)).cuda()
 pipe = TrackingPipeline(H, W, 30.0, default_settings(), batch=B, max_det=8192, capacity=8192, rows_per_flush=4 * F * 8192)
 L = _lib.lib()
 PH = {9: "link entry", 10: "counters", 11: "tables cleared", 17: "rows loaded", 18: "column minima", 19: "column winners", 12: "claims", 13: "ageing", 14: "compaction", 15: "registration", 16: "link end",
-      4: "track entry", 5: "track slot known", 6: "track filters done", 7: "track next minimum"}
-ORDER = [9, 10, 11, 17, 18, 19, 12, 13, 14, 15, 16, 4, 5, 6, 7]
+      4: "track entry", 5: "track slot known", 6: "track filters done", 7: "track block 0 done", 8: "track last block done"}
+ORDER = [9, 10, 11, 17, 18, 19, 12, 13, 14, 15, 16, 4, 5, 6, 7, 8]
 
 
 def read_ring():
@@ -27,10 +27,21 @@ def read_ring():
     return sorted((int(t), int(tag) >> 40, int(tag) & 0xFFFFFFFF) for tag, t in a[:k])
 
 
+def wave_ends():
+    """frame & 63 -> when the last wave of that frame's k_track finished (the newest such frame)"""
+    buf = (ctypes.c_ulonglong * (64 * 8192))()
+    L.ysmr_debug_read_wave_end(buf)
+    return np.array(buf[:], dtype=np.uint64).reshape(64, 8192).max(axis=1)
+
+
 def report(title, ev, keep):
     by = {}
+    ends = wave_ends()
+    newest = max(fr for _, ph, fr in ev if ph == 4)
     for t, ph, fr in ev:
         if ph in PH and keep(fr): by.setdefault(fr, {})[ph] = t
+    for fr in by:                      # (the per-wave slots hold the last 64 frames only)
+        if fr > newest - 60: by[fr][8] = int(ends[fr & 63])
     rows = []
     for fr in sorted(by):
         d, nx = by[fr], by.get(fr + 1)
@@ -39,7 +50,7 @@ def report(title, ev, keep):
             rows.append(np.diff(ts))
     r = np.array(rows) / 100.0          # s_memrealtime ticks at 100 MHz
     print(f"{title}: {len(r)} frames; median / mean / p90 us")
-    names = [f"{PH[a]} -> {PH[b]}" for a, b in zip(ORDER, ORDER[1:])] + ["track block 0 done -> next link entry"]
+    names = [f"{PH[a]} -> {PH[b]}" for a, b in zip(ORDER, ORDER[1:])] + ["track last block done -> next link entry"]
     for i, nm in enumerate(names):
         print(f"  {nm:44s} {np.median(r[:, i]):7.2f} {r[:, i].mean():7.2f} {np.percentile(r[:, i], 90):7.2f}")
     tot = r.sum(axis=1)

@@ -8,12 +8,10 @@ d = json.loads(sys.stdin.read()); g = d['diagnostics']
 print(round(d['value']), 'frames/s  threshold', round(g['threshold_us_per_batch']['avg']), 'components', round(g['components_us_per_batch']['avg']), 'us/batch  link', round(g['link_us_per_frame']['avg'], 1), 'us/frame (min', round(g['link_us_per_frame']['min'], 1), ')')"; }
 run A=0
 run YSMR_COLLECT_BLOCKS=1024
-run YSMR_COLLECT_BLOCKS=768
-run YSMR_COLLECT_BLOCKS=512
-run YSMR_GEO_BLOCKS=768
-run YSMR_GEO_BLOCKS=512
+run YSMR_COLLECT_BLOCKS=1024 YSMR_GEO_BLOCKS=512
+run YSMR_COLLECT_BLOCKS=1024 YSMR_GEO_BLOCKS=512 YSMR_THR_BLOCKS=512
+run YSMR_COLLECT_BLOCKS=768 YSMR_GEO_BLOCKS=512 YSMR_THR_BLOCKS=512
+run YSMR_COLLECT_BLOCKS=1024 YSMR_GEO_BLOCKS=256 YSMR_THR_BLOCKS=512
 run YSMR_THR_BLOCKS=512
-run YSMR_COLLECT_BLOCKS=1024 YSMR_GEO_BLOCKS=768
-run YSMR_COLLECT_BLOCKS=768 YSMR_GEO_BLOCKS=768 YSMR_THR_BLOCKS=512
-run YSMR_COLLECT_BLOCKS=512 YSMR_GEO_BLOCKS=512 YSMR_CLEAR_BLOCKS=256
+run YSMR_GEO_BLOCKS=512
 run A=0

@@ -127,11 +127,18 @@ __device__ unsigned int g_ring_n;
 extern "C" int ysmr_debug_read_ring(unsigned long long *out, unsigned int *n) { hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring), sizeof(unsigned long long) * 8192); if (e == hipSuccess) e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_ring_n), 4); return (int)e; }
 extern "C" int ysmr_debug_read_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32); }
 #define LRING(k) do { if (threadIdx.x == 0) RING(((10ull + (k)) << 40) | (unsigned)frame); } while (0)   // k_link phases
+// when every wave of a frame's k_track finished (plain stores, one slot per wave; the host takes the maximum)
+__device__ unsigned long long g_wave_end[64 * 8192];
+#define TRACK_END() do { if ((threadIdx.x & 63) == 0 && i < 8192) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_wave_end[(frame & 63) * 8192 + i] = t_; } } while (0)
+#define TRACK_END_TO_RING() do {} while (0)
+extern "C" int ysmr_debug_read_wave_end(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_end), sizeof(unsigned long long) * 64 * 8192); }
 #else
 #define GSTAMP(k) do {} while (0)
 #define BSTAMP(k) do {} while (0)
 #define RING(tag) do {} while (0)
 #define LRING(k) do {} while (0)
+#define TRACK_END() do {} while (0)
+#define TRACK_END_TO_RING() do {} while (0)
 #endif
 
 namespace {
@@ -844,6 +851,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
             if (rowmin_grid(t, i, p0, p1, next_det, next_grid, lane, gh)) {
                 if (blockIdx.x == 0 && threadIdx.x == 0) RING((7ull << 40) | (unsigned)frame);   // next row minimum known
                 BSTAMP(3);
+                TRACK_END();
                 return;
             }
             load_chunk(first, next_det, m_next, 0, lane);
@@ -1041,7 +1049,7 @@ __device__ int cpython_order_block(const int *unused, int n_unused, int m, int n
     return collect(out);
 }
 
-// LDS_TABLES: the per-column winner tables and per-row claims fit in LDS (12 B per detection column + 4 B per track
+// LDS_TABLES: the per-column winner tables fit in LDS (12 B per detection column; the per-row claims are in HBM: 4 B per track
 // row <= 140 KiB, e.g. 8192 / 8192): the claim rounds cost LDS atomics.  Otherwise they live in HBM (three rounds of
 // device-scope atomics, ~6 us more at 5000 rows) and capacity / max_det are only bounded by 65536.
 template <typename DetT, bool LDS_TABLES>
@@ -1054,7 +1062,9 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     extern __shared__ unsigned long long s_dyn[];
     unsigned long long *s_col_key = LDS_TABLES ? s_dyn : t.link_key;                                        // [max_det]
     int *s_col_row = LDS_TABLES ? reinterpret_cast<int *>(s_dyn + t.max_det) : t.link_row;                  // [max_det]
-    int *s_claim = LDS_TABLES ? reinterpret_cast<int *>(s_dyn + t.max_det) + t.max_det : t.link_claim;     // [capacity]
+    // (a row's claim is written and read back by one thread only: it lives in HBM, and the workgroup asks a compute unit
+    // for 12 bytes of LDS per column, not 16 -- 96 KB at 8192, which fits beside four of k_windows' workgroups)
+    int *s_claim = t.link_claim;                                                                            // [capacity]
     // (in HBM, a value another wave has just changed with an atomic is read past this CU's L1)
     auto key_of = [&](int c) {
         if constexpr (LDS_TABLES) return s_col_key[c];
@@ -1070,6 +1080,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
     const int tid = threadIdx.x;
     const int cap = t.capacity;
     if (tid == 0) RING((9ull << 40) | (unsigned)frame);    // entry (before the first load)
+    TRACK_END_TO_RING();
     const int n = *t.n_tracks, nfree0 = *t.n_free;
     int nfree_now = nfree0;        // (the register-resident path keeps the height of the free stack here)
     const int m = det_count(m_host, m_dev, t.max_det, t.err);
@@ -1157,7 +1168,7 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
             const bool mine = r < n && row_of(pa[k]) == r;
             used += __popcll(__ballot(mine));
             if (r >= n) continue;
-            s_claim[r] = mine ? pa[k] : -1;
+            if (claim_out) s_claim[r] = mine ? pa[k] : -1;
             if (mine) {
                 t.gone[po[k]] = 0;
                 pg[k] = -1;          // claimed (ageing below skips it; claim_row below)
@@ -1868,7 +1879,7 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
     } else {
         const TrackerDev &d = t->d;
         if (!rowmin_done) hipLaunchKernelGGL(k_rowmin<DetT>, wgrid, dim3(256), 0, st, d, det, m, m_dev, 0, nullptr, grid);
-        const size_t link_lds = 12 * (size_t)d.max_det + 4 * (size_t)d.capacity;
+        const size_t link_lds = 12 * (size_t)d.max_det;
 #ifdef YSMR_TUNING
         static const bool hbm_tables = getenv("YSMR_LINK_TABLES") && !strcmp(getenv("YSMR_LINK_TABLES"), "hbm");
 #else
