@@ -1049,8 +1049,8 @@ __device__ int cpython_order_block(const int *unused, int n_unused, int m, int n
     return collect(out);
 }
 
-// LDS_TABLES: the per-column winner tables fit in LDS (12 B per detection column; the per-row claims are in HBM: 4 B per track
-// row <= 140 KiB, e.g. 8192 / 8192): the claim rounds cost LDS atomics.  Otherwise they live in HBM (three rounds of
+// LDS_TABLES: the per-column winner tables fit in LDS (12 B per detection column <= 140 KiB, e.g. 96 KiB at 8192; the
+// per-row claims are in HBM): the claim rounds cost LDS atomics.  Otherwise the tables live in HBM (three rounds of
 // device-scope atomics, ~6 us more at 5000 rows) and capacity / max_det are only bounded by 65536.
 template <typename DetT, bool LDS_TABLES>
 __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT *__restrict__ det, int m_host,
