@@ -1,4 +1,7 @@
 #!/bin/bash
+# A/B of k_frame's wave priority (s_setprio 0..3) on one box: build scripts/var_prio<N>.so first (track.hip with the level
+# replaced, linked like scripts/build_tuning.sh); end-to-end frames/s, the threshold kernel's time beside the link, the link's
+# time per frame.  Result: profiles/r03_ab_link_priority.log.
 R=$GRAFT_REPO_ROOT
 for i in 1 2 3; do
   for v in prio3 prio2 prio1 prio0; do
