@@ -210,7 +210,8 @@ def main():
                                                      frames_ready=False), f0, evs, sampled)   # (the clip is resident in HBM)
                     if pending[k] is not None and not args.detect_only:
                         (slot, res, ready), p0, pevs, psampled = pending[k]
-                        pipes[k].link(slot, res, ready, p0, link_events if (psampled and DIAG & 2) else None, events=pevs)
+                        pipes[k].link(slot, res, ready, p0, link_events if (psampled and DIAG & 2) else None, events=pevs,
+                                      nxt=nxt[0] if nxt is not None else None)
                     pending[k] = nxt
         if timed:
             enqueue_s.append(time.perf_counter() - t_host)

@@ -235,6 +235,18 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
  * to rows_dev (capacity rows_capacity) starting at *row_count_dev, which is advanced; rows of a
  * frame are contiguous and in ascending id order.  Overflow sets *row_count_dev past capacity
  * (rows beyond capacity are dropped); the host checks after synchronising. */
+/* ysmr_tracker_run when the caller knows which frame comes next: after_det_dev f32 [max_det][5] / after_count_dev i32 [1]
+ * are the detections of the frame that follows this call's last one (the next batch's first frame, already on the device
+ * and complete before this call's LAST launch executes: the caller orders that with an event on `stream`).  The last
+ * launch then also finds that frame's nearest detections, as every other launch of the call does for its successor, and
+ * the next ysmr_tracker_run / _chained call that starts at after_det_dev skips the launch that would have done it
+ * (8-11 us per batch).  Both NULL = ysmr_tracker_run.  The two-launch link of large tables ignores them. */
+int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
+                             int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev,
+                             const float *after_det_dev, const int32_t *after_count_dev);
+/* 1 when the handle links with one launch per frame (the case ysmr_tracker_run_chained serves), else 0 */
+int ysmr_tracker_fused(ysmr_tracker *t);
+
 int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev,
                      const int32_t *det_count_dev, int batch, int32_t first_frame_index,
                      ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev);

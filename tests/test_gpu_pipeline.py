@@ -220,16 +220,17 @@ def test_resident_clip_needs_no_wait_behind_the_link():
                     dev.record_stream(pipe.side)
                     nxt = (pipe.detect_async(dev, frames_ready=ev), f0)
                 else:
-                    nxt = (pipe.detect_async(resident[f0:f0 + b], frames_ready=False if mode == "resident" else None), f0)
+                    nxt = (pipe.detect_async(resident[f0:f0 + b], frames_ready=False if mode in ("resident", "chained") else None), f0)
             if pending is not None:
                 (slot, res, ready), p0 = pending
-                pipe.link(slot, res, ready, p0)
+                # ("chained": the batch's last launch also finds the next batch's first row minima, ysmr_tracker_run_chained)
+                pipe.link(slot, res, ready, p0, nxt=nxt[0] if (mode == "chained" and nxt is not None) else None)
             pending = nxt
         return pipe.take_rows()
 
     ref = run("blanket")
     assert len(ref) > 1000
-    for mode in ("resident", "event"):
+    for mode in ("resident", "event", "chained"):
         got = run(mode)
         assert got.tobytes() == ref.tobytes(), mode
 

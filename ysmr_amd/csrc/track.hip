@@ -93,6 +93,8 @@ struct ysmr_tracker {
     std::vector<double> gains_host;
     bool set_base;                 // fused path: the next k_rowmin also sets row_base from base_ptr
     const long long *base_ptr;
+    const void *rowmin_for = nullptr;   // fused path: the frame (its detections' address) whose row minima the last launch of
+                                        // the previous ysmr_tracker_run_chained call has already left in the state
     void *grid_block = nullptr;    // split path: DetGrid arrays for grid_frames frames (allocated by ysmr_tracker_run)
     int grid_frames = 0;
     DetGrid grid(int f) const
@@ -1531,7 +1533,8 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
                                                          long long rows_capacity, long long *row_count_ext,
                                                          int32_t *n_rows_out, int32_t *claim_out, int32_t *n_before_out,
                                                          int32_t *new_cols_out, int32_t *n_new_out,
-                                                         const DetT *__restrict__ next_det, const int32_t *next_m_dev)
+                                                         const DetT *__restrict__ next_det, const int32_t *next_m_dev,
+                                                         int base_from_ext)
 {
     extern __shared__ unsigned long long s_raw[];
     __shared__ int s_n_used, s_n_dead, s_set_state[2];
@@ -1573,7 +1576,8 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     const int32_t *mn_ptr = next_det ? next_m_dev : a.n_tracks;
     const int n_raw = *a.n_tracks, nfree_raw = *a.n_free, id0_raw = *a.next_id;
     const int m_raw = *m_ptr, mn_raw = *mn_ptr;
-    const long long row_base = a.row_base[0];
+    // (first frame of a run whose k_rowmin -- which also takes the caller's row count as the base -- was not needed)
+    const long long row_base = base_from_ext ? (row_count_ext ? *row_count_ext : 0ll) : a.row_base[0];
     const int n = __builtin_amdgcn_readfirstlane(n_raw);
     const int nfree = __builtin_amdgcn_readfirstlane(nfree_raw), id0 = __builtin_amdgcn_readfirstlane(id0_raw);
     int m = __builtin_amdgcn_readfirstlane(m_host < 0 ? m_raw : m_host);
@@ -1857,7 +1861,7 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
                     ysmr_row *rows, long long rows_capacity, long long *row_count, int32_t *n_rows, int32_t *claim,
                     int32_t *n_before, int32_t *new_cols, int32_t *n_new, bool rowmin_done, const DetT *next_det,
                     const int32_t *next_m_dev, DetGrid grid = DetGrid{nullptr, nullptr, nullptr, nullptr},
-                    DetGrid next_grid = DetGrid{nullptr, nullptr, nullptr, nullptr})
+                    DetGrid next_grid = DetGrid{nullptr, nullptr, nullptr, nullptr}, bool base_from_ext = false)
 {
     const DetGrid no_grid{nullptr, nullptr, nullptr, nullptr};
     const dim3 wgrid((t->d.capacity + 3) / 4);
@@ -1870,11 +1874,12 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
         // the filter bank is unrolled at compile time: 3 covers tracking.ini's default (and 1, 2), 8 the rest
         if (a.n_f <= 3)
             hipLaunchKernelGGL((k_frame<DetT, 3>), wgrid, dim3(FRAME_THREADS), t->frame_lds, st, a, b, det, m, m_dev, frame,
-                               rows, rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new, next_det, next_m_dev);
+                               rows, rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new, next_det, next_m_dev,
+                               base_from_ext ? 1 : 0);
         else
             hipLaunchKernelGGL((k_frame<DetT, YSMR_MAX_FILTERS>), wgrid, dim3(FRAME_THREADS), t->frame_lds, st, a, b, det, m,
                                m_dev, frame, rows, rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new,
-                               next_det, next_m_dev);
+                               next_det, next_m_dev, base_from_ext ? 1 : 0);
         t->par ^= 1;
     } else {
         const TrackerDev &d = t->d;
@@ -2062,6 +2067,7 @@ int ysmr_tracker_reset(ysmr_tracker *t, void *stream)
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
     int n = t->d.capacity > t->d.max_det ? t->d.capacity : t->d.max_det;
     t->par = 0;
+    t->rowmin_for = nullptr;
     hipLaunchKernelGGL(k_tracker_reset, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
@@ -2085,6 +2091,7 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
     if (m < 0 && !m_dev) return ysmr::fail(YSMR_ERR_ARG, "m < 0 requires m_dev");
     if (m > t->d.max_det) return ysmr::fail(YSMR_ERR_CAPACITY, "m = %d exceeds max_det = %d", m, t->d.max_det);
     if (!det_dev && m != 0) return ysmr::fail(YSMR_ERR_ARG, "det_dev is NULL");
+    t->rowmin_for = nullptr;
     if (t->fused) { t->set_base = true; t->base_ptr = nullptr; }
     if (det_is_f64)
         return launch_update_t<double>(t, (hipStream_t)stream, (const double *)det_dev, m, m_dev, frame_index, rows_dev,
@@ -2095,13 +2102,20 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
                                   n_new_dev, false, nullptr, nullptr);
 }
 
-int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
-                     int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev)
+int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
+                             int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev,
+                             const float *after_det_dev, const int32_t *after_count_dev)
 {
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
     if (!det_dev || !det_count_dev || !rows_dev || !row_count_dev || batch <= 0)
         return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev, rows_dev, row_count_dev must be set and batch > 0");
-    if (t->fused) { t->set_base = true; t->base_ptr = (const long long *)row_count_dev; }
+    if ((after_det_dev == nullptr) != (after_count_dev == nullptr))
+        return ysmr::fail(YSMR_ERR_ARG, "after_det_dev and after_count_dev go together");
+    if (!t->fused) { after_det_dev = nullptr; after_count_dev = nullptr; }   // (the split path needs the next batch's grid)
+    // the previous call may have left this call's first row minima behind (it was told this frame comes next)
+    const bool have_rowmin = t->fused && t->rowmin_for != nullptr && t->rowmin_for == (const void *)det_dev;
+    t->rowmin_for = nullptr;
+    if (t->fused) { t->set_base = !have_rowmin; t->base_ptr = (const long long *)row_count_dev; }
     const DetGrid no_grid{nullptr, nullptr, nullptr, nullptr};
     bool grids = false;
     if (!t->fused) {
@@ -2120,17 +2134,29 @@ int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const 
         grids = true;
     }
     for (int f = 0; f < batch; ++f) {
-        const bool has_next = f + 1 < batch;
+        const bool inside = f + 1 < batch, has_next = inside || after_det_dev != nullptr;
+        const float *next_det = inside ? det_dev + (size_t)(f + 1) * t->d.max_det * 5 : after_det_dev;
+        const int32_t *next_m = inside ? det_count_dev + f + 1 : after_count_dev;
         int rc = launch_update_t<float>(t, (hipStream_t)stream, det_dev + (size_t)f * t->d.max_det * 5, -1,
                                         det_count_dev + f, first_frame_index + f, rows_dev, (long long)rows_capacity,
                                         (long long *)row_count_dev, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                        f > 0, has_next ? det_dev + (size_t)(f + 1) * t->d.max_det * 5 : nullptr,
-                                        has_next ? det_count_dev + f + 1 : nullptr, grids ? t->grid(f) : no_grid,
-                                        grids && has_next ? t->grid(f + 1) : no_grid);
+                                        f > 0 || have_rowmin, has_next ? next_det : nullptr, has_next ? next_m : nullptr,
+                                        grids ? t->grid(f) : no_grid, grids && inside ? t->grid(f + 1) : no_grid,
+                                        f == 0 && have_rowmin);
         if (rc) return rc;
     }
+    if (after_det_dev) t->rowmin_for = (const void *)after_det_dev;
     return YSMR_OK;
 }
+
+int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
+                     int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev)
+{
+    return ysmr_tracker_run_chained(t, stream, det_dev, det_count_dev, batch, first_frame_index, rows_dev, rows_capacity,
+                                    row_count_dev, nullptr, nullptr);
+}
+
+int ysmr_tracker_fused(ysmr_tracker *t) { return t && t->fused ? 1 : 0; }
 
 int ysmr_tracker_peek(ysmr_tracker *t, void *stream, int32_t *ids_dev, double *xy_dev, int32_t *disappeared_dev,
                       int32_t *n_dev)

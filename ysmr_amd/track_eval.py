@@ -104,6 +104,7 @@ class TrackingPipeline:
                                  use_gsff=not settings["disable gsff"], capacity=capacity, max_det=max_det,
                                  device=self.device)
         self.capacity = int(capacity)
+        self._chain = self.trk.fused        # (the two-launch link of large tables has nothing to chain)
         n_rows = self.B * self.capacity if rows_per_flush is None else int(rows_per_flush)
         self.rows = torch.empty(n_rows * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
         self.row_count = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -187,22 +188,39 @@ class TrackingPipeline:
         self.row_count.zero_()
 
     @_on_own_device
-    def link(self, slot, res, ready, first_frame, link_events=None, events=None):
+    def link(self, slot, res, ready, first_frame, link_events=None, events=None, nxt=None):
         """Link one detected batch on the current stream; rows accumulate in self.rows.
         ``link_events``: list that receives a (start, stop, frames, host_seconds) record around the batch's
-        launches -- HIP events on the link stream, and how long the host took to issue them."""
+        launches -- HIP events on the link stream, and how long the host took to issue them.
+        ``nxt``: the (slot, result, ready_event) ``detect_async`` returned for the batch that follows, if it has been
+        issued: the one-launch link then lets this batch's last launch find the next batch's first row minima
+        (``ysmr_tracker_run_chained``: no separate launch for them at the start of the next ``link``); the next batch's
+        detection only has to be complete by that last launch."""
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ready)
+        n = int(res.det_count.shape[0])
+
+        def run():
+            if nxt is None or n < 2 or not self._chain:
+                self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
+                return
+            nres, nready = nxt[1], nxt[2]
+            self.trk.run(res.det[:n - 1], res.det_count[:n - 1], first_frame, self.rows, self.row_count,
+                         after=(res.det[n - 1], res.det_count[n - 1:]))
+            cur.wait_event(nready)
+            self.trk.run(res.det[n - 1:], res.det_count[n - 1:], first_frame + n - 1, self.rows, self.row_count,
+                         after=(nres.det[0], nres.det_count[0:1]))
+
         if link_events is None:
-            self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
+            run()
         else:
             e0, e1 = (events[3], events[4]) if events else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             e0.record(cur)
             t0 = time.perf_counter()
-            self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
+            run()
             host = time.perf_counter() - t0
             e1.record(cur)
-            link_events.append((e0, e1, int(res.det_count.shape[0]), host))
+            link_events.append((e0, e1, n, host))
         done = self._ev[slot]["done"]
         done.record(cur)
         self._done[slot] = done
@@ -367,7 +385,7 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
                     if persist_to:
                         _persist_chunk(persist_to, chunks[-1], len(chunks) == 1)
                     rows_upper = 0
-                res = pipe.link(slot, r, ready, p0)
+                res = pipe.link(slot, r, ready, p0, nxt=nxt[0])
                 rows_upper += cnt * pipe.capacity
                 frames_done = p0 + cnt
                 if not checked_early:           # a video too dense for the buffers is found out after its

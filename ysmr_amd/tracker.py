@@ -77,16 +77,24 @@ class DeviceTracker:
         _lib.check(rc, "ysmr_tracker_update")
 
     @_on_own_device
-    def run(self, det, det_count, first_frame, rows, row_count):
+    def run(self, det, det_count, first_frame, rows, row_count, after=None):
         """Frames [first_frame, first_frame + B): det f32 [B,max_det,5], det_count i32 [B] on device;
-        rows: uint8 buffer viewed as ysmr_row[]; row_count: int64 device scalar (advanced)."""
+        rows: uint8 buffer viewed as ysmr_row[]; row_count: int64 device scalar (advanced).
+        ``after``: (det f32 [max_det,5], count i32 [1]) of the frame that follows the last one of this call
+        (``ysmr_tracker_run_chained``); it must be complete before this call's last launch executes."""
         b = det_count.numel()
         if det.shape[1] != self.max_det:
             raise ValueError("det must be [B, max_det, 5] with the tracker's max_det")
-        rc = _lib.lib().ysmr_tracker_run(self._handle, _lib.stream_ptr(self.device), det.data_ptr(), det_count.data_ptr(),
-                                         b, int(first_frame), rows.data_ptr(),
-                                         rows.numel() // _lib.ROW_DTYPE.itemsize, row_count.data_ptr())
-        _lib.check(rc, "ysmr_tracker_run")
+        a_det, a_cnt = (None, None) if after is None else (after[0].data_ptr(), after[1].data_ptr())
+        rc = _lib.lib().ysmr_tracker_run_chained(self._handle, _lib.stream_ptr(self.device), det.data_ptr(),
+                                                 det_count.data_ptr(), b, int(first_frame), rows.data_ptr(),
+                                                 rows.numel() // _lib.ROW_DTYPE.itemsize, row_count.data_ptr(), a_det, a_cnt)
+        _lib.check(rc, "ysmr_tracker_run_chained")
+
+    @property
+    def fused(self):
+        """True when the handle links with one launch per frame (``k_frame``)."""
+        return bool(_lib.lib().ysmr_tracker_fused(self._handle))
 
     @_on_own_device
     def info(self):
