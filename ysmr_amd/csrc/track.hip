@@ -498,9 +498,21 @@ __device__ __forceinline__ double wave_total(double v)
 // (l & 31) + 32 q -- x in lanes 0..31, y in lanes 32..63 -- so that for a decoupled gain (x-hat
 // from x only, y-hat from y only: every constant-velocity LSF gain) one 5-step half-wave reduction
 // yields both sums.  In memory the history stays [entry][coordinate].
+// Entry e is the measurement of e frames ago (NEWEST FIRST, shifted by one lane every frame and written back whole: one
+// 512-byte store, as a ring's single new entry was one store instruction too).  The gain that multiplies a lane's entry
+// is then a property of the lane: it is fetched with the very first loads of the kernel (FirGains), where a ring needed
+// its head -- part of the state -- before it could even address the gain table (1150 of the filter bank's 6000 cycles
+// were that gather and its index arithmetic).
 __device__ __forceinline__ int hist_entry(int lane, int q) { return (lane & 31) + 32 * q; }
 __device__ __forceinline__ int hist_comp(int lane) { return lane >> 5; }
 
+__device__ __forceinline__ double wave_shr1_f64(double v)   // the value of lane - 1
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double lane_value(double v, int src_lane)
 {
     long long b = __double_as_longlong(v);
@@ -519,12 +531,31 @@ __device__ __forceinline__ double half_wave_totals(double v)
     return v;
 }
 
+// This lane's gains: for each filter the coefficient of history entry (lane & 31) in the x-hat row (lanes 0..31) or the
+// y-hat row (lanes 32..63) of a DECOUPLED gain; 0 where the entry lies beyond the filter's horizon.  Depends on nothing
+// but the lane, so it is requested before the track's state is known.  (Entries 32.. -- horizons beyond 32 frames --
+// and coupled gains fetch theirs where they are used.)
+template <int NF>
+struct FirGains { double g[NF]; };
+template <int NF>
+__device__ __forceinline__ void fir_gains_fetch(const TrackerDev &t, const double *gains, int lane, FirGains<NF> &G)
+{
+    const int comp = hist_comp(lane), e = hist_entry(lane, 0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int N = t.n_i[f < t.n_f ? f : 0];
+        const bool in = f < t.n_f && e < t.hist_cap && e < N && t.gains_decoupled;
+        const double g = gains[in ? t.gain_off[f] + comp * (2 * N + 1) + 2 * (N - 1 - e) : 0];
+        G.g[f] = in ? g : 0.0;
+    }
+}
+
 // FIR estimates of ALL active filters at once (rows 0 and 1 of gain f times the last n_f[f]
 // measurements: lsff_calc, gsff.py:156-177).  Branch-free over the filter bank so that the
 // independent reductions interleave; filters >= mode are computed on masked zeros and discarded.
 template <int NF>
 __device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const double *gains, const TrackRegs &h, int lane,
-                                             int mode, int head, double *x0, double *x1)
+                                             int mode, const FirGains<NF> &G, double *x0, double *x1)
 {
     const int L = t.hist_cap;
     const int comp = hist_comp(lane);
@@ -532,23 +563,16 @@ __device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const double *
     if (t.gains_decoupled) {
         double p[NF];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) p[f] = 0.0;
+        for (int f = 0; f < NF; ++f) p[f] = (f < mode) ? G.g[f] * h.v[0] : 0.0;      // (G.g is 0 beyond the horizon)
+        if (L > 32) {                      // (uniform) horizons beyond 32 frames: the second register of the history
+            const int e = hist_entry(lane, 1);
 #pragma unroll
-        for (int q = 0; q < TRACK_VALS; ++q) {
-            const int e = hist_entry(lane, q);
-            int age = head - 1 - e;          // 0 = newest
-            if (age < 0) age += L;
-            double g[NF];
-            bool in[NF];
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {   // unconditional gathers (clamped index, masked product)
-                const int N = t.n_i[f];
-                in[f] = (f < mode) && (e < L) && (age < N);
-                const int idx = in[f] ? comp * (2 * N + 1) + 2 * (N - 1 - age) : 0;
-                g[f] = gains[t.gain_off[f] + idx];
+            for (int f = 0; f < NF; ++f) {
+                const int N = t.n_i[f < t.n_f ? f : 0];
+                const bool in = (f < mode) && (e < L) && (e < N);
+                const double g = gains[in ? t.gain_off[f] + comp * (2 * N + 1) + 2 * (N - 1 - e) : 0];
+                p[f] = in ? p[f] + g * h.v[1] : p[f];
             }
-#pragma unroll
-            for (int f = 0; f < NF; ++f) p[f] = in[f] ? p[f] + g[f] * h.v[q] : p[f];
         }
         GSTAMP(9);
 #pragma unroll
@@ -566,18 +590,16 @@ __device__ __forceinline__ void fir_wave_all(const TrackerDev &t, const double *
     for (int f = 0; f < NF; ++f) { p0[f] = 0.0; p1[f] = 0.0; }
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) {
-        const int e = hist_entry(lane, q);
-        int age = head - 1 - e;          // 0 = newest
-        if (age < 0) age += L;
+        const int e = hist_entry(lane, q);          // = age: 0 is the newest measurement
         double ga[NF], gb[NF];
         bool in[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const int N = t.n_i[f];
-            in[f] = (f < mode) && (e < L) && (age < N);
-            const int col = in[f] ? 2 * (N - 1 - age) + comp : 0;
-            ga[f] = gains[t.gain_off[f] + col];
-            gb[f] = gains[t.gain_off[f] + 2 * N + col];
+            const int N = t.n_i[f < t.n_f ? f : 0];
+            in[f] = (f < mode) && (e < L) && (e < N);
+            const int col = in[f] ? 2 * (N - 1 - e) + comp : 0;
+            ga[f] = gains[t.gain_off[f < t.n_f ? f : 0] + col];
+            gb[f] = gains[t.gain_off[f < t.n_f ? f : 0] + 2 * N + col];
         }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -602,7 +624,7 @@ template <int NF>
 struct GsffState {
     TrackRegs h;
     double w[NF], xh0[NF], xh1[NF];
-    int len, head, mode;
+    int len, mode;
     double raw;          // this lane's field of the slot's record, as fetched (decoded by gsff_decode)
 };
 // Issue every load of a track's filter state; no load depends on another, so one round trip.
@@ -630,7 +652,6 @@ __device__ __forceinline__ void gsff_decode(const TrackerDev &t, GsffState<NF> &
         return __longlong_as_double(((long long)__builtin_amdgcn_readlane(hi, k) << 32) | (unsigned int)__builtin_amdgcn_readlane(lo, k));
     };
     s.len = __builtin_amdgcn_readlane(lo, 0);
-    s.head = __builtin_amdgcn_readlane(hi, 0);
     s.mode = __builtin_amdgcn_readlane(lo, 1);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -643,7 +664,7 @@ __device__ __forceinline__ void gsff_decode(const TrackerDev &t, GsffState<NF> &
 template <int NF>
 __device__ __forceinline__ void gsff_blank(GsffState<NF> &s)
 {
-    s.len = s.head = s.mode = 0;
+    s.len = s.mode = 0;
     s.raw = 0.0;         // (decodes to an empty bank)
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) s.h.v[q] = 0.0;
@@ -652,14 +673,14 @@ __device__ __forceinline__ void gsff_blank(GsffState<NF> &s)
 }
 template <int NF>
 __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gains, int slot, int lane, double z0,
-                                          double z1, bool fresh_track, GsffState<NF> &st, double &o0, double &o1,
-                                          double &p0, double &p1)
+                                          double z1, bool fresh_track, GsffState<NF> &st, const FirGains<NF> &G,
+                                          double &o0, double &o1, double &p0, double &p1)
 {
     const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
     GSTAMP(0);
     double *hist = t.hist + (size_t)slot * 2 * L;
     gsff_decode(t, st);
-    int len = st.len, head = st.head, mode = st.mode;
+    int len = st.len, mode = st.mode;
     TrackRegs &h = st.h;
     double (&w)[NF] = st.w;
     double (&xh0)[NF] = st.xh0;
@@ -673,7 +694,6 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
         for (int q = 0; q < TRACK_VALS; ++q)
             if (hist_entry(lane, q) < t.n_i[0]) h.v[q] = hist_comp(lane) ? z1 : z0;
         len = t.n_i[0];
-        head = len % L;
     }
     bool grew = false;
     if (mode < nf) {
@@ -685,7 +705,7 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     }
     if (grew) {
         const double w0 = 1.0 / (double)mode;
-        fir_wave_all<NF>(t, gains, h, lane, mode, head, xh0, xh1);
+        fir_wave_all<NF>(t, gains, h, lane, mode, G, xh0, xh1);
 #pragma unroll
         for (int f = 0; f < NF; ++f)
             if (f < mode) w[f] = w0;
@@ -693,16 +713,19 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
     GSTAMP(2);
     // append the measurement and start the predict-step FIR (gsff.py:204-249) right away: it reads
     // only the history, so its reductions overlap the likelihood arithmetic below
-    const int at = head;
-#pragma unroll
-    for (int q = 0; q < TRACK_VALS; ++q)
-        if (hist_entry(lane, q) == at) h.v[q] = hist_comp(lane) ? z1 : z0;
-    if (++head == L) head = 0;
+    // (every entry one frame older: one lane up; the measurement becomes entry 0 of each half)
+    if (L > 32) {                          // (uniform) the second register takes over what leaves the first
+        const double cx = lane_value(h.v[0], 31), cy = lane_value(h.v[0], 63);
+        h.v[1] = wave_shr1_f64(h.v[1]);
+        h.v[1] = (lane & 31) == 0 ? (hist_comp(lane) ? cy : cx) : h.v[1];
+    }
+    h.v[0] = wave_shr1_f64(h.v[0]);
+    h.v[0] = (lane & 31) == 0 ? (hist_comp(lane) ? z1 : z0) : h.v[0];
     if (len < L) ++len;
     double nx0[NF], nx1[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) { nx0[f] = 0.0; nx1[f] = 0.0; }
-    fir_wave_all<NF>(t, gains, h, lane, mode, head, nx0, nx1);
+    fir_wave_all<NF>(t, gains, h, lane, mode, G, nx0, nx1);
     GSTAMP(3);
     // likelihoods (gsff.py:179-202): lane f evaluates filter f's exp(), the results are broadcast
     // (the float64 exp is ~150 instructions; doing the n_f of them one after the other on every
@@ -766,14 +789,14 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) {
         const int e = hist_entry(lane, q);
-        if (e < L && (fresh || e == at)) hist[2 * e + hist_comp(lane)] = h.v[q];
+        if (e < L && (q == 0 || L > 32)) hist[2 * e + hist_comp(lane)] = h.v[q];     // the whole history, shifted
     }
     if (lane == 0) {
         t.pos[slot] = p0;
         t.pos[cap + slot] = p1;
     }
     {   // the record, one store: every lane picks its field
-        double val = __longlong_as_double(lane == 0 ? ((long long)head << 32) | (unsigned int)len : (long long)(unsigned int)mode);
+        double val = __longlong_as_double(lane == 0 ? (long long)(unsigned int)len : (long long)(unsigned int)mode);
 #pragma unroll
         for (int f = 0; f < NF; ++f)
             if (f < nf) {
@@ -800,6 +823,8 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     const int slot_spec = t.order[min(i, cap - 1)];
     const int claim_spec = t.claim_row[min(i, cap - 1)];
     const GridHdr gh = grid_hdr(next_grid);
+    FirGains<NF> G;
+    if (t.use_gsff) fir_gains_fetch(t, t.gains, threadIdx.x & 63, G);
     const int n_live = *t.n_tracks, claims_by_row = t.n_tracks[4];
     if (i >= n_live) return;
     const int lane = threadIdx.x & 63;
@@ -830,7 +855,7 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
         bw = t.info[slot]; bh = t.info[cap + slot]; ba = t.info[2 * cap + slot];
     }
     double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
-    if (t.use_gsff) gsff_wave(t, t.gains, slot, lane, z0, z1, false, st, o0, o1, p0, p1);
+    if (t.use_gsff) gsff_wave(t, t.gains, slot, lane, z0, z1, false, st, G, o0, o1, p0, p1);
     if (blockIdx.x == 0 && threadIdx.x == 0) RING((6ull << 40) | (unsigned)frame);   // filter bank done
     BSTAMP(2);
     if (lane == 0) {
@@ -1564,7 +1589,8 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     // Speculation for phase B: unless a track ahead of row i is deregistered this frame, row i of
     // the new table is row i of the old one, keeps its slot and can only claim row_arg[i].
     int slot_s = a.order[min(i, cap - 1)], c_s = a.row_arg[min(i, cap - 1)];
-    const double gain0 = a.gain_total > 0 ? a.gains[min(tid, a.gain_total - 1)] : 0.0;
+    FirGains<NF> G;                    // (this lane's filter gains, straight from the table: no copy of it in LDS)
+    if (a.use_gsff) fir_gains_fetch(a, a.gains, lane, G);
     // the next frame's detections do not depend on this frame's state either (rows past m_next
     // of the [max_det][5] frame slice are stale; rowmin_wave masks them)
     DetChunk<DetT> first;
@@ -1619,8 +1645,6 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
             for (int k = 0; k < 5; ++k) dd[k] = det[(size_t)c_s * 5 + k];
         }
     }
-    if (tid < a.gain_total) L.gains[tid] = gain0;
-    for (int k = tid + FRAME_THREADS; k < a.gain_total; k += FRAME_THREADS) L.gains[k] = a.gains[k];
     // row r = tid + 256 k of the old table: from the registers above for k < SPEC_ROWS, from HBM beyond
     auto row_inputs = [&](int k, int r, int &o_, int &g_, int &a_, unsigned long long &key_) {
         if (k < SPEC_ROWS) {
@@ -1767,7 +1791,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
         }
         double o0 = z0, o1 = z1, p0 = z0, p1 = z1;
         STAMP(5);
-        if (a.use_gsff) gsff_wave(a, L.gains, slot, lane, z0, z1, fresh_track, S, o0, o1, p0, p1);
+        if (a.use_gsff) gsff_wave(a, a.gains, slot, lane, z0, z1, fresh_track, S, G, o0, o1, p0, p1);
         else if (lane == 0) { a.pos[slot] = z0; a.pos[cap + slot] = z1; }
         STAMP(6);
         if (lane == 0) {
