@@ -818,14 +818,17 @@ __global__ __launch_bounds__(256) void k_track(TrackerDev t, int frame, ysmr_row
     BSTAMP(0);
     // one round trip: the table size, this wave's slot (row i of a table of `capacity` rows: valid memory whatever n is)
     // and the next frame's grid header are requested together
+    // (one straight-line block, the counters first -- see k_frame: a branch in here costs a scalar load of the arguments
+    // behind it and a wait of its own)
     const int cap = t.capacity;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_live = *t.n_tracks, claims_by_row = t.n_tracks[4];
     const int slot_spec = t.order[min(i, cap - 1)];
     const int claim_spec = t.claim_row[min(i, cap - 1)];
-    const GridHdr gh = grid_hdr(next_grid);
+    const float *hdr = next_grid.start ? next_grid.hdr : reinterpret_cast<const float *>(t.n_tracks);   // (always readable)
+    const GridHdr gh{hdr[0], hdr[1], hdr[2], hdr[3]};
     FirGains<NF> G;
-    if (t.use_gsff) fir_gains_fetch(t, t.gains, threadIdx.x & 63, G);
-    const int n_live = *t.n_tracks, claims_by_row = t.n_tracks[4];
+    fir_gains_fetch(t, t.gains, threadIdx.x & 63, G);
     if (i >= n_live) return;
     const int lane = threadIdx.x & 63;
     // the next frame's detections do not depend on this frame's state: fetch them first
@@ -1573,7 +1576,22 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     if (blockIdx.x == 0 && threadIdx.x == 0) RING((2ull << 40) | (unsigned)frame);
 #endif
     // ---- round trip 1: everything that can be addressed without knowing n or m is requested
-    // together with the counters (entries past n / m are stale and never used)
+    // together with the counters (entries past n / m are stale and never used).  ONE straight-line block, the
+    // counters first: every branch in here made the compiler fetch the kernel arguments it needs behind it in a
+    // separate scalar load with its own wait, and the counters -- which the first decision waits for -- were requested
+    // at the end of that chain of waits (4 k cycles from entry to the exit test).  (Passing what this block is addressed
+    // with as eight leading pointer arguments, so that one 64-byte scalar load precedes the requests, was 6 % SLOWER end
+    // to end, with or without kernel-argument preload.)
+    // All counters in the same round trip: the two detection counts are read through pointers that
+    // are always valid (a dummy when the count comes from the host / there is no next frame), so
+    // that no load hides behind a branch and a wait
+    const int32_t *m_ptr = m_host < 0 ? m_dev : a.n_tracks;
+    const int32_t *mn_ptr = next_det ? next_m_dev : a.n_tracks;
+    const int n_raw = *a.n_tracks, nfree_raw = *a.n_free, id0_raw = *a.next_id;
+    const int m_raw = *m_ptr, mn_raw = *mn_ptr;
+    // (first frame of a run whose k_rowmin -- which also takes the caller's row count as the base -- was not needed)
+    const long long *base_ptr = (base_from_ext && row_count_ext) ? row_count_ext : a.row_base;
+    const long long row_base_raw = *base_ptr;
     constexpr int SPEC_ROWS = 3;       // table rows tid + 256k, k < 3, are fetched before n is known
     const int i = blockIdx.x * 4 + wave;
     int so[SPEC_ROWS], sg[SPEC_ROWS], sa[SPEC_ROWS];
@@ -1589,21 +1607,13 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     // Speculation for phase B: unless a track ahead of row i is deregistered this frame, row i of
     // the new table is row i of the old one, keeps its slot and can only claim row_arg[i].
     int slot_s = a.order[min(i, cap - 1)], c_s = a.row_arg[min(i, cap - 1)];
-    FirGains<NF> G;                    // (this lane's filter gains, straight from the table: no copy of it in LDS)
-    if (a.use_gsff) fir_gains_fetch(a, a.gains, lane, G);
+    FirGains<NF> G;                    // (this lane's filter gains, straight from the table: no copy of it in LDS;
+    fir_gains_fetch(a, a.gains, lane, G);   //  without the filter bank the table has one readable entry and every gain is 0)
     // the next frame's detections do not depend on this frame's state either (rows past m_next
-    // of the [max_det][5] frame slice are stale; rowmin_wave masks them)
+    // of the [max_det][5] frame slice are stale; rowmin_wave masks them; without a next frame this frame's are read)
     DetChunk<DetT> first;
-    if (next_det) load_chunk(first, next_det, md, 0, lane);
-    // all counters in the same round trip: the two detection counts are read through pointers that
-    // are always valid (a dummy when the count comes from the host / there is no next frame), so
-    // that no load hides behind a branch and a wait
-    const int32_t *m_ptr = m_host < 0 ? m_dev : a.n_tracks;
-    const int32_t *mn_ptr = next_det ? next_m_dev : a.n_tracks;
-    const int n_raw = *a.n_tracks, nfree_raw = *a.n_free, id0_raw = *a.next_id;
-    const int m_raw = *m_ptr, mn_raw = *mn_ptr;
-    // (first frame of a run whose k_rowmin -- which also takes the caller's row count as the base -- was not needed)
-    const long long row_base = base_from_ext ? (row_count_ext ? *row_count_ext : 0ll) : a.row_base[0];
+    load_chunk(first, next_det ? next_det : det, md, 0, lane);
+    const long long row_base = (base_from_ext && !row_count_ext) ? 0ll : row_base_raw;
     const int n = __builtin_amdgcn_readfirstlane(n_raw);
     const int nfree = __builtin_amdgcn_readfirstlane(nfree_raw), id0 = __builtin_amdgcn_readfirstlane(id0_raw);
     int m = __builtin_amdgcn_readfirstlane(m_host < 0 ? m_raw : m_host);
