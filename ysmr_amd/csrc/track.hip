@@ -626,20 +626,32 @@ struct GsffState {
     double w[NF], xh0[NF], xh1[NF];
     int len, mode;
     double raw;          // this lane's field of the slot's record, as fetched (decoded by gsff_decode)
+    // where the slot's state lives, worked out when it is fetched and kept for the write-back (re-reading the three base
+    // pointers and the record stride from the kernel's arguments there cost four scalar loads, each with its own wait)
+    double *hist_p, *rec_p, *pos_p;
+    int rec_lanes;       // rec_stride
 };
+template <int NF>
+__device__ __forceinline__ void gsff_point(const TrackerDev &t, int slot, GsffState<NF> &s)
+{
+    s.hist_p = t.hist + (size_t)slot * 2 * t.hist_cap;
+    s.rec_p = t.rec + (size_t)slot * t.rec_stride;
+    s.pos_p = t.pos + slot;
+    s.rec_lanes = t.rec_stride;
+}
 // Issue every load of a track's filter state; no load depends on another, so one round trip.
 template <int NF>
 __device__ __forceinline__ void gsff_fetch(const TrackerDev &t, int slot, int lane, GsffState<NF> &s)
 {
-    const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
-    const double *hist = t.hist + (size_t)slot * 2 * L;
-    s.raw = lane < t.rec_stride ? t.rec[(size_t)slot * t.rec_stride + lane] : 0.0;
+    const int L = t.hist_cap;
+    gsff_point(t, slot, s);
+    const double *hist = s.hist_p;
+    s.raw = lane < s.rec_lanes ? s.rec_p[lane] : 0.0;
 #pragma unroll
     for (int q = 0; q < TRACK_VALS; ++q) {
         const int e = hist_entry(lane, q);
         s.h.v[q] = (e < L) ? hist[2 * e + hist_comp(lane)] : 0.0;
     }
-    (void)cap; (void)nf;
 }
 // the fields of the fetched record, broadcast to the wave (v_readlane: the wait for the load lands here)
 template <int NF>
@@ -678,7 +690,7 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
 {
     const int cap = t.capacity, nf = t.n_f, L = t.hist_cap;
     GSTAMP(0);
-    double *hist = t.hist + (size_t)slot * 2 * L;
+    double *hist = st.hist_p;
     gsff_decode(t, st);
     int len = st.len, mode = st.mode;
     TrackRegs &h = st.h;
@@ -792,8 +804,8 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
         if (e < L && (q == 0 || L > 32)) hist[2 * e + hist_comp(lane)] = h.v[q];     // the whole history, shifted
     }
     if (lane == 0) {
-        t.pos[slot] = p0;
-        t.pos[cap + slot] = p1;
+        st.pos_p[0] = p0;
+        st.pos_p[cap] = p1;
     }
     {   // the record, one store: every lane picks its field
         double val = __longlong_as_double(lane == 0 ? (long long)(unsigned int)len : (long long)(unsigned int)mode);
@@ -804,7 +816,7 @@ __device__ __forceinline__ void gsff_wave(const TrackerDev &t, const double *gai
                 val = lane == 2 + nf + f ? xh0[f] : val;
                 val = lane == 2 + 2 * nf + f ? xh1[f] : val;
             }
-        if (lane < t.rec_stride) t.rec[(size_t)slot * t.rec_stride + lane] = val;
+        if (lane < st.rec_lanes) st.rec_p[lane] = val;
     }
     GSTAMP(6);
 }
@@ -1790,6 +1802,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
 #pragma unroll
             for (int k = 0; k < 5; ++k) dd[k] = det[(size_t)c * 5 + k];
             gsff_blank(S);    // nothing of the slot's previous owner is read
+            gsff_point(a, slot, S);
             if (lane == 0) a.id[slot] = id_s;
         }
         double z0 = zs0, z1 = zs1;
