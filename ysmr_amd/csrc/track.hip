@@ -1667,14 +1667,11 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
             for (int k = 0; k < 5; ++k) dd[k] = det[(size_t)c_s * 5 + k];
         }
     }
-    // row r = tid + 256 k of the old table: from the registers above for k < SPEC_ROWS, from HBM beyond
-    auto row_inputs = [&](int k, int r, int &o_, int &g_, int &a_, unsigned long long &key_) {
-        if (k < SPEC_ROWS) {
-            o_ = k == 0 ? so[0] : k == 1 ? so[1] : so[2];
-            g_ = k == 0 ? sg[0] : k == 1 ? sg[1] : sg[2];
-            a_ = k == 0 ? sa[0] : k == 1 ? sa[1] : sa[2];
-            key_ = k == 0 ? sk[0] : k == 1 ? sk[1] : sk[2];
-        } else if (r < n) {
+    // row r = tid + 256 k of the old table: from the registers above for k < SPEC_ROWS (the passes over them are
+    // unrolled: picking so[k] with a run-time k was eight selects per row and pass on a wave that pays for every
+    // instruction), from HBM beyond
+    auto row_from_hbm = [&](int r, int &o_, int &g_, int &a_, unsigned long long &key_) {
+        if (r < n) {
             o_ = a.order[r]; g_ = a.gone[r]; a_ = a.row_arg[r];
             key_ = (unsigned long long)__double_as_longlong(a.row_min[r]);
         }
@@ -1682,17 +1679,27 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     __syncthreads();
     STAMP(2);
     if (n > 0 && m > 0) {   // winner of a column = proposer with the smallest (distance, row)
-        for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
+#pragma unroll
+        for (int k = 0; k < SPEC_ROWS; ++k) {
+            const int r = k * FRAME_THREADS + tid;
+            if (r < n) atomicMin(&L.col_key[sa[k]], sk[k]);
+        }
+        for (int r0 = SPEC_ROWS * FRAME_THREADS; r0 < n; r0 += FRAME_THREADS) {
             const int r = r0 + tid;
             int o_ = 0, g_ = 0, a_ = 0; unsigned long long key_ = 0;
-            row_inputs(r0 / FRAME_THREADS, r, o_, g_, a_, key_);
+            row_from_hbm(r, o_, g_, a_, key_);
             if (r < n) atomicMin(&L.col_key[a_], key_);
         }
         __syncthreads();
-        for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
+#pragma unroll
+        for (int k = 0; k < SPEC_ROWS; ++k) {
+            const int r = k * FRAME_THREADS + tid;
+            if (r < n && sk[k] == L.col_key[sa[k]]) atomicMin(&L.col_row[sa[k]], r);
+        }
+        for (int r0 = SPEC_ROWS * FRAME_THREADS; r0 < n; r0 += FRAME_THREADS) {
             const int r = r0 + tid;
             int o_ = 0, g_ = 0, a_ = 0; unsigned long long key_ = 0;
-            row_inputs(r0 / FRAME_THREADS, r, o_, g_, a_, key_);
+            row_from_hbm(r, o_, g_, a_, key_);
             if (r < n && key_ == L.col_key[a_]) atomicMin(&L.col_row[a_], r);
         }
         __syncthreads();
@@ -1703,10 +1710,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
     // known to the thread that ranks it, so nothing goes through LDS in between
     int used = 0;   // claims made by this wave's rows (wave-uniform)
     int n_keep = 0;
-    for (int r0 = 0; r0 < n; r0 += FRAME_THREADS) {
-        const int r = r0 + tid;
-        int o_ = 0, g = 0, c = 0; unsigned long long key_ = 0;
-        row_inputs(r0 / FRAME_THREADS, r, o_, g, c, key_);
+    auto sweep_chunk = [&](int chunk, int r, int o_, int g, int c) {
         bool mine = false, keep = false;
         if (r < n) {
             mine = (m > 0) && (L.col_row[c] == r);
@@ -1717,13 +1721,22 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
         }
         used += __popcll(__ballot(mine));
         int total;
-        const int ex = block_flag_rank(keep, L.scan + ((r0 / FRAME_THREADS) & 1) * 4, &total);
+        const int ex = block_flag_rank(keep, L.scan + (chunk & 1) * 4, &total);
         if (keep) L.inv[n_keep + ex] = r;
         if (r < n && !keep && blockIdx.x == 0) {
             const int k = atomicAdd(&s_n_dead, 1);
             a.free_slots[nfree + k] = o_;   // entries above n_free are read by nobody this frame
         }
         n_keep += total;
+    };
+#pragma unroll
+    for (int k = 0; k < SPEC_ROWS; ++k)
+        if (k * FRAME_THREADS < n) sweep_chunk(k, k * FRAME_THREADS + tid, so[k], sg[k], sa[k]);     // (uniform)
+    for (int r0 = SPEC_ROWS * FRAME_THREADS; r0 < n; r0 += FRAME_THREADS) {
+        const int r = r0 + tid;
+        int o_ = 0, g = 0, c = 0; unsigned long long key_ = 0;
+        row_from_hbm(r, o_, g, c, key_);
+        sweep_chunk(r0 / FRAME_THREADS, r, o_, g, c);
     }
     if (lane == 0 && used) atomicAdd(&s_n_used, used);   // one LDS atomic per wave, not per thread
     __syncthreads();
