@@ -173,7 +173,7 @@ __device__ __forceinline__ double dpp_min(double v)
     int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
     int hi = __builtin_amdgcn_update_dpp(0x7FF00000, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
     const double o = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-    return o < v ? o : v;
+    return __builtin_fmin(o, v);      // (one v_min_f64; squared distances are never NaN)
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_min(int v)
@@ -237,7 +237,7 @@ __device__ __forceinline__ void rowmin_wave(const TrackerDev &t, int row, double
             double s = dx * dx;
             s = s + dy * dy;
             s = j < m ? s : inf;
-            lane_min = s < lane_min ? s : lane_min;
+            lane_min = __builtin_fmin(s, lane_min);
         }
     }
     const double s_min = wave_min(lane_min);
@@ -381,7 +381,7 @@ __device__ __forceinline__ bool rowmin_grid(const TrackerDev &t, int row, double
             const double dy = py - (double)c.y;
             double s = dx * dx;
             s = s + dy * dy;
-            lane_min = s < lane_min ? s : lane_min;
+            lane_min = __builtin_fmin(s, lane_min);
         }
         const double s_min = wave_min(lane_min);
         // distance from the track to the outside of the block [cx-k, cx+k] x [cy-k, cy+k]; a side of the block on
