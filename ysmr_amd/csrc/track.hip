@@ -227,16 +227,23 @@ __device__ __forceinline__ void rowmin_wave(const TrackerDev &t, int row, double
     const bool multi = m > CHUNK;
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     double lane_min = inf;
+    // entries past m (stale rows of the frame slice / the clamped tail of the last chunk) are moved out of the way ONCE,
+    // in their 32-bit x: 1e30 squared is finite, larger than any real squared distance and never "near" the minimum --
+    // no select on the 64-bit distance in either pass
+    auto mask_tail = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < ROWMIN_U; ++u)
+            first.qx[u] = (j0 + u * 64 + lane < m) ? first.qx[u] : (DetT)1e30f;
+    };
     for (int j0 = 0; j0 < m; j0 += CHUNK) {
         if (j0 > 0) load_chunk(first, det, m, j0, lane);
+        mask_tail(j0);
 #pragma unroll
         for (int u = 0; u < ROWMIN_U; ++u) {
-            const int j = j0 + u * 64 + lane;
             const double dx = px - (double)first.qx[u];
             const double dy = py - (double)first.qy[u];
             double s = dx * dx;
             s = s + dy * dy;
-            s = j < m ? s : inf;
             lane_min = __builtin_fmin(s, lane_min);
         }
     }
@@ -245,7 +252,7 @@ __device__ __forceinline__ void rowmin_wave(const TrackerDev &t, int row, double
     int cand = 0x7FFFFFFF;
     bool inexact = false;
     for (int j0 = 0; j0 < m; j0 += CHUNK) {
-        if (multi) load_chunk(first, det, m, j0, lane);
+        if (multi) { load_chunk(first, det, m, j0, lane); mask_tail(j0); }
 #pragma unroll
         for (int u = 0; u < ROWMIN_U; ++u) {
             const int j = j0 + u * 64 + lane;
@@ -253,7 +260,7 @@ __device__ __forceinline__ void rowmin_wave(const TrackerDev &t, int row, double
             const double dy = py - (double)first.qy[u];
             double s = dx * dx;
             s = s + dy * dy;
-            const bool near = (j < m) && (s <= near_limit);
+            const bool near = s <= near_limit;
             cand = near ? min(cand, j) : cand;
             inexact = inexact || (near && s != s_min);
         }
