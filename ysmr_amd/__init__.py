@@ -10,7 +10,9 @@ import os as _os
 
 # Kernel arguments in device memory (the HIP runtime reads this when it is loaded, i.e. at `import torch`): the link is one
 # short kernel per frame whose first instructions read their arguments -- from host memory that is a PCIe round trip per
-# launch (measured: 90 k -> 62 k frames/s end to end with HIP_FORCE_DEV_KERNARG=0).  A value the user set is kept.
+# launch (measured: 90 k -> 62 k frames/s end to end with HIP_FORCE_DEV_KERNARG=0).  A value the user set is kept; the
+# default only takes effect when this package is imported before torch (bench.py sets it itself) -- ROCm 7.2's own default
+# is device memory as well.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 __version__ = "0.1.0"
