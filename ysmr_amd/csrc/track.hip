@@ -27,6 +27,13 @@
 #define YSMR_MAX_FILTERS 8
 
 struct TrackerDev {
+    // what the link kernels' first round of loads is addressed with, together at the head of the structure: one scalar
+    // load of the kernel's arguments fetches them all
+    int *n_tracks, *next_id, *err, *n_free;
+    int *order, *gone;
+    int *row_arg;                 // [cap]
+    double *row_min;              // [cap]
+    long long *row_base;          // first output row of the current frame (k_link -> k_gsff)
     int capacity, max_det, n_f, use_gsff, hist_cap, table_cap, gain_total, gone_by_row;
     int gains_decoupled;             // x-hat reads only x columns, y-hat only y columns (every closed-form gain)
     double max_gone, lik_min;
@@ -34,9 +41,8 @@ struct TrackerDev {
     int gain_off[YSMR_MAX_FILTERS];  // filter i: row0 at gains[gain_off[i]], row1 at +2*n_i[i]
     const double *gains;
     // persistent state
-    int *n_tracks, *next_id, *err, *n_free;
-    int *order, *free_slots;
-    int *id, *gone;
+    int *free_slots;
+    int *id;
     double *pos;      // [2][cap]
     float *info;      // [3][cap]
     double *hist;     // [cap][hist_cap][2]  (one contiguous ring per track slot)
@@ -48,14 +54,11 @@ struct TrackerDev {
     int rec_stride;
     // per-frame scratch
     int *unused;                  // [max_det] unclaimed detection columns, ascending
-    double *row_min;              // [cap]
-    int *row_arg;                 // [cap]
     int *row_gone;                // [cap] split path: `gone` of the track in a row, written with the row minimum (k_link then
                                   // has everything a row's claim and ageing need from ONE round of loads by row)
     int *dead;                    // [cap]
     int *new_cols;                // [max_det]
     int *set_table;               // [2][table_cap] CPython set model
-    long long *row_base;          // first output row of the current frame (k_link -> k_gsff)
     // split path (tables too large for LDS): k_link's per-column winners and per-row claims
     unsigned long long *link_key; // [max_det]
     int *link_row;                // [max_det]
