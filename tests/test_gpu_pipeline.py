@@ -148,7 +148,12 @@ def test_4k_dense_field_through_every_filter_and_a_tracks_whole_life(oracle):
     last_ids = set(ref[ref[:, 0] == n_frames - 1][:, 1].astype(int))
     assert lost_rows > 1000 and len(first_ids - last_ids) > 50 and next_id > len(first_ids) + 100, (lost_rows, len(first_ids - last_ids), next_id)
     assert next_id == ref_trk.next_id and n_tracks == len(last_ids)
+    from conftest import parity_report
+    report = parity_report(got, ref_rows)
+    _write_parity("4k_32_frames", report)
     compare_rows(got, ref_rows)
+    assert report["worst_well_conditioned_relative"] <= 1e-9, report
+    assert report["beyond_1e-5_with_shadows_within_1e-5"] == 0, report
 
 
 def test_reader_protocol_reported_against_delivered_frames(tmp_path, oracle):
@@ -631,12 +636,31 @@ def test_rows_can_be_persisted_while_the_video_runs(tmp_path, monkeypatch):
     assert open(whole[4], "rb").read() == open(kept[4], "rb").read()
 
 
+ROUND = "r04"
+
+
+def _write_parity(name, report):
+    """The round's parity record: under gpurun_out/ (what comes back from the GPU box) and, where the tree is
+    writable, under profiles/ with the round in the name -- DESIGN.md section 2 quotes that file."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for folder in ("gpurun_out", "profiles"):
+        try:
+            os.makedirs(os.path.join(root, folder), exist_ok=True)
+            with open(os.path.join(root, folder, f"{ROUND}_parity_{name}.json"), "w") as fh:
+                json.dump(report, fh, indent=1)
+        except OSError:
+            pass
+
+
 def test_bench_config_rows_hold_1e9_outside_the_oracles_ill_conditioned_set(tmp_path, oracle):
     """BASELINE configs[2] at full size (1228x922, ~500 blobs, 200 frames) through track_bacteria: every
     row the reference's arithmetic determines is within 1e-9 of the oracle; the rows it does not determine
-    (oracle shadow filters, conftest.compare_rows) are a small, counted fraction.  The numbers go to
-    gpurun_out/parity_bench_config.json (quoted in DESIGN.md section 2)."""
-    import json
+    (oracle shadow filters, conftest.compare_rows) are a small, counted fraction, each within conftest.AMPLIFICATION
+    x what one ulp does to the reference itself, and every row beyond north_star's 1e-5 relative is one whose own
+    +-1-ulp shadows are more than 1e-5 apart (the claim "the reference does not determine this row to 1e-5", tested).
+    The numbers go to profiles/r04_parity_bench_config.json (quoted in DESIGN.md section 2)."""
+    from conftest import parity_report
     from ysmr_amd.synth import SyntheticVideo
     from ysmr_amd.track_eval import track_bacteria
     frames = SyntheticVideo(922, 1228, 500, seed=0, fps=30.0).frames(200)
@@ -646,25 +670,17 @@ def test_bench_config_rows_hold_1e9_outside_the_oracles_ill_conditioned_set(tmp_
     assert res is not None
     ref_rows, _ = oracle.track_frames(frames, fps=30.0, shadows=2)
     got = _rows_from_df(res[0])
-    n_loose, worst = compare_rows(got, ref_rows)
+    report = parity_report(got, ref_rows)
+    _write_parity("bench_config", report)
     ref = np.array(ref_rows)
-    lost = int((got["disappeared"] > 0).sum())
-    dev = np.maximum(np.abs(got["x"] - ref[:, 2]) / np.maximum(1, np.abs(ref[:, 2])),
-                     np.abs(got["y"] - ref[:, 3]) / np.maximum(1, np.abs(ref[:, 3])))
-    well = ref[:, 7] <= oracle.OracleTracker.ILL_CONDITIONED
-    tied = np.isinf(ref[:, 7])
-    report = {"rows": len(got), "rows_of_lost_tracks": lost, "ill_conditioned_rows": n_loose,
-              "ill_conditioned_fraction": n_loose / len(got), "worst_ill_conditioned_px": worst,
-              "ill_conditioned_rows_beyond_1e-5_relative": int((dev[~well & ~tied] > 1e-5).sum()),
-              "rows_of_tie_assigned_tracks": int(tied.sum()),
-              "worst_well_conditioned_relative": float(dev[well].max())}
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_bench_config.json"), "w") as fh:
-        json.dump(report, fh, indent=1)
-    assert lost > 5000                          # the clip does lose tracks (2 % dropout)
-    assert n_loose < 0.03 * len(got), report
-    assert report["worst_well_conditioned_relative"] <= 1e-9
+    marked = ref[:, 7] > oracle.OracleTracker.ILL_CONDITIONED       # the marked rows themselves, for tests/tools/parity_rows.py
+    np.savez(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", ROUND + "_parity_bench_rows.npz"),
+             ref=ref[marked], x=got["x"][marked], y=got["y"][marked], gone=got["disappeared"][marked])
+    n_loose, worst = compare_rows(got, ref_rows)
+    assert report["rows_of_lost_tracks"] > 5000             # the clip does lose tracks (2 % dropout)
+    assert n_loose == report["ill_conditioned_rows"] < 0.03 * len(got), report
+    assert report["worst_well_conditioned_relative"] <= 1e-9, report
+    assert report["beyond_1e-5_with_shadows_within_1e-5"] == 0, report
 
 
 def test_config0_full_size_through_ysmr_with_the_default_settings(tmp_path, oracle):
