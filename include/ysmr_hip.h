@@ -42,7 +42,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   9
+#define YSMR_ABI_VERSION   10
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -246,6 +246,17 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
                              const float *after_det_dev, const int32_t *after_count_dev);
 /* 1 when the handle links with one launch per frame (the case ysmr_tracker_run_chained serves), else 0 */
 int ysmr_tracker_fused(ysmr_tracker *t);
+
+/* How ysmr_tracker_run links a batch.  A handle whose configuration allows it -- tracking.ini's defaults do: up to three
+ * filters with horizons of at most 31 frames, capacity <= 512, max_det <= 2456 -- links a whole batch with ONE launch
+ * (one workgroup, a track per lane, the filter state in registers from the first frame to the last); every other handle,
+ * and ysmr_tracker_update, run one launch (or two, for large tables) per frame.  Same rows either way.
+ *   ysmr_tracker_batched    1 when ysmr_tracker_run takes the one-launch-per-batch path, else 0
+ *   ysmr_tracker_link_mode  mode 0: the library's choice (default); 1: one launch per frame even where a batch launch
+ *                           would serve (measurement and tests).  Takes effect with the next call; the track table is
+ *                           carried over. */
+int ysmr_tracker_batched(ysmr_tracker *t);
+int ysmr_tracker_link_mode(ysmr_tracker *t, int mode);
 
 int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev,
                      const int32_t *det_count_dev, int batch, int32_t first_frame_index,

@@ -73,6 +73,26 @@ struct TrackerDev {
     int *claim_row;               // [capacity]
 };
 
+// ---- the batch link (batch_link.h): one workgroup links a whole batch of frames per launch, a track per lane
+constexpr int BL_THREADS = 512;       // seats: one track per lane
+constexpr int BL_WAVES = BL_THREADS / 64;
+constexpr int BL_HB = 32;             // history entries per track held in registers (hist_cap <= 32)
+constexpr int BL_NF = 3;              // filters (n_f <= 3)
+constexpr int BL_MAX_BATCH = 64;      // frames per launch (the grid block is sized for it; longer batches are cut)
+constexpr int BL_TABLE = 4096;        // CPython set model table, 32-bit slots (as FRAME_TABLE)
+constexpr int BL_F64 = 2 * BL_HB + 3 * BL_NF + 2;   // hx, hy, w, xa, xb, px, py
+constexpr int BL_KMAX = 4;            // rings of cells searched before a lane scans every detection
+
+struct BatchDev {
+    double *f64;        // [BL_F64][seat_cap]
+    float *f32;         // [3][seat_cap]      box of the last claimed detection (0 while lost)
+    int *i32;           // [4][seat_cap]      id, gone, history length, mode
+    char *grid;         // [BL_MAX_BATCH][grid_stride] bytes, written by k_bgrid
+    unsigned grid_stride;   // bytes per frame (a multiple of 1024)
+    int seat_cap;
+};
+
+struct BlGains { double alpha[BL_NF][2], beta[BL_NF][2]; };    // [filter][x / y row]; batch_link.h: bl_fir
 // Uniform grid over one frame's detections (split path): the nearest detection of a track is looked for in the
 // cells around it instead of among all of them (25 M distances per frame at 5000 x 5000).
 constexpr int GRID_N = 128;                         // cells per side
@@ -98,8 +118,16 @@ struct ysmr_tracker {
     const long long *base_ptr;
     const void *rowmin_for = nullptr;   // fused path: the frame (its detections' address) whose row minima the last launch of
                                         // the previous ysmr_tracker_run_chained call has already left in the state
-    void *grid_block = nullptr;    // split path: DetGrid arrays for grid_frames frames (allocated by ysmr_tracker_run)
-    int grid_frames = 0;
+    void *grid_block = nullptr;    // split path: DetGrid arrays for grid_frames frames; batch link: k_bgrid's blocks
+    int grid_frames = 0;           //   (allocated by ysmr_tracker_create: no allocation on the call path)
+    // batch link (batch_link.h): the handle can link a whole batch per launch; where the state rests right now
+    BatchDev bd;
+    bool batchable = false;        // configuration served by k_batch (three filters of <= 31 frames, <= 512 tracks, ...)
+    bool in_batch = false;         // the state rests in the seat-major arrays of `bd` (else: the per-slot layout)
+    int link_mode = 0;             // ysmr_tracker_link_mode: 0 = the library's choice, 1 = one (or two) launches per frame
+    size_t batch_lds = 0;
+    BlGains bgains;
+    bool use_batch() const { return batchable && link_mode == 0; }
     DetGrid grid(int f) const
     {
         char *b = (char *)grid_block;
@@ -1510,12 +1538,13 @@ __device__ __forceinline__ int block_flag_rank(bool f, int *s_cnt, int *total)
 // at a time; the final walk writes the iteration order the same way.  LDS operations of one wave execute in order, so
 // nothing but program order is needed between these steps.
 // Returns the number of keys, or -1 if the model would need a table larger than FRAME_TABLE.
+template <int THREADS, int TABLE>
 __device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_used, int *out, uint32_t *table,
                                  uint32_t *list, int *s_state)
 {
     const int tid = threadIdx.x;
     if ((m >> 2) > n_used) {
-        for (int k = tid; k < n_unused; k += FRAME_THREADS) out[k] = unused[k];
+        for (int k = tid; k < n_unused; k += THREADS) out[k] = unused[k];
         __syncthreads();
         return n_unused;
     }
@@ -1536,7 +1565,7 @@ __device__ int cpython_order_lds(const int *unused, int n_unused, int m, int n_u
             const unsigned minused = (unsigned)fill > 50000u ? (unsigned)fill * 2u : (unsigned)fill * 4u;
             unsigned newsize = 8;
             while (newsize <= minused) newsize <<= 1;
-            if ((int)newsize > FRAME_TABLE) { result = -1; break; }
+            if ((int)newsize > TABLE) { result = -1; break; }
             int cnt = 0;
             for (unsigned i0 = 0; i0 <= mask; i0 += 64) {   // the old table in slot order -> list
                 const uint32_t e = i0 + lane <= mask ? table[i0 + lane] : SET_EMPTY32;
@@ -1772,7 +1801,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
             STAMP(12);
             {
                 // (col_row is dead once the unclaimed columns are listed: it holds the model's list)
-                int cnt = cpython_order_lds(L.unused, base, m, s_n_used, L.newcols, reinterpret_cast<uint32_t *>(L.table),
+                int cnt = cpython_order_lds<FRAME_THREADS, FRAME_TABLE>(L.unused, base, m, s_n_used, L.newcols, reinterpret_cast<uint32_t *>(L.table),
                                             reinterpret_cast<uint32_t *>(L.col_row), s_set_state);
                 if (cnt < 0) { if (blockIdx.x == 0 && tid == 0) atomicOr(a.err, ERR_TRACK_CAPACITY); cnt = 0; }
                 n_new = cnt;
@@ -1887,6 +1916,8 @@ __global__ __launch_bounds__(FRAME_THREADS) void k_frame(TrackerDev a, TrackerDe
         }
     }
 }
+
+#include "batch_link.h"
 
 __global__ void k_tracker_reset(TrackerDev t)
 {
@@ -2068,6 +2099,10 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     // parity-1 copies of the arrays k_frame double-buffers
     const size_t o_scal1 = take(sizeof(int) * 16), o_order1 = take(sizeof(int) * cap), o_gone1 = take(sizeof(int) * cap);
     const size_t o_rmin1 = take(sizeof(double) * cap), o_rarg1 = take(sizeof(int) * cap);
+    // the batch link's rest format (seat-major) and its gain table
+    const size_t seat_cap = ysmr::align_up(cap, 64);
+    const size_t o_b64 = take(sizeof(double) * BL_F64 * seat_cap), o_b32 = take(sizeof(float) * 3 * seat_cap);
+    const size_t o_bi = take(sizeof(int) * 4 * seat_cap);
     t->block_bytes = off;
     hipError_t e = hipMalloc(&t->block, off);
     if (e != hipSuccess) {
@@ -2090,6 +2125,9 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     d.link_key = (unsigned long long *)(b + o_lkey); d.link_row = (int *)(b + o_lrow); d.link_claim = (int *)(b + o_lclaim);
     d.claim_slot = (int *)(b + o_cslot);
     d.claim_row = (int *)(b + o_crow);
+    t->bd.f64 = (double *)(b + o_b64); t->bd.f32 = (float *)(b + o_b32); t->bd.i32 = (int *)(b + o_bi);
+    t->bd.seat_cap = (int)seat_cap;
+    t->bd.grid = nullptr; t->bd.grid_stride = 0;
     t->d1 = d;
     {
         TrackerDev &q = t->d1;
@@ -2120,11 +2158,53 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->frame_lds) != hipSuccess) t->fused = false;
     }
     t->d.gone_by_row = t->d1.gone_by_row = t->fused ? 1 : 0;
+    // The batch link serves what tracking.ini's defaults ask for: up to three filters with horizons of at most 31 frames
+    // (hist_cap <= 32 register entries), decoupled gains, tables of at most 512 tracks -- a track per lane of ONE
+    // workgroup -- and detection counts whose tables fit its LDS.  Everything else links with one (or two) launches per
+    // frame as before.
+    t->batch_lds = bl_lds_bytes(max_det);
+    t->batchable = t->fused && d.n_f <= BL_NF && d.hist_cap <= BL_HB && (!use_gsff || d.gains_decoupled) &&
+                   capacity <= BL_THREADS && t->batch_lds <= 150 * 1024 && !(mode_env && strcmp(mode_env, "batch"));
+    if (t->batchable &&
+        hipFuncSetAttribute((const void *)k_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->batch_lds) != hipSuccess)
+        t->batchable = false;
+    // the gains as the batch kernel takes them: affine in the age of a measurement (batch_link.h: bl_fir)
+    std::memset(&t->bgains, 0, sizeof(t->bgains));
+    if (use_gsff && t->batchable)
+        for (int f = 0; f < d.n_f && t->batchable; ++f) {
+            const int N = d.n_i[f];
+            const double *g = t->gains_host.data() + d.gain_off[f];
+            for (int c = 0; c < 2 && t->batchable; ++c) {
+                auto gain = [&](int a) { return c ? g[2 * N + 2 * (N - 1 - a) + 1] : g[2 * (N - 1 - a)]; };   // age a, row c
+                const double alpha = gain(0), beta = N > 1 ? gain(0) - gain(1) : 0.0;
+                for (int a = 0; a < N; ++a)
+                    if (std::fabs(gain(a) - (alpha - beta * a)) > 1e-14 * std::fabs(alpha)) t->batchable = false;
+                t->bgains.alpha[f][c] = alpha;
+                t->bgains.beta[f][c] = beta;
+            }
+        }
+    // the per-frame grids of a batch: sized here, once, for BL_MAX_BATCH frames (longer batches are cut to that)
+    {
+        const size_t per = t->batchable ? (size_t)bl_grid_dwords_max(max_det) * 4 : ysmr_tracker::grid_bytes_per_frame(max_det);
+        if (t->batchable || !t->fused) {
+            e = hipMalloc(&t->grid_block, per * BL_MAX_BATCH);
+            if (e != hipSuccess) {
+                (void)hipFree(t->block);
+                delete t;
+                return ysmr::fail(YSMR_ERR_HIP, "hipMalloc(%zu) failed: %s", per * BL_MAX_BATCH, hipGetErrorString(e));
+            }
+            t->grid_frames = BL_MAX_BATCH;
+            t->bd.grid = (char *)t->grid_block;
+            t->bd.grid_stride = (unsigned)per;
+        }
+    }
     e = hipMemset(t->block, 0, off);
     if (e == hipSuccess && gain_doubles)
         e = hipMemcpy(b + o_gain, t->gains_host.data(), sizeof(double) * gain_doubles, hipMemcpyHostToDevice);
+
     if (e != hipSuccess) {
         (void)hipFree(t->block);
+        if (t->grid_block) (void)hipFree(t->grid_block);
         delete t;
         return ysmr::fail(YSMR_ERR_HIP, "tracker state initialisation failed: %s", hipGetErrorString(e));
     }
@@ -2138,6 +2218,7 @@ int ysmr_tracker_reset(ysmr_tracker *t, void *stream)
     int n = t->d.capacity > t->d.max_det ? t->d.capacity : t->d.max_det;
     t->par = 0;
     t->rowmin_for = nullptr;
+    t->in_batch = t->use_batch();      // (an empty table is the same in both layouts)
     hipLaunchKernelGGL(k_tracker_reset, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
@@ -2153,6 +2234,41 @@ int ysmr_tracker_destroy(ysmr_tracker *t)
     return YSMR_OK;
 }
 
+// where the state rests: the seat-major arrays of the batch link, or the per-slot layout of the per-frame kernels
+static int state_to_std(ysmr_tracker *t, hipStream_t st)
+{
+    if (!t->in_batch) return YSMR_OK;
+    hipLaunchKernelGGL(k_to_std, dim3((t->d.capacity + 255) / 256), dim3(256), 0, st, t->d, t->bd);
+    YSMR_LAUNCH_CHECK();
+    t->in_batch = false;
+    t->par = 0;
+    t->rowmin_for = nullptr;
+    return YSMR_OK;
+}
+static int state_to_batch(ysmr_tracker *t, hipStream_t st)
+{
+    if (t->in_batch) return YSMR_OK;
+    hipLaunchKernelGGL(k_to_batch, dim3((t->d.capacity + 255) / 256), dim3(256), 0, st, t->cur(), t->bd);
+    YSMR_LAUNCH_CHECK();
+    if (t->par) {      // the counters live in the parity-0 words from here on
+        YSMR_HIP_CHECK(hipMemcpyAsync(t->d.n_tracks, t->d1.n_tracks, sizeof(int) * 2, hipMemcpyDeviceToDevice, st));
+    }
+    t->in_batch = true;
+    t->par = 0;
+    t->rowmin_for = nullptr;
+    return YSMR_OK;
+}
+
+int ysmr_tracker_link_mode(ysmr_tracker *t, int mode)
+{
+    if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
+    if (mode != 0 && mode != 1) return ysmr::fail(YSMR_ERR_ARG, "link mode must be 0 (the library's choice) or 1 (per-frame launches)");
+    t->link_mode = mode;       // (the state changes its layout at the next call that needs the other one)
+    return YSMR_OK;
+}
+
+int ysmr_tracker_batched(ysmr_tracker *t) { return t && t->use_batch() ? 1 : 0; }
+
 int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int det_is_f64, int m,
                         const int32_t *m_dev, int32_t frame_index, ysmr_row *rows_dev, int32_t *n_rows_dev,
                         int32_t *claim_col_dev, int32_t *n_before_dev, int32_t *new_cols_dev, int32_t *n_new_dev)
@@ -2161,6 +2277,7 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
     if (m < 0 && !m_dev) return ysmr::fail(YSMR_ERR_ARG, "m < 0 requires m_dev");
     if (m > t->d.max_det) return ysmr::fail(YSMR_ERR_CAPACITY, "m = %d exceeds max_det = %d", m, t->d.max_det);
     if (!det_dev && m != 0) return ysmr::fail(YSMR_ERR_ARG, "det_dev is NULL");
+    if (int rc = state_to_std(t, (hipStream_t)stream)) return rc;     // (one frame at a time: the per-frame kernels)
     t->rowmin_for = nullptr;
     if (t->fused) { t->set_base = true; t->base_ptr = nullptr; }
     if (det_is_f64)
@@ -2181,6 +2298,22 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
         return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev, rows_dev, row_count_dev must be set and batch > 0");
     if ((after_det_dev == nullptr) != (after_count_dev == nullptr))
         return ysmr::fail(YSMR_ERR_ARG, "after_det_dev and after_count_dev go together");
+    if (t->use_batch()) {
+        // one launch links the batch (cut to the BL_MAX_BATCH frames the grid block holds); `after` has nothing to save here
+        if (int rc = state_to_batch(t, (hipStream_t)stream)) return rc;
+        for (int f0 = 0; f0 < batch; f0 += BL_MAX_BATCH) {
+            const int nb = batch - f0 < BL_MAX_BATCH ? batch - f0 : BL_MAX_BATCH;
+            const float *det = det_dev + (size_t)f0 * t->d.max_det * 5;
+            hipLaunchKernelGGL(k_bgrid, dim3(nb), dim3(256), 0, (hipStream_t)stream, det, det_count_dev + f0, t->d.max_det,
+                               t->bd.grid, t->bd.grid_stride);
+            hipLaunchKernelGGL(k_batch, dim3(1), dim3(BL_THREADS), t->batch_lds, (hipStream_t)stream, t->d, t->bd, det,
+                               det_count_dev + f0, nb, first_frame_index + f0, rows_dev, (long long)rows_capacity,
+                               (long long *)row_count_dev, t->bgains);
+            YSMR_LAUNCH_CHECK();
+        }
+        return YSMR_OK;
+    }
+    if (int rc = state_to_std(t, (hipStream_t)stream)) return rc;
     if (!t->fused) { after_det_dev = nullptr; after_count_dev = nullptr; }   // (the split path needs the next batch's grid)
     // the previous call may have left this call's first row minima behind (it was told this frame comes next)
     const bool have_rowmin = t->fused && t->rowmin_for != nullptr && t->rowmin_for == (const void *)det_dev;
@@ -2192,11 +2325,14 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
         // large tables: a uniform grid over every frame's detections, built for the whole batch in one launch
         // (the detections of a batch are all there before the first frame is linked)
         const size_t per = ysmr_tracker::grid_bytes_per_frame(t->d.max_det);
-        if (batch > t->grid_frames) {
-            if (t->grid_block) { YSMR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); YSMR_HIP_CHECK(hipFree(t->grid_block)); }
-            t->grid_block = nullptr; t->grid_frames = 0;
-            YSMR_HIP_CHECK(hipMalloc(&t->grid_block, per * (size_t)batch));
-            t->grid_frames = batch;
+        if (batch > t->grid_frames) {      // (the grid block was sized by ysmr_tracker_create: longer batches go in pieces)
+            for (int f0 = 0; f0 < batch; f0 += t->grid_frames) {
+                const int nb = batch - f0 < t->grid_frames ? batch - f0 : t->grid_frames;
+                if (int rc = ysmr_tracker_run_chained(t, stream, det_dev + (size_t)f0 * t->d.max_det * 5, det_count_dev + f0, nb,
+                                                      first_frame_index + f0, rows_dev, rows_capacity, row_count_dev, nullptr, nullptr))
+                    return rc;
+            }
+            return YSMR_OK;
         }
         hipLaunchKernelGGL(k_grid_build<float>, dim3(batch), dim3(1024), 0, (hipStream_t)stream, det_dev, det_count_dev,
                            t->d.max_det, (char *)t->grid_block, per);
@@ -2226,14 +2362,18 @@ int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const 
                                     row_count_dev, nullptr, nullptr);
 }
 
-int ysmr_tracker_fused(ysmr_tracker *t) { return t && t->fused ? 1 : 0; }
+int ysmr_tracker_fused(ysmr_tracker *t) { return t && t->fused && !t->use_batch() ? 1 : 0; }
 
 int ysmr_tracker_peek(ysmr_tracker *t, void *stream, int32_t *ids_dev, double *xy_dev, int32_t *disappeared_dev,
                       int32_t *n_dev)
 {
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
-    hipLaunchKernelGGL(k_peek, dim3((t->d.capacity + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->cur(), ids_dev,
-                       xy_dev, disappeared_dev, n_dev);
+    if (t->in_batch)
+        hipLaunchKernelGGL(k_peek_batch, dim3((t->d.capacity + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d, t->bd,
+                           ids_dev, xy_dev, disappeared_dev, n_dev);
+    else
+        hipLaunchKernelGGL(k_peek, dim3((t->d.capacity + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->cur(), ids_dev,
+                           xy_dev, disappeared_dev, n_dev);
     YSMR_LAUNCH_CHECK();
     return YSMR_OK;
 }

@@ -96,6 +96,16 @@ class DeviceTracker:
         """True when the handle links with one launch per frame (``k_frame``)."""
         return bool(_lib.lib().ysmr_tracker_fused(self._handle))
 
+    @property
+    def batched(self):
+        """True when ``run`` links a whole batch with one launch (``k_batch``: a track per lane of one workgroup)."""
+        return bool(_lib.lib().ysmr_tracker_batched(self._handle))
+
+    def link_mode(self, mode):
+        """0: the library's choice; 1: one launch per frame even where a batch launch would serve (measurement, tests).
+        The track table is carried over."""
+        _lib.check(_lib.lib().ysmr_tracker_link_mode(self._handle, int(mode)), "ysmr_tracker_link_mode")
+
     @_on_own_device
     def info(self):
         """(live tracks, next id, sticky error bits); synchronises."""
