@@ -39,7 +39,10 @@
 //   [16, 16 + SW)      start[G * G + 1] as u16: first item of each cell (row-major), the last entry = m
 //   [.., + 2 * MP)     centres (x, y) f32 of the detections in cell order;  MP = m rounded up to 8
 //   [.., + MP / 2)     their column numbers as u16
-__host__ __device__ inline int bl_grid_n(int m) { return m <= 1024 ? 32 : 64; }
+// (cells per side so that a cell holds ~0.45 detections: the three cells of a row of the 3 x 3 block around a prediction
+// then hold more than five candidates once in 200 rows, and the block reaches one cell -- ~1.7 mean nearest-neighbour
+// distances -- beyond the prediction's own cell)
+__host__ __device__ inline int bl_grid_n(int m) { return m <= 128 ? 16 : (m <= 600 ? 32 : (m <= 1300 ? 48 : 64)); }
 __host__ __device__ inline int bl_start_dwords(int G) { return ((G * G + 2) / 2 + 3) / 4 * 4; }
 __host__ __device__ inline int bl_pad8(int m) { return (m + 7) / 8 * 8; }
 __host__ __device__ inline int bl_grid_dwords(int m)   // rounded up to whole 1-KiB pieces (one LDS-DMA wave-instruction)
@@ -49,8 +52,11 @@ __host__ __device__ inline int bl_grid_dwords(int m)   // rounded up to whole 1-
 }
 __host__ __device__ inline int bl_grid_dwords_max(int max_det)
 {
-    const int a = bl_grid_dwords(max_det), b = bl_grid_dwords(max_det < 1024 ? max_det : 1024);
-    return a > b ? a : b;
+    int most = bl_grid_dwords(max_det);
+    const int steps[4] = {128, 600, 1300, max_det};      // (the size is monotone in m between two changes of the grid)
+    for (int k = 0; k < 4; ++k)
+        if (steps[k] <= max_det && bl_grid_dwords(steps[k]) > most) most = bl_grid_dwords(steps[k]);
+    return most;
 }
 
 // One workgroup per frame: bounding box of the centres, G x G cells over it with one cell of margin, counting sort.
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void k_bgrid(const float *__restrict__ det_all
     };
     for (int j = tid; j < m; j += 256) atomicAdd(&s_cnt[cell_of(j)], 1);
     __syncthreads();
-    // exclusive scan of the counts: K consecutive cells per thread (K = 4 or 16), wave scan, wave sums
+    // exclusive scan of the counts: K consecutive cells per thread (K = 1, 4, 9 or 16), wave scan, wave sums
     const int K = cells / 256;
     int local[16], sum = 0;
 #pragma unroll
@@ -117,15 +123,15 @@ __global__ __launch_bounds__(256) void k_bgrid(const float *__restrict__ det_all
     __syncthreads();
     int before = incl - sum;
     for (int k = 0; k < w; ++k) before += s_wave_sum[k];
+    unsigned short *start16 = reinterpret_cast<unsigned short *>(start);
 #pragma unroll
-    for (int k = 0; k < 16; k += 2)
+    for (int k = 0; k < 16; ++k)
         if (k < K) {
-            const int a = before + local[k], b = before + local[k + 1];
-            s_cnt[tid * K + k] = a;
-            s_cnt[tid * K + k + 1] = b;
-            start[(tid * K + k) >> 1] = (uint32_t)a | ((uint32_t)b << 16);
+            const int at = before + local[k];
+            s_cnt[tid * K + k] = at;
+            start16[tid * K + k] = (unsigned short)at;
         }
-    if (tid == 255) start[cells >> 1] = (uint32_t)m;
+    if (tid == 255) { start16[cells] = (unsigned short)m; start16[cells + 1] = 0; }
     __syncthreads();
     for (int j = tid; j < m; j += 256) {
         const int at = atomicAdd(&s_cnt[cell_of(j)], 1);
@@ -309,75 +315,188 @@ __device__ __forceinline__ void bl_gsff(BlSeat &S, const TrackerDev &t, const Bl
 }
 
 // Nearest detection of a prediction among the frame's detections in LDS: D.min(1) / D.argmin(1) of tracker.py:151-163.
-struct BlNear { double s; int q, col; };
-__device__ __forceinline__ BlNear bl_search(const uint32_t *buf, double px, double py, int m)
+//
+// Fast path, per lane, straight-line and in FLOAT: the 3 x 3 cells around the prediction are three runs of the cell-ordered
+// list (one per row of cells); their six bounds come with one round of LDS reads, the first five candidates of each run
+// with a second.  A candidate's float squared distance and its slot become ONE 32-bit key (a non-negative float orders
+// like its bits; the slot number replaces the four lowest mantissa bits), and the two smallest keys are kept with a
+// minimum and a median-of-three per candidate -- no second pass, no index bookkeeping.  A run with more than five
+// candidates is finished in a loop on the same two registers.  Float decides only what float can decide: the result
+// stands when the second smallest key lies outside the float error band of the smallest (then the smallest is the
+// float64 argmin among the block's candidates, and no tie rule is needed) and nothing outside the block can be as near
+// (the block's boundary is farther than the best distance, with a margin far above rounding; cells were assigned in
+// float arithmetic too).  Its float64 squared distance is then evaluated once, for the claim key.  Everything else -- a
+// lost track far from every detection, two candidates a hair apart, an exact tie -- is left to bl_search_wave.
+// Error band: |fx - px| <= 2^-24 * 4096 = 2.4e-4 for coordinates below 4096, the candidates are float already, so a float
+// squared distance of a candidate within ~100 px is off by less than 2 * 200 * 2.4e-4 + 3 * 2^-24 * s < 0.1 + 2e-7 s, and the
+// key drops 2^-19 s more.
+struct BlNear { double s; float zx, zy; int col; bool done; };
+// The kernel's dynamic LDS, at namespace scope and addressed by OFFSET everywhere: a pointer that went through an array
+// or a struct of pointers comes back generic, and the compiler then reads LDS with flat_load -- twice the latency and a
+// 64-bit address per access (97 of them in the first build of this kernel).
+extern __shared__ __attribute__((aligned(16))) unsigned long long bl_lds[];
+__device__ __forceinline__ uint32_t *bl_u32(int dword_off) { return reinterpret_cast<uint32_t *>(bl_lds) + dword_off; }
+struct BlGridView {
+    int start, xy, items, G;       // dword offsets into bl_lds; cells per side
+    float x0, y0, cell, inv;
+    __device__ __forceinline__ int start_at(int i) const { return reinterpret_cast<const unsigned short *>(bl_u32(start))[i]; }
+    __device__ __forceinline__ int item_at(int i) const { return reinterpret_cast<const unsigned short *>(bl_u32(items))[i]; }
+    __device__ __forceinline__ float2 xy_at(int i) const { return reinterpret_cast<const float2 *>(bl_u32(xy))[i]; }
+};
+__device__ __forceinline__ BlGridView bl_grid_view(int buf, int m)     // buf: dword offset of the frame's block
 {
-    const float *hdr = reinterpret_cast<const float *>(buf);
-    const double x0 = (double)hdr[0], y0 = (double)hdr[1], cell = (double)hdr[2], inv = (double)hdr[3];
-    const int G = bl_grid_n(m);
-    const unsigned short *start = reinterpret_cast<const unsigned short *>(buf + 16);
-    const float2 *xy = reinterpret_cast<const float2 *>(buf + 16 + bl_start_dwords(G));
-    const unsigned short *items = reinterpret_cast<const unsigned short *>(buf + 16 + bl_start_dwords(G) + 2 * bl_pad8(m));
-    int cx = (int)floor((px - x0) * inv), cy = (int)floor((py - y0) * inv);
+    const float *hdr = reinterpret_cast<const float *>(bl_u32(buf));
+    BlGridView g;
+    g.G = bl_grid_n(m);
+    g.start = buf + 16;
+    g.xy = buf + 16 + bl_start_dwords(g.G);
+    g.items = buf + 16 + bl_start_dwords(g.G) + 2 * bl_pad8(m);
+    g.x0 = hdr[0]; g.y0 = hdr[1]; g.cell = hdr[2]; g.inv = hdr[3];
+    return g;
+}
+__device__ __forceinline__ double bl_dist2(double px, double py, float2 c)
+{
+    const double dx = px - (double)c.x;
+    const double dy = py - (double)c.y;
+    double s = dx * dx;
+    s = s + dy * dy;
+    return s;
+}
+__device__ __forceinline__ float bl_dist2f(float fx, float fy, float2 c)
+{
+    const float dx = fx - c.x, dy = fy - c.y;
+    return __builtin_fmaf(dy, dy, dx * dx);
+}
+__device__ __forceinline__ uint32_t bl_med3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return max(min(a, b), min(max(a, b), c));           // (v_med3_u32)
+}
+__device__ __forceinline__ BlNear bl_search(const BlGridView &g, double px, double py, int m)
+{
+    constexpr int R = 3, C = 5;
+    const int G = g.G;
+    const float fx = (float)px, fy = (float)py;
+    int cx = (int)floorf((fx - g.x0) * g.inv), cy = (int)floorf((fy - g.y0) * g.inv);
     cx = cx < 0 ? 0 : (cx > G - 1 ? G - 1 : cx);
     cy = cy < 0 ? 0 : (cy > G - 1 ? G - 1 : cy);
-    const double inf = __longlong_as_double(0x7FF0000000000000ll);
-    BlNear r{inf, 0, 0x7FFFFFFF};
-    for (int k = 1; k <= BL_KMAX + 1; ++k) {
-        const bool whole = k > BL_KMAX;                   // a track far from everything: every detection
-        const int xl = whole ? 0 : max(cx - k, 0), xh = whole ? G - 1 : min(cx + k, G - 1);
-        const int yl = whole ? 0 : max(cy - k, 0), yh = whole ? G - 1 : min(cy + k, G - 1);
-        // smallest squared distance, the smallest one above it, and the lowest column among the equal smallest
-        double best = inf, second = inf;
-        int bq = 0, bcol = 0x7FFFFFFF;
-        for (int iy = yl; iy <= yh; ++iy) {
-            const int a = start[iy * G + xl], b = start[iy * G + xh + 1];
-            for (int q = a; q < b; ++q) {
-                const float2 c = xy[q];
-                const double dx = px - (double)c.x;
-                const double dy = py - (double)c.y;
-                double s = dx * dx;
-                s = s + dy * dy;
-                if (s < best) { second = best; best = s; bq = q; bcol = items[q]; }
-                else if (s == best) { const int col = items[q]; if (col < bcol) { bcol = col; bq = q; } }
-                else if (s < second) second = s;
-            }
-        }
-        // distance from the track to the outside of the block of cells; a side of the block on the edge of the grid has
-        // nothing beyond it (every detection lies inside the grid).  1e-3 of a cell: cells were assigned in float arithmetic
-        double bound = inf;
-        if (!whole) {
-            if (xl > 0) bound = fmin(bound, px - (x0 + xl * cell));
-            if (xh < G - 1) bound = fmin(bound, (x0 + (xh + 1) * cell) - px);
-            if (yl > 0) bound = fmin(bound, py - (y0 + yl * cell));
-            if (yh < G - 1) bound = fmin(bound, (y0 + (yh + 1) * cell) - py);
-            bound -= 1e-3 * cell;
-        }
-        const bool done = bound == inf || (best < inf && bound > 0.0 && bound * bound > best * (1.0 + 1e-9));
-        if (!done) continue;
-        // sqrt is monotone but two different s can round to the same root, and then the lower column wins: only when some
-        // s lies within 2^-48 (relative) above the smallest are the rounded roots themselves compared
-        if (second <= best + best * 0x1p-48) {
-            const double d_min = sqrt(best), near_limit = best + best * 0x1p-48;
-            for (int iy = yl; iy <= yh; ++iy) {
-                const int a = start[iy * G + xl], b = start[iy * G + xh + 1];
-                for (int q = a; q < b; ++q) {
-                    const float2 c = xy[q];
-                    const double dx = px - (double)c.x;
-                    const double dy = py - (double)c.y;
-                    double s = dx * dx;
-                    s = s + dy * dy;
-                    if (s <= near_limit && sqrt(s) == d_min) { const int col = items[q]; if (col < bcol) { bcol = col; bq = q; } }
-                }
-            }
-        }
-        r.s = best; r.q = bq; r.col = bcol;
-        return r;
+    const int xl = max(cx - 1, 0), xh = min(cx + 1, G - 1), yl = max(cy - 1, 0), yh = min(cy + 1, G - 1);
+    int a[R], b[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int iy = min(yl + r, G - 1);
+        a[r] = g.start_at(iy * G + xl);
+        b[r] = g.start_at(iy * G + xh + 1);
+        if (yl + r > yh) b[r] = a[r];                   // (a block cut by the edge of the grid has fewer rows)
     }
-    return r;   // (not reached: the last round is `whole` and always done)
+    uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;        // the two smallest keys
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float d2 = bl_dist2f(fx, fy, g.xy_at(min(a[r] + j, m - 1)));
+            uint32_t key = (__float_as_uint(d2) & 0xFFFFFFF0u) | (uint32_t)(C * r + j);
+            key = a[r] + j < b[r] ? key : 0xFFFFFFFFu;
+            hi = bl_med3(lo, hi, key);
+            lo = min(lo, key);
+        }
+    int q_extra = 0;
+    bool more = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) more = more || (b[r] - a[r] > C);
+    if (more) {                                        // the runs' sixth and later candidates: slot 15, position kept aside
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            for (int qq = a[r] + C; qq < b[r]; ++qq) {
+                const uint32_t key = (__float_as_uint(bl_dist2f(fx, fy, g.xy_at(qq))) & 0xFFFFFFF0u) | 15u;
+                q_extra = key < lo ? qq : q_extra;
+                hi = bl_med3(lo, hi, key);
+                lo = min(lo, key);
+            }
+    }
+    const float best = __uint_as_float(lo & 0xFFFFFFF0u), second = __uint_as_float(hi & 0xFFFFFFF0u);
+    const float band = best + (0.2f + 5e-6f * best);   // (twice the error bound: both distances are off)
+    const int slot = (int)(lo & 15u);
+    const int run = slot >= 2 * C ? 2 : (slot >= C ? 1 : 0);
+    const int bq = slot == 15 ? q_extra : (run == 2 ? a[2] : (run == 1 ? a[1] : a[0])) + slot - C * run;
+    // distance to the outside of the block; a side on the edge of the grid has nothing beyond it
+    const float big = 3.0e38f;
+    float bound = big;
+    if (xl > 0) bound = fminf(bound, fx - (g.x0 + (float)xl * g.cell));
+    if (xh < G - 1) bound = fminf(bound, (g.x0 + (float)(xh + 1) * g.cell) - fx);
+    if (yl > 0) bound = fminf(bound, fy - (g.y0 + (float)yl * g.cell));
+    if (yh < G - 1) bound = fminf(bound, (g.y0 + (float)(yh + 1) * g.cell) - fy);
+    bound -= 1e-3f * g.cell;
+    const bool found = lo != 0xFFFFFFFFu;
+    const bool inside = bound >= big * 0.5f || (bound > 0.f && bound * bound > band);
+    const float2 c = g.xy_at(found ? bq : 0);
+    BlNear r;
+    r.s = bl_dist2(px, py, c);
+    r.zx = c.x; r.zy = c.y;
+    r.col = g.item_at(found ? bq : 0);
+    r.done = found && inside && !(second <= band);     // (hi = 0xFFFFFFFF reads as a NaN: no second candidate)
+    return r;
+}
+
+// The same for ONE track by the whole wave, exactly: every detection of the frame, 512 at a time (eight per lane, their
+// reads in flight together), rowmin_wave's three passes: the smallest squared distance; the lowest column within 2^-48 of
+// it; the rounded roots themselves only if some s differs from the smallest at all.  px, py, the result: wave-uniform.
+__device__ __forceinline__ BlNear bl_search_wave(const BlGridView &g, double px, double py, int m, int lane)
+{
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double lane_min = inf;
+    for (int j0 = 0; j0 < m; j0 += 512) {
+        float2 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = g.xy_at(min(j0 + u * 64 + lane, m - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double s = bl_dist2(px, py, c[u]);
+            lane_min = (j0 + u * 64 + lane < m) ? __builtin_fmin(lane_min, s) : lane_min;
+        }
+    }
+    const double s_min = wave_min(lane_min);
+    const double near_limit = s_min + s_min * 0x1p-48;
+    int cand = 0x7FFFFFFF;
+    bool inexact = false;
+    for (int j0 = 0; j0 < m; j0 += 512) {
+        float2 c[8];
+        int it[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = min(j0 + u * 64 + lane, m - 1); c[u] = g.xy_at(j); it[u] = g.item_at(j); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * 64 + lane;
+            const double s = bl_dist2(px, py, c[u]);
+            const bool near = j < m && s <= near_limit;
+            cand = near ? min(cand, (it[u] << 15) | j) : cand;          // (column, then position: both below 32768)
+            inexact = inexact || (near && s != s_min);
+        }
+    }
+    if (__any(inexact)) {
+        const double d_min = sqrt(s_min);
+        cand = 0x7FFFFFFF;
+        for (int j = lane; j < m; j += 64) {
+            const double s = bl_dist2(px, py, g.xy_at(j));
+            if (s <= near_limit && sqrt(s) == d_min) cand = min(cand, (g.item_at(j) << 15) | j);
+        }
+    }
+    const int win = wave_min(cand);
+    const float2 c = g.xy_at(win & 0x7FFF);
+    BlNear r;
+    r.s = s_min; r.zx = c.x; r.zy = c.y; r.col = win >> 15; r.done = true;
+    return r;
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------
+#ifdef YSMR_STAMPS
+__device__ unsigned long long g_bstamps[BL_WAVES][16];
+#ifndef YSMR_BL_FRAME
+#define YSMR_BL_FRAME 40
+#endif
+#define BLSTAMP(k) do { if (f == YSMR_BL_FRAME && lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_bstamps[wave][k] = t_; } } while (0)
+#else
+#define BLSTAMP(k) do {} while (0)
+#endif
 struct BlShared {      // static part of the LDS
     int cnt[BL_MAX_BATCH];           // detections per frame (clamped)
     int used[2], n_dead[2];          // per frame parity: claims made, tracks deregistered
@@ -397,16 +516,17 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
                                                       ysmr_row *rows, long long rows_capacity, long long *row_count,
                                                       BlGains gt)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_dyn[];
     __shared__ BlShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int md = t.max_det, mdp = bl_md_padded(md);
     const int bufw = bl_grid_dwords_max(md);
-    unsigned long long *s_key[2] = {s_dyn, s_dyn + mdp};                          // smallest proposing distance per column
-    uint32_t *s_cid[2] = {reinterpret_cast<uint32_t *>(s_dyn + 2 * mdp), reinterpret_cast<uint32_t *>(s_dyn + 2 * mdp) + mdp};
-    uint32_t *s_buf[2] = {s_cid[1] + mdp, s_cid[1] + mdp + bufw};                 // the frames' detections (k_bgrid blocks)
-    uint32_t *s_tab = s_buf[1] + bufw;                                            // CPython set model
+    // LDS by offset (bl_lds): per frame parity p the smallest proposing distance per column (u64), the winning id per
+    // column (u32) and the frame's detections (k_bgrid's block); the CPython set model's table
+    auto key_at = [&](int p) { return bl_lds + p * mdp; };
+    auto cid_at = [&](int p) { return bl_u32(4 * mdp + p * mdp); };
+    auto buf_off = [&](int p) { return 6 * mdp + p * bufw; };
+    const int tab_off = 6 * mdp + 2 * bufw;
     const int seats = min(t.capacity, BL_THREADS);
 
     // ---- start of the batch: counters, this lane's track, the first frame's detections
@@ -426,45 +546,74 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         const int pieces = bl_grid_dwords(sh.cnt[f]) >> 8;
         const char *src = bd.grid + (size_t)bd.grid_stride * f;
         for (int c = wave; c < pieces; c += BL_WAVES) {
-            const uint32_t lds = (uint32_t)(uintptr_t)(s_buf[f & 1] + c * 256);
+            const uint32_t lds = (uint32_t)(uintptr_t)(bl_u32(buf_off(f & 1) + c * 256));
             const uint32_t off = (uint32_t)c * 1024u + (uint32_t)lane * 16u;
             asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(off), "s"(src) : "memory");
         }
     };
     dma(0);
-    for (int c = tid; c < sh.cnt[0]; c += BL_THREADS) { s_key[0][c] = ~0ull; s_cid[0][c] = 0xFFFFFFFFu; }
+    for (int c = tid; c < sh.cnt[0]; c += BL_THREADS) { key_at(0)[c] = ~0ull; cid_at(0)[c] = 0xFFFFFFFFu; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int f = 0; f < batch; ++f) {
         const int par = f & 1;
         const int m = sh.cnt[f], m_next = f + 1 < batch ? sh.cnt[f + 1] : 0;
-        const uint32_t *buf = s_buf[par];
+        BLSTAMP(0);
         if (f + 1 < batch) dma(f + 1);
+        BLSTAMP(1);
         // ---- each track proposes its nearest detection (tracker.py:151-163)
         const bool propose = S.alive && m > 0;
-        BlNear nr{0.0, 0, 0};
+        const BlGridView gv = bl_grid_view(buf_off(par), m);
+        BlNear nr{0.0, 0.f, 0.f, 0, true};
         unsigned long long key = 0;
-        if (propose) {
-            nr = bl_search(buf, S.px, S.py, m);
-            key = (unsigned long long)__double_as_longlong(sqrt(nr.s));
-            atomicMin(&s_key[par][nr.col], key);
+        if (propose) nr = bl_search(gv, S.px, S.py, m);
+        BLSTAMP(11);
+        {   // the lanes the 5 x 5 cells did not settle, one after the other, by the whole wave
+            unsigned long long todo = __ballot(propose && !nr.done);
+#ifdef YSMR_STAMPS
+            if (f == YSMR_BL_FRAME && lane == 0) g_bstamps[wave][12] = __popcll(todo);
+#endif
+            while (todo) {
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const BlNear w = bl_search_wave(gv, lane_value(S.px, l), lane_value(S.py, l), m, lane);
+                if (lane == l) nr = w;
+            }
         }
+        if (propose) {      // (round 1 on the SQUARED distance: a non-negative double orders like its bits)
+            key = (unsigned long long)__double_as_longlong(nr.s);
+            atomicMin(&key_at(par)[nr.col], key);
+        }
+        BLSTAMP(2);
         block_sync<true>();
+        BLSTAMP(3);
         // (the other parity's tables and counters were last read before the end of the previous frame)
-        for (int c = tid; c < m_next; c += BL_THREADS) { s_key[par ^ 1][c] = ~0ull; s_cid[par ^ 1][c] = 0xFFFFFFFFu; }
+        for (int c = tid; c < m_next; c += BL_THREADS) { key_at(par ^ 1)[c] = ~0ull; cid_at(par ^ 1)[c] = 0xFFFFFFFFu; }
         if (tid == 0) { sh.used[par ^ 1] = 0; sh.n_dead[par ^ 1] = 0; }
-        if (propose && key == s_key[par][nr.col]) atomicMin(&s_cid[par][nr.col], (uint32_t)S.id);
+        if (propose) {
+            // the proposers at the column's smallest DISTANCE contend by id (tracker.py:158: ascending row minimum, then
+            // row).  sqrt is monotone, so that is the smallest s -- and, once in a blue moon, an s a few ulps above it
+            // that rounds to the same root: only those take the square roots
+            const unsigned long long kmin = key_at(par)[nr.col];
+            bool tie = key == kmin;
+            if (!tie) {
+                const double smin = __longlong_as_double((long long)kmin);
+                if (nr.s <= smin + smin * 0x1p-48) tie = sqrt(nr.s) == sqrt(smin);
+            }
+            if (tie) atomicMin(&cid_at(par)[nr.col], (uint32_t)S.id);
+        }
+        BLSTAMP(4);
         block_sync<true>();
+        BLSTAMP(5);
         // ---- claims (tracker.py:171-189), ageing and deregistration (:95-107, 198-211)
         const bool age = (m == 0) || (n > 0 && n >= m);
-        const bool mine = propose && s_cid[par][nr.col] == (uint32_t)S.id;
+        const bool mine = propose && cid_at(par)[nr.col] == (uint32_t)S.id;
         double z0 = S.px, z1 = S.py;
         float box[3] = {S.info[0], S.info[1], S.info[2]};
         bool fresh = false, died = false;
         if (mine) {
-            const float2 c = reinterpret_cast<const float2 *>(buf + 16 + bl_start_dwords(bl_grid_n(m)))[nr.q];
-            z0 = (double)c.x; z1 = (double)c.y;
+            z0 = (double)nr.zx; z1 = (double)nr.zy;
             const float *d = det_all + ((size_t)f * md + nr.col) * 5;
             box[0] = d[2]; box[1] = d[3]; box[2] = d[4];
             S.gone = 0;
@@ -486,8 +635,8 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         // ---- registration (tracker.py:135-137, 212-217): unclaimed columns become tracks, in CPython set order
         int n_new = 0, n_new_all = 0;
         if (m > 0 && (n == 0 || n < m)) {        // (uniform; nobody was aged in such a frame)
-            int *unused = reinterpret_cast<int *>(s_key[par ^ 1]), *newcols = unused + mdp;
-            uint32_t *list = s_cid[par ^ 1];
+            int *unused = reinterpret_cast<int *>(key_at(par ^ 1)), *newcols = unused + mdp;
+            uint32_t *list = cid_at(par ^ 1);
             __syncthreads();
             if (n == 0) {
                 for (int c = tid; c < m; c += BL_THREADS) newcols[c] = c;
@@ -497,7 +646,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
                 const int K = (m + BL_THREADS - 1) / BL_THREADS;
                 const int c0 = tid * K, c1 = min(c0 + K, m);
                 int cnt = 0;
-                for (int c = c0; c < c1; ++c) cnt += s_cid[par][c] == 0xFFFFFFFFu;
+                for (int c = c0; c < c1; ++c) cnt += cid_at(par)[c] == 0xFFFFFFFFu;
                 int incl = cnt;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
@@ -507,9 +656,9 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
 #pragma unroll
                 for (int k = 0; k < BL_WAVES; ++k) { const int v = sh.wave_cnt[0][k]; at += k < wave ? v : 0; total += v; }
                 for (int c = c0; c < c1; ++c)
-                    if (s_cid[par][c] == 0xFFFFFFFFu) unused[at++] = c;
+                    if (cid_at(par)[c] == 0xFFFFFFFFu) unused[at++] = c;
                 __syncthreads();
-                int cnt_set = cpython_order_lds<BL_THREADS, BL_TABLE>(unused, total, m, sh.used[par], newcols, s_tab, list, sh.set_state);
+                int cnt_set = cpython_order_lds<BL_THREADS, BL_TABLE>(unused, total, m, sh.used[par], newcols, bl_u32(tab_off), list, sh.set_state);
                 if (cnt_set < 0) { if (tid == 0) atomicOr(t.err, ERR_TRACK_CAPACITY); cnt_set = 0; }
                 n_new_all = cnt_set;
             }
@@ -535,21 +684,25 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
                 S.alive = true; fresh = true;
             }
             __syncthreads();     // (the lists lived in the next frame's tables)
-            for (int c = tid; c < m_next; c += BL_THREADS) { s_key[par ^ 1][c] = ~0ull; s_cid[par ^ 1][c] = 0xFFFFFFFFu; }
+            for (int c = tid; c < m_next; c += BL_THREADS) { key_at(par ^ 1)[c] = ~0ull; cid_at(par ^ 1)[c] = 0xFFFFFFFFu; }
         }
         // ---- the filter bank (tracker.py:219-227)
+        BLSTAMP(6);
         double o0 = z0, o1 = z1;
         if (S.alive) {
-            S.info[0] = box[0]; S.info[1] = box[1]; S.info[2] = box[2];
             if (t.use_gsff) bl_gsff(S, t, gt, z0, z1, fresh, o0, o1);
             else { S.px = z0; S.py = z1; }
         }
         // ---- end of the frame: the next frame's detections have landed, the frame's counts are complete
+        BLSTAMP(7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BLSTAMP(8);
         __syncthreads();
+        BLSTAMP(9);
         const int n_dead = sh.n_dead[par];
         if (n_dead && S.alive)
             for (int k = 0; k < n_dead; ++k) S.rank -= sh.dead_id[par][k] < S.id;
+        if (S.alive) { S.info[0] = box[0]; S.info[1] = box[1]; S.info[2] = box[2]; }   // (the claimed box: requested before the filter bank)
         const int n_live = n - n_dead + n_new;
         if (S.alive && base + S.rank < rows_capacity) {      // track_eval.py:313-316
             ysmr_row rr;
@@ -564,6 +717,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         base += n_live;
         n = n_live;
         next_id += n_new_all;
+        BLSTAMP(10);
     }
     // ---- end of the batch: the table goes back to HBM in row order
     if (S.alive) bl_seat_store(S, bd, S.rank);

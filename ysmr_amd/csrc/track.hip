@@ -81,7 +81,6 @@ constexpr int BL_NF = 3;              // filters (n_f <= 3)
 constexpr int BL_MAX_BATCH = 64;      // frames per launch (the grid block is sized for it; longer batches are cut)
 constexpr int BL_TABLE = 4096;        // CPython set model table, 32-bit slots (as FRAME_TABLE)
 constexpr int BL_F64 = 2 * BL_HB + 3 * BL_NF + 2;   // hx, hy, w, xa, xb, px, py
-constexpr int BL_KMAX = 4;            // rings of cells searched before a lane scans every detection
 
 struct BatchDev {
     double *f64;        // [BL_F64][seat_cap]
@@ -2266,6 +2265,10 @@ int ysmr_tracker_link_mode(ysmr_tracker *t, int mode)
     t->link_mode = mode;       // (the state changes its layout at the next call that needs the other one)
     return YSMR_OK;
 }
+
+#ifdef YSMR_STAMPS
+int ysmr_debug_read_bstamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(unsigned long long) * BL_WAVES * 16); }
+#endif
 
 int ysmr_tracker_batched(ysmr_tracker *t) { return t && t->use_batch() ? 1 : 0; }
 

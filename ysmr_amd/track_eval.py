@@ -87,7 +87,13 @@ class TrackingPipeline:
         # register) and the link waits for them: 80.7 k against 85.7 k frames/s end to end, and giving it the chip to itself
         # between two batches' link chains costs more (77.8 k) than its 15 % buy (profiles/r03_threshold_kernels_in_the_pipeline.log;
         # at 4K 14.8 k against 15.2 k).  Detection without a link has no neighbour and takes the matrix-pipe kernel.
-        beside_fused_link = bool(link)
+        self.trk = DeviceTracker(max_disappeared=fps, fps=fps, n_min=settings["minimum horizon size"],
+                                 n_max=settings["maximum horizon size"], n_f=settings["number of LSFFs"],
+                                 use_gsff=not settings["disable gsff"], capacity=capacity, max_det=max_det,
+                                 device=self.device)
+        # (a handle that links a whole batch with ONE launch -- one workgroup on one compute unit -- is nobody's neighbour:
+        # detection then takes the matrix-pipe kernel and its full resident grids)
+        beside_fused_link = bool(link) and self.trk.fused
         #: the threshold kernel is issued on the LINK stream, between two batches' link chains, where it has the chip to
         #: itself (the labelling chain still runs beside the link, on the side stream)
         self.exclusive_threshold = False
@@ -99,10 +105,6 @@ class TrackingPipeline:
                              mean_state=mean_state, cv_flavour=settings.get("opencv version"),
                              threshold_variant=1 if beside_fused_link else 0)
                     for _ in range(2)]
-        self.trk = DeviceTracker(max_disappeared=fps, fps=fps, n_min=settings["minimum horizon size"],
-                                 n_max=settings["maximum horizon size"], n_f=settings["number of LSFFs"],
-                                 use_gsff=not settings["disable gsff"], capacity=capacity, max_det=max_det,
-                                 device=self.device)
         self.capacity = int(capacity)
         self._chain = self.trk.fused        # (the two-launch link of large tables has nothing to chain)
         n_rows = self.B * self.capacity if rows_per_flush is None else int(rows_per_flush)
