@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1228)
     ap.add_argument("--blobs", type=int, default=500)
     ap.add_argument("--max-det", type=int, default=2048)
-    ap.add_argument("--capacity", type=int, default=2048)
+    ap.add_argument("--capacity", type=int, default=768,
+                    help="live tracks the link's tables hold (the clip peaks at ~535); <= 768 links a whole batch with one launch")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="independent video streams processed concurrently on each GPU (the metric's configuration is 1)")
     ap.add_argument("--channels", type=int, default=1, choices=(1, 3),

@@ -248,8 +248,9 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
 int ysmr_tracker_fused(ysmr_tracker *t);
 
 /* How ysmr_tracker_run links a batch.  A handle whose configuration allows it -- tracking.ini's defaults do: up to three
- * filters with horizons of at most 31 frames, capacity <= 512, max_det <= 2456 -- links a whole batch with ONE launch
- * (one workgroup, a track per lane, the filter state in registers from the first frame to the last); every other handle,
+ * filters with horizons of at most 31 frames, capacity <= 1024, max_det <= 2456 -- links a whole batch with ONE launch
+ * (one workgroup, a track per lane, the filter state in registers from the first frame to the last, the measurement
+ * history in a ring in HBM); every other handle,
  * and ysmr_tracker_update, run one launch (or two, for large tables) per frame.  Same rows either way.
  *   ysmr_tracker_batched    1 when ysmr_tracker_run takes the one-launch-per-batch path, else 0
  *   ysmr_tracker_link_mode  mode 0: the library's choice (default); 1: one launch per frame even where a batch launch

@@ -15,7 +15,8 @@ frames = torch.from_numpy(SyntheticVideo(H, W, blobs, seed=0).frames(F)).cuda()
 pipe = TrackingPipeline(H, W, 30.0, default_settings(), batch=B, max_det=md, capacity=cap, rows_per_flush=F * cap)
 res0 = pipe.det[0].detect(frames[:B]); res1 = pipe.det[1].detect(frames[B:]); torch.cuda.synchronize()
 L = _lib.lib()
-buf = (ctypes.c_ulonglong * (8 * 16))()
+NW = int(os.environ.get("BL_WAVES", "16"))
+buf = (ctypes.c_ulonglong * (NW * 16))()
 names = ["dma issue", "search + key atomic", "barrier A", "clear next tables + id atomic", "barrier B", "claims / ageing / registration",
          "filter bank", "wait vmcnt(0)", "barrier D", "ranks + row"]
 acc = []
@@ -26,15 +27,15 @@ for rep in range(6):
     t0.record(); pipe.trk.run(res1.det, res1.det_count, B, pipe.rows, pipe.row_count); t1.record()
     torch.cuda.synchronize()
     L.ysmr_debug_read_bstamps(buf)
-    full = np.array(buf[:], dtype=np.int64).reshape(8, 16)
+    full = np.array(buf[:], dtype=np.int64).reshape(NW, 16)
     a = full[:, :11]
     acc.append(a)
     print("   fast path per wave:", (full[:, 11] - full[:, 1]).tolist(), " lanes left to the wave search:", full[:, 12].tolist())
     print(f"rep {rep}: launch pair {t0.elapsed_time(t1) * 1e3:.1f} us for {B} frames; frame (wave 0) {a[0, 10] - a[0, 0]} cycles")
 a = np.median(np.array(acc), axis=0)
 d = np.diff(a, axis=1)
-print("%-44s" % "phase (cycles of s_memtime, 100 MHz? no: shader clock)", " ".join(f"w{w:<6d}" for w in range(8)))
+print("%-44s" % "phase (cycles of s_memtime, 100 MHz? no: shader clock)", " ".join(f"w{w:<6d}" for w in range(NW)))
 for k, n in enumerate(names):
-    print("%-44s" % n, " ".join(f"{d[w, k]:<7.0f}" for w in range(8)))
-print("%-44s" % "frame", " ".join(f"{a[w, 10] - a[w, 0]:<7.0f}" for w in range(8)))
+    print("%-44s" % n, " ".join(f"{d[w, k]:<7.0f}" for w in range(NW)))
+print("%-44s" % "frame", " ".join(f"{a[w, 10] - a[w, 0]:<7.0f}" for w in range(NW)))
 print(pipe.trk.info())

@@ -1,35 +1,45 @@
 // batch_link.h -- the link of a whole BATCH of frames in one launch (included by track.hip, inside its namespace).
 //
 // CentroidTracker.update (ysmr/tracker.py:93-230) + GaussianSumFIR.correct / predict (ysmr/gsff.py:204-347) + row
-// emission (ysmr/track_eval.py:313-316) for `batch` consecutive frames: ONE workgroup of 512 threads on ONE compute
-// unit, a track per LANE, the track's whole state -- 32 measurements of history, the filter bank's weights and
-// estimates, prediction, box, id, counters -- in the lane's registers from the first frame of the batch to the last.
-// Per frame nothing is loaded or stored but the frame's detections (in) and its rows (out):
+// emission (ysmr/track_eval.py:313-316) for `batch` consecutive frames: ONE workgroup of 1024 threads on ONE compute
+// unit, a track per LANE, everything a frame needs of a track -- the filter bank's window sums, weights and estimates,
+// prediction, box, id, counters: 55 registers -- in the lane from the first frame of the batch to the last.
 //
 //   detections   k_bgrid (one workgroup per frame, the whole batch at once, before this kernel) bins every frame's
 //                detections into a uniform grid of cells (counting sort) and leaves header | cell starts (u16) |
 //                centres in cell order | their column numbers (u16) as one contiguous block per frame; this kernel
 //                brings the block of frame f+1 into LDS by LDS-DMA while it works on frame f.
-//   row minimum  tracker.py:151-163 reads only D.min(1) and D.argmin(1): a lane looks at the cells around its
-//                prediction (3 x 3, then wider rings while a nearer detection could hide outside: the same bound and
-//                the same tie rule -- lowest column among equal ROUNDED distances -- as rowmin_grid / rowmin_wave).
+//   row minimum  tracker.py:151-163 reads only D.min(1) and D.argmin(1): a lane looks at the 3 x 3 cells around its
+//                prediction, in float, and evaluates the winner once in float64 (bl_search); what float cannot decide
+//                -- a candidate a hair from the best, a nearer detection possibly outside the block -- the wave settles
+//                exactly over all detections (bl_search_wave: rowmin_wave's tie rule, lowest column among equal ROUNDED
+//                distances).
 //   claims       the winner of a detection column is the proposer with the smallest (distance, id): two LDS atomicMin
 //                rounds (ids ascend with table rows, so (distance, id) orders like the reference's (distance, row)).
 //   lifecycle    ageing / deregistration per lane; a lane that loses its track is simply free; new tracks take free
 //                lanes, in CPython set order of the unclaimed columns (cpython_order_lds).  Table ROWS (the order of the
 //                reference's OrderedDict = ascending id = the order of a frame's rows) are kept as a per-lane rank:
 //                a death lowers the rank of every younger track by one, a birth appends.
-//   filter bank  per lane, serial: three FIR estimates per coordinate as fused multiply-add chains over the register
-//                history (gains zero-padded to the 32 entries, newest first), three exp(), three divisions.
+//   filter bank  The gain of a constant-velocity least-squares filter is AFFINE in the age a of a measurement:
+//                g_N[a] = alpha_N - beta_N a (closed_form_gain), so x-hat_N = alpha_N S0_N - beta_N S1_N with the window
+//                sums S0_N = sum_{a<N} h[a], S1_N = sum_{a<N} a h[a].  A new measurement z turns them into
+//                S1' = S1 + S0 - N h[N-1], S0' = S0 + z - h[N-1]: six sums per coordinate in registers, updated with four
+//                operations each, and of the 31 measurements of history a frame touches FOUR: the one it appends and the
+//                three that leave the windows.  The history therefore lives in HBM, a ring of 32 frames x 1024 seats
+//                (every live track appends exactly one measurement per frame, so one head serves all seats and a ring
+//                position is one coalesced line per wave); the leaving entries are requested before the claims and used
+//                after them.  The sums are recomputed from the ring, exactly, at the start of every launch, so rounding
+//                drift is bounded by one batch (64 updates: ~1e-11 px, the size of a from-scratch sum's own rounding).
 //   rows         one 40-byte ysmr_row per live lane at rows[base + rank], fire and forget.
 //
 // Three workgroup barriers per frame (after each atomic round, and at the end of the frame, where the next frame's
-// detections must have landed); no global round trip on the frame-to-frame chain except the lane's own claimed box
-// (requested after the claims, consumed after the filter bank).
+// detections must have landed).  Why not the history in registers (the first build of this kernel: 158 registers per
+// track): 512 tracks fill a compute unit's register file, BASELINE configs[2] holds up to 535; and a frame then costs the
+// 186 float64 operations of re-summing and shifting 62 values per track, on ONE unit's float64 pipe (7.4 us per frame).
 //
-// Between launches the state rests in HBM in seat-major arrays (field by field, a track per column, in table order):
-// coalesced lane-wise loads at the start of a launch and stores at its end.  k_to_std / k_to_batch convert to and from
-// the per-slot layout of k_frame / k_link + k_track (ysmr_tracker_update, tables beyond this kernel's 512 seats).
+// Between launches the small state rests in HBM seat by seat (a seat keeps its track for the track's whole life; free
+// seats are flagged), next to the ring.  k_to_std / k_to_batch convert to and from the per-slot layout of k_frame /
+// k_link + k_track (ysmr_tracker_update, tables beyond this kernel's 1024 seats).
 #pragma once
 
 // (BL_* constants and struct BatchDev: track.hip, next to TrackerDev -- the host handle holds one)
@@ -59,10 +69,15 @@ __host__ __device__ inline int bl_grid_dwords_max(int max_det)
     return most;
 }
 
-// One workgroup per frame: bounding box of the centres, G x G cells over it with one cell of margin, counting sort.
-__global__ __launch_bounds__(256) void k_bgrid(const float *__restrict__ det_all, const int32_t *__restrict__ det_count,
-                                               int max_det, char *grid, unsigned grid_stride)
+// One workgroup per frame: bounding box of the centres, G x G cells over it with one cell of margin, counting sort.  The
+// detections are read ONCE (up to BG_PER per thread, kept in registers through the three passes), the block is assembled
+// in LDS and leaves with 16-byte stores: one round of loads and one of stores instead of the five dependent round trips of
+// the first version (35 us per batch beside the next batch's detection kernels).
+constexpr int BG_THREADS = 256, BG_PER = 10;      // 2560 >= the 2456 detections a one-launch link serves
+__global__ __launch_bounds__(BG_THREADS) void k_bgrid(const float *__restrict__ det_all, const int32_t *__restrict__ det_count,
+                                                      int max_det, char *grid, unsigned grid_stride)
 {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_out[];      // the block as it will lie in HBM
     __shared__ int s_cnt[64 * 64];
     __shared__ float s_red[4][4];
     __shared__ int s_wave_sum[4];
@@ -71,16 +86,21 @@ __global__ __launch_bounds__(256) void k_bgrid(const float *__restrict__ det_all
     int m = det_count[f];
     m = m < 0 ? 0 : (m > max_det ? max_det : m);
     const int G = bl_grid_n(m), cells = G * G;
-    uint32_t *out = reinterpret_cast<uint32_t *>(grid + (size_t)grid_stride * f);
-    uint32_t *start = out + 16;
-    float2 *xy = reinterpret_cast<float2 *>(start + bl_start_dwords(G));
-    unsigned short *items = reinterpret_cast<unsigned short *>(reinterpret_cast<uint32_t *>(xy) + 2 * bl_pad8(m));
-    for (int c = tid; c < cells; c += 256) s_cnt[c] = 0;
-    float lo_x = 3.0e38f, lo_y = 3.0e38f, hi_x = -3.0e38f, hi_y = -3.0e38f;
-    for (int j = tid; j < m; j += 256) {
-        const float x = det[(size_t)j * 5], y = det[(size_t)j * 5 + 1];
-        lo_x = fminf(lo_x, x); hi_x = fmaxf(hi_x, x); lo_y = fminf(lo_y, y); hi_y = fmaxf(hi_y, y);
+    unsigned short *start16 = reinterpret_cast<unsigned short *>(s_out + 16);
+    float2 *xy = reinterpret_cast<float2 *>(s_out + 16 + bl_start_dwords(G));
+    unsigned short *items = reinterpret_cast<unsigned short *>(s_out + 16 + bl_start_dwords(G) + 2 * bl_pad8(m));
+    float x[BG_PER], y[BG_PER];
+#pragma unroll
+    for (int k = 0; k < BG_PER; ++k) {
+        const int j = tid + k * BG_THREADS;
+        x[k] = j < m ? det[(size_t)j * 5] : 0.f;
+        y[k] = j < m ? det[(size_t)j * 5 + 1] : 0.f;
     }
+    for (int c = tid; c < cells; c += BG_THREADS) s_cnt[c] = 0;
+    float lo_x = 3.0e38f, lo_y = 3.0e38f, hi_x = -3.0e38f, hi_y = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < BG_PER; ++k)
+        if (tid + k * BG_THREADS < m) { lo_x = fminf(lo_x, x[k]); hi_x = fmaxf(hi_x, x[k]); lo_y = fminf(lo_y, y[k]); hi_y = fmaxf(hi_y, y[k]); }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         lo_x = fminf(lo_x, __shfl_xor(lo_x, d)); hi_x = fmaxf(hi_x, __shfl_xor(hi_x, d));
@@ -97,21 +117,25 @@ __global__ __launch_bounds__(256) void k_bgrid(const float *__restrict__ det_all
     const float extent = fmaxf(fmaxf(hi_x - lo_x, hi_y - lo_y), 1.0f);
     const float cell = extent / (float)(G - 2), inv = 1.0f / cell;
     const float x0 = lo_x - cell, y0 = lo_y - cell;
+    if (tid < 16) s_out[tid] = 0;
+    __syncthreads();
     if (tid == 0) {
-        float *h = reinterpret_cast<float *>(out);
+        float *h = reinterpret_cast<float *>(s_out);
         h[0] = x0; h[1] = y0; h[2] = cell; h[3] = inv;
-        out[4] = (uint32_t)G; out[5] = (uint32_t)m;
+        s_out[4] = (uint32_t)G; s_out[5] = (uint32_t)m;
     }
-    auto cell_of = [&](int j) {
-        int cx = (int)floorf((det[(size_t)j * 5] - x0) * inv), cy = (int)floorf((det[(size_t)j * 5 + 1] - y0) * inv);
+    int cell_of[BG_PER];
+#pragma unroll
+    for (int k = 0; k < BG_PER; ++k) {
+        int cx = (int)floorf((x[k] - x0) * inv), cy = (int)floorf((y[k] - y0) * inv);
         cx = cx < 0 ? 0 : (cx > G - 1 ? G - 1 : cx);
         cy = cy < 0 ? 0 : (cy > G - 1 ? G - 1 : cy);
-        return cy * G + cx;
-    };
-    for (int j = tid; j < m; j += 256) atomicAdd(&s_cnt[cell_of(j)], 1);
+        cell_of[k] = cy * G + cx;
+        if (tid + k * BG_THREADS < m) atomicAdd(&s_cnt[cell_of[k]], 1);
+    }
     __syncthreads();
     // exclusive scan of the counts: K consecutive cells per thread (K = 1, 4, 9 or 16), wave scan, wave sums
-    const int K = cells / 256;
+    const int K = cells / BG_THREADS;
     int local[16], sum = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k)
@@ -123,7 +147,6 @@ __global__ __launch_bounds__(256) void k_bgrid(const float *__restrict__ det_all
     __syncthreads();
     int before = incl - sum;
     for (int k = 0; k < w; ++k) before += s_wave_sum[k];
-    unsigned short *start16 = reinterpret_cast<unsigned short *>(start);
 #pragma unroll
     for (int k = 0; k < 16; ++k)
         if (k < K) {
@@ -131,31 +154,41 @@ __global__ __launch_bounds__(256) void k_bgrid(const float *__restrict__ det_all
             s_cnt[tid * K + k] = at;
             start16[tid * K + k] = (unsigned short)at;
         }
-    if (tid == 255) { start16[cells] = (unsigned short)m; start16[cells + 1] = 0; }
+    if (tid == BG_THREADS - 1) { start16[cells] = (unsigned short)m; start16[cells + 1] = 0; }
+    // (the padding of the lists reads as far away, should a lane ever look at it)
+    for (int j = m + tid; j < bl_pad8(m); j += BG_THREADS) { xy[j] = make_float2(1.0e30f, 1.0e30f); items[j] = 0; }
     __syncthreads();
-    for (int j = tid; j < m; j += 256) {
-        const int at = atomicAdd(&s_cnt[cell_of(j)], 1);
-        items[at] = (unsigned short)j;
-        xy[at] = make_float2(det[(size_t)j * 5], det[(size_t)j * 5 + 1]);
+#pragma unroll
+    for (int k = 0; k < BG_PER; ++k) {
+        const int j = tid + k * BG_THREADS;
+        if (j < m) {
+            const int at = atomicAdd(&s_cnt[cell_of[k]], 1);
+            items[at] = (unsigned short)j;
+            xy[at] = make_float2(x[k], y[k]);
+        }
     }
+    __syncthreads();
+    uint4 *out = reinterpret_cast<uint4 *>(grid + (size_t)grid_stride * f);
+    const uint4 *img = reinterpret_cast<const uint4 *>(s_out);
+    for (int i = tid; i < bl_grid_dwords(m) / 4; i += BG_THREADS) out[i] = img[i];
 }
 
 // ---- a track in registers -------------------------------------------------------------------------------------------
 struct BlSeat {
-    double hx[BL_HB], hy[BL_HB];            // measurements, newest first
-    double w[BL_NF], xa[BL_NF], xb[BL_NF];  // filter weights, x-hat rows 0 / 1
-    double px, py;                          // CentroidTracker.objects[id]: the prediction (tracker.py:225)
+    double s0x[BL_NF], s1x[BL_NF], s0y[BL_NF], s1y[BL_NF];   // window sums of the three horizons (x, y)
+    double w[BL_NF], xa[BL_NF], xb[BL_NF];                   // filter weights, x-hat rows 0 / 1
+    double px, py;                                           // CentroidTracker.objects[id]: the prediction (tracker.py:225)
     float info[3];
     int id, gone, len, mode, rank;
     bool alive;
 };
+// rest format, seat-major: f64 [BL_SF64][seat_cap] = w, xa, xb, px, py, the twelve window sums; f32 [3][seat_cap];
+// i32 [6][seat_cap] = id, gone, history length, mode, rank, alive; ring double2 [BL_HB][seat_cap]
 
 __device__ __forceinline__ void bl_seat_blank(BlSeat &S)
 {
 #pragma unroll
-    for (int e = 0; e < BL_HB; ++e) { S.hx[e] = 0.0; S.hy[e] = 0.0; }
-#pragma unroll
-    for (int f = 0; f < BL_NF; ++f) { S.w[f] = 0.0; S.xa[f] = 0.0; S.xb[f] = 0.0; }
+    for (int f = 0; f < BL_NF; ++f) { S.s0x[f] = S.s1x[f] = S.s0y[f] = S.s1y[f] = 0.0; S.w[f] = S.xa[f] = S.xb[f] = 0.0; }
     S.px = S.py = 0.0;
     S.info[0] = S.info[1] = S.info[2] = 0.f;
     S.id = S.gone = S.len = S.mode = S.rank = 0;
@@ -167,18 +200,18 @@ __device__ __forceinline__ void bl_seat_load(BlSeat &S, const BatchDev &bd, int 
     const size_t sc = (size_t)bd.seat_cap;
     const double *p = bd.f64 + at;
 #pragma unroll
-    for (int e = 0; e < BL_HB; ++e) { S.hx[e] = p[sc * e]; S.hy[e] = p[sc * (BL_HB + e)]; }
+    for (int f = 0; f < BL_NF; ++f) { S.w[f] = p[sc * f]; S.xa[f] = p[sc * (BL_NF + f)]; S.xb[f] = p[sc * (2 * BL_NF + f)]; }
+    S.px = p[sc * (3 * BL_NF)];
+    S.py = p[sc * (3 * BL_NF + 1)];
 #pragma unroll
     for (int f = 0; f < BL_NF; ++f) {
-        S.w[f] = p[sc * (2 * BL_HB + f)];
-        S.xa[f] = p[sc * (2 * BL_HB + BL_NF + f)];
-        S.xb[f] = p[sc * (2 * BL_HB + 2 * BL_NF + f)];
+        const double *q = p + sc * (3 * BL_NF + 2 + 4 * f);
+        S.s0x[f] = q[0]; S.s1x[f] = q[sc]; S.s0y[f] = q[2 * sc]; S.s1y[f] = q[3 * sc];
     }
-    S.px = p[sc * (2 * BL_HB + 3 * BL_NF)];
-    S.py = p[sc * (2 * BL_HB + 3 * BL_NF + 1)];
 #pragma unroll
     for (int k = 0; k < 3; ++k) S.info[k] = bd.f32[sc * k + at];
     S.id = bd.i32[at]; S.gone = bd.i32[sc + at]; S.len = bd.i32[2 * sc + at]; S.mode = bd.i32[3 * sc + at];
+    S.rank = bd.i32[4 * sc + at];
 }
 
 __device__ __forceinline__ void bl_seat_store(const BlSeat &S, const BatchDev &bd, int at)
@@ -186,89 +219,109 @@ __device__ __forceinline__ void bl_seat_store(const BlSeat &S, const BatchDev &b
     const size_t sc = (size_t)bd.seat_cap;
     double *p = bd.f64 + at;
 #pragma unroll
-    for (int e = 0; e < BL_HB; ++e) { p[sc * e] = S.hx[e]; p[sc * (BL_HB + e)] = S.hy[e]; }
+    for (int f = 0; f < BL_NF; ++f) { p[sc * f] = S.w[f]; p[sc * (BL_NF + f)] = S.xa[f]; p[sc * (2 * BL_NF + f)] = S.xb[f]; }
+    p[sc * (3 * BL_NF)] = S.px;
+    p[sc * (3 * BL_NF + 1)] = S.py;
 #pragma unroll
     for (int f = 0; f < BL_NF; ++f) {
-        p[sc * (2 * BL_HB + f)] = S.w[f];
-        p[sc * (2 * BL_HB + BL_NF + f)] = S.xa[f];
-        p[sc * (2 * BL_HB + 2 * BL_NF + f)] = S.xb[f];
+        double *q = p + sc * (3 * BL_NF + 2 + 4 * f);
+        q[0] = S.s0x[f]; q[sc] = S.s1x[f]; q[2 * sc] = S.s0y[f]; q[3 * sc] = S.s1y[f];
     }
-    p[sc * (2 * BL_HB + 3 * BL_NF)] = S.px;
-    p[sc * (2 * BL_HB + 3 * BL_NF + 1)] = S.py;
 #pragma unroll
     for (int k = 0; k < 3; ++k) bd.f32[sc * k + at] = S.info[k];
     bd.i32[at] = S.id; bd.i32[sc + at] = S.gone; bd.i32[2 * sc + at] = S.len; bd.i32[3 * sc + at] = S.mode;
+    bd.i32[4 * sc + at] = S.rank;
 }
 
-// FIR estimates of the three filters (lsff_calc, gsff.py:156-177: rows 0 / 1 of the gain times the last N measurements)
-// from the register history.  The gain of a constant-velocity least-squares filter is AFFINE in the age a of a
-// measurement: g_N[a] = alpha_N - beta_N * a  (closed_form_gain: c_j = 1/N + t_j (N+1)/2 / sum t^2, t_j = (N-1)/2 - a), so
-//     x-hat_N = alpha_N * S0_N - beta_N * S1_N,   S0_N = sum_{a<N} h[a],   S1_N = sum_{a<N} a h[a],
-// and the three horizons share ONE pass over the history: two running sums per coordinate, read off where a horizon
-// ends (a uniform bit test per entry).  124 float64 operations instead of 3 x 2 x N multiply-adds against a table of
-// gains that no register file holds (192 constants; as scalar operands they spilled, 1200 v_readlane / v_writelane).
-// Rounding differs from the table form by ~1e-11 px on positions of ~1e3 px (the sums reach 5e5 before they are scaled).
-// (struct BlGains { alpha[filter][x / y row], beta[..][..] }: track.hip, the host handle holds one)
-__device__ __forceinline__ void bl_fir(const BlSeat &S, const BlGains &g, int n0, int n1, int n2, unsigned ends,
-                                       double *x0, double *x1)
+// A ring entry as this compute unit's L2 holds it: the ring is written and read back by the same launch, frames apart;
+// sc1 loads pass the unit's L1 (it is not refreshed by stores, the unit's own included, in any way the ISA promises).
+__device__ __forceinline__ double2 bl_ring_load(const BatchDev &bd, int pos, int seat)
 {
+    const double *p = reinterpret_cast<const double *>(bd.ring + (size_t)pos * bd.seat_cap + seat);
+    double2 v;
+    v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+__device__ __forceinline__ void bl_ring_store(const BatchDev &bd, int pos, int seat, double x, double y)
+{
+    bd.ring[(size_t)pos * bd.seat_cap + seat] = make_double2(x, y);
+}
+
+// The window sums of a track from its history, exactly: the measurement of age a (0 = newest) is at ring position
+// head - 1 - a; a filter's window holds the newest min(N, len) of them.  Done for every track at the frames whose index
+// is a multiple of BL_REFRESH (a schedule in FRAME numbers: the rows of a video must not depend on how its frames were cut
+// into batches), and by k_to_batch.
+__device__ __forceinline__ void bl_sums_from_ring(BlSeat &S, const BatchDev &bd, int seat, int head, int n0, int n1, int n2)
+{
+    const int lim[BL_NF] = {min(n0, S.len), min(n1, S.len), min(n2, S.len)};
     double s0x = 0.0, s1x = 0.0, s0y = 0.0, s1y = 0.0;
-    double q0x[BL_NF], q1x[BL_NF], q0y[BL_NF], q1y[BL_NF];
-#pragma unroll
-    for (int f = 0; f < BL_NF; ++f) { q0x[f] = q1x[f] = q0y[f] = q1y[f] = 0.0; }
-#pragma unroll
-    for (int a = 0; a < BL_HB; ++a) {
-        s0x = s0x + S.hx[a];
-        s0y = s0y + S.hy[a];
-        if (a > 0) {
-            s1x = __builtin_fma((double)a, S.hx[a], s1x);
-            s1y = __builtin_fma((double)a, S.hy[a], s1y);
+    for (int a = 0; a < BL_HB - 1; ++a) {
+        const double2 e = bl_ring_load(bd, (head - 1 - a) & (BL_HB - 1), seat);
+        if (a < S.len) {
+            s0x = s0x + e.x;
+            s0y = s0y + e.y;
+            s1x = __builtin_fma((double)a, e.x, s1x);
+            s1y = __builtin_fma((double)a, e.y, s1y);
         }
-        if (__builtin_amdgcn_readfirstlane((ends >> a) & 1u)) {    // a horizon ends with this entry (uniform)
-            if (a + 1 == n0) { q0x[0] = s0x; q1x[0] = s1x; q0y[0] = s0y; q1y[0] = s1y; }
-            else if (a + 1 == n1) { q0x[1] = s0x; q1x[1] = s1x; q0y[1] = s0y; q1y[1] = s1y; }
-            else { q0x[2] = s0x; q1x[2] = s1x; q0y[2] = s0y; q1y[2] = s1y; }
-        }
-    }
 #pragma unroll
-    for (int f = 0; f < BL_NF; ++f) {
-        x0[f] = g.alpha[f][0] * q0x[f] - g.beta[f][0] * q1x[f];
-        x1[f] = g.alpha[f][1] * q0y[f] - g.beta[f][1] * q1y[f];
+        for (int f = 0; f < BL_NF; ++f)
+            if (a + 1 == lim[f]) { S.s0x[f] = s0x; S.s1x[f] = s1x; S.s0y[f] = s0y; S.s1y[f] = s1y; }
     }
 }
 
 // GaussianSumFIR.correct + predict of one track by its lane (gsff.py:204-347; the statement order of gsff_wave).
-__device__ __forceinline__ void bl_gsff(BlSeat &S, const TrackerDev &t, const BlGains &gt, double z0, double z1,
-                                        bool fresh, double &o0, double &o1)
+// leave[f]: the measurement of age N_f - 1 (requested by the caller before the claims); head: the ring position this
+// frame's measurement takes.
+// (struct BlGains { alpha[filter][x / y row], beta[..][..] }: track.hip, the host handle holds one)
+__device__ __forceinline__ void bl_gsff(BlSeat &S, const TrackerDev &t, const BatchDev &bd, const BlGains &g, int seat, int head,
+                                        const double2 (&leave)[BL_NF], double z0, double z1, bool fresh, double &o0, double &o1)
 {
     const int nf = t.n_f, L = t.hist_cap;
-    const int n0 = t.n_i[0], n1 = nf > 1 ? t.n_i[1] : 0, n2 = nf > 2 ? t.n_i[2] : 0;
-    const unsigned ends = (1u << (n0 - 1)) | (nf > 1 ? 1u << (n1 - 1) : 0u) | (nf > 2 ? 1u << (n2 - 1) : 0u);
+    const int n_i[BL_NF] = {t.n_i[0], nf > 1 ? t.n_i[1] : 0x7FFFFFFF, nf > 2 ? t.n_i[2] : 0x7FFFFFFF};
     int len = fresh ? 0 : S.len, mode = fresh ? 0 : S.mode;
-    if (len == 0) {      // history starts as n_i[0] copies of the first measurement (entries beyond are never read)
+    if (len == 0) {      // history starts as n_i[0] copies of the first measurement (gsff.py:281)
+        const int n0 = n_i[0];
+        const double c1 = (double)(n0 * (n0 - 1) / 2);
 #pragma unroll
-        for (int e = 0; e < BL_HB; ++e) { S.hx[e] = z0; S.hy[e] = z1; }
+        for (int f = 0; f < BL_NF; ++f) {
+            S.s0x[f] = (double)n0 * z0; S.s1x[f] = c1 * z0;
+            S.s0y[f] = (double)n0 * z1; S.s1y[f] = c1 * z1;
+        }
+        for (int a = 0; a < n0; ++a) bl_ring_store(bd, (head - 1 - a) & (BL_HB - 1), seat, z0, z1);
         len = n0;
     }
     bool grew = false;   // gsff.py:283-289: while len(history) >= n_i[mode]: mode += 1
-    if (mode == 0 && 0 < nf && len >= n0) { mode = 1; grew = true; }
-    if (mode == 1 && 1 < nf && len >= n1) { mode = 2; grew = true; }
-    if (mode == 2 && 2 < nf && len >= n2) { mode = 3; grew = true; }
-    if (grew) {
-        double x0[BL_NF], x1[BL_NF];
-        bl_fir(S, gt, n0, n1, n2, ends, x0, x1);
+    if (mode == 0 && 0 < nf && len >= n_i[0]) { mode = 1; grew = true; }
+    if (mode == 1 && 1 < nf && len >= n_i[1]) { mode = 2; grew = true; }
+    if (mode == 2 && 2 < nf && len >= n_i[2]) { mode = 3; grew = true; }
+    if (grew) {          // the estimates of every active filter from the history as it stands, uniform weights
         const double w0 = mode == 1 ? 1.0 : (mode == 2 ? 0.5 : 1.0 / 3.0);
 #pragma unroll
         for (int f = 0; f < BL_NF; ++f)
-            if (f < mode) { S.xa[f] = x0[f]; S.xb[f] = x1[f]; S.w[f] = w0; }
+            if (f < mode) {
+                S.xa[f] = g.alpha[f][0] * S.s0x[f] - g.beta[f][0] * S.s1x[f];
+                S.xb[f] = g.alpha[f][1] * S.s0y[f] - g.beta[f][1] * S.s1y[f];
+                S.w[f] = w0;
+            }
     }
-    // append the measurement: every entry one frame older
-#pragma unroll
-    for (int e = BL_HB - 1; e > 0; --e) { S.hx[e] = S.hx[e - 1]; S.hy[e] = S.hy[e - 1]; }
-    S.hx[0] = z0; S.hy[0] = z1;
-    if (len < L) ++len;
+    // append the measurement: every entry one frame older, the entry of age N - 1 leaves a full window
     double nx0[BL_NF], nx1[BL_NF];
-    bl_fir(S, gt, n0, n1, n2, ends, nx0, nx1);
+#pragma unroll
+    for (int f = 0; f < BL_NF; ++f) {
+        const bool full = len >= n_i[f];
+        // (a track born in this frame: its history is copies of z, written above -- after `leave` was requested)
+        const double lx = full ? (fresh ? z0 : leave[f].x) : 0.0, ly = full ? (fresh ? z1 : leave[f].y) : 0.0;
+        const double nn = -(double)(f < nf ? n_i[f] : 0);
+        S.s1x[f] = __builtin_fma(nn, lx, S.s1x[f] + S.s0x[f]);
+        S.s1y[f] = __builtin_fma(nn, ly, S.s1y[f] + S.s0y[f]);
+        S.s0x[f] = (S.s0x[f] + z0) - lx;
+        S.s0y[f] = (S.s0y[f] + z1) - ly;
+        nx0[f] = g.alpha[f][0] * S.s0x[f] - g.beta[f][0] * S.s1x[f];
+        nx1[f] = g.alpha[f][1] * S.s0y[f] - g.beta[f][1] * S.s1y[f];
+    }
+    bl_ring_store(bd, head, seat, z0, z1);
+    if (len < L) ++len;
     // likelihoods of the measurement under last frame's estimates (gsff.py:179-202)
     double lik[BL_NF], total = 0.0;
 #pragma unroll
@@ -369,7 +422,9 @@ __device__ __forceinline__ float bl_dist2f(float fx, float fy, float2 c)
 }
 __device__ __forceinline__ uint32_t bl_med3(uint32_t a, uint32_t b, uint32_t c)
 {
-    return max(min(a, b), min(max(a, b), c));           // (v_med3_u32)
+    uint32_t r;                                          // (the compiler spells the median out as three min / max)
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 __device__ __forceinline__ BlNear bl_search(const BlGridView &g, double px, double py, int m)
 {
@@ -388,12 +443,23 @@ __device__ __forceinline__ BlNear bl_search(const BlGridView &g, double px, doub
         b[r] = g.start_at(iy * G + xh + 1);
         if (yl + r > yh) b[r] = a[r];                   // (a block cut by the edge of the grid has fewer rows)
     }
+    // every candidate's read is issued before the first is used (left to itself the compiler, short of registers, waits
+    // for each read before it issues the next: fifteen LDS round trips in a row); a slot beyond the end of its run reads
+    // whatever follows in LDS and is masked afterwards
+    float2 c[R * C];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float2 *run = reinterpret_cast<const float2 *>(bl_u32(g.xy)) + a[r];
+#pragma unroll
+        for (int j = 0; j < C; ++j) c[C * r + j] = run[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;        // the two smallest keys
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            const float d2 = bl_dist2f(fx, fy, g.xy_at(min(a[r] + j, m - 1)));
+            const float d2 = bl_dist2f(fx, fy, c[C * r + j]);
             uint32_t key = (__float_as_uint(d2) & 0xFFFFFFF0u) | (uint32_t)(C * r + j);
             key = a[r] + j < b[r] ? key : 0xFFFFFFFFu;
             hi = bl_med3(lo, hi, key);
@@ -428,10 +494,10 @@ __device__ __forceinline__ BlNear bl_search(const BlGridView &g, double px, doub
     bound -= 1e-3f * g.cell;
     const bool found = lo != 0xFFFFFFFFu;
     const bool inside = bound >= big * 0.5f || (bound > 0.f && bound * bound > band);
-    const float2 c = g.xy_at(found ? bq : 0);
+    const float2 cw = g.xy_at(found ? bq : 0);
     BlNear r;
-    r.s = bl_dist2(px, py, c);
-    r.zx = c.x; r.zy = c.y;
+    r.s = bl_dist2(px, py, cw);
+    r.zx = cw.x; r.zy = cw.y;
     r.col = g.item_at(found ? bq : 0);
     r.done = found && inside && !(second <= band);     // (hi = 0xFFFFFFFF reads as a NaN: no second candidate)
     return r;
@@ -528,9 +594,11 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
     auto buf_off = [&](int p) { return 6 * mdp + p * bufw; };
     const int tab_off = 6 * mdp + 2 * bufw;
     const int seats = min(t.capacity, BL_THREADS);
+    const int nf = t.n_f;
+    const int hn[BL_NF] = {t.n_i[0], nf > 1 ? t.n_i[1] : 1, nf > 2 ? t.n_i[2] : 1};    // horizons (ring offsets of the leavers)
 
     // ---- start of the batch: counters, this lane's track, the first frame's detections
-    int n = *t.n_tracks, next_id = *t.next_id;
+    int n = *t.n_tracks, next_id = *t.next_id, head = *bd.head & (BL_HB - 1);
     long long base = *row_count;
     for (int f = tid; f < batch; f += BL_THREADS) {
         int m = det_count[f];
@@ -540,7 +608,10 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
     if (tid < 2) { sh.used[tid] = 0; sh.n_dead[tid] = 0; }
     BlSeat S;
     bl_seat_blank(S);
-    if (tid < n) { bl_seat_load(S, bd, tid); S.alive = true; S.rank = tid; }
+    if (n > 0 && tid < seats && bd.i32[5 * (size_t)bd.seat_cap + tid]) {     // (an empty table: whatever the flags say)
+        bl_seat_load(S, bd, tid);
+        S.alive = true;
+    }
     __syncthreads();
     auto dma = [&](int f) {        // frame f's block -> s_buf[f & 1], whole 1-KiB pieces, a wave-instruction each
         const int pieces = bl_grid_dwords(sh.cnt[f]) >> 8;
@@ -560,6 +631,8 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         const int par = f & 1;
         const int m = sh.cnt[f], m_next = f + 1 < batch ? sh.cnt[f + 1] : 0;
         BLSTAMP(0);
+        if (((frame0 + f) & (BL_REFRESH - 1)) == 0 && S.alive && t.use_gsff)      // (uniform but for `alive`: see bl_sums_from_ring)
+            bl_sums_from_ring(S, bd, tid, head, t.n_i[0], nf > 1 ? t.n_i[1] : 0, nf > 2 ? t.n_i[2] : 0);
         if (f + 1 < batch) dma(f + 1);
         BLSTAMP(1);
         // ---- each track proposes its nearest detection (tracker.py:151-163)
@@ -580,6 +653,15 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
                 const BlNear w = bl_search_wave(gv, lane_value(S.px, l), lane_value(S.py, l), m, lane);
                 if (lane == l) nr = w;
             }
+        }
+        // the measurements that leave the filters' windows with this frame (used behind the claims)
+        double2 leave[BL_NF];
+#pragma unroll
+        for (int k = 0; k < BL_NF; ++k) leave[k] = make_double2(0.0, 0.0);
+        if (S.alive && t.use_gsff) {
+#pragma unroll
+            for (int k = 0; k < BL_NF; ++k)
+                if (k < nf) leave[k] = bl_ring_load(bd, (head - hn[k]) & (BL_HB - 1), tid);
         }
         if (propose) {      // (round 1 on the SQUARED distance: a non-negative double orders like its bits)
             key = (unsigned long long)__double_as_longlong(nr.s);
@@ -690,7 +772,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         BLSTAMP(6);
         double o0 = z0, o1 = z1;
         if (S.alive) {
-            if (t.use_gsff) bl_gsff(S, t, gt, z0, z1, fresh, o0, o1);
+            if (t.use_gsff) bl_gsff(S, t, bd, gt, tid, head, leave, z0, z1, fresh, o0, o1);
             else { S.px = z0; S.py = z1; }
         }
         // ---- end of the frame: the next frame's detections have landed, the frame's counts are complete
@@ -717,81 +799,112 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         base += n_live;
         n = n_live;
         next_id += n_new_all;
+        head = (head + 1) & (BL_HB - 1);
         BLSTAMP(10);
     }
-    // ---- end of the batch: the table goes back to HBM in row order
-    if (S.alive) bl_seat_store(S, bd, S.rank);
-    if (tid == 0) { *t.n_tracks = n; *t.next_id = next_id; *row_count = base; }
+    // ---- end of the batch: the small state goes back to HBM, seat by seat
+    if (tid < seats) {
+        bd.i32[5 * (size_t)bd.seat_cap + tid] = S.alive ? 1 : 0;
+        if (S.alive) bl_seat_store(S, bd, tid);
+    }
+    if (tid == 0) { *t.n_tracks = n; *t.next_id = next_id; *row_count = base; *bd.head = head; }
 }
 
 // ---- conversions between the seat-major rest format and the per-slot layout of k_frame / k_link + k_track ----------
-// (a: the CURRENT parity view of the per-slot state)
+// (a: the CURRENT parity view of the per-slot state; table row r takes seat r)
 __global__ void k_to_batch(TrackerDev a, BatchDev bd)
 {
     const int n = *a.n_tracks, cap = a.capacity, L = a.hist_cap, nf = a.n_f;
+    const int head = *bd.head & (BL_HB - 1);
     const size_t sc = (size_t)bd.seat_cap;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < bd.seat_cap; r += gridDim.x * blockDim.x) {
+        bd.i32[5 * sc + r] = r < n ? 1 : 0;
+        if (r >= n) continue;
         const int slot = a.order[r];
-        double *p = bd.f64 + r;
         const double *hist = a.hist + (size_t)slot * 2 * L;
-        for (int e = 0; e < BL_HB; ++e) {
-            p[sc * e] = e < L ? hist[2 * e] : 0.0;
-            p[sc * (BL_HB + e)] = e < L ? hist[2 * e + 1] : 0.0;
-        }
+        for (int e = 0; e < L && e < BL_HB - 1; ++e)           // entry e: the measurement of e frames ago
+            bd.ring[(size_t)((head - 1 - e) & (BL_HB - 1)) * sc + r] = make_double2(hist[2 * e], hist[2 * e + 1]);
+        double *p = bd.f64 + r;
         const double *rec = a.rec + (size_t)slot * a.rec_stride;
         for (int f = 0; f < BL_NF; ++f) {
-            p[sc * (2 * BL_HB + f)] = f < nf ? rec[2 + f] : 0.0;
-            p[sc * (2 * BL_HB + BL_NF + f)] = f < nf ? rec[2 + nf + f] : 0.0;
-            p[sc * (2 * BL_HB + 2 * BL_NF + f)] = f < nf ? rec[2 + 2 * nf + f] : 0.0;
+            p[sc * f] = f < nf ? rec[2 + f] : 0.0;
+            p[sc * (BL_NF + f)] = f < nf ? rec[2 + nf + f] : 0.0;
+            p[sc * (2 * BL_NF + f)] = f < nf ? rec[2 + 2 * nf + f] : 0.0;
         }
-        p[sc * (2 * BL_HB + 3 * BL_NF)] = a.pos[slot];
-        p[sc * (2 * BL_HB + 3 * BL_NF + 1)] = a.pos[cap + slot];
+        p[sc * (3 * BL_NF)] = a.pos[slot];
+        p[sc * (3 * BL_NF + 1)] = a.pos[cap + slot];
+        {   // the window sums, exactly as bl_sums_from_ring forms them
+            const int len = (int)(__double_as_longlong(rec[0]) & 0xFFFFFFFFll);
+            double s0x = 0.0, s1x = 0.0, s0y = 0.0, s1y = 0.0;
+            for (int e = 0; e < BL_HB - 1; ++e) {
+                if (e < len && e < L) {
+                    s0x = s0x + hist[2 * e];
+                    s0y = s0y + hist[2 * e + 1];
+                    s1x = __builtin_fma((double)e, hist[2 * e], s1x);
+                    s1y = __builtin_fma((double)e, hist[2 * e + 1], s1y);
+                }
+                for (int f = 0; f < BL_NF; ++f)
+                    if (f < nf && e + 1 == min(a.n_i[f], len)) {
+                        double *q = p + sc * (3 * BL_NF + 2 + 4 * f);
+                        q[0] = s0x; q[sc] = s1x; q[2 * sc] = s0y; q[3 * sc] = s1y;
+                    }
+            }
+        }
         for (int k = 0; k < 3; ++k) bd.f32[sc * k + r] = a.info[k * cap + slot];
         bd.i32[r] = a.id[slot];
         bd.i32[sc + r] = a.gone[a.gone_by_row ? r : slot];
         bd.i32[2 * sc + r] = (int)(__double_as_longlong(rec[0]) & 0xFFFFFFFFll);
         bd.i32[3 * sc + r] = (int)(__double_as_longlong(rec[1]) & 0xFFFFFFFFll);
+        bd.i32[4 * sc + r] = r;
     }
 }
 
-// (d: the parity-0 view; row r takes slot r, the free stack hands out slot n next)
+// (d: the parity-0 view; the track in seat s goes to table row rank[s], which takes slot rank[s]; the free stack hands
+// out slot n next)
 __global__ void k_to_std(TrackerDev d, BatchDev bd)
 {
     const int n = *d.n_tracks, cap = d.capacity, L = d.hist_cap, nf = d.n_f;
+    const int head = *bd.head & (BL_HB - 1);
     const size_t sc = (size_t)bd.seat_cap;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < cap; r += gridDim.x * blockDim.x) {
-        if (r < cap - n) d.free_slots[r] = cap - 1 - r;
-        if (r == 0) *d.n_free = cap - n;
-        if (r >= n) continue;
-        const double *p = bd.f64 + r;
+    const int span = cap > bd.seat_cap ? cap : bd.seat_cap;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < span; s += gridDim.x * blockDim.x) {
+        if (s < cap - n) d.free_slots[s] = cap - 1 - s;
+        if (s == 0) *d.n_free = cap - n;
+        if (s >= bd.seat_cap || n == 0 || !bd.i32[5 * sc + s]) continue;
+        const int r = bd.i32[4 * sc + s];
+        const double *p = bd.f64 + s;
         double *hist = d.hist + (size_t)r * 2 * L;
-        for (int e = 0; e < L && e < BL_HB; ++e) { hist[2 * e] = p[sc * e]; hist[2 * e + 1] = p[sc * (BL_HB + e)]; }
-        double *rec = d.rec + (size_t)r * d.rec_stride;
-        rec[0] = __longlong_as_double((long long)(unsigned int)bd.i32[2 * sc + r]);
-        rec[1] = __longlong_as_double((long long)(unsigned int)bd.i32[3 * sc + r]);
-        for (int f = 0; f < nf && f < BL_NF; ++f) {
-            rec[2 + f] = p[sc * (2 * BL_HB + f)];
-            rec[2 + nf + f] = p[sc * (2 * BL_HB + BL_NF + f)];
-            rec[2 + 2 * nf + f] = p[sc * (2 * BL_HB + 2 * BL_NF + f)];
+        for (int e = 0; e < L && e < BL_HB - 1; ++e) {
+            const double2 v = bd.ring[(size_t)((head - 1 - e) & (BL_HB - 1)) * sc + s];
+            hist[2 * e] = v.x; hist[2 * e + 1] = v.y;
         }
-        d.pos[r] = p[sc * (2 * BL_HB + 3 * BL_NF)];
-        d.pos[cap + r] = p[sc * (2 * BL_HB + 3 * BL_NF + 1)];
-        for (int k = 0; k < 3; ++k) d.info[k * cap + r] = bd.f32[sc * k + r];
-        d.id[r] = bd.i32[r];
+        double *rec = d.rec + (size_t)r * d.rec_stride;
+        rec[0] = __longlong_as_double((long long)(unsigned int)bd.i32[2 * sc + s]);
+        rec[1] = __longlong_as_double((long long)(unsigned int)bd.i32[3 * sc + s]);
+        for (int f = 0; f < nf && f < BL_NF; ++f) {
+            rec[2 + f] = p[sc * f];
+            rec[2 + nf + f] = p[sc * (BL_NF + f)];
+            rec[2 + 2 * nf + f] = p[sc * (2 * BL_NF + f)];
+        }
+        d.pos[r] = p[sc * (3 * BL_NF)];
+        d.pos[cap + r] = p[sc * (3 * BL_NF + 1)];
+        for (int k = 0; k < 3; ++k) d.info[k * cap + r] = bd.f32[sc * k + s];
+        d.id[r] = bd.i32[s];
         d.order[r] = r;
-        d.gone[r] = bd.i32[sc + r];       // (row r = slot r: right for either indexing)
-        d.row_gone[r] = bd.i32[sc + r];
+        d.gone[r] = bd.i32[sc + s];       // (row r = slot r: right for either indexing)
+        d.row_gone[r] = bd.i32[sc + s];
     }
 }
 
 __global__ void k_peek_batch(TrackerDev t, BatchDev bd, int32_t *ids, double *xy, int32_t *gone, int32_t *n_out)
 {
-    const int n = *t.n_tracks;
     const size_t sc = (size_t)bd.seat_cap;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && n_out) *n_out = n;
-    if (i >= n) return;
-    if (ids) ids[i] = bd.i32[i];
-    if (xy) { xy[2 * i] = bd.f64[sc * (2 * BL_HB + 3 * BL_NF) + i]; xy[2 * i + 1] = bd.f64[sc * (2 * BL_HB + 3 * BL_NF + 1) + i]; }
-    if (gone) gone[i] = bd.i32[sc + i];
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *t.n_tracks;
+    if (s == 0 && n_out) *n_out = n;
+    if (s >= bd.seat_cap || n == 0 || !bd.i32[5 * sc + s]) return;
+    const int i = bd.i32[4 * sc + s];
+    if (ids) ids[i] = bd.i32[s];
+    if (xy) { xy[2 * i] = bd.f64[sc * (3 * BL_NF) + s]; xy[2 * i + 1] = bd.f64[sc * (3 * BL_NF + 1) + s]; }
+    if (gone) gone[i] = bd.i32[sc + s];
 }

@@ -19,6 +19,7 @@
 //
 // All arithmetic is float64 like the reference; -ffp-contract=off keeps mul/add unfused.
 #include "common.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -74,18 +75,24 @@ struct TrackerDev {
 };
 
 // ---- the batch link (batch_link.h): one workgroup links a whole batch of frames per launch, a track per lane
-constexpr int BL_THREADS = 512;       // seats: one track per lane
+#ifndef YSMR_BL_THREADS
+#define YSMR_BL_THREADS 768
+#endif
+constexpr int BL_THREADS = YSMR_BL_THREADS;      // seats: one track per lane
 constexpr int BL_WAVES = BL_THREADS / 64;
-constexpr int BL_HB = 32;             // history entries per track held in registers (hist_cap <= 32)
+constexpr int BL_HB = 32;             // ring of measurements per seat (hist_cap <= 32; a power of two)
 constexpr int BL_NF = 3;              // filters (n_f <= 3)
 constexpr int BL_MAX_BATCH = 64;      // frames per launch (the grid block is sized for it; longer batches are cut)
 constexpr int BL_TABLE = 4096;        // CPython set model table, 32-bit slots (as FRAME_TABLE)
-constexpr int BL_F64 = 2 * BL_HB + 3 * BL_NF + 2;   // hx, hy, w, xa, xb, px, py
+constexpr int BL_SF64 = 3 * BL_NF + 2 + 4 * BL_NF;   // w, xa, xb, px, py, the window sums
+constexpr int BL_REFRESH = 64;        // frames between two exact recomputations of the window sums (a power of two)
 
 struct BatchDev {
-    double *f64;        // [BL_F64][seat_cap]
+    double2 *ring;      // [BL_HB][seat_cap]  the measurements of the last BL_HB frames, seat by seat
+    double *f64;        // [BL_SF64][seat_cap]
     float *f32;         // [3][seat_cap]      box of the last claimed detection (0 while lost)
-    int *i32;           // [4][seat_cap]      id, gone, history length, mode
+    int *i32;           // [6][seat_cap]      id, gone, history length, mode, table row, seat taken
+    int *head;          // ring position of the next frame's measurements
     char *grid;         // [BL_MAX_BATCH][grid_stride] bytes, written by k_bgrid
     unsigned grid_stride;   // bytes per frame (a multiple of 1024)
     int seat_cap;
@@ -121,7 +128,7 @@ struct ysmr_tracker {
     int grid_frames = 0;           //   (allocated by ysmr_tracker_create: no allocation on the call path)
     // batch link (batch_link.h): the handle can link a whole batch per launch; where the state rests right now
     BatchDev bd;
-    bool batchable = false;        // configuration served by k_batch (three filters of <= 31 frames, <= 512 tracks, ...)
+    bool batchable = false;        // configuration served by k_batch (three filters of <= 31 frames, <= 1024 tracks, ...)
     bool in_batch = false;         // the state rests in the seat-major arrays of `bd` (else: the per-slot layout)
     int link_mode = 0;             // ysmr_tracker_link_mode: 0 = the library's choice, 1 = one (or two) launches per frame
     size_t batch_lds = 0;
@@ -2099,9 +2106,10 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const size_t o_scal1 = take(sizeof(int) * 16), o_order1 = take(sizeof(int) * cap), o_gone1 = take(sizeof(int) * cap);
     const size_t o_rmin1 = take(sizeof(double) * cap), o_rarg1 = take(sizeof(int) * cap);
     // the batch link's rest format (seat-major) and its gain table
-    const size_t seat_cap = ysmr::align_up(cap, 64);
-    const size_t o_b64 = take(sizeof(double) * BL_F64 * seat_cap), o_b32 = take(sizeof(float) * 3 * seat_cap);
-    const size_t o_bi = take(sizeof(int) * 4 * seat_cap);
+    const size_t seat_cap = BL_THREADS;
+    const size_t o_ring = take(sizeof(double2) * BL_HB * seat_cap);
+    const size_t o_b64 = take(sizeof(double) * BL_SF64 * seat_cap), o_b32 = take(sizeof(float) * 3 * seat_cap);
+    const size_t o_bi = take(sizeof(int) * 6 * seat_cap);
     t->block_bytes = off;
     hipError_t e = hipMalloc(&t->block, off);
     if (e != hipSuccess) {
@@ -2124,7 +2132,9 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     d.link_key = (unsigned long long *)(b + o_lkey); d.link_row = (int *)(b + o_lrow); d.link_claim = (int *)(b + o_lclaim);
     d.claim_slot = (int *)(b + o_cslot);
     d.claim_row = (int *)(b + o_crow);
+    t->bd.ring = (double2 *)(b + o_ring);
     t->bd.f64 = (double *)(b + o_b64); t->bd.f32 = (float *)(b + o_b32); t->bd.i32 = (int *)(b + o_bi);
+    t->bd.head = scal + 12;
     t->bd.seat_cap = (int)seat_cap;
     t->bd.grid = nullptr; t->bd.grid_stride = 0;
     t->d1 = d;
@@ -2158,12 +2168,12 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     }
     t->d.gone_by_row = t->d1.gone_by_row = t->fused ? 1 : 0;
     // The batch link serves what tracking.ini's defaults ask for: up to three filters with horizons of at most 31 frames
-    // (hist_cap <= 32 register entries), decoupled gains, tables of at most 512 tracks -- a track per lane of ONE
+    // (hist_cap <= 32 ring entries), gains affine in a measurement's age, tables of at most 1024 tracks -- a track per lane of ONE
     // workgroup -- and detection counts whose tables fit its LDS.  Everything else links with one (or two) launches per
     // frame as before.
     t->batch_lds = bl_lds_bytes(max_det);
     t->batchable = t->fused && d.n_f <= BL_NF && d.hist_cap <= BL_HB && (!use_gsff || d.gains_decoupled) &&
-                   capacity <= BL_THREADS && t->batch_lds <= 150 * 1024 && !(mode_env && strcmp(mode_env, "batch"));
+                   capacity <= BL_THREADS && t->batch_lds <= 140 * 1024 && !(mode_env && strcmp(mode_env, "batch"));
     if (t->batchable &&
         hipFuncSetAttribute((const void *)k_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->batch_lds) != hipSuccess)
         t->batchable = false;
@@ -2237,7 +2247,7 @@ int ysmr_tracker_destroy(ysmr_tracker *t)
 static int state_to_std(ysmr_tracker *t, hipStream_t st)
 {
     if (!t->in_batch) return YSMR_OK;
-    hipLaunchKernelGGL(k_to_std, dim3((t->d.capacity + 255) / 256), dim3(256), 0, st, t->d, t->bd);
+    hipLaunchKernelGGL(k_to_std, dim3((std::max(t->d.capacity, t->bd.seat_cap) + 255) / 256), dim3(256), 0, st, t->d, t->bd);
     YSMR_LAUNCH_CHECK();
     t->in_batch = false;
     t->par = 0;
@@ -2247,7 +2257,7 @@ static int state_to_std(ysmr_tracker *t, hipStream_t st)
 static int state_to_batch(ysmr_tracker *t, hipStream_t st)
 {
     if (t->in_batch) return YSMR_OK;
-    hipLaunchKernelGGL(k_to_batch, dim3((t->d.capacity + 255) / 256), dim3(256), 0, st, t->cur(), t->bd);
+    hipLaunchKernelGGL(k_to_batch, dim3((t->bd.seat_cap + 255) / 256), dim3(256), 0, st, t->cur(), t->bd);
     YSMR_LAUNCH_CHECK();
     if (t->par) {      // the counters live in the parity-0 words from here on
         YSMR_HIP_CHECK(hipMemcpyAsync(t->d.n_tracks, t->d1.n_tracks, sizeof(int) * 2, hipMemcpyDeviceToDevice, st));
@@ -2307,8 +2317,8 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
         for (int f0 = 0; f0 < batch; f0 += BL_MAX_BATCH) {
             const int nb = batch - f0 < BL_MAX_BATCH ? batch - f0 : BL_MAX_BATCH;
             const float *det = det_dev + (size_t)f0 * t->d.max_det * 5;
-            hipLaunchKernelGGL(k_bgrid, dim3(nb), dim3(256), 0, (hipStream_t)stream, det, det_count_dev + f0, t->d.max_det,
-                               t->bd.grid, t->bd.grid_stride);
+            hipLaunchKernelGGL(k_bgrid, dim3(nb), dim3(BG_THREADS), t->bd.grid_stride, (hipStream_t)stream, det, det_count_dev + f0,
+                               t->d.max_det, t->bd.grid, t->bd.grid_stride);
             hipLaunchKernelGGL(k_batch, dim3(1), dim3(BL_THREADS), t->batch_lds, (hipStream_t)stream, t->d, t->bd, det,
                                det_count_dev + f0, nb, first_frame_index + f0, rows_dev, (long long)rows_capacity,
                                (long long *)row_count_dev, t->bgains);
@@ -2372,7 +2382,7 @@ int ysmr_tracker_peek(ysmr_tracker *t, void *stream, int32_t *ids_dev, double *x
 {
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
     if (t->in_batch)
-        hipLaunchKernelGGL(k_peek_batch, dim3((t->d.capacity + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d, t->bd,
+        hipLaunchKernelGGL(k_peek_batch, dim3((t->bd.seat_cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d, t->bd,
                            ids_dev, xy_dev, disappeared_dev, n_dev);
     else
         hipLaunchKernelGGL(k_peek, dim3((t->d.capacity + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->cur(), ids_dev,

@@ -64,7 +64,7 @@ class TrackingPipeline:
     appends every full buffer to ``<name>_list.csv`` as the reference does, so that an interrupted run keeps what was
     tracked.  ``link=False``: detection only (no tracker neighbour: the matrix-pipe threshold kernel is used)."""
 
-    def __init__(self, height, width, fps, settings, batch=64, max_det=2048, capacity=2048, device="cuda:0",
+    def __init__(self, height, width, fps, settings, batch=64, max_det=2048, capacity=768, device="cuda:0",
                  rows_per_flush=None, link=True):
         self.device = torch.device(device)
         self.B = int(batch)
@@ -252,7 +252,7 @@ class TrackingPipeline:
 
 #: device-side limits when neither the call nor the settings dict name any; a video that exceeds them is
 #: re-run with doubled limits (up to LIMIT_MAX), so they only decide how much HBM the first attempt takes
-DEFAULT_BATCH, DEFAULT_MAX_DET, DEFAULT_CAPACITY, LIMIT_MAX = 64, 2048, 2048, 32768
+DEFAULT_BATCH, DEFAULT_MAX_DET, DEFAULT_CAPACITY, LIMIT_MAX = 64, 2048, 768, 32768
 
 
 def track_bacteria(video_path, settings=None, result_folder=None, batch=None, max_det=None, capacity=None,
@@ -325,7 +325,7 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
         outcome = _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_det, capacity, device,
                                settings, logger, list_name if settings.get("hip persist rows") else None)
         if outcome[0] == "overflow" and 2 * max(max_det, capacity) <= LIMIT_MAX:
-            max_det, capacity = 2 * max_det, 2 * capacity
+            max_det, capacity = 2 * max_det, max(2 * capacity, max_det)
             logger.warning("More objects than the device buffers hold in file {}: running it again with "
                            "max_det = {}, capacity = {}".format(video_path, max_det, capacity))
             continue
