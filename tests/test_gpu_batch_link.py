@@ -226,3 +226,46 @@ def test_batch_link_capacity_overflow_is_reported(torch_cuda):
     trk.run(det, cnt, 0, rows, count)
     n, next_id, err = trk.info()
     assert n == 8 and err & 1 and next_id == 12 and int(count.item()) == 8
+
+
+def test_prepared_batches_give_the_same_rows(torch_cuda):
+    """``ysmr_tracker_prepare`` on another stream (the detection stream of a pipeline) takes the binning launch off the
+    link stream; the rows are those of an unprepared run, also when a prepared block is left unused and when the two
+    blocks are used out of turn."""
+    torch = torch_cuda
+    from ysmr_amd import _lib
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    rng = np.random.default_rng(2)
+    base = rng.uniform(0, 1000, (200, 2))
+    dets, cnts = [], []
+    for b in range(5):
+        det = torch.zeros(16, 256, 5, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(16, dtype=torch.int32, device="cuda")
+        for i in range(16):
+            keep = rng.random(200) > 0.06
+            xy = (base + rng.normal(0, 0.5, base.shape))[keep]
+            det[i, :len(xy), :2] = torch.from_numpy(xy.astype(np.float32)).cuda()
+            det[i, :len(xy), 2:] = 2.0
+            cnt[i] = len(xy)
+        dets.append(det); cnts.append(cnt)
+    kw = dict(max_disappeared=4.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=256, max_det=256)
+    out = []
+    side = torch.cuda.Stream()
+    for prepared in (False, True):
+        trk = DeviceTracker(**kw)
+        rows = torch.empty(5 * 16 * 256 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        count = torch.zeros(1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        for b in range(5):
+            if prepared and b != 3:                      # (batch 3: prepared for nobody -- run bins it itself)
+                side.wait_stream(torch.cuda.current_stream())    # (a block is free once the run that used it has executed)
+                with torch.cuda.stream(side):
+                    trk.prepare(dets[b], cnts[b], slot=b & 1)
+                    if b == 1:
+                        trk.prepare(dets[4], cnts[4], slot=0)   # a block prepared early, for a later batch; used in its turn
+                torch.cuda.current_stream().wait_stream(side)
+            trk.run(dets[b], cnts[b], 16 * b, rows, count)
+        torch.cuda.synchronize()
+        assert trk.info()[2] == 0
+        out.append(rows_to_numpy(rows, int(count.item())).copy())
+    assert len(out[0]) > 10000 and out[0].tobytes() == out[1].tobytes()

@@ -48,7 +48,7 @@ ABI_VERSION = 10   # YSMR_ABI_VERSION of include/ysmr_hip.h these argtypes were 
 EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_detect_workspace_init",
            "ysmr_threshold_batch", "ysmr_threshold_batch_variant", "ysmr_threshold_timing", "ysmr_fault_inject", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
-           "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_run_chained", "ysmr_tracker_fused", "ysmr_tracker_batched", "ysmr_tracker_link_mode", "ysmr_tracker_peek",
+           "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_run_chained", "ysmr_tracker_fused", "ysmr_tracker_batched", "ysmr_tracker_link_mode", "ysmr_tracker_prepare", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
            "ysmr_rows_format_csv", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks",
            "ysmr_evaluate_workspace_bytes", "ysmr_evaluate_tracks", "ysmr_unpack_dib_batch")
@@ -136,6 +136,7 @@ def lib():
     L.ysmr_tracker_fused.argtypes = [vp]
     L.ysmr_tracker_batched.argtypes = [vp]
     L.ysmr_tracker_link_mode.argtypes = [vp, ci]
+    L.ysmr_tracker_prepare.argtypes = [vp, vp, vp, vp, ci, ci]
     L.ysmr_tracker_info.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
                                     ctypes.POINTER(ctypes.c_int32)]
     L.ysmr_rows_sort_workspace_bytes.argtypes = [ctypes.c_longlong]

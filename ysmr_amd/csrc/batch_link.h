@@ -334,9 +334,12 @@ __device__ __forceinline__ void bl_gsff(BlSeat &S, const TrackerDev &t, const Ba
         lik[f] = l;
         total = (f < mode) ? total + l * S.w[f] : total;
     }
+    // w_i <- lik_i w_i / total (gsff.py:333-336) as lik_i w_i * (1 / total): one division for the three weights; a weight
+    // may differ from the quotient in its last bit (the per-frame kernels divide three times)
+    const double r_total = 1.0 / total;
 #pragma unroll
     for (int f = 0; f < BL_NF; ++f) {
-        const double wn = lik[f] * S.w[f] / total;
+        const double wn = (lik[f] * S.w[f]) * r_total;
         S.w[f] = (f < mode) ? wn : S.w[f];
     }
     // output = np.sum(x_hat * w, axis=1) = a0 + (a1 + a2)
@@ -432,6 +435,7 @@ __device__ __forceinline__ BlNear bl_search(const BlGridView &g, double px, doub
     const int G = g.G;
     const float fx = (float)px, fy = (float)py;
     int cx = (int)floorf((fx - g.x0) * g.inv), cy = (int)floorf((fy - g.y0) * g.inv);
+    const bool in_grid = cx >= 0 && cx < G && cy >= 0 && cy < G;
     cx = cx < 0 ? 0 : (cx > G - 1 ? G - 1 : cx);
     cy = cy < 0 ? 0 : (cy > G - 1 ? G - 1 : cy);
     const int xl = max(cx - 1, 0), xh = min(cx + 1, G - 1), yl = max(cy - 1, 0), yh = min(cy + 1, G - 1);
@@ -484,16 +488,22 @@ __device__ __forceinline__ BlNear bl_search(const BlGridView &g, double px, doub
     const int slot = (int)(lo & 15u);
     const int run = slot >= 2 * C ? 2 : (slot >= C ? 1 : 0);
     const int bq = slot == 15 ? q_extra : (run == 2 ? a[2] : (run == 1 ? a[1] : a[0])) + slot - C * run;
-    // distance to the outside of the block; a side on the edge of the grid has nothing beyond it
-    const float big = 3.0e38f;
-    float bound = big;
-    if (xl > 0) bound = fminf(bound, fx - (g.x0 + (float)xl * g.cell));
-    if (xh < G - 1) bound = fminf(bound, (g.x0 + (float)(xh + 1) * g.cell) - fx);
-    if (yl > 0) bound = fminf(bound, fy - (g.y0 + (float)yl * g.cell));
-    if (yh < G - 1) bound = fminf(bound, (g.y0 + (float)(yh + 1) * g.cell) - fy);
-    bound -= 1e-3f * g.cell;
+    // Nothing outside the block is as near: a prediction inside the grid lies in its own cell, a whole cell away from the
+    // block's boundary -- one comparison for nearly every lane; the others measure the distance to the outside of the
+    // block (a side on the edge of the grid has nothing beyond it)
     const bool found = lo != 0xFFFFFFFFu;
-    const bool inside = bound >= big * 0.5f || (bound > 0.f && bound * bound > band);
+    const float reach = 0.998f * g.cell;
+    bool inside = in_grid && band < reach * reach;
+    if (!inside) {
+        const float big = 3.0e38f;
+        float bound = big;
+        if (xl > 0) bound = fminf(bound, fx - (g.x0 + (float)xl * g.cell));
+        if (xh < G - 1) bound = fminf(bound, (g.x0 + (float)(xh + 1) * g.cell) - fx);
+        if (yl > 0) bound = fminf(bound, fy - (g.y0 + (float)yl * g.cell));
+        if (yh < G - 1) bound = fminf(bound, (g.y0 + (float)(yh + 1) * g.cell) - fy);
+        bound -= 1e-3f * g.cell;
+        inside = bound >= big * 0.5f || (bound > 0.f && bound * bound > band);
+    }
     const float2 cw = g.xy_at(found ? bq : 0);
     BlNear r;
     r.s = bl_dist2(px, py, cw);
@@ -595,6 +605,8 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
     const int tab_off = 6 * mdp + 2 * bufw;
     const int seats = min(t.capacity, BL_THREADS);
     const int nf = t.n_f;
+    const int gone_max = (int)floor(t.max_gone);        // tracker.py:104, 208: disappeared > maxDisappeared, a float
+    // (max_disappeared < 32000 for a one-launch handle, so the conversion is exact)
     const int hn[BL_NF] = {t.n_i[0], nf > 1 ? t.n_i[1] : 1, nf > 2 ? t.n_i[2] : 1};    // horizons (ring offsets of the leavers)
 
     // ---- start of the batch: counters, this lane's track, the first frame's detections
@@ -702,7 +714,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         } else if (S.alive && age) {
             ++S.gone;
             box[0] = box[1] = box[2] = 0.f;
-            if ((double)S.gone > t.max_gone) { S.alive = false; died = true; }
+            if (S.gone > gone_max) { S.alive = false; died = true; }
         }
         {
             const unsigned long long bm = __ballot(mine), bx = __ballot(died);

@@ -133,6 +133,8 @@ struct ysmr_tracker {
     int link_mode = 0;             // ysmr_tracker_link_mode: 0 = the library's choice, 1 = one (or two) launches per frame
     size_t batch_lds = 0;
     BlGains bgains;
+    // ysmr_tracker_prepare: which batch each of the two caller-named grid blocks was binned for (block 2 is run's own)
+    struct Prepared { const void *det = nullptr; const void *count = nullptr; int batch = 0; } prepared[2];
     bool use_batch() const { return batchable && link_mode == 0; }
     DetGrid grid(int f) const
     {
@@ -2195,12 +2197,13 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     // the per-frame grids of a batch: sized here, once, for BL_MAX_BATCH frames (longer batches are cut to that)
     {
         const size_t per = t->batchable ? (size_t)bl_grid_dwords_max(max_det) * 4 : ysmr_tracker::grid_bytes_per_frame(max_det);
+        const size_t blocks = t->batchable ? 3 : 1;      // (two for ysmr_tracker_prepare's callers, one for ysmr_tracker_run itself)
         if (t->batchable || !t->fused) {
-            e = hipMalloc(&t->grid_block, per * BL_MAX_BATCH);
+            e = hipMalloc(&t->grid_block, per * BL_MAX_BATCH * blocks);
             if (e != hipSuccess) {
                 (void)hipFree(t->block);
                 delete t;
-                return ysmr::fail(YSMR_ERR_HIP, "hipMalloc(%zu) failed: %s", per * BL_MAX_BATCH, hipGetErrorString(e));
+                return ysmr::fail(YSMR_ERR_HIP, "hipMalloc(%zu) failed: %s", per * BL_MAX_BATCH * blocks, hipGetErrorString(e));
             }
             t->grid_frames = BL_MAX_BATCH;
             t->bd.grid = (char *)t->grid_block;
@@ -2282,6 +2285,19 @@ int ysmr_debug_read_bstamps(unsigned long long *out) { return (int)hipMemcpyFrom
 
 int ysmr_tracker_batched(ysmr_tracker *t) { return t && t->use_batch() ? 1 : 0; }
 
+int ysmr_tracker_prepare(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch, int slot)
+{
+    if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
+    if (!det_dev || !det_count_dev || batch <= 0 || slot < 0 || slot > 1)
+        return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev must be set, batch > 0, slot 0 or 1");
+    if (!t->use_batch() || batch > BL_MAX_BATCH) return YSMR_OK;       // (nothing to prepare: ysmr_tracker_run does it all)
+    hipLaunchKernelGGL(k_bgrid, dim3(batch), dim3(BG_THREADS), t->bd.grid_stride, (hipStream_t)stream, det_dev, det_count_dev,
+                       t->d.max_det, t->bd.grid + (size_t)slot * BL_MAX_BATCH * t->bd.grid_stride, t->bd.grid_stride);
+    YSMR_LAUNCH_CHECK();
+    t->prepared[slot].det = det_dev; t->prepared[slot].count = det_count_dev; t->prepared[slot].batch = batch;
+    return YSMR_OK;
+}
+
 int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int det_is_f64, int m,
                         const int32_t *m_dev, int32_t frame_index, ysmr_row *rows_dev, int32_t *n_rows_dev,
                         int32_t *claim_col_dev, int32_t *n_before_dev, int32_t *new_cols_dev, int32_t *n_new_dev)
@@ -2317,9 +2333,20 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
         for (int f0 = 0; f0 < batch; f0 += BL_MAX_BATCH) {
             const int nb = batch - f0 < BL_MAX_BATCH ? batch - f0 : BL_MAX_BATCH;
             const float *det = det_dev + (size_t)f0 * t->d.max_det * 5;
-            hipLaunchKernelGGL(k_bgrid, dim3(nb), dim3(BG_THREADS), t->bd.grid_stride, (hipStream_t)stream, det, det_count_dev + f0,
-                               t->d.max_det, t->bd.grid, t->bd.grid_stride);
-            hipLaunchKernelGGL(k_batch, dim3(1), dim3(BL_THREADS), t->batch_lds, (hipStream_t)stream, t->d, t->bd, det,
+            // the batch's detections binned frame by frame: by ysmr_tracker_prepare ahead of this call, or here
+            int block = 2;
+            for (int s = 0; s < 2; ++s)
+                if (f0 == 0 && batch <= BL_MAX_BATCH && t->prepared[s].det == (const void *)det_dev &&
+                    t->prepared[s].count == (const void *)det_count_dev && t->prepared[s].batch == batch) {
+                    block = s;
+                    t->prepared[s] = ysmr_tracker::Prepared();       // (good for one call)
+                }
+            BatchDev bd = t->bd;
+            bd.grid = t->bd.grid + (size_t)block * BL_MAX_BATCH * t->bd.grid_stride;
+            if (block == 2)
+                hipLaunchKernelGGL(k_bgrid, dim3(nb), dim3(BG_THREADS), t->bd.grid_stride, (hipStream_t)stream, det,
+                                   det_count_dev + f0, t->d.max_det, bd.grid, bd.grid_stride);
+            hipLaunchKernelGGL(k_batch, dim3(1), dim3(BL_THREADS), t->batch_lds, (hipStream_t)stream, t->d, bd, det,
                                det_count_dev + f0, nb, first_frame_index + f0, rows_dev, (long long)rows_capacity,
                                (long long *)row_count_dev, t->bgains);
             YSMR_LAUNCH_CHECK();

@@ -106,6 +106,7 @@ class TrackingPipeline:
                              threshold_variant=1 if beside_fused_link else 0)
                     for _ in range(2)]
         self.capacity = int(capacity)
+        self._link = bool(link)
         self._chain = self.trk.fused        # (the two-launch link of large tables has nothing to chain)
         n_rows = self.B * self.capacity if rows_per_flush is None else int(rows_per_flush)
         self.rows = torch.empty(n_rows * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
@@ -165,6 +166,8 @@ class TrackingPipeline:
                     e2 = events[2] if events else torch.cuda.Event(enable_timing=True)
                     e2.record(self.side)
                     chain_events.append((e1, e2, frames_dev.shape[0]))
+            if self._link and self.trk.batched:      # the link's binning of these detections, off the link stream
+                self.trk.prepare(res.det, res.det_count, slot)
             ready = self._ev[slot]["ready"]
             ready.record(self.side)
         return slot, res, ready

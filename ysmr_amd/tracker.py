@@ -91,6 +91,14 @@ class DeviceTracker:
                                                  rows.numel() // _lib.ROW_DTYPE.itemsize, row_count.data_ptr(), a_det, a_cnt)
         _lib.check(rc, "ysmr_tracker_run_chained")
 
+    @_on_own_device
+    def prepare(self, det, det_count, slot):
+        """Bin a batch's detections for the ``run`` that follows, on the CURRENT stream (``ysmr_tracker_prepare``: takes
+        that launch off the link stream's chain when called on the detection stream).  No-op unless ``batched``."""
+        rc = _lib.lib().ysmr_tracker_prepare(self._handle, _lib.stream_ptr(self.device), det.data_ptr(), det_count.data_ptr(),
+                                             det_count.numel(), int(slot))
+        _lib.check(rc, "ysmr_tracker_prepare")
+
     @property
     def fused(self):
         """True when the handle links with one launch per frame (``k_frame``)."""
