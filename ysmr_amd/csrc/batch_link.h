@@ -282,6 +282,8 @@ __device__ __forceinline__ void bl_gsff(BlSeat &S, const TrackerDev &t, const Ba
     int len = fresh ? 0 : S.len, mode = fresh ? 0 : S.mode;
     if (len == 0) {      // history starts as n_i[0] copies of the first measurement (gsff.py:281)
         const int n0 = n_i[0];
+#pragma unroll
+        for (int f = 0; f < BL_NF; ++f) { S.w[f] = 0.0; S.xa[f] = 0.0; S.xb[f] = 0.0; }
         const double c1 = (double)(n0 * (n0 - 1) / 2);
 #pragma unroll
         for (int f = 0; f < BL_NF; ++f) {
@@ -295,13 +297,15 @@ __device__ __forceinline__ void bl_gsff(BlSeat &S, const TrackerDev &t, const Ba
     if (mode == 0 && 0 < nf && len >= n_i[0]) { mode = 1; grew = true; }
     if (mode == 1 && 1 < nf && len >= n_i[1]) { mode = 2; grew = true; }
     if (mode == 2 && 2 < nf && len >= n_i[2]) { mode = 3; grew = true; }
+    // Filters that are not switched on yet carry weight 0 (and finite estimates): every sum below may then run over all
+    // three without a select -- adding a zero term is exact, so a0 + (a1 + a2) is the reference's a0, or a0 + a1
     if (grew) {          // the estimates of every active filter from the history as it stands, uniform weights
         const double w0 = mode == 1 ? 1.0 : (mode == 2 ? 0.5 : 1.0 / 3.0);
 #pragma unroll
         for (int f = 0; f < BL_NF; ++f)
             if (f < mode) {
-                S.xa[f] = g.alpha[f][0] * S.s0x[f] - g.beta[f][0] * S.s1x[f];
-                S.xb[f] = g.alpha[f][1] * S.s0y[f] - g.beta[f][1] * S.s1y[f];
+                S.xa[f] = __builtin_fma(-g.beta[f][0], S.s1x[f], g.alpha[f][0] * S.s0x[f]);
+                S.xb[f] = __builtin_fma(-g.beta[f][1], S.s1y[f], g.alpha[f][1] * S.s0y[f]);
                 S.w[f] = w0;
             }
     }
@@ -317,8 +321,8 @@ __device__ __forceinline__ void bl_gsff(BlSeat &S, const TrackerDev &t, const Ba
         S.s1y[f] = __builtin_fma(nn, ly, S.s1y[f] + S.s0y[f]);
         S.s0x[f] = (S.s0x[f] + z0) - lx;
         S.s0y[f] = (S.s0y[f] + z1) - ly;
-        nx0[f] = g.alpha[f][0] * S.s0x[f] - g.beta[f][0] * S.s1x[f];
-        nx1[f] = g.alpha[f][1] * S.s0y[f] - g.beta[f][1] * S.s1y[f];
+        nx0[f] = __builtin_fma(-g.beta[f][0], S.s1x[f], g.alpha[f][0] * S.s0x[f]);
+        nx1[f] = __builtin_fma(-g.beta[f][1], S.s1y[f], g.alpha[f][1] * S.s0y[f]);
     }
     bl_ring_store(bd, head, seat, z0, z1);
     if (len < L) ++len;
@@ -332,41 +336,21 @@ __device__ __forceinline__ void bl_gsff(BlSeat &S, const TrackerDev &t, const Ba
         double l = exp(-0.5 * q);
         if (l < t.lik_min) l = t.lik_min;
         lik[f] = l;
-        total = (f < mode) ? total + l * S.w[f] : total;
+        total = total + l * S.w[f];
     }
     // w_i <- lik_i w_i / total (gsff.py:333-336) as lik_i w_i * (1 / total): one division for the three weights; a weight
     // may differ from the quotient in its last bit (the per-frame kernels divide three times)
     const double r_total = 1.0 / total;
 #pragma unroll
-    for (int f = 0; f < BL_NF; ++f) {
-        const double wn = (lik[f] * S.w[f]) * r_total;
-        S.w[f] = (f < mode) ? wn : S.w[f];
-    }
+    for (int f = 0; f < BL_NF; ++f) S.w[f] = (lik[f] * S.w[f]) * r_total;
     // output = np.sum(x_hat * w, axis=1) = a0 + (a1 + a2)
-    double f0 = 0.0, f1 = 0.0, r0 = 0.0, r1 = 0.0;
-#pragma unroll
-    for (int f = 0; f < BL_NF; ++f)
-        if (f < mode) {
-            const double a = S.xa[f] * S.w[f], b = S.xb[f] * S.w[f];
-            if (f == 0) { f0 = a; f1 = b; }
-            else if (f == 1) { r0 = a; r1 = b; }
-            else { r0 = r0 + a; r1 = r1 + b; }
-        }
-    o0 = mode > 1 ? f0 + r0 : f0;
-    o1 = mode > 1 ? f1 + r1 : f1;
+    o0 = S.xa[0] * S.w[0] + (S.xa[1] * S.w[1] + S.xa[2] * S.w[2]);
+    o1 = S.xb[0] * S.w[0] + (S.xb[1] * S.w[1] + S.xb[2] * S.w[2]);
     // predict: the new estimates, weighted
-    f0 = f1 = r0 = r1 = 0.0;
 #pragma unroll
-    for (int f = 0; f < BL_NF; ++f)
-        if (f < mode) {
-            S.xa[f] = nx0[f]; S.xb[f] = nx1[f];
-            const double a = S.xa[f] * S.w[f], b = S.xb[f] * S.w[f];
-            if (f == 0) { f0 = a; f1 = b; }
-            else if (f == 1) { r0 = a; r1 = b; }
-            else { r0 = r0 + a; r1 = r1 + b; }
-        }
-    S.px = mode > 1 ? f0 + r0 : f0;
-    S.py = mode > 1 ? f1 + r1 : f1;
+    for (int f = 0; f < BL_NF; ++f) { S.xa[f] = nx0[f]; S.xb[f] = nx1[f]; }
+    S.px = S.xa[0] * S.w[0] + (S.xa[1] * S.w[1] + S.xa[2] * S.w[2]);
+    S.py = S.xb[0] * S.w[0] + (S.xb[1] * S.w[1] + S.xb[2] * S.w[2]);
     S.len = len; S.mode = mode;
 }
 
@@ -579,6 +563,7 @@ struct BlShared {      // static part of the LDS
     int dead_id[2][BL_THREADS];      // ids of the tracks deregistered in the frame
     int wave_cnt[2][BL_WAVES];       // registration: per-wave counts of the two ranked lists
     int set_state[2];
+    int top;                         // one past the highest seat ever taken
 };
 
 __host__ __device__ inline int bl_md_padded(int max_det) { return (max_det + 3) / 4 * 4; }
@@ -618,6 +603,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         sh.cnt[f] = m < 0 ? 0 : m;
     }
     if (tid < 2) { sh.used[tid] = 0; sh.n_dead[tid] = 0; }
+    if (tid == 0) sh.top = 0;
     BlSeat S;
     bl_seat_blank(S);
     if (n > 0 && tid < seats && bd.i32[5 * (size_t)bd.seat_cap + tid]) {     // (an empty table: whatever the flags say)
@@ -625,10 +611,19 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         S.alive = true;
     }
     __syncthreads();
+    if (lane == 0 && __ballot(S.alive)) atomicMax(&sh.top, 64 * (wave + 1));
+    __syncthreads();
+    // The chores of a frame -- the next frame's LDS-DMA, clearing its tables -- go to the waves that hold no track, when
+    // there are any: with 9 of 12 waves in use, three of them share one SIMD and set the frame's pace, and the idle waves
+    // sit on the other SIMDs.  (Seats are handed out lowest first, so the waves in use are the first ones.)
+    int helpers_from = (sh.top + 63) >> 6;               // first wave without a track; BL_WAVES: none
+    auto chore_first = [&]() { return helpers_from < BL_WAVES ? tid - 64 * helpers_from : tid; };
+    auto chore_stride = [&]() { return helpers_from < BL_WAVES ? 64 * (BL_WAVES - helpers_from) : BL_THREADS; };
     auto dma = [&](int f) {        // frame f's block -> s_buf[f & 1], whole 1-KiB pieces, a wave-instruction each
         const int pieces = bl_grid_dwords(sh.cnt[f]) >> 8;
         const char *src = bd.grid + (size_t)bd.grid_stride * f;
-        for (int c = wave; c < pieces; c += BL_WAVES) {
+        const int w0 = helpers_from < BL_WAVES ? helpers_from : 0, nw = BL_WAVES - w0;
+        for (int c = wave - w0; c >= 0 && c < pieces; c += nw) {
             const uint32_t lds = (uint32_t)(uintptr_t)(bl_u32(buf_off(f & 1) + c * 256));
             const uint32_t off = (uint32_t)c * 1024u + (uint32_t)lane * 16u;
             asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(off), "s"(src) : "memory");
@@ -683,8 +678,8 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         block_sync<true>();
         BLSTAMP(3);
         // (the other parity's tables and counters were last read before the end of the previous frame)
-        for (int c = tid; c < m_next; c += BL_THREADS) { key_at(par ^ 1)[c] = ~0ull; cid_at(par ^ 1)[c] = 0xFFFFFFFFu; }
-        if (tid == 0) { sh.used[par ^ 1] = 0; sh.n_dead[par ^ 1] = 0; }
+        for (int c = chore_first(); c >= 0 && c < m_next; c += chore_stride()) { key_at(par ^ 1)[c] = ~0ull; cid_at(par ^ 1)[c] = 0xFFFFFFFFu; }
+        if (tid == BL_THREADS - 1) { sh.used[par ^ 1] = 0; sh.n_dead[par ^ 1] = 0; }
         if (propose) {
             // the proposers at the column's smallest DISTANCE contend by id (tracker.py:158: ascending row minimum, then
             // row).  sqrt is monotone, so that is the smallest s -- and, once in a blue moon, an s a few ulps above it
@@ -776,9 +771,11 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
                 box[0] = d[2]; box[1] = d[3]; box[2] = d[4];
                 S.id = next_id + fr; S.rank = n + fr; S.gone = 0;
                 S.alive = true; fresh = true;
+                atomicMax(&sh.top, tid + 1);
             }
             __syncthreads();     // (the lists lived in the next frame's tables)
             for (int c = tid; c < m_next; c += BL_THREADS) { key_at(par ^ 1)[c] = ~0ull; cid_at(par ^ 1)[c] = 0xFFFFFFFFu; }
+            helpers_from = (sh.top + 63) >> 6;
         }
         // ---- the filter bank (tracker.py:219-227)
         BLSTAMP(6);
@@ -838,10 +835,12 @@ __global__ void k_to_batch(TrackerDev a, BatchDev bd)
             bd.ring[(size_t)((head - 1 - e) & (BL_HB - 1)) * sc + r] = make_double2(hist[2 * e], hist[2 * e + 1]);
         double *p = bd.f64 + r;
         const double *rec = a.rec + (size_t)slot * a.rec_stride;
-        for (int f = 0; f < BL_NF; ++f) {
-            p[sc * f] = f < nf ? rec[2 + f] : 0.0;
-            p[sc * (BL_NF + f)] = f < nf ? rec[2 + nf + f] : 0.0;
-            p[sc * (2 * BL_NF + f)] = f < nf ? rec[2 + 2 * nf + f] : 0.0;
+        const int mode_r = (int)(__double_as_longlong(rec[1]) & 0xFFFFFFFFll);
+        for (int f = 0; f < BL_NF; ++f) {      // (a filter that is not switched on: weight 0, as k_batch keeps it)
+            const bool on = f < nf && f < mode_r;
+            p[sc * f] = on ? rec[2 + f] : 0.0;
+            p[sc * (BL_NF + f)] = on ? rec[2 + nf + f] : 0.0;
+            p[sc * (2 * BL_NF + f)] = on ? rec[2 + 2 * nf + f] : 0.0;
         }
         p[sc * (3 * BL_NF)] = a.pos[slot];
         p[sc * (3 * BL_NF + 1)] = a.pos[cap + slot];
