@@ -67,7 +67,11 @@ extern "C" {
  * every compute unit, and ysmr_components_batch launches k_windows / k_geometry with the smaller resident grids that
  * leave the link's workgroups their 59 KB of LDS per unit (detection alone is ~8 % slower that way). */
 #define YSMR_BESIDE_LINK     4
-#define YSMR_CV_FLAVOUR_MASK 7
+/* ... and the hint for a handle that links a whole batch with one launch (ysmr_tracker_batched): that launch holds ONE
+ * compute unit for the length of the batch.  The matrix-pipe threshold kernel, which gives every compute unit one
+ * workgroup, then cuts its rows for the 255 units that are there (same bytes). */
+#define YSMR_BESIDE_BATCH_LINK 8
+#define YSMR_CV_FLAVOUR_MASK 15
 
 /* One output row: a live track in one frame (ysmr/track_eval.py:313-316,
  * CSV columns TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE). */
@@ -235,12 +239,10 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
  * to rows_dev (capacity rows_capacity) starting at *row_count_dev, which is advanced; rows of a
  * frame are contiguous and in ascending id order.  Overflow sets *row_count_dev past capacity
  * (rows beyond capacity are dropped); the host checks after synchronising. */
-/* ysmr_tracker_run when the caller knows which frame comes next: after_det_dev f32 [max_det][5] / after_count_dev i32 [1]
- * are the detections of the frame that follows this call's last one (the next batch's first frame, already on the device
- * and complete before this call's LAST launch executes: the caller orders that with an event on `stream`).  The last
- * launch then also finds that frame's nearest detections, as every other launch of the call does for its successor, and
- * the next ysmr_tracker_run / _chained call that starts at after_det_dev skips the launch that would have done it
- * (8-11 us per batch).  Both NULL = ysmr_tracker_run.  The two-launch link of large tables ignores them. */
+/* ysmr_tracker_run with two more arguments, kept for callers written against ABI 9: after_det_dev f32 [max_det][5] /
+ * after_count_dev i32 [1] named the frame that follows this call's last one, so that the last launch of a one-launch-per-
+ * frame handle could find that frame's nearest detections too.  Since ABI 10 both are IGNORED (they may be NULL): the
+ * shortcut read a counter its own launch writes, and the handles it paid for link a whole batch with one launch now. */
 int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
                              int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev,
                              const float *after_det_dev, const int32_t *after_count_dev);

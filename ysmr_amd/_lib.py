@@ -23,6 +23,8 @@ DET_STALLED = 4
 CV_DEFAULT, CV_ANGLE_PRE451, CV_GRAY_3X = 0, 1, 2
 #: scheduling hint in the same argument: the one-launch link runs on another stream beside the call (YSMR_BESIDE_LINK)
 BESIDE_LINK = 4
+#: ... and for the one-launch-per-batch link, which holds one compute unit (YSMR_BESIDE_BATCH_LINK)
+BESIDE_BATCH_LINK = 8
 
 
 def cv_flavour_of(version):

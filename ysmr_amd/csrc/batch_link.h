@@ -497,12 +497,42 @@ __device__ __forceinline__ BlNear bl_search(const BlGridView &g, double px, doub
     return r;
 }
 
-// The same for ONE track by the whole wave, exactly: every detection of the frame, 512 at a time (eight per lane, their
-// reads in flight together), rowmin_wave's three passes: the smallest squared distance; the lowest column within 2^-48 of
-// it; the rounded roots themselves only if some s differs from the smallest at all.  px, py, the result: wave-uniform.
+// The same for ONE track by the whole wave over EVERY detection of the frame, 512 at a time (eight per lane, their reads
+// in flight together).  First in float, like bl_search: when exactly one detection lies within the float error band of
+// the smallest float distance it is the argmin, and its float64 distance is evaluated once (a lost track far from
+// everything: most calls end here).  Otherwise exactly, rowmin_wave's three passes: the smallest squared distance; the
+// lowest column within 2^-48 of it; the rounded roots themselves only if some s differs from the smallest at all.
+// px, py, the result: wave-uniform.
 __device__ __forceinline__ BlNear bl_search_wave(const BlGridView &g, double px, double py, int m, int lane)
 {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    BlNear r;
+    r.done = true;
+    if (m <= 512) {
+        const float fx = (float)px, fy = (float)py;
+        float sf[8];
+        int lo = 0x7F800000;                              // (a non-negative float orders like its bits, as an int too)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = u * 64 + lane;
+            sf[u] = j < m ? bl_dist2f(fx, fy, g.xy_at(min(j, m - 1))) : 3.0e38f;
+            lo = min(lo, (int)__float_as_uint(sf[u]));
+        }
+        const float best = __uint_as_float((uint32_t)wave_min(lo));
+        const float band = best + (0.2f + 5e-6f * best);
+        int n_near = 0, jn = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long b = __ballot(sf[u] <= band);
+            n_near += (int)__popcll(b);
+            if (b) jn = u * 64 + __builtin_ctzll(b);
+        }
+        if (n_near == 1) {
+            const float2 c = g.xy_at(jn);
+            r.s = bl_dist2(px, py, c); r.zx = c.x; r.zy = c.y; r.col = g.item_at(jn);
+            return r;
+        }
+    }
     double lane_min = inf;
     for (int j0 = 0; j0 < m; j0 += 512) {
         float2 c[8];
@@ -542,8 +572,7 @@ __device__ __forceinline__ BlNear bl_search_wave(const BlGridView &g, double px,
     }
     const int win = wave_min(cand);
     const float2 c = g.xy_at(win & 0x7FFF);
-    BlNear r;
-    r.s = s_min; r.zx = c.x; r.zy = c.y; r.col = win >> 15; r.done = true;
+    r.s = s_min; r.zx = c.x; r.zy = c.y; r.col = win >> 15;
     return r;
 }
 

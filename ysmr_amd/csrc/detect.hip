@@ -2217,7 +2217,8 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
     t_thr_events[0] = t_thr_events[1] = nullptr;
     const bool timed = ev0 || ev1;
     if (variant != 1 && ysmr_thr::supported(H, W, channels, t_low, t_high, use_high))
-        return ysmr_thr::launch(st, frames, cls, batch, H, W, inv, t_low, t_high, use_high, gk.k, knobs().thr_blocks,
+        return ysmr_thr::launch(st, frames, cls, batch, H, W, inv, t_low, t_high, use_high, gk.k,
+                                knobs().thr_blocks > 0 ? knobs().thr_blocks : ((cv_flavour & YSMR_BESIDE_BATCH_LINK) ? 255 : 0),
                                 variant >= 2 ? variant - 1 : 0, ev0, ev1);
     if (variant >= 2) return ysmr::fail(YSMR_ERR_ARG, "the matrix-pipe threshold kernel does not serve this geometry");
     const int t_gap = use_high ? (t_high > t_low ? t_high - t_low : t_low - t_high) : 0;

@@ -8,8 +8,7 @@ namespace ysmr_thr {
 struct Params {
     int H, W, batch;
     int panels, panel_w;   // column panels of at most 1232 columns (a multiple of 16 wide, the last one may be narrower)
-    int bands, band_h;     // bands of rows (a multiple of 16 high)
-    int by_xcd;            // frames are dealt to the 8 XCDs
+    int by_xcd;            // frames are dealt to the 8 XCDs (a grid that is a multiple of 8)
     int inv, use_high, t_low, t_high;
     // x = S * (theta - v) * sign + 127.5 saturates to byte 0 / 255 outside EPS of the level theta (v = mean - blurred)
     float x_mul, neg_x_mul, lo_add, hi_minus_lo;

@@ -259,23 +259,28 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
     if (tid == 0) L.n_list = 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    const int per_frame = P.panels * P.bands;
-    long long first, stride, count;
-    int f_mul, f_add;
-    if (P.by_xcd) {
-        first = blockIdx.x >> 3; stride = gridDim.x >> 3; count = (long long)(P.batch >> 3) * per_frame; f_mul = 8; f_add = (int)(blockIdx.x & 7u);
-    } else {
-        first = blockIdx.x; stride = gridDim.x; count = (long long)P.batch * per_frame; f_mul = 1; f_add = 0;
-    }
+    // Work: the rows of every (frame, panel) column, laid end to end and cut into one equal range per workgroup -- whatever
+    // the number of workgroups (256; 255 when the batch link holds a compute unit: with one item per workgroup and one unit
+    // short, the last item started when the others ended and the kernel took twice its time).  A range that crosses the
+    // end of a column is two items (each re-filters its own 16 halo rows).  With a grid that is a multiple of 8 every XCD
+    // works through whole frames (f = 8 k + xcd), so a range's halo rows come out of the XCD's own L2.
+    const int groups = P.by_xcd ? 8 : 1;
+    const long long cols = (long long)(P.batch / groups) * P.panels, rows_all = cols * H;
+    const long long nb = gridDim.x / groups, bi = P.by_xcd ? (blockIdx.x >> 3) : blockIdx.x;
+    long long g0 = rows_all * bi / nb;
+    const long long g1 = rows_all * (bi + 1) / nb;
+    const int f_add = P.by_xcd ? (int)(blockIdx.x & 7u) : 0;
 
-    for (long long item = first; item < count; item += stride) {
+    while (g0 < g1) {
         ThrItem it;
         {
-            const int rem = (int)(item % per_frame);
-            it.f = (int)(item / per_frame) * f_mul + f_add;
-            const int panel = rem % P.panels, band = rem / P.panels;
+            const long long col = g0 / H;
+            it.f = (int)(col / P.panels) * groups + f_add;
+            const int panel = (int)(col % P.panels);
             it.x0 = panel * P.panel_w; it.x1 = min(it.x0 + P.panel_w, W);
-            it.y0 = band * P.band_h;   it.y1 = min(it.y0 + P.band_h, H);
+            it.y0 = (int)(g0 % H);
+            it.y1 = (int)min((long long)H, it.y0 + (g1 - g0));
+            g0 += it.y1 - it.y0;
         }
         const uint8_t *frame = frames + (size_t)it.f * H * W;
         uint8_t *dst = cls + (size_t)it.f * H * W;
@@ -588,16 +593,6 @@ int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H
     P.panel_w = ((W + P.panels - 1) / P.panels + 15) & ~15;
     P.panels = (W + P.panel_w - 1) / P.panel_w;
     const int blocks = blocks_wanted > 0 ? blocks_wanted : 256 * (int)((160 * 1024) / sizeof(Lds));   // every CU full
-    // bands: as tall as they can be while every resident workgroup still has an item (an item re-filters 16 halo rows),
-    // a multiple of 16 rows, at least 32
-    {
-        const long long columns = (long long)batch * P.panels;
-        const long long per_col = std::max<long long>(1, blocks / std::max<long long>(1, columns));
-        int bh = (int)((H + per_col - 1) / per_col);
-        bh = std::max(32, (bh + 15) & ~15);
-        P.band_h = bh;
-        P.bands = (H + bh - 1) / bh;
-    }
     P.inv = inv; P.use_high = use_high; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
     for (int i = 0; i < 6; ++i) P.kw[i] = gauss11[i];
     // v = mean - b.  BINARY: bit = (b - m > t) <=> v < -t - 0.5;  INV: bit = (b - m <= t) <=> v > -t - 0.5 (ties: exact path).
@@ -609,9 +604,9 @@ int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H
     // one level: the second byte is always 0x00 and both class bits come from the first
     P.hi_minus_lo = use_high ? sgn * S * (float)(t_low - t_high) : -1e30f;
     P.lo_bits = use_high ? 0x01010101u : 0x03030303u;
-    const long long items = (long long)batch * P.panels * P.bands;
-    long long grid = std::min<long long>(items, blocks);
-    P.by_xcd = (batch % 8 == 0 && grid % 8 == 0 && grid / 8 <= (long long)(batch / 8) * P.panels * P.bands) ? 1 : 0;
+    // (no workgroup with fewer than 32 rows: an item re-filters 16 halo rows)
+    long long grid = std::max<long long>(1, std::min<long long>((long long)batch * P.panels * H / 32, blocks));
+    P.by_xcd = (batch % 8 == 0 && grid % 8 == 0) ? 1 : 0;
     const size_t lds = sizeof(Lds);
     auto kern = variant == 2 ? k_threshold_mfma<2> : k_threshold_mfma<0>;
     YSMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

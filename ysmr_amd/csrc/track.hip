@@ -2354,7 +2354,12 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
         return YSMR_OK;
     }
     if (int rc = state_to_std(t, (hipStream_t)stream)) return rc;
-    if (!t->fused) { after_det_dev = nullptr; after_count_dev = nullptr; }   // (the split path needs the next batch's grid)
+    // `after` is accepted and ignored since ABI 10.  A launch that had the next call's first row minima ready had to take
+    // its first output row from *row_count_dev -- the word its own first workgroup advances, with nothing ordering the
+    // other workgroups' reads before that write once the grid no longer fits the chip -- and recognised "the next call" by
+    // the address of its detections alone.  What it saved was one of a batch's 65 launches (+0.6 % at best); the handles
+    // that this mattered for now link a batch with ONE launch.
+    after_det_dev = nullptr; after_count_dev = nullptr;
     // the previous call may have left this call's first row minima behind (it was told this frame comes next)
     const bool have_rowmin = t->fused && t->rowmin_for != nullptr && t->rowmin_for == (const void *)det_dev;
     t->rowmin_for = nullptr;

@@ -103,11 +103,11 @@ class TrackingPipeline:
             self.exclusive_threshold = mode.startswith("exclusive")
         self.det = [Detector(self.B, height, width, max_det=max_det, params=params, device=self.device,
                              mean_state=mean_state, cv_flavour=settings.get("opencv version"),
-                             threshold_variant=1 if beside_fused_link else 0)
+                             threshold_variant=1 if beside_fused_link else 0,
+                             beside_batch_link=bool(link) and self.trk.batched)
                     for _ in range(2)]
         self.capacity = int(capacity)
         self._link = bool(link)
-        self._chain = self.trk.fused        # (the two-launch link of large tables has nothing to chain)
         n_rows = self.B * self.capacity if rows_per_flush is None else int(rows_per_flush)
         self.rows = torch.empty(n_rows * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
         self.row_count = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -197,24 +197,14 @@ class TrackingPipeline:
         """Link one detected batch on the current stream; rows accumulate in self.rows.
         ``link_events``: list that receives a (start, stop, frames, host_seconds) record around the batch's
         launches -- HIP events on the link stream, and how long the host took to issue them.
-        ``nxt``: the (slot, result, ready_event) ``detect_async`` returned for the batch that follows, if it has been
-        issued: the one-launch link then lets this batch's last launch find the next batch's first row minima
-        (``ysmr_tracker_run_chained``: no separate launch for them at the start of the next ``link``); the next batch's
-        detection only has to be complete by that last launch."""
+        ``nxt``: accepted and ignored (round 3 let a batch's last per-frame launch look ahead into the next batch: ABI 10
+        dropped that, include/ysmr_hip.h)."""
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ready)
         n = int(res.det_count.shape[0])
 
         def run():
-            if nxt is None or n < 2 or not self._chain:
-                self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
-                return
-            nres, nready = nxt[1], nxt[2]
-            self.trk.run(res.det[:n - 1], res.det_count[:n - 1], first_frame, self.rows, self.row_count,
-                         after=(res.det[n - 1], res.det_count[n - 1:]))
-            cur.wait_event(nready)
-            self.trk.run(res.det[n - 1:], res.det_count[n - 1:], first_frame + n - 1, self.rows, self.row_count,
-                         after=(nres.det[0], nres.det_count[0:1]))
+            self.trk.run(res.det, res.det_count, first_frame, self.rows, self.row_count)
 
         if link_events is None:
             run()

@@ -80,8 +80,7 @@ class DeviceTracker:
     def run(self, det, det_count, first_frame, rows, row_count, after=None):
         """Frames [first_frame, first_frame + B): det f32 [B,max_det,5], det_count i32 [B] on device;
         rows: uint8 buffer viewed as ysmr_row[]; row_count: int64 device scalar (advanced).
-        ``after``: (det f32 [max_det,5], count i32 [1]) of the frame that follows the last one of this call
-        (``ysmr_tracker_run_chained``); it must be complete before this call's last launch executes."""
+        ``after``: ignored since ABI 10 (``ysmr_tracker_run_chained``)."""
         b = det_count.numel()
         if det.shape[1] != self.max_det:
             raise ValueError("det must be [B, max_det, 5] with the tracker's max_det")
