@@ -58,14 +58,13 @@ def oracle():
 #: How far an ill-conditioned row may move, as a multiple of what the oracle's own one-ulp shadows moved it
 #: (compare_rows).  Set from measurement, not from taste: 4 x the largest ratio deviation / sens that any test of the
 #: suite produced on the final code of the round (every comparison that meets marked rows appends its ratio to
-#: gpurun_out/r04_parity_ratios.jsonl; profiles/r04_parity_ratios.jsonl is the round's copy): 12.8 on a 48-frame
+#: gpurun_out/r04_parity_ratios.jsonl; profiles/r04_parity_ratios.jsonl is the round's copy): 2.4 on a 48-frame
 #: dark-on-bright clip (its marked rows sit in the exponential phase of a weight tie, where a rounding difference of a
-#: few ulps -- the batch link's window sums against the oracle's dot products -- leads the one-ulp shadows by a few
-#: frames), 0.08 at the bench configuration.  Round 3 allowed 1000 x and 50 px without recording how much was used.
-AMPLIFICATION = 50.0
-#: ... and in pixels: 4 x the largest deviation of a marked row seen in the suite (3.6 px, same test); the filters of a
-#: lost track disagree by no more than that after the second it stays registered.
-ABS_LIMIT_PX = 15.0
+#: few ulps -- the batch link's window sums against the oracle's dot products -- leads the one-ulp shadows by a frame
+#: or two), 0.08 at the bench configuration.  Round 3 allowed 1000 x and 50 px without recording how much was used.
+AMPLIFICATION = 10.0
+#: ... and in pixels: 4 x the largest deviation of a marked row seen in the suite (1.3 px, same test)
+ABS_LIMIT_PX = 5.0
 
 
 def parity_report(got, ref_rows):
