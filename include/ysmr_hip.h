@@ -69,7 +69,8 @@ extern "C" {
 #define YSMR_BESIDE_LINK     4
 /* ... and the hint for a handle that links a whole batch with one launch (ysmr_tracker_batched): that launch holds ONE
  * compute unit for the length of the batch.  The matrix-pipe threshold kernel, which gives every compute unit one
- * workgroup, then cuts its rows for the 255 units that are there (same bytes). */
+ * workgroup, then cuts its rows for 31 workgroups per XCD instead of 32 -- whichever XCD the link sits on, none gets a
+ * workgroup it cannot place before another has finished (same bytes). */
 #define YSMR_BESIDE_BATCH_LINK 8
 #define YSMR_CV_FLAVOUR_MASK 15
 
@@ -122,11 +123,13 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
                          int channels, int inv, int t_low, int t_high, int use_high,
                          uint8_t *cls_dev, int cv_flavour);
 
-/* Fault injection for the library's own tests: YSMR_FAULT_RESIDUE_STALL makes the NEXT ysmr_components_batch /
- * ysmr_detect_batch call of this process behave as if one workgroup of its barrier kernel never became resident -- the
- * barrier times out (quickly), every frame's status gets YSMR_DET_STALLED and the call returns. */
-#define YSMR_FAULT_RESIDUE_STALL 1
-int ysmr_fault_inject(int what);
+/* Fault injection for the library's own test of YSMR_DET_STALLED, through the workspace the caller owns (there is no
+ * process-wide switch): a workspace whose header word at byte offset YSMR_WS_FAULT_OFFSET holds
+ * YSMR_WS_FAULT_RESIDUE_STALL makes the NEXT ysmr_components_batch / ysmr_detect_batch call on THAT workspace behave as if
+ * one workgroup of its barrier kernel never became resident -- the barrier times out (quickly), every frame's status gets
+ * YSMR_DET_STALLED and the call returns; the call clears the word.  ysmr_detect_workspace_init clears it too. */
+#define YSMR_WS_FAULT_OFFSET        32
+#define YSMR_WS_FAULT_RESIDUE_STALL 0xFA17057Au
 
 /* Measurement aid: the NEXT ysmr_threshold_batch / _variant call of this host thread hands the two HIP events (hipEvent_t
  * created with timing enabled; either may be NULL) to its kernel dispatch (hipExtLaunchKernel), which sets them to the

@@ -221,7 +221,8 @@ def test_detect_bench_batch_frame_by_frame(torch_cuda, oracle):
 
 
 def test_stalled_barrier_is_reported_and_the_next_call_recovers(torch_cuda, oracle):
-    """k_residue's software grid barrier gives up when a workgroup never arrives (ysmr_fault_inject makes one stay away):
+    """k_residue's software grid barrier gives up when a workgroup never arrives (a word in the test's own workspace
+    header makes one stay away, include/ysmr_hip.h: YSMR_WS_FAULT_RESIDUE_STALL):
     every frame of that call reports YSMR_DET_STALLED, the call returns, and the NEXT call on the same detector -- the same
     label map, mask and workspace, which the stalled call left half written -- gives the oracle's result again."""
     from ysmr_amd import _lib
@@ -245,12 +246,13 @@ def test_stalled_barrier_is_reported_and_the_next_call_recovers(torch_cuda, orac
 
     first = big_blobs(video.frames(3))
     _compare(oracle, first, run(first), p, max_det=512)
-    assert _lib.lib().ysmr_fault_inject(1) == 0
+    word = torch.tensor([_lib.WS_FAULT_RESIDUE_STALL], dtype=torch.int64).to(torch.int32).view(torch.uint8).cuda()
+    det._ws[_lib.WS_FAULT_OFFSET:_lib.WS_FAULT_OFFSET + 4] = word
     stalled = run(big_blobs(video.frames(3)))
     assert (stalled["status"] & _lib.DET_STALLED).all(), stalled["status"]
     after = big_blobs(video.frames(3))
     _compare(oracle, after, run(after), p, max_det=512)
-    assert _lib.lib().ysmr_fault_inject(99) != 0
+    assert int(det._ws[_lib.WS_FAULT_OFFSET:_lib.WS_FAULT_OFFSET + 4].view(torch.int32).item()) == 0     # (good for one call)
 
 
 def test_detect_dense_noise_stresses_union_find(torch_cuda, oracle):

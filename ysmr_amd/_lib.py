@@ -25,6 +25,8 @@ CV_DEFAULT, CV_ANGLE_PRE451, CV_GRAY_3X = 0, 1, 2
 BESIDE_LINK = 4
 #: ... and for the one-launch-per-batch link, which holds one compute unit (YSMR_BESIDE_BATCH_LINK)
 BESIDE_BATCH_LINK = 8
+#: test hook in a detection workspace's header (include/ysmr_hip.h)
+WS_FAULT_OFFSET, WS_FAULT_RESIDUE_STALL = 32, 0xFA17057A
 
 
 def cv_flavour_of(version):
@@ -48,7 +50,7 @@ ROW_DTYPE = np.dtype([("frame", "<i4"), ("track_id", "<i4"), ("x", "<f8"), ("y",
 ABI_VERSION = 10   # YSMR_ABI_VERSION of include/ysmr_hip.h these argtypes were written against
 
 EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_detect_workspace_init",
-           "ysmr_threshold_batch", "ysmr_threshold_batch_variant", "ysmr_threshold_timing", "ysmr_fault_inject", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
+           "ysmr_threshold_batch", "ysmr_threshold_batch_variant", "ysmr_threshold_timing", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_run_chained", "ysmr_tracker_fused", "ysmr_tracker_batched", "ysmr_tracker_link_mode", "ysmr_tracker_prepare", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
@@ -110,6 +112,12 @@ def lib():
         raise YsmrLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
     vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     L.ysmr_abi_version.restype = ci
+    if os.environ.get("HIP_FORCE_DEV_KERNARG") == "0":
+        # (a launch's first instructions read its arguments: from host memory that is a PCIe round trip per launch --
+        # 90 k -> 62 k frames/s with one launch per frame; ROCm's default and this package's is 1)
+        import logging
+        logging.getLogger("ysmr").warning("HIP_FORCE_DEV_KERNARG=0 is in force: kernel arguments in host memory cost the "
+                                          "per-frame link about a third of its rate; unset it or set it to 1")
     if L.ysmr_abi_version() != ABI_VERSION:
         raise YsmrLibraryError(f"{LIB_PATH} has ABI version {L.ysmr_abi_version()}, this host code binds version "
                                f"{ABI_VERSION} (include/ysmr_hip.h): rebuild the library (make -C ysmr_amd/csrc)")
@@ -120,7 +128,6 @@ def lib():
     L.ysmr_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci]
     L.ysmr_threshold_batch_variant.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci]
     L.ysmr_threshold_timing.argtypes = [vp, vp]
-    L.ysmr_fault_inject.argtypes = [ci]
     L.ysmr_mean_threshold_state_bytes.argtypes = [ci]
     L.ysmr_mean_threshold_state_bytes.restype = ctypes.c_size_t
     L.ysmr_mean_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, vp, vp, vp, vp, ci]

@@ -702,7 +702,8 @@ struct WsHeader {
     unsigned long long labels;   // label map / final mask the component tables refer to
     unsigned long long mask;
     unsigned long long total;    // batch * H * W of that call
-    uint32_t cur;                // (always 0: one list)
+    uint32_t fault;              // YSMR_WS_FAULT_RESIDUE_STALL (written by a TEST into its own workspace): the next call's
+                                 // barrier kernel behaves as if one workgroup never became resident; cleared by that call
     uint32_t count[2];           // [0] residue pixels found (may exceed cap: list incomplete)
     uint32_t pad;                // ticket counter of k_clear
     int32_t batch, H, W, max_det;
@@ -1545,8 +1546,6 @@ __device__ __forceinline__ void pass_bbox_euler(const uint8_t *__restrict__ cls,
 // once; five near-empty launches cost 25 us per batch), otherwise the passes are separated by a software grid
 // barrier (all RESIDUE_BLOCKS blocks are resident: 128 x 256 threads, no LDS to speak of).
 constexpr int RESIDUE_BLOCKS = 128;
-// (fault injection, ysmr_fault_inject: the library's own test of the bail-out below)
-static std::atomic<int> g_fault_residue_stall{0};
 
 __device__ __forceinline__ bool grid_barrier(uint32_t *counter, uint32_t target, uint32_t spin_limit = 20000000u)
 {
@@ -1581,10 +1580,12 @@ __device__ __forceinline__ void pass_tag_roots(uint32_t *labels, const Geo &g, c
 }
 
 __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels, uint8_t *mask, Geo g, int batch, PixelList pl,
-                                                 CompTables t, uint32_t *barrier, int32_t *status, int fault)
+                                                 CompTables t, uint32_t *barrier, int32_t *status)
 {
     DET_RING(5);
     const uint32_t listed = pl.hdr->count[0];   // (written by k_windows, the previous launch: every block sees the same)
+    // (fault injection by the library's own test, through the workspace it owns: include/ysmr_hip.h)
+    const bool fault = pl.hdr->fault == YSMR_WS_FAULT_RESIDUE_STALL;
     if (listed == 0u && !fault) return;
     // (fault injection: block 0 never arrives at the first barrier, as a workgroup that found no compute unit would not)
     if (fault && blockIdx.x == 0) return;
@@ -1628,6 +1629,7 @@ __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels,
         // these buffers clear everything -- label map, mask, counters and this barrier word -- instead of walking the
         // component boxes (k_clear; k_compact keeps the flag).
         pl.hdr->dense = 1u;
+        pl.hdr->fault = 0u;
         for (int f = 0; f < batch; ++f) atomicOr(&status[f], YSMR_DET_STALLED);
     }
 }
@@ -2218,7 +2220,7 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
     const bool timed = ev0 || ev1;
     if (variant != 1 && ysmr_thr::supported(H, W, channels, t_low, t_high, use_high))
         return ysmr_thr::launch(st, frames, cls, batch, H, W, inv, t_low, t_high, use_high, gk.k,
-                                knobs().thr_blocks > 0 ? knobs().thr_blocks : ((cv_flavour & YSMR_BESIDE_BATCH_LINK) ? 255 : 0),
+                                knobs().thr_blocks > 0 ? knobs().thr_blocks : ((cv_flavour & YSMR_BESIDE_BATCH_LINK) ? 248 : 0),
                                 variant >= 2 ? variant - 1 : 0, ev0, ev1);
     if (variant >= 2) return ysmr::fail(YSMR_ERR_ARG, "the matrix-pipe threshold kernel does not serve this geometry");
     const int t_gap = use_high ? (t_high > t_low ? t_high - t_low : t_low - t_high) : 0;
@@ -2354,7 +2356,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
                            batch, w.pixels, t);
     }
     hipLaunchKernelGGL(k_residue, dim3(RESIDUE_BLOCKS), tb, 0, st, cls_dev, labels, mask_dev, g, batch, w.pixels, t, w.arena_used + 1,
-                       status_dev, g_fault_residue_stall.exchange(0));
+                       status_dev);
     YSMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rank, dim3(batch, (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) < 32 ? (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) : 32), dim3(RANK_THREADS), 0, st, t, labels, g.HW,
                        width, height, status_dev, w.pixels.hdr, w.n_holed, w.holed);
@@ -2367,13 +2369,6 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
                        reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total, batch, height, width,
                        (cv_flavour & YSMR_CV_ANGLE_PRE451) != 0);
     YSMR_LAUNCH_CHECK();
-    return YSMR_OK;
-}
-
-int ysmr_fault_inject(int what)
-{
-    if (what != YSMR_FAULT_RESIDUE_STALL) return ysmr::fail(YSMR_ERR_ARG, "unknown fault %d", what);
-    g_fault_residue_stall.store(1);
     return YSMR_OK;
 }
 

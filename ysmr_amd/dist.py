@@ -67,7 +67,7 @@ def finish(info: RankInfo):
 # an upload stream).  On an 8-GPU node that is ~50 busy host threads; left to the scheduler they end up on the far socket
 # and share cores, and the link chain -- which has only ~1.4x the host time it needs -- slows down.
 def physical_device(ordinal, env=None) -> str:
-    """The entry of the parent's HIP_VISIBLE_DEVICES (or ROCR_VISIBLE_DEVICES) that its device ``ordinal`` is; the ordinal
+    """The entry of the parent's HIP_VISIBLE_DEVICES (or CUDA_VISIBLE_DEVICES, which HIP honours too) that its device ``ordinal`` is; the ordinal
     itself when neither is set.  A worker process that is to see only that GPU gets this value as HIP_VISIBLE_DEVICES."""
     env = os.environ if env is None else env
     for key in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
@@ -88,15 +88,26 @@ def usable_gpus(dev_root="/dev/dri"):
 
 
 def pci_bus_id(index=0):
-    """'0000:c1:00.0' of HIP device ``index`` of this process (asks the HIP runtime: initialises it), or None."""
+    """'0000:c1:00.0' of HIP device ``index`` of this process, or None.  Asked of the HIP runtime that torch has loaded
+    (the library mapped into this process, found in /proc/self/maps): dlopen-ing "libamdhip64.so" by name may bring in a
+    SECOND runtime -- a pip torch wheel carries its own copy -- and two runtimes on one GPU is one too many."""
     import ctypes
     try:
-        hip = ctypes.CDLL("libamdhip64.so")
+        import torch  # noqa: F401  (loads the runtime)
+        path = None
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        if path is None:
+            return None
+        hip = ctypes.CDLL(path)
         buf = ctypes.create_string_buffer(64)
         if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) != 0:
             return None
         return buf.value.decode().lower()
-    except OSError:
+    except (OSError, ImportError):
         return None
 
 

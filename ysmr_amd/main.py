@@ -147,6 +147,7 @@ def _gpu_worker(args):
             pass    # the parent counted GPUs this process cannot open (a device cgroup): _visible() folds and says so
         else:
             os.environ["HIP_VISIBLE_DEVICES"] = args[2]
+            os.environ.pop("CUDA_VISIBLE_DEVICES", None)     # (the parent's restriction is folded into args[2]: dist.physical_device)
             jobs = [(j[0], j[1], j[2], "cuda:0") + tuple(j[4:]) for j in jobs]
         pinned = dist.pin_to_gpu(0)
         logging.getLogger("ysmr").getChild(__name__).debug(
