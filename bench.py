@@ -228,7 +228,12 @@ def main():
     torch.cuda.synchronize()
     dist.barrier(info)
     torch.cuda.synchronize()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0, info, device=dev if args.dist_backend == "nccl" else "cpu")
+    red = dev if args.dist_backend == "nccl" else "cpu"
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, info, device=red)
+    # (how many ranks reached this line with their steps done, and what they did: a SCALE record then shows that N ranks
+    # took part, not one rank's figure times N)
+    ranks_seen = int(round(dist.sum_over_ranks(1.0, info, device=red)))
+    frames_done = int(round(dist.sum_over_ranks(float(S * F * args.steps), info, device=red)))
 
     # the path must have produced sane output: no overflow/arena flags, no tracker errors, rows
     n_rows = 0
@@ -265,9 +270,10 @@ def main():
                      (W, H, args.blobs), "custom geometry")
         out = {
             "metric": "frames/sec detect+link, 1228x922 ~500 blobs, 1/2/4/8 GPU; HBM GB/s %peak",
-            "value": world * S * F * args.steps / elapsed,
+            "value": frames_done / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

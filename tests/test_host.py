@@ -463,6 +463,35 @@ def test_gpu_worker_sees_only_its_gpu_and_sits_next_to_it(tmp_path, monkeypatch)
     assert "HIP_VISIBLE_DEVICES" not in os.environ and calls == ["cuda:5", "cuda:5"]
 
 
+def test_eight_ranks_get_eight_disjoint_cpu_sets_and_all_streams(tmp_path):
+    """An 8-GPU node as sysfs would describe it (two sockets, four GPUs each, every GPU with a NUMA-local range of its
+    own): ``dist.pin_to_gpu`` gives the eight ranks eight disjoint CPU sets, ``dist.shard`` deals sixteen streams two to a
+    rank with none left over, and ``physical_device`` names eight different GPUs."""
+    from ysmr_amd import dist
+    sys_root = tmp_path / "sys"
+    buses = []
+    for g in range(8):
+        bus = "0000:%02x:00.0" % (0x05 + 0x10 * g)
+        dev = sys_root / "bus" / "pci" / "devices" / bus
+        dev.mkdir(parents=True)
+        lo = 16 * g + (0 if g < 4 else 64)             # socket 0: cpus 0-63 (+ SMT 128-191), socket 1: 128.. shifted
+        (dev / "local_cpulist").write_text(f"{lo}-{lo + 15},{lo + 256}-{lo + 271}\n")
+        buses.append(bus)
+    sets = []
+    for rank in range(8):
+        got = dist.pin_to_gpu(rank, str(sys_root), bus_id=buses[rank], allowed=range(0, 512), setter=lambda cpus: None)
+        assert got and len(got) == 32
+        sets.append(got)
+    for a in range(8):
+        for b in range(a + 1, 8):
+            assert not (sets[a] & sets[b]), (a, b)
+    streams = list(range(16))
+    dealt = [dist.shard(streams, r, 8) for r in range(8)]
+    assert all(len(d) == 2 for d in dealt) and sorted(sum(dealt, [])) == streams
+    assert sorted({dist.physical_device(r, {}) for r in range(8)}) == [str(r) for r in range(8)]
+    assert [dist.physical_device(r, {"HIP_VISIBLE_DEVICES": "7,6,5,4,3,2,1,0"}) for r in range(8)] == list("76543210")
+
+
 def test_ysmr_multiprocess_stays_in_process_once_the_gpu_is_initialised(tmp_path, monkeypatch, caplog):
     """A process that already holds a GPU context must not start workers from itself (the worker would be
     forked/exec'ed out of a GPU-initialised parent): the per-GPU workers then run as threads."""

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import os
 
-__all__ = ["RankInfo", "rank_info", "init", "shard", "barrier", "max_over_ranks", "finish", "pci_bus_id", "local_cpus",
+__all__ = ["RankInfo", "rank_info", "init", "shard", "barrier", "max_over_ranks", "sum_over_ranks", "finish", "pci_bus_id", "local_cpus",
            "pin_to_gpu", "physical_device", "usable_gpus"]
 
 
@@ -52,6 +52,17 @@ def max_over_ranks(value: float, info: RankInfo, device="cpu") -> float:
     import torch.distributed as dist
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, info: RankInfo, device="cpu") -> float:
+    """All-reduced sum (bench.py: how many ranks finished their steps, how many frames they linked)."""
+    if info.world <= 1:
+        return float(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
 
