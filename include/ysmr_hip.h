@@ -101,6 +101,11 @@ int ysmr_unpack_dib_batch(void *stream, const uint8_t *raw_dev, int n_frames, si
                           int width, int bytes_per_pixel, int row_stride, int bottom_up,
                           const uint8_t *palette_dev, uint8_t *frames_dev);
 
+/* HOST function: n bytes of the open file `fd`, from `offset` on, into `dst` (e.g. the pinned staging buffer of a frame
+ * feed) by `threads` positional reads side by side (<= 0: 8).  What cap.read() does for an uncompressed file, a batch of
+ * frames at a time (ysmr/track_eval.py:159). */
+int ysmr_file_read(int fd, void *dst, size_t n, long long offset, int threads);
+
 /* ---- detection: a1-a6 ------------------------------------------------------------------- */
 
 /* Bytes of scratch ysmr_detect_batch needs for this geometry. */
@@ -308,6 +313,11 @@ int    ysmr_rows_sort(void *stream, const ysmr_row *rows_dev, long long n_rows, 
 size_t ysmr_rows_csv_bound(long long n_rows, int with_header);
 int    ysmr_rows_format_csv(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas,
                             int threads, char *out, size_t out_capacity, size_t *out_length);
+
+/* HOST function: the same text written to `path` (created or truncated), every formatting thread writing its own
+ * piece at its place in the file; *out_length (may be NULL) receives the number of bytes. */
+int    ysmr_rows_write_csv(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas,
+                           int threads, const char *path, size_t *out_length);
 
 /* HOST function: the seven DataFrame columns (dtypes of helper_file.py:881-889).
  * via_pandas (here and above): the reference does not keep the tracker's float64 values, it prints

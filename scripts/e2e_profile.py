@@ -10,9 +10,11 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 d = tempfile.mkdtemp(dir="/tmp")
 path = os.path.join(d, "clip.npy"); np.save(path, SyntheticVideo(922, 1228, 500, seed=0).frames(F))
 s = default_settings(**{"user input": False, "select files": False, "display video analysis": False, "log to file": False})
-for rep in range(2):
+for rep in range(3):
     t0 = time.perf_counter(); res = track_bacteria(path, settings=dict(s), result_folder=d); dt = time.perf_counter() - t0
     print(f"run {rep}: {dt*1e3:.0f} ms -> {F/dt:.0f} frames/s ({len(res[0])} rows)")
+    from ysmr_amd import track_eval as _te
+    print("   marks (ms since the pass began):", {k: round(v * 1e3, 1) for k, v in _te.LAST_PASS_MARKS.items()})
 pr = cProfile.Profile(); pr.enable()
 t0 = time.perf_counter(); res = track_bacteria(path, settings=dict(s), result_folder=d); dt = time.perf_counter() - t0
 pr.disable()

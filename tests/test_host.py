@@ -525,3 +525,26 @@ def test_worker_selects_the_device_of_its_job(monkeypatch):
     monkeypatch.setattr(main, "analyse", lambda path, **kw: seen.append(("analyse", kw["device"])) or True)
     assert main._worker(("x.npy", {}, "out", "cuda:5")) == ("x.npy", True)
     assert seen == [("enter", "cuda:5"), ("analyse", "cuda:5"), ("exit", "cuda:5")]
+
+
+def test_csv_written_by_the_formatting_threads_equals_the_one_buffer_form(tmp_path):
+    """``ysmr_rows_write_csv`` (every thread formats its range and writes its own piece at its place in the file) leaves
+    the bytes of ``ysmr_rows_format_csv``, with and without header, for tables below and above the size at which the
+    work is split, and for the thread counts that do not divide the rows."""
+    from ysmr_amd import _lib
+    from ysmr_amd.helper_file import rows_to_csv_bytes, rows_to_csv_file
+    rng = np.random.default_rng(3)
+    for n, threads in ((0, 0), (7, 0), (5000, 3), (40001, 7), (40001, 0)):
+        rows = np.zeros(n, _lib.ROW_DTYPE)
+        rows["track_id"] = np.sort(rng.integers(0, 900, n))
+        rows["frame"] = rng.integers(0, 100000, n)
+        rows["x"], rows["y"] = rng.uniform(-5, 4000, n), rng.uniform(0, 1e-3, n)
+        rows["w"], rows["h"], rows["angle"] = rng.uniform(0, 30, n), rng.uniform(0, 30, n), rng.uniform(-90, 90, n)
+        rows["w"][::7] = 0
+        for header in (True, False):
+            for via in (True, False):
+                path = tmp_path / f"t_{n}_{threads}_{header}_{via}.csv"
+                path.write_bytes(b"stale content that is longer than a short table's text " * 3)
+                length = rows_to_csv_file(rows, str(path), header=header, via_pandas=via, threads=threads)
+                want = rows_to_csv_bytes(rows, header=header, via_pandas=via)
+                assert length == len(want) and path.read_bytes() == want

@@ -54,8 +54,8 @@ EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_run_chained", "ysmr_tracker_fused", "ysmr_tracker_batched", "ysmr_tracker_link_mode", "ysmr_tracker_prepare", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
-           "ysmr_rows_format_csv", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks",
-           "ysmr_evaluate_workspace_bytes", "ysmr_evaluate_tracks", "ysmr_unpack_dib_batch")
+           "ysmr_rows_format_csv", "ysmr_rows_write_csv", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks",
+           "ysmr_evaluate_workspace_bytes", "ysmr_evaluate_tracks", "ysmr_unpack_dib_batch", "ysmr_file_read")
 
 SELECT_OK, SELECT_TOO_SHORT, SELECT_TOO_SHORT_CLEANED, SELECT_NONE = 0, 1, 2, 3
 
@@ -154,6 +154,8 @@ def lib():
     L.ysmr_rows_csv_bound.argtypes = [ctypes.c_longlong, ci]
     L.ysmr_rows_csv_bound.restype = ctypes.c_size_t
     L.ysmr_rows_format_csv.argtypes = [vp, ctypes.c_longlong, ci, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.ysmr_file_read.argtypes = [ci, vp, ctypes.c_size_t, ctypes.c_longlong, ci]
+    L.ysmr_rows_write_csv.argtypes = [vp, ctypes.c_longlong, ci, ci, ci, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
     L.ysmr_rows_columns.argtypes = [vp, ctypes.c_longlong, ci, vp, vp, vp, vp, vp, vp, vp]
     L.ysmr_select_workspace_bytes.argtypes = [ctypes.c_longlong, ci]
     L.ysmr_select_workspace_bytes.restype = ctypes.c_size_t

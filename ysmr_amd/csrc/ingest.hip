@@ -5,6 +5,13 @@
 // where they are used.  Pure byte shuffling: the result is the frame sequence cap.read() owes (tests/test_gpu_pipeline.py
 // builds it from the clip that went into the file).
 #include "common.h"
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <unistd.h>
 
 namespace {
 
@@ -90,5 +97,36 @@ extern "C" int ysmr_unpack_dib_batch(void *stream, const uint8_t *raw_dev, int n
         hipLaunchKernelGGL(k_unpack_dib<false>, dim3((unsigned)blocks), dim3(256), 0, st, raw_dev, raw_frame_bytes, n_frames, height,
                            width, bytes_per_pixel, row_stride, bottom_up, palette_dev, frames_dev);
     YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+// HOST function: n bytes of an open file from `offset` on into `dst` (pinned staging memory of a frame feed), by `threads`
+// positional reads side by side -- the kernel copies page-cache pages straight into dst.  One native call per batch of
+// frames: the same reads issued from a Python thread pool cost the feed's producer thread a handful of GIL hand-overs per
+// piece while the caller's thread issues launches (2.0 ms per 72 MB batch instead of the 1.0 ms the reads take).
+extern "C" int ysmr_file_read(int fd, void *dst, size_t n, long long offset, int threads)
+{
+    if (fd < 0 || (!dst && n) || offset < 0) return ysmr::fail(YSMR_ERR_ARG, "fd, dst and offset must be valid");
+    int nt = std::max(1, std::min(threads > 0 ? threads : 8, 64));
+    if (n < ((size_t)8 << 20)) nt = 1;
+    std::atomic<int> bad{0};
+    auto piece = [&](size_t lo, size_t hi) {
+        while (lo < hi) {
+            const ssize_t got = ::pread(fd, (char *)dst + lo, hi - lo, (off_t)(offset + (long long)lo));
+            if (got <= 0) { bad.store(got == 0 ? -1 : errno ? errno : -1); return; }
+            lo += (size_t)got;
+        }
+    };
+    if (nt == 1) piece(0, n);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) {
+            const size_t lo = (n * (size_t)t / nt) & ~(size_t)4095, hi = t + 1 == nt ? n : (n * (size_t)(t + 1) / nt) & ~(size_t)4095;
+            pool.emplace_back(piece, lo, hi);
+        }
+        for (auto &th : pool) th.join();
+    }
+    if (bad.load()) return ysmr::fail(YSMR_ERR_ARG, "short read of %zu bytes at offset %lld: %s", n, offset,
+                                      bad.load() > 0 ? std::strerror(bad.load()) : "end of file");
     return YSMR_OK;
 }

@@ -364,11 +364,15 @@ def _rows_csv_buffer(rows, header, via_pandas, threads):
 
 
 def rows_to_csv_file(rows, path, header=True, via_pandas=True, threads=0):
-    """:func:`rows_to_csv_bytes` written straight to ``path`` (no intermediate ``bytes`` copy)."""
-    buf = _rows_csv_buffer(rows, header, via_pandas, threads)
-    with open(path, "wb") as fh:
-        fh.write(memoryview(buf))
-    return len(buf)
+    """:func:`rows_to_csv_bytes` written straight to ``path`` by the formatting threads themselves
+    (``ysmr_rows_write_csv``: each writes its own piece at its place in the file)."""
+    import ctypes
+    from . import _lib
+    rows = np.ascontiguousarray(rows, dtype=_lib.ROW_DTYPE)
+    n = ctypes.c_size_t(0)
+    _lib.check(_lib.lib().ysmr_rows_write_csv(rows.ctypes.data, len(rows), int(bool(header)), int(bool(via_pandas)), int(threads),
+                                              os.fsencode(path), ctypes.byref(n)), "ysmr_rows_write_csv")
+    return n.value
 
 
 def rows_to_dataframe(rows, via_pandas=True):

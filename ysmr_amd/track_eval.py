@@ -30,6 +30,9 @@ from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
 __all__ = ["track_bacteria", "TrackingPipeline", "select_tracks", "evaluate_tracks"]
 
+#: where the wall time of the last _device_pass went, in seconds since it began (diagnostics: scripts/e2e_profile.py)
+LAST_PASS_MARKS = {}
+
 #: most rows kept on the device for one video (40 B each); longer tables are moved to the host in between
 ROW_BUDGET_MAX = 32 << 20
 
@@ -367,8 +370,12 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
         checked_early = False
         row_capacity = pipe.rows.numel() // _lib.ROW_DTYPE.itemsize
         rows_upper = 0     # host-side bound on the rows in the device buffer (no sync per batch)
+        LAST_PASS_MARKS.clear()
+        LAST_PASS_MARKS["pipeline built"] = time.perf_counter() - t_start
         feed = DeviceFrameFeed(video, pipe.B, pipe.device)
+        LAST_PASS_MARKS["feed built"] = time.perf_counter() - t_start
         for dev, f0, n_read, feed_slot in feed:
+            LAST_PASS_MARKS.setdefault("first batch on the device", time.perf_counter() - t_start)
             nxt = (pipe.detect_async(dev), f0, n_read)
             feed.release(feed_slot, nxt[0][2])   # the batch's frames are free once its detection has run
             if pending is not None:
@@ -397,9 +404,11 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
                     _persist_chunk(persist_to, chunks[-1], len(chunks) == 1)
             res = pipe.link(slot, r, ready, p0)
             frames_done = p0 + cnt
+        LAST_PASS_MARKS["last batch issued"] = time.perf_counter() - t_start
         if res is not None:
             torch.cuda.synchronize(pipe.device)
             t_frames = time.perf_counter()
+            LAST_PASS_MARKS["last batch linked"] = t_frames - t_start
             pipe.check(res)
             if chunks:      # did not fit: gather on the host, order on the device in one go
                 chunks.append(pipe.take_rows())
