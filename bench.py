@@ -256,13 +256,15 @@ def main():
         avg_ms = sum(ms) / len(ms)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "threshold_pmc.json")
+        thr_kernel = "k_threshold_strip" if pipe.det[0].threshold_variant == 1 else "k_threshold_mfma"
+        pmc_name = "threshold_pmc.json" if thr_kernel == "k_threshold_strip" else "threshold_mfma_pmc.json"
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc) and not mean_gray:
             try:
                 rec = json.load(open(pmc))
-                if rec.get("batch") == B and rec.get("height") == H and rec.get("width") == W:
+                if rec.get("batch") == B and rec.get("height") == H and rec.get("width") == W and rec.get("kernel") == thr_kernel:
                     traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/threshold_pmc.json (separate rocprofv3 --pmc run of this geometry, not this run)"
+                    traffic_source = f"profiles/{pmc_name} (separate rocprofv3 --pmc run of this kernel and geometry, not this run)"
             except Exception:
                 traffic = None
         which = {(1228, 922, 500): "BASELINE configs[2], the configuration the metric is quoted on",
@@ -287,8 +289,7 @@ def main():
                                    + (" -- DETECTION ONLY (BASELINE configs[1]), not the metric's configuration" if args.detect_only else ""),
                        "frames_per_step": F, "detect_batch": B, "channels": args.channels, "streams": world * S, "parallelism": f"{S} stream{'s' if S > 1 else ''}/GPU x{world}",
                        "rows_per_step": n_rows, "tracks_alive": n_tracks, "ids_issued": next_id},
-            "roofline": {"kernel": "k_gray_sums+k_mean_levels+k_level_threshold" if mean_gray else
-                         ("k_threshold_strip" if pipe.det[0].threshold_variant == 1 else "k_threshold_mfma"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_gray_sums+k_mean_levels+k_level_threshold" if mean_gray else thr_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "launches_timed": len(ms),
@@ -296,9 +297,9 @@ def main():
                                         "HIP events set by the kernel's own dispatch (hipExtLaunchKernel start/stop): the duration "
                                         "a kernel trace reports, inside the timed region")},
         }
-        # what the headline is made of, so that one line says which part was slow on this box: the link is a chain
-        # of one launch per frame (k_frame), so `value` ~ 1e6 / link.us_per_frame.avg as long as the host keeps ahead
-        # (host_enqueue_ms_per_step well below ms_per_step) and detection (threshold + chain) hides behind it
+        # what the headline is made of, so that one line says which part was slow on this box: the link of a batch is one
+        # launch on one compute unit (k_batch), frames strictly in order, so `value` ~ 1e6 / link.us_per_frame.avg as long
+        # as detection (threshold + chain, on the other stream) hides behind it and the host keeps ahead
         diag = {"threshold_us_per_batch": stats_us([m * 1e3 for m in ms]),
                 "components_us_per_batch": stats_us([e0.elapsed_time(e1) * 1e3 for e0, e1, _ in chain_events]),
                 "link_us_per_frame": stats_us([e0.elapsed_time(e1) * 1e3 / n for e0, e1, n, _ in link_events]),

@@ -168,8 +168,61 @@ template <typename F> float time_sets(F launch)
     return t[t.size() / 2];
 }
 
-int main()
+// Round 4: the same launches timed as a TRAIN -- all SETS launches back to back between one pair of events, divided by
+// SETS.  An event pair around ONE launch (time_sets) also measures the pair's own distance on an idle queue.
+template <typename F> float time_train(F launch, int sets = SETS)
 {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int s = 0; s < sets; ++s) launch(s);
+    hipDeviceSynchronize();
+    std::vector<float> t;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        for (int s = 0; s < sets; ++s) launch(s);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); t.push_back(ms * 1e3f / sets);
+    }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
+
+__global__ void k_nothing() {}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && argv[1][0] == 't') {       // "train": the ceiling question only
+        uint8_t *in, *out;
+        hipMalloc(&in, BATCH * SETS + 4096); hipMalloc(&out, BATCH * SETS + 4096);
+        hipMemset(in, 0x28, BATCH * SETS); hipMemset(out, 0, BATCH * SETS);
+        const double mb = 2.0 * BATCH / 1e6;
+        auto report = [&](const char *name, float us, double mbytes) { printf("%-76s %7.1f us  %6.0f GB/s  %.3f of 8 TB/s\n", name, us, mbytes / us * 1e3, mbytes / us * 1e3 / 8000.0); };
+        {
+            float one = time_sets([&](int) { hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, 0); });
+            float train = time_train([&](int) { hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, 0); });
+            printf("empty kernel: %.1f us between an event pair around one launch, %.1f us per launch in a train of %d\n", one, train, SETS);
+        }
+        for (int blocks : {512, 1024, 2048, 4096, 8192}) {
+            auto go = [&](int s) { hipLaunchKernelGGL(k_linear, dim3(blocks), dim3(256), 0, 0, (const uint4 *)(in + BATCH * s), (uint4 *)(out + BATCH * s), BATCH / 16); };
+            char nm[128];
+            snprintf(nm, 128, "A linear copy, %d blocks: event pair per launch, 8 distinct batches", blocks); report(nm, time_sets(go), mb);
+            snprintf(nm, 128, "A linear copy, %d blocks: train of 8 distinct batches", blocks); report(nm, time_train(go), mb);
+            auto same = [&](int) { go(0); };
+            snprintf(nm, 128, "A linear copy, %d blocks: train on ONE batch (145 MB: fits the 256 MiB Infinity Cache)", blocks); report(nm, time_train(same), mb);
+        }
+        for (int blocks : {2048, 8192}) {
+            auto big = [&](int) { hipLaunchKernelGGL(k_linear, dim3(blocks), dim3(256), 0, 0, (const uint4 *)in, (uint4 *)out, BATCH * SETS / 16); };
+            char nm[128];
+            snprintf(nm, 128, "A linear copy of all 8 batches in one launch (1.16 GB moved), %d blocks", blocks); report(nm, time_train(big, 2), mb * SETS);
+        }
+        for (int blocks : {256, 512}) {
+            const int band_h = 240, bands = (H + band_h - 1) / band_h;
+            auto go = [&](int s) { hipLaunchKernelGGL(k_rowblocks, dim3(blocks), dim3(512), 0, 0, in + BATCH * s, out + BATCH * s, band_h, bands); };
+            char nm[128];
+            snprintf(nm, 128, "D row blocks through LDS, %d blocks x 512: event pair per launch", blocks); report(nm, time_sets(go), mb);
+            snprintf(nm, 128, "D row blocks through LDS, %d blocks x 512: train of 8 distinct batches", blocks); report(nm, time_train(go), mb);
+        }
+        return 0;
+    }
     uint8_t *in, *out;
     hipMalloc(&in, BATCH * SETS + 4096); hipMalloc(&out, BATCH * SETS + 4096);
     hipMemset(in, 0x28, BATCH * SETS); hipMemset(out, 0, BATCH * SETS);
