@@ -82,7 +82,10 @@ constexpr int TM_RAW_PITCH = 16 * TM_RAW_CHUNKS;
 constexpr int TM_RAW_PIECES = (TM_ROWS * TM_RAW_CHUNKS + 63) / 64;       // 1 KiB DMA pieces per step
 constexpr int TM_PIECES_PER_WAVE = (TM_RAW_PIECES + TM_WAVES - 1) / TM_WAVES;
 constexpr int TM_OUT_PITCH = 16 * TM_PER_WAVE;               // bytes per row of a wave's class-byte staging
-constexpr int TM_LIST_CAP = 248;                             // ambiguous pixels a work item can list
+#ifndef TM_LIST_CAP_N
+#define TM_LIST_CAP_N 248
+#endif
+constexpr int TM_LIST_CAP = TM_LIST_CAP_N;                   // ambiguous pixels a workgroup can list
 
 struct ThrItem {
     int f, x0, x1, y0, y1;
@@ -186,7 +189,8 @@ struct Lds {
     _Float16 tile[TM_POS][TM_COL_PITCH];                 // blurred pixels [column position][row of a 2 x 16-row ring]
     uint8_t raw[2][TM_ROWS * TM_RAW_PITCH];              // gray rows of a step: row r, columns x0 - 24 ... at r * 16 * (chunks per row)
     uint32_t out[TM_WAVES][TM_ROWS * TM_OUT_PITCH / 4];  // a wave's class bytes of a step
-    uint32_t list[TM_LIST_CAP];                          // ambiguous pixels: y << 16 | x
+    uint32_t list[TM_LIST_CAP];                          // ambiguous pixels: y << 16 | x ...
+    uint16_t list_f[TM_LIST_CAP];                        // ... and their frame (the list is worked off once per workgroup)
     uint32_t n_list;
 };
 static_assert(sizeof(Lds) <= 160 * 1024, "LDS of one CU");
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
     const long long g1 = rows_all * (bi + 1) / nb;
     const int f_add = P.by_xcd ? (int)(blockIdx.x & 7u) : 0;
 
+    uint32_t n_kept = 0;                                   // listed pixels of the items done so far
     while (g0 < g1) {
         ThrItem it;
         {
@@ -303,10 +308,12 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         const int part_c = lane < 16 ? 1 : (W - (it.x0 - 24)) >> 4;
         const int part_col = it.x0 - 24 + 16 * part_c;
         const bool part_on = wave == TM_WAVES - 1 && lane < 32 && part_c < nch && (lane < 16 ? edge_l : edge_r);
-        auto request_raw = [&](int j) __attribute__((always_inline)) {
+        // (returns the number of DMA instructions this wave issued: the step waits with a COUNTED vmcnt)
+        auto request_raw = [&](int j) __attribute__((always_inline)) -> int {
 #ifdef TM_DBG_NOLOAD
-            return;
+            return 0;
 #endif
+            int issued = 0;
             const int r0 = yb(j) + 1;
 #pragma unroll
             for (int k = 0; k < TM_PIECES_PER_WAVE; ++k) {
@@ -317,7 +324,9 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                     const int col = it.x0 - 24 + 16 * c;
                     const uint32_t lds = (uint32_t)(uintptr_t)&L.raw[j & 1][piece * 1024];
                     const uint32_t off = (uint32_t)clampi(r0 + r, 0, H - 1) * (uint32_t)W + (uint32_t)max(col, 0);
-                    if (r < TM_ROWS && col >= 0 && col + 16 <= W)
+                    const bool on = r < TM_ROWS && col >= 0 && col + 16 <= W;
+                    issued += __builtin_amdgcn_ballot_w64(on) != 0ull ? 1 : 0;     // (no lane: the instruction is branched over)
+                    if (on)
                         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(off), "s"(frame) : "memory");
                 }
             }
@@ -338,8 +347,8 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                     *reinterpret_cast<u32x4 *>(&L.raw[j & 1][(lane & 15) * 16 * nch + 16 * part_c]) = v;   // (rows lie 16 nch bytes apart: the DMA's chunk order)
                 }
             }
+            return issued;
         };
-        auto finish_raw = [&](int) __attribute__((always_inline)) {};
 
         // ---- blur: gray block j -> row sums (kept for two steps) -> tile block j ------------------------------------------
         uint32_t hst[TM_PER_WAVE][4];
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                                     const int y = oy + 4 * q + r;
                                     if (((amb >> (8 * r)) & 0xFFu) && y < it.y1) {
                                         const uint32_t slot = atomicAdd(&L.n_list, 1u);
-                                        if (slot < (uint32_t)TM_LIST_CAP) L.list[slot] = ((uint32_t)y << 16) | (uint32_t)x;
+                                        if (slot < (uint32_t)TM_LIST_CAP) { L.list[slot] = ((uint32_t)y << 16) | (uint32_t)x; L.list_f[slot] = (uint16_t)it.f; }
                                     }
                                 }
                             }
@@ -494,8 +503,16 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 }
                 if (bi & 1) __builtin_amdgcn_sched_barrier(0);
             }
-            // the wave's 16 rows x 80 bytes leave as 16-byte pieces: piece = (row, 16 columns)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        // the wave's 16 rows x 80 bytes leave as 16-byte pieces: piece = (row, 16 columns)
+        auto store_step = [&](int s) __attribute__((always_inline)) {
+#ifdef TM_DBG_NOFILTER
+            return;
+#endif
+            const int oy = it.y0 + TM_ROWS * (s - 1);
+            const uint8_t *wout = reinterpret_cast<const uint8_t *>(L.out[wave]);
+            const int u0s = u0;
+            (void)u0s;
             const int rows = min(TM_ROWS, it.y1 - oy);
             const int xw = it.x0 + 16 * u0;                               // first column of this wave's tiles
 #pragma unroll
@@ -527,50 +544,65 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         };
 
         // ---- the walk ------------------------------------------------------------------------------------------------
-        request_raw(-1); finish_raw(-1);
-        request_raw(0); finish_raw(0);
+        // vmcnt retires DMA and stores together, in issue order.  A step needs the gray rows requested ONE step ago, so it
+        // waits until only the DMA instructions it has just issued itself are outstanding -- the class-map stores go out after
+        // that wait and are never waited for inside the walk (round 3 waited vmcnt(0) at every step's second barrier: the
+        // stores' round trip to HBM, twice per 16 rows).
+        auto wait_all_but = [&](int n) __attribute__((always_inline)) {      // n: wave-uniform
+            static_assert(TM_PIECES_PER_WAVE <= 3, "counted wait");
+            if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        };
+        request_raw(-1);
+        request_raw(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         blur_step(-1, std::integral_constant<int, 1>{}, std::true_type{});                                       // row sums of the sixteen gray rows above the first block
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (nblk >= 1) request_raw(1);
         blur_any(0);
-        if (nblk >= 1) finish_raw(1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int s = 0; s <= nblk; ++s) {
-            if (s + 2 <= nblk) request_raw(s + 2);               // into the buffer the blur of step s has finished with
+            int mine = 0;
+            if (s + 2 <= nblk) mine = request_raw(s + 2);        // into the buffer the blur of step s has finished with
             if (s >= 1) filter_step(s);
-            if (s + 2 <= nblk) finish_raw(s + 2);
+            wait_all_but(__builtin_amdgcn_readfirstlane(mine));  // the rows of step s + 1 have landed (and every older store)
+            if (s >= 1) store_step(s);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (s + 1 <= nblk) blur_any(s + 1);           // overwrites the tile block of step s - 1
-            // this step's DMA pieces are read after the NEXT barrier pair; the class-map stores are waited for with them
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
 
-        // ---- ambiguous pixels: cv2's own arithmetic, sixteen lanes per pixel -------------------------------------------
-        const uint32_t n_amb = L.n_list;
-        if (__builtin_expect(n_amb != 0u, 0)) {
-            if (n_amb <= (uint32_t)TM_LIST_CAP) {
-                for (uint32_t e0 = 0; e0 < n_amb; e0 += TM_THREADS / 16) {
-                    const uint32_t e = e0 + (uint32_t)(tid >> 4);
-                    const uint32_t ent = L.list[min(e, n_amb - 1)];
-                    const int y = (int)(ent >> 16), x = (int)(ent & 0xFFFFu);
-                    const uint32_t c = exact_class(frame, P, y, x, lane, reinterpret_cast<uint8_t *>(L.out) + 256 * (tid >> 4));
-                    if (e < n_amb && l16 == 0) dst[(size_t)y * W + x] = (uint8_t)c;
-                }
-            } else {
-                // more than the list holds (a frame made to sit on the levels): the whole item again, exactly
-                const int npx = PW * (it.y1 - it.y0);
-                for (int p0 = 0; p0 < npx; p0 += TM_THREADS / 16) {
-                    const int p = min(p0 + (tid >> 4), npx - 1);
-                    const int y = it.y0 + p / PW, x = it.x0 + p % PW;
-                    const uint32_t c = exact_class(frame, P, y, x, lane, reinterpret_cast<uint8_t *>(L.out) + 256 * (tid >> 4));
-                    if (p0 + (tid >> 4) < npx && l16 == 0) dst[(size_t)y * W + x] = (uint8_t)c;
-                }
+        // ---- an item whose ambiguous pixels outgrew the list (a frame made to sit on the levels): all of it again, exactly ----
+        const uint32_t n_now = L.n_list;
+        if (__builtin_expect(n_now > (uint32_t)TM_LIST_CAP, 0)) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");          // (the item's own stores lie under these bytes)
+            const int npx = PW * (it.y1 - it.y0);
+            for (int p0 = 0; p0 < npx; p0 += TM_THREADS / 16) {
+                const int p = min(p0 + (tid >> 4), npx - 1);
+                const int y = it.y0 + p / PW, x = it.x0 + p % PW;
+                const uint32_t c = exact_class(frame, P, y, x, lane, reinterpret_cast<uint8_t *>(L.out) + 256 * (tid >> 4));
+                if (p0 + (tid >> 4) < npx && l16 == 0) dst[(size_t)y * W + x] = (uint8_t)c;
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (tid == 0) L.n_list = 0;
+            if (tid == 0) L.n_list = n_kept;                  // (what the earlier items of this workgroup listed stays)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else n_kept = n_now;
+    }
+
+    // ---- ambiguous pixels of all of this workgroup's items: cv2's own arithmetic, sixteen lanes per pixel -----------------
+    // (once per workgroup: the code is cold, its first pixel costs microseconds of instruction fetch)
+    if (__builtin_expect(n_kept != 0u, 0)) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");              // the walk's stores lie under these bytes
+        for (uint32_t e0 = 0; e0 < n_kept; e0 += TM_THREADS / 16) {
+            const uint32_t e = e0 + (uint32_t)(tid >> 4);
+            const uint32_t ent = L.list[min(e, n_kept - 1)];
+            const size_t fo = (size_t)L.list_f[min(e, n_kept - 1)] * H * W;
+            const int y = (int)(ent >> 16), x = (int)(ent & 0xFFFFu);
+            const uint32_t c = exact_class(frames + fo, P, y, x, lane, reinterpret_cast<uint8_t *>(L.out) + 256 * (tid >> 4));
+            if (e < n_kept && l16 == 0) cls[fo + (size_t)y * W + x] = (uint8_t)c;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
