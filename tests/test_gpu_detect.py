@@ -108,10 +108,11 @@ def test_threshold_matrix_pipe_kernel(torch_cuda, oracle, h, w):
 
 def test_threshold_matrix_pipe_distance(torch_cuda, oracle):
     """How far is the matrix pipe's mean from cv2's float32 chain?  The shipped kernel re-evaluates every pixel within
-    EPS = 1/512 of a level; variant 2 only those within 1/2048.  On uniform noise s - mean is spread over +-128, about
-    1/100 of the pixels per unit near the levels, so a distance d between the two means beyond 1/2048 would show as
-    ~ 4 (d - 1/2048) / 100 wrong bytes per pixel: none are allowed (an earlier build that decided everything but exact
-    ties differed in 3 of these 3.9 M bytes, i.e. d ~ 2e-5)."""
+    EPS = 1/256 of a level; variant 2 only those within 1/512 (round 3 also ran 1/2048; since round 4 the scale 127.5 / EPS
+    is an f16 operand, which ends at 1/512).  On uniform noise s - mean is spread over +-128, about 1/100 of the pixels per
+    unit near the levels, so a distance d between the two means beyond 1/512 would show as ~ 4 (d - 1/512) / 100 wrong
+    bytes per pixel: none are allowed (an earlier build that decided everything but exact ties differed in 3 of these
+    3.9 M bytes, i.e. d ~ 2e-5)."""
     from ysmr_amd.detect import Detector, threshold_params
     torch = torch_cuda
     rng = np.random.default_rng(7)

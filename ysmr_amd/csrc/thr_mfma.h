@@ -19,7 +19,7 @@ struct Params {
 // geometry / arguments the kernel serves (everything else stays on k_threshold_strip / k_threshold)
 bool supported(int H, int W, int channels, int t_low, int t_high, int use_high);
 
-// variant: 0 = shipped (EPS = 1/512), 1 = EPS = 1/2048 (diagnostic: a quarter of the margin), 2 = every pixel through the
+// variant: 0 = shipped (EPS = 1/256), 1 = EPS = 1/512 (diagnostic: half the margin), 2 = every pixel through the
 // exact path (diagnostic)
 // ev_start / ev_stop (either may be null): events the dispatch itself updates (hipExtLaunchKernel)
 int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H, int W, int inv, int t_low, int t_high,

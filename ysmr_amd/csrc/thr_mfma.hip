@@ -43,7 +43,7 @@
 // 5 x 32 x 2^-24 x 255 = 2.4e-3 if every partial sum were rounded on its own and all errors lined up, and 5 x 2^-24 x 255
 // = 8e-5 with one rounding per MFMA; cv2's own chain is within 22 x 2^-24 x 255 = 3.3e-4 of the real mean: 3.1e-3 in all if
 // every worst case held at once, which EPS covers (round 3 shipped 1/512, covered by measurement only).  MEASURED
-// (tests/test_gpu_detect.py::test_threshold_matrix_pipe_distance): with EPS = 1/2048 the kernel still reproduces the
+// (tests/test_gpu_detect.py::test_threshold_matrix_pipe_distance): with EPS = 1/2048 (round 3; 1/512 since) the kernel still reproduces the
 // oracle byte for byte on 3.9 M pixels of uniform noise, and an earlier build that decided everything but exact ties
 // differed in 3 of them -- a distance of about 2e-5, a hundredth of EPS.
 #include "common.h"
@@ -86,6 +86,24 @@ constexpr int TM_OUT_PITCH = 16 * TM_PER_WAVE;               // bytes per row of
 #define TM_LIST_CAP_N 248
 #endif
 constexpr int TM_LIST_CAP = TM_LIST_CAP_N;                   // ambiguous pixels a workgroup can list
+
+#ifdef YSMR_STAMPS
+// phases of one workgroup's walk (stamps build): [wave][step][stamp]; scripts/thr_stamps.py
+constexpr int TM_ST_STEPS = 20, TM_ST_N = 8;
+__device__ unsigned long long g_tm_stamps[TM_WAVES][TM_ST_STEPS][TM_ST_N];
+#define TMSTAMP(step, k) do { if (blockIdx.x == TM_ST_BLOCK && (step) < TM_ST_STEPS && lane == 0) g_tm_stamps[wave][step][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef TM_ST_BLOCK
+#define TM_ST_BLOCK 100
+#endif
+#else
+#define TMSTAMP(step, k) do {} while (0)
+#endif
+
+// The lane number, opaque to the optimiser: addresses built from it are worked out where they are used (one add in front
+// of a phase, the blocks then differ by immediate offsets) instead of being hoisted out of the walk as dozens of
+// loop-invariant registers -- which is what spilled (every reload of a spilled register waits vmcnt(0), i.e. for the class-map
+// stores and the DMA in flight).
+__device__ __forceinline__ int opaque_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
 
 struct ThrItem {
     int f, x0, x1, y0, y1;
@@ -196,8 +214,8 @@ struct Lds {
 static_assert(sizeof(Lds) <= 160 * 1024, "LDS of one CU");
 static_assert(sizeof(Lds::out) >= 256 * (TM_THREADS / 16), "the exact path's windows live in the class-byte staging");
 
-// f16 bit pattern of the small integers 0..4 (the blur's column taps)
-__device__ __forceinline__ uint32_t small_f16(int w) { return w == 0 ? 0u : w == 1 ? 0x3C00u : w == 2 ? 0x4000u : w == 3 ? 0x4200u : 0x4400u; }
+// f16 bit pattern of w / 16 for w = 0..4 (the blur's column taps carry the division by 16)
+__device__ __forceinline__ uint32_t small_f16(int w) { return w == 0 ? 0u : w == 1 ? 0x2C00u : w == 2 ? 0x3000u : w == 3 ? 0x3200u : 0x3400u; }
 
 template <int EPS_MODE>
 __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__restrict__ frames, uint8_t *__restrict__ cls,
@@ -224,6 +242,11 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
     // positions 4q + (j & 3) of one block each; variant v: the RIGHT block (u = t + 1) sits in half v.  Position i of block u
     // is column 16u - 8 + i, output n is column 16t + n: tap = column_in - n + 5.  These taps carry the classification's scale.
     uint32_t thh[4], thl[4];          // (variant 0; variant 1 likewise)
+    // The row pass runs TRANSPOSED (taps as the A operand, the column-filtered values as B): its result then has a lane
+    // hold four consecutive COLUMNS of one row (columns 4q + r of row l16) -- one dword of class bytes.  Its accumulator
+    // starts at lo_add - x_mul b in that same layout: one more product, blurred tile (A: column l16, window rows k) times
+    // B [k][n] = -x_mul if window row k is output row n (k = n + 8), on top of lo_add.
+    uint32_t bid[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         uint32_t b1 = 0;
@@ -233,13 +256,14 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             b1 |= (uint32_t)(d == 0 ? 2 : (d == 1 || d == -1) ? 1 : 0) << (8 * e);
         }
         thi[jj] = b1;
-        uint32_t v0 = 0, bh = 0, bl = 0, hh = 0, hl = 0;
+        uint32_t v0 = 0, bh = 0, bl = 0, hh = 0, hl = 0, bd = 0;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int j = 2 * jj + e, k = 8 * q + j;
             const int w0 = 4 * q + (j & 3) + ((j >> 2) == 0 ? 16 : 0);
             const int d0 = w0 - 15 - l16;
             v0 |= small_f16(d0 == 0 ? 2 : (d0 == 1 || d0 == -1) ? 1 : 0) << (16 * e);
+            bd |= (k == l16 + 8 ? f16_bits(P.neg_x_mul) : 0u) << (16 * e);
             int taps[2] = {k - l16 - 3, -8 + 4 * q + (j & 3) + ((j >> 2) == 0 ? 16 : 0) - l16 + 5};
             uint32_t hb[2], lb[2];
 #pragma unroll
@@ -252,11 +276,20 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             bh |= hb[0] << (16 * e); bl |= lb[0] << (16 * e);
             hh |= hb[1] << (16 * e); hl |= lb[1] << (16 * e);
         }
-        tv[jj] = v0;
+        tv[jj] = v0; bid[jj] = bd;
         tbh[jj] = bh; tbl[jj] = bl;
         thh[jj] = hh; thl[jj] = hl;
     }
     const i32x4 THI = {(int)thi[0], (int)thi[1], (int)thi[2], (int)thi[3]};
+    // accumulator presets (kept in registers: an MFMA whose preset stays live writes its result elsewhere, no copies).
+    // Row sums: 0x6400 + 512 + sum over (gray - 128) = the f16 BIT PATTERN of 1024 + row sum (0 .. 1020).
+    // Column sums: the taps are (1, 2, 1) / 16, so the product is 256 + S / 16 exactly; + 768.5 and a round-toward-zero
+    // conversion at 1024 + x, where f16 counts in ones, leaves 1024 + ((S + 8) >> 4).
+    i32x4 K_ROW = {0x6600, 0x6600, 0x6600, 0x6600};
+    f32x4 K_COL = {768.5f, 768.5f, 768.5f, 768.5f};
+    f32x4 K_LO = {P.lo_add, P.lo_add, P.lo_add, P.lo_add};
+    asm volatile("" : "+v"(K_ROW), "+v"(K_COL), "+v"(K_LO));   // (opaque: not rematerialised as four moves per use)
+    const half8_t BID = as_half8(bid[0], bid[1], bid[2], bid[3]);
     const half8_t TBh = as_half8(tbh[0], tbh[1], tbh[2], tbh[3]), TBl = as_half8(tbl[0], tbl[1], tbl[2], tbl[3]);
 
     // every tile entry and gray byte must be a finite number from the first read on (they meet zero taps)
@@ -308,25 +341,42 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         const int part_c = lane < 16 ? 1 : (W - (it.x0 - 24)) >> 4;
         const int part_col = it.x0 - 24 + 16 * part_c;
         const bool part_on = wave == TM_WAVES - 1 && lane < 32 && part_c < nch && (lane < 16 ? edge_l : edge_r);
-        // (returns the number of DMA instructions this wave issued: the step waits with a COUNTED vmcnt)
+        // What a lane fetches does not change along the walk: chunk (r, c) of every 16-row block -- worked out once per item.
+        uint32_t rq_off[TM_PIECES_PER_WAVE];               // r W + column, for blocks that lie inside the image
+        bool rq_on[TM_PIECES_PER_WAVE];
+        int rq_n = 0;                                       // DMA instructions per request: the step waits with a COUNTED vmcnt
+        auto rq_chunk = [&](int k, int &r, int &col) __attribute__((always_inline)) {
+            const uint32_t ci = (uint32_t)(wave + TM_WAVES * k) * 64u + (uint32_t)lane;
+            r = (int)((ci * nch_recip) >> 16);
+            col = it.x0 - 24 + 16 * ((int)ci - r * nch);
+        };
+#pragma unroll
+        for (int k = 0; k < TM_PIECES_PER_WAVE; ++k) {
+            int r, col;
+            rq_chunk(k, r, col);
+            rq_off[k] = (uint32_t)r * (uint32_t)W + (uint32_t)max(col, 0);
+            rq_on[k] = wave + TM_WAVES * k < npieces && r < TM_ROWS && col >= 0 && col + 16 <= W;
+            rq_n += __builtin_amdgcn_ballot_w64(rq_on[k]) != 0ull ? 1 : 0;          // (no lane: the instruction is branched over)
+        }
+        rq_n = __builtin_amdgcn_readfirstlane(rq_n);
         auto request_raw = [&](int j) __attribute__((always_inline)) -> int {
 #ifdef TM_DBG_NOLOAD
             return 0;
 #endif
-            int issued = 0;
             const int r0 = yb(j) + 1;
+            const bool inside = r0 >= 0 && r0 + TM_ROWS <= H;                  // (wave-uniform)
 #pragma unroll
             for (int k = 0; k < TM_PIECES_PER_WAVE; ++k) {
                 const int piece = wave + TM_WAVES * k;
                 if (piece < npieces) {   // wave-uniform
-                    const uint32_t ci = (uint32_t)piece * 64u + (uint32_t)lane;
-                    const int r = (int)((ci * nch_recip) >> 16), c = (int)ci - r * nch;
-                    const int col = it.x0 - 24 + 16 * c;
                     const uint32_t lds = (uint32_t)(uintptr_t)&L.raw[j & 1][piece * 1024];
-                    const uint32_t off = (uint32_t)clampi(r0 + r, 0, H - 1) * (uint32_t)W + (uint32_t)max(col, 0);
-                    const bool on = r < TM_ROWS && col >= 0 && col + 16 <= W;
-                    issued += __builtin_amdgcn_ballot_w64(on) != 0ull ? 1 : 0;     // (no lane: the instruction is branched over)
-                    if (on)
+                    uint32_t off = rq_off[k] + (uint32_t)(r0 * W);
+                    if (!inside) {       // rows above / below the image repeat its first / last row
+                        int r, col;
+                        rq_chunk(k, r, col);
+                        off = (uint32_t)clampi(r0 + r, 0, H - 1) * (uint32_t)W + (uint32_t)max(col, 0);
+                    }
+                    if (rq_on[k])
                         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(off), "s"(frame) : "memory");
                 }
             }
@@ -347,7 +397,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                     *reinterpret_cast<u32x4 *>(&L.raw[j & 1][(lane & 15) * 16 * nch + 16 * part_c]) = v;   // (rows lie 16 nch bytes apart: the DMA's chunk order)
                 }
             }
-            return issued;
+            return rq_n;
         };
 
         // ---- blur: gray block j -> row sums (kept for two steps) -> tile block j ------------------------------------------
@@ -367,6 +417,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             // the image repeats the nearest inside, and that row's neighbours reflect
             uint32_t tvv[4] = {tv[2 * PAR], tv[2 * PAR + 1], tv[2 - 2 * PAR], tv[3 - 2 * PAR]};
             if (!SUMS_ONLY && (yb(j) < 1 || yb(j) + TM_ROWS > H - 1)) {   // wave-uniform
+                const int lc = opaque_lane(lane), l16 = lc & 15, q = lc >> 4;          // (cold: nothing of it hoisted out of the walk)
                 const int yc = clampi(yb(j) + l16, 0, H - 1);
                 const int ra = reflect101(yc - 1, H), rc = reflect101(yc + 1, H);
 #pragma unroll
@@ -382,35 +433,36 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 }
             }
             const half8_t TV = as_half8(tvv[0], tvv[1], tvv[2], tvv[3]);
+            const int lo = opaque_lane(lane), l16o = lo & 15, qo = lo >> 4;
+            const uint8_t *rawp = raw + l16o * 16 * nch + 16 * u0 + 16 * qo;
+            uint2 *cellp = reinterpret_cast<uint2 *>(&L.tile[16 * u0 + l16o][16 * PAR + 4 * qo]);
 #pragma unroll
             for (int bi = 0; bi < TM_PER_WAVE; ++bi) {
                 const int u = u0 + bi;
                 if (u <= ntiles) {   // wave-uniform
-                    u32x4 a = *reinterpret_cast<const u32x4 *>(raw + l16 * 16 * nch + 16 * u + 16 * q);
+                    u32x4 a = *reinterpret_cast<const u32x4 *>(rawp + 16 * bi);
                     a ^= 0x80808080u;
-                    // sum over (gray - 128) + 0x6400 + 512 = the f16 bit pattern of 1024 + row sum (0 .. 1020)
-                    i32x4 ch = {0x6600, 0x6600, 0x6600, 0x6600};
-                    ch = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), THI, ch, 0, 0, 0);
+                    const i32x4 ch = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), THI, K_ROW, 0, 0, 0);
                     hst[bi][2 * PAR] = ((uint32_t)ch[1] << 16) | (uint32_t)ch[0];
                     hst[bi][2 * PAR + 1] = ((uint32_t)ch[3] << 16) | (uint32_t)ch[2];
                     if (!SUMS_ONLY) {
-                        f32x4 y = {0.f, 0.f, 0.f, 0.f};
-                        y = __builtin_amdgcn_mfma_f32_16x16x32_f16(TV, as_half8(hst[bi][0], hst[bi][1], hst[bi][2], hst[bi][3]), y, 0, 0, 0);
-                        // y = 4096 + S; (S + 8) >> 4 = floor(y / 16 + 768.5 - 1024): round toward zero at 1024 + x, where f16 counts in ones
+                        const f32x4 y = __builtin_amdgcn_mfma_f32_16x16x32_f16(TV, as_half8(hst[bi][0], hst[bi][1], hst[bi][2], hst[bi][3]), K_COL, 0, 0, 0);
+                        // y = 1024.5 + S / 16, exactly
                         const half2_t bias = {(_Float16)1024.0f, (_Float16)1024.0f};
-                        const uint32_t b01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(__builtin_fmaf(y[0], 0.0625f, 768.5f), __builtin_fmaf(y[1], 0.0625f, 768.5f))) - bias);
-                        const uint32_t b23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(__builtin_fmaf(y[2], 0.0625f, 768.5f), __builtin_fmaf(y[3], 0.0625f, 768.5f))) - bias);
-                        uint2 *cell = reinterpret_cast<uint2 *>(&L.tile[16 * u + l16][16 * PAR + 4 * q]);
-                        // (positions beyond column W - 1 belong to the lane that holds that column, below)
-                        if (!edge_r || 16 * u + l16 <= PW + 7) *cell = make_uint2(b01, b23);
+                        const uint32_t b01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(y[0], y[1])) - bias);
+                        const uint32_t b23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(y[2], y[3])) - bias);
+                        uint2 *cell = cellp + bi * (16 * TM_COL_PITCH / 4);
+                        // (positions beyond column W - 1 in the block of that column are rewritten by the lane that holds it, below:
+                        // a wave's LDS accesses complete in order; a block wholly beyond it -- wave-uniform -- stays away)
+                        if (!edge_r || 16 * u <= PW + 7) *cell = make_uint2(b01, b23);
                         // the Gaussian's REPLICATE border: columns < 0 repeat column 0 (position 8), columns >= W column W - 1
                         if (edge_l && u == 0) {                          // wave-uniform
-                            if (l16 == 8)
+                            if (l16o == 8)
 #pragma unroll
                                 for (int e = 1; e <= 8; ++e) cell[-e * (TM_COL_PITCH / 4)] = make_uint2(b01, b23);
                         }
                         if (edge_r && u == (PW + 7) >> 4) {              // wave-uniform: the block of column W - 1
-                            if (l16 == ((PW + 7) & 15))
+                            if (l16o == ((PW + 7) & 15))
                                 for (int e = 1; PW + 7 + e < 16 * ntiles + 16; ++e) cell[e * (TM_COL_PITCH / 4)] = make_uint2(b01, b23);
                         }
                     }
@@ -425,11 +477,10 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             return;
 #endif
             const int oy = it.y0 + TM_ROWS * (s - 1);            // first output row
-            uint8_t *wout = reinterpret_cast<uint8_t *>(L.out[wave]);
-            // window rows 8q .. 8q + 7 of this lane's column (A operand of the column pass)
-            const _Float16 *colp = &L.tile[l16][(q >> 1 ? (s & 1) : ((s - 1) & 1)) * 16 + 8 * (q & 1)];
-            // the centre pixels of this lane's output column, rows 4q .. 4q + 3 = window rows 8 + 4q ...
-            const _Float16 *cpix = &L.tile[8 + l16][(q >> 1 ? (s & 1) * 16 : ((s - 1) & 1) * 16 + 8) + 4 * (q & 1)];
+            const int lo = opaque_lane(lane), l16o = lo & 15, qo = lo >> 4;
+            uint8_t *wout = reinterpret_cast<uint8_t *>(L.out[wave]) + l16o * TM_OUT_PITCH + 4 * qo;      // this lane's dword of a tile's staging rows
+            // window rows 8q .. 8q + 7 of this lane's column (A operand of the column pass), from the wave's first block on
+            const _Float16 *colp = &L.tile[16 * u0 + l16o][(qo >> 1 ? (s & 1) : ((s - 1) & 1)) * 16 + 8 * (qo & 1)];
             uint32_t xh[4] = {0, 0, 0, 0}, xl[4] = {0, 0, 0, 0};
             const half8_t THh[2] = {as_half8(thh[0], thh[1], thh[2], thh[3]), as_half8(thh[2], thh[3], thh[0], thh[1])};
             const half8_t THl[2] = {as_half8(thl[0], thl[1], thl[2], thl[3]), as_half8(thl[2], thl[3], thl[0], thl[1])};
@@ -438,7 +489,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 const int u = u0 + bi;                            // column block: positions 16u .. 16u + 15
                 const int hsel = bi & 1;
                 if (bi == 0 ? u < ntiles : u - 1 < ntiles) {      // some tile of this wave uses the block (wave-uniform)
-                    const half8_t A = *reinterpret_cast<const half8_t *>(colp + 16 * u * TM_COL_PITCH);
+                    const half8_t A = *reinterpret_cast<const half8_t *>(colp + 16 * bi * TM_COL_PITCH);
                     f32x4 cv = {0.f, 0.f, 0.f, 0.f};
 #ifndef TM_DBG_NOMFMA
                     cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, TBh, cv, 0, 0, 0);
@@ -456,18 +507,19 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                     const int t = u - 1, ti = bi - 1;
                     if (t < ntiles) {   // wave-uniform
                         // x_lo = x_mul (mean - b) + lo_add: the taps carry x_mul, the accumulator starts at lo_add - x_mul b
-                        const uint2 sc = *reinterpret_cast<const uint2 *>(cpix + 16 * t * TM_COL_PITCH);
-                        f32x4 c2 = {mad_f16_lo(sc.x, P.neg_x_mul, P.lo_add), mad_f16_hi(sc.x, P.neg_x_mul, P.lo_add),
-                                    mad_f16_lo(sc.y, P.neg_x_mul, P.lo_add), mad_f16_hi(sc.y, P.neg_x_mul, P.lo_add)};
+                        // (the centre pixels: columns 16t + l16 = positions 16t + 8 + l16, this lane's window rows)
+                        const half8_t Ab = *reinterpret_cast<const half8_t *>(colp + (16 * ti + 8) * TM_COL_PITCH);
                         const half8_t XH = as_half8(xh[0], xh[1], xh[2], xh[3]), XL = as_half8(xl[0], xl[1], xl[2], xl[3]);
 #ifndef TM_DBG_NOMFMA
-                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(XH, THh[hsel], c2, 0, 0, 0);
-                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(XH, THl[hsel], c2, 0, 0, 0);
-                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(XL, THh[hsel], c2, 0, 0, 0);
+                        f32x4 c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab, BID, K_LO, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THh[hsel], XH, c2, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THl[hsel], XH, c2, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THh[hsel], XL, c2, 0, 0, 0);
 #else
-                        c2[0] += (float)XH[0] + (float)XL[1]; c2[1] += (float)XH[2]; c2[2] += (float)XL[4]; c2[3] += (float)XH[6];
+                        f32x4 c2 = K_LO;
+                        c2[0] += (float)XH[0] + (float)XL[1] + (float)Ab[0]; c2[1] += (float)XH[2]; c2[2] += (float)XL[4]; c2[3] += (float)XH[6];
 #endif
-                        // c2[r] = x_lo at output row 4q + r, column 16t + l16; x saturates to byte 0x00 / 0xFF when the mean is
+                        // c2[r] = x_lo at output COLUMN 16t + 4q + r, row l16; x saturates to byte 0x00 / 0xFF when the mean is
                         // farther than EPS from the level, on the side that clears / sets the bit; x_hi = x_lo + (hi_add - lo_add)
                         uint32_t pk_lo = 0, pk_hi = 0;
 #pragma unroll
@@ -483,54 +535,75 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                         uint32_t amb = (z ^ (z >> 1)) & 0x7F7F7F7Fu;
                         if (EPS_MODE == 2) amb = 0x01010101u;          // diagnostic build: every pixel takes the exact path
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(amb != 0u) != 0ull, 0)) {
-                            const int x = it.x0 + 16 * t + l16;
-                            if (amb != 0u && x < it.x1) {
+                            const int lc = opaque_lane(lane), l16 = lc & 15, q = lc >> 4;      // (cold)
+                            const int y = oy + l16;
+                            if (amb != 0u && y < it.y1) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const int y = oy + 4 * q + r;
-                                    if (((amb >> (8 * r)) & 0xFFu) && y < it.y1) {
+                                    const int x = it.x0 + 16 * t + 4 * q + r;
+                                    if (((amb >> (8 * r)) & 0xFFu) && x < it.x1) {
                                         const uint32_t slot = atomicAdd(&L.n_list, 1u);
                                         if (slot < (uint32_t)TM_LIST_CAP) { L.list[slot] = ((uint32_t)y << 16) | (uint32_t)x; L.list_f[slot] = (uint16_t)it.f; }
                                     }
                                 }
                             }
                         }
-                        // 4 rows x 1 column per lane -> bytes of the wave's staging rows
-                        uint8_t *ob = wout + (4 * q) * TM_OUT_PITCH + 16 * ti + l16;
-                        ob[0] = (uint8_t)cb; ob[TM_OUT_PITCH] = (uint8_t)(cb >> 8); ob[2 * TM_OUT_PITCH] = (uint8_t)(cb >> 16);
-                        ob[3 * TM_OUT_PITCH] = (uint8_t)(cb >> 24);
+                        // 1 row x 4 columns per lane: one dword of the wave's staging rows
+                        *reinterpret_cast<uint32_t *>(wout + 16 * ti) = cb;
                     }
                 }
                 if (bi & 1) __builtin_amdgcn_sched_barrier(0);
             }
         };
         // the wave's 16 rows x 80 bytes leave as 16-byte pieces: piece = (row, 16 columns)
+        // (which 16-byte piece of its 16 rows x 80 bytes a lane stores does not change along the walk either)
+        constexpr int ST_ITERS = (TM_ROWS * TM_PER_WAVE + 63) / 64;
+        int st_lds[ST_ITERS], st_g[ST_ITERS];
+        bool st_full[ST_ITERS], st_part[ST_ITERS];
+        auto st_piece = [&](int k, int &r, int &x) __attribute__((always_inline)) {
+            const int pc = lane + 64 * k;
+            r = pc / TM_PER_WAVE;
+            x = it.x0 + 16 * u0 + 16 * (pc - r * TM_PER_WAVE);
+        };
+#pragma unroll
+        for (int k = 0; k < ST_ITERS; ++k) {
+            int r, x;
+            st_piece(k, r, x);
+            st_lds[k] = r * TM_OUT_PITCH + (x - it.x0 - 16 * u0);
+            st_g[k] = r * W + x;
+            st_full[k] = r < TM_ROWS && it.x1 - x >= 16;
+            st_part[k] = r < TM_ROWS && it.x1 - x > 0 && it.x1 - x < 16;      // (4, 8 or 12 bytes left in the row)
+        }
         auto store_step = [&](int s) __attribute__((always_inline)) {
 #ifdef TM_DBG_NOFILTER
             return;
 #endif
             const int oy = it.y0 + TM_ROWS * (s - 1);
             const uint8_t *wout = reinterpret_cast<const uint8_t *>(L.out[wave]);
-            const int u0s = u0;
-            (void)u0s;
-            const int rows = min(TM_ROWS, it.y1 - oy);
-            const int xw = it.x0 + 16 * u0;                               // first column of this wave's tiles
+            const int rows = min(TM_ROWS, it.y1 - oy);                         // (below 16 in an item's last step only)
+            uint8_t *base = dst + (size_t)oy * W;                              // (wave-uniform)
 #pragma unroll
-            for (int k = 0; k < (TM_ROWS * TM_PER_WAVE + 63) / 64; ++k) {
-                const int pc = lane + 64 * k;
-                const int r = pc / TM_PER_WAVE, c = pc - r * TM_PER_WAVE;
-                const int x = xw + 16 * c;
+            for (int k = 0; k < ST_ITERS; ++k) {
+                bool full = st_full[k], part = st_part[k];
+                if (rows < TM_ROWS) {    // wave-uniform
+                    int r, x;
+                    st_piece(k, r, x);
+                    full = full && r < rows; part = part && r < rows;
+                }
 #ifdef TM_DBG_NOSTORE
-                if (pc < TM_ROWS * TM_PER_WAVE && r < rows && x < it.x1 && lane == 77) {
-#else
-                if (pc < TM_ROWS * TM_PER_WAVE && r < rows && x < it.x1) {
+                full = full && lane == 77; part = false;
 #endif
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(wout + r * TM_OUT_PITCH + 16 * c);
-                    uint8_t *g = dst + (size_t)(oy + r) * W + x;
-                    const int nb = it.x1 - x;                             // bytes left in the row: 4, 8, 12 or >= 16
-                    if (nb >= 16) __builtin_memcpy(g, &v, 16);
-                    else {
-                        uint32_t *g4 = reinterpret_cast<uint32_t *>(g);
+                if (full) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(wout + st_lds[k]);
+                    __builtin_memcpy(base + st_g[k], &v, 16);
+                }
+                if (__builtin_amdgcn_ballot_w64(part) != 0ull) {
+                    if (part) {
+                        int r, x;
+                        st_piece(k, r, x);
+                        const int nb = it.x1 - x;
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(wout + st_lds[k]);
+                        uint32_t *g4 = reinterpret_cast<uint32_t *>(base + st_g[k]);
                         g4[0] = v[0];
                         if (nb >= 8) g4[1] = v[1];
                         if (nb >= 12) g4[2] = v[2];
@@ -565,13 +638,21 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int s = 0; s <= nblk; ++s) {
             int mine = 0;
+            TMSTAMP(s, 0);
             if (s + 2 <= nblk) mine = request_raw(s + 2);        // into the buffer the blur of step s has finished with
+            TMSTAMP(s, 1);
             if (s >= 1) filter_step(s);
+            TMSTAMP(s, 2);
             wait_all_but(__builtin_amdgcn_readfirstlane(mine));  // the rows of step s + 1 have landed (and every older store)
+            TMSTAMP(s, 3);
             if (s >= 1) store_step(s);
+            TMSTAMP(s, 4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            TMSTAMP(s, 5);
             if (s + 1 <= nblk) blur_any(s + 1);           // overwrites the tile block of step s - 1
+            TMSTAMP(s, 6);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            TMSTAMP(s, 7);
         }
 
         // ---- an item whose ambiguous pixels outgrew the list (a frame made to sit on the levels): all of it again, exactly ----
@@ -608,6 +689,10 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
 
 }  // namespace
 
+#ifdef YSMR_STAMPS
+extern "C" int ysmr_debug_read_thr_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tm_stamps), sizeof(g_tm_stamps)); }
+#endif
+
 namespace ysmr_thr {
 
 bool supported(int H, int W, int channels, int t_low, int t_high, int use_high)
@@ -632,7 +717,8 @@ int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H
     // x = sign * S * (theta - v) + 127.5 leaves [0, 255) exactly when v is EPS = 127.5 / S or more away from theta
     // (EPS = 1/256 since round 4: above the worst case of the header's bound, 3.1e-3, not only above what was measured;
     //  the undecided pixels double -- from two per frame to four.  The row pass's f16 taps carry S: S < 65504 / 0.2006)
-    const float eps = variant == 1 ? 1.0f / 2048.0f : 1.0f / 256.0f;
+    // (variant 1, diagnostic: half the margin -- 127.5 / eps is an f16 tap of the accumulator's preset, so 1/512 is the least)
+    const float eps = variant == 1 ? 1.0f / 512.0f : 1.0f / 256.0f;
     const float S = 127.5f / eps, sgn = inv ? -1.0f : 1.0f;
     P.x_mul = -sgn * S; P.neg_x_mul = sgn * S;
     P.lo_add = sgn * S * (-(float)t_low - 0.5f) + 127.5f;
