@@ -203,6 +203,65 @@ __device__ __forceinline__ uint32_t exact_class(const uint8_t *frame, const ysmr
     return (uint32_t)(lo | (hi << 1));
 }
 
+// The same arithmetic for ONE pixel per WAVE, laid out for latency (the list of a workgroup holds a handful of pixels and
+// the whole unit waits for them): the 13 x 13 gray window in one round of loads (three bytes per lane), the 11 x 11
+// blurred pixels two per lane, the eleven row chains on eleven lanes, the column pass from their registers.  About 2 us
+// for the first pixel against 6-7 us for exact_class's rolled loops (profiles/r04_thr_refine.log).
+// scratch: 208 + 528 bytes of the wave's own.
+__device__ __forceinline__ uint32_t exact_class_wave(const uint8_t *frame, const ysmr_thr::Params &P, int y, int x, int lane, uint8_t *scratch)
+{
+    const int H = P.H, W = P.W;
+    uint8_t *win = scratch;                                        // [13][16]: gray[clamp(y - 6 + a)][clamp(x - 6 + b)]
+    float *bl = reinterpret_cast<float *>(scratch + 208);          // [11][12]: blurred pixels of the Gaussian's window
+    uint8_t g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int e = min(lane + 64 * k, 168), a = e / 13, b = e - 13 * a;
+        g[k] = frame[(size_t)clampi(y - 6 + a, 0, H - 1) * W + clampi(x - 6 + b, 0, W - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int e = min(lane + 64 * k, 168), a = e / 13, b = e - 13 * a;
+        win[16 * a + b] = g[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = min(lane + 64 * k, 120), dy = e / 11, i = e - 11 * dy;
+        // the Gaussian's row y - 5 + dy and column x - 5 + i (REPLICATE: clamped); the blur around them reflects
+        const int yy = clampi(y - 5 + dy, 0, H - 1), xx = clampi(x - 5 + i, 0, W - 1);
+        const int ra = reflect101(yy - 1, H) - (y - 6), rb = yy - (y - 6), rc = reflect101(yy + 1, H) - (y - 6);
+        const int ca = reflect101(xx - 1, W) - (x - 6), cb = xx - (x - 6), cc = reflect101(xx + 1, W) - (x - 6);
+        const uint32_t sum = win[16 * ra + ca] + 2u * win[16 * ra + cb] + win[16 * ra + cc] +
+                             2u * (win[16 * rb + ca] + 2u * win[16 * rb + cb] + win[16 * rb + cc]) +
+                             win[16 * rc + ca] + 2u * win[16 * rc + cb] + win[16 * rc + cc];
+        bl[12 * dy + i] = (float)((sum + 8u) >> 4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // row pass: lane dy < 11 runs cv2's ascending chain over its row; column pass: the symmetric form, in every lane
+    const float *row = bl + 12 * min(lane, 10);
+    float v[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) v[i] = row[i];
+    const float centre = bl[12 * 5 + 5];
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) acc = __builtin_fmaf(v[i], tap_weight(P, i), acc);
+    auto at = [&](int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), l)); };
+    float m = __builtin_fmaf(at(5), P.kw[5], 0.0f);
+#pragma unroll
+    for (int j = 1; j <= 5; ++j) m = __builtin_fmaf(at(5 + j) + at(5 - j), P.kw[5 - j], m);
+    const int mi = clampi((int)__builtin_rintf(m), 0, 255);
+    const int d = (int)centre - mi;
+    const int lo = P.inv ? (d <= P.t_low) : (d > P.t_low);
+    const int hi = P.use_high ? (P.inv ? (d <= P.t_high) : (d > P.t_high)) : lo;
+    return (uint32_t)(lo | (hi << 1));
+}
+
 struct Lds {
     _Float16 tile[TM_POS][TM_COL_PITCH];                 // blurred pixels [column position][row of a 2 x 16-row ring]
     uint8_t raw[2][TM_ROWS * TM_RAW_PITCH];              // gray rows of a step: row r, columns x0 - 24 ... at r * 16 * (chunks per row)
@@ -213,6 +272,7 @@ struct Lds {
 };
 static_assert(sizeof(Lds) <= 160 * 1024, "LDS of one CU");
 static_assert(sizeof(Lds::out) >= 256 * (TM_THREADS / 16), "the exact path's windows live in the class-byte staging");
+static_assert(sizeof(Lds::out) >= 768 * TM_WAVES, "and so does the wave-per-pixel form's scratch");
 
 // f16 bit pattern of w / 16 for w = 0..4 (the blur's column taps carry the division by 16)
 __device__ __forceinline__ uint32_t small_f16(int w) { return w == 0 ? 0u : w == 1 ? 0x2C00u : w == 2 ? 0x3000u : w == 3 ? 0x3200u : 0x3400u; }
@@ -674,15 +734,18 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
 
     // ---- ambiguous pixels of all of this workgroup's items: cv2's own arithmetic, sixteen lanes per pixel -----------------
     // (once per workgroup: the code is cold, its first pixel costs microseconds of instruction fetch)
+#ifdef TM_DBG_NOREFINE
+    n_kept = 0;
+#endif
     if (__builtin_expect(n_kept != 0u, 0)) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");              // the walk's stores lie under these bytes
-        for (uint32_t e0 = 0; e0 < n_kept; e0 += TM_THREADS / 16) {
-            const uint32_t e = e0 + (uint32_t)(tid >> 4);
+        for (uint32_t e0 = 0; e0 < n_kept; e0 += TM_WAVES) {          // a pixel per wave
+            const uint32_t e = e0 + (uint32_t)wave;
             const uint32_t ent = L.list[min(e, n_kept - 1)];
             const size_t fo = (size_t)L.list_f[min(e, n_kept - 1)] * H * W;
             const int y = (int)(ent >> 16), x = (int)(ent & 0xFFFFu);
-            const uint32_t c = exact_class(frames + fo, P, y, x, lane, reinterpret_cast<uint8_t *>(L.out) + 256 * (tid >> 4));
-            if (e < n_kept && l16 == 0) cls[fo + (size_t)y * W + x] = (uint8_t)c;
+            const uint32_t c = exact_class_wave(frames + fo, P, y, x, lane, reinterpret_cast<uint8_t *>(L.out) + 768 * wave);
+            if (e < n_kept && lane == 0) cls[fo + (size_t)y * W + x] = (uint8_t)c;
         }
     }
 }
