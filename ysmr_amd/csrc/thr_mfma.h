@@ -12,6 +12,7 @@ struct Params {
     int inv, use_high, t_low, t_high;
     // x = S * (theta - v) * sign + 127.5 saturates to byte 0 / 255 outside EPS of the level theta (v = mean - blurred)
     float x_mul, neg_x_mul, lo_add, hi_minus_lo;
+    int start_rows;        // the cost of starting an item, in rows of the walk (how the rows are cut into ranges)
     uint32_t lo_bits;      // class bits taken from the first level's byte (both when there is one level)
     float kw[6];           // the Gaussian's distinct weights k[0..5] (k[i] == k[10 - i]), cv2's float32 values
 };

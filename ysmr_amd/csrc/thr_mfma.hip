@@ -67,6 +67,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define TM_MAX_PANEL_N 1232
 #endif
 constexpr int TM_WAVES = TM_WAVES_N, TM_THREADS = 64 * TM_WAVES;
+#ifndef TM_START_ROWS_N
+#define TM_START_ROWS_N 48
+#endif
+constexpr int TM_START_ROWS = TM_START_ROWS_N;               // what an item's start costs, in rows of the walk (swept: profiles/r04_thr_start_rows.log)
 constexpr int TM_ROWS = 16;                                  // rows per step (one MFMA tile row block)
 constexpr int TM_MAX_PANEL = TM_MAX_PANEL_N;                 // columns per panel, a multiple of 16 (1232: 77 tiles of 16)
 constexpr int TM_MAX_TILES = TM_MAX_PANEL / 16;              // output tiles t: columns 16t .. 16t + 15 of the panel
@@ -365,8 +369,15 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
     const int groups = P.by_xcd ? 8 : 1;
     const long long cols = (long long)(P.batch / groups) * P.panels, rows_all = cols * H;
     const long long nb = gridDim.x / groups, bi = P.by_xcd ? (blockIdx.x >> 3) : blockIdx.x;
-    long long g0 = rows_all * bi / nb;
-    const long long g1 = rows_all * (bi + 1) / nb;
+    // Equal COST, not equal rows: starting an item (two blocks of rows fetched and blurred before the first output row)
+    // costs what P.start_rows rows of the walk cost, and a range that holds the top of a column starts two items.  The cut
+    // is even in a space where every column is that much longer (its top repeated); a position there maps back to a row.
+    // (The host passes 0 when the workgroups divide the columns evenly: every range then starts exactly one item.)
+    (void)rows_all;
+    const long long vh = H + P.start_rows, v_all = cols * vh;
+    auto real_row = [&](long long v) { const long long c = v / vh, r = v - c * vh; return c * H + (r > P.start_rows ? r - P.start_rows : 0); };
+    long long g0 = real_row(v_all * bi / nb);
+    const long long g1 = bi + 1 == nb ? cols * H : real_row(v_all * (bi + 1) / nb);
     const int f_add = P.by_xcd ? (int)(blockIdx.x & 7u) : 0;
 
     uint32_t n_kept = 0;                                   // listed pixels of the items done so far
@@ -791,6 +802,10 @@ int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H
     // (no workgroup with fewer than 32 rows: an item re-filters 16 halo rows)
     long long grid = std::max<long long>(1, std::min<long long>((long long)batch * P.panels * H / 32, blocks));
     P.by_xcd = (batch % 8 == 0 && grid % 8 == 0) ? 1 : 0;
+    {
+        const long long groups = P.by_xcd ? 8 : 1, cols = (long long)(batch / groups) * P.panels, nb = grid / groups;
+        P.start_rows = nb % cols == 0 ? 0 : TM_START_ROWS;
+    }
     const size_t lds = sizeof(Lds);
     auto kern = variant == 2 ? k_threshold_mfma<2> : k_threshold_mfma<0>;
     YSMR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
