@@ -9,6 +9,7 @@ ap.add_argument("--height", type=int, default=922); ap.add_argument("--width", t
 ap.add_argument("--reps", type=int, default=3); ap.add_argument("--real", action="store_true")
 ap.add_argument("--bgr", action="store_true", help="3-channel input (gray replicated)")
 ap.add_argument("--variant", type=int, default=0, help="ysmr_threshold_batch_variant: 0 = matrix-pipe kernel, 1 = float32-chain strip kernel")
+ap.add_argument("--beside", action="store_true", help="the grid the kernel takes beside the batch link (YSMR_BESIDE_BATCH_LINK: 248 workgroups)")
 a = ap.parse_args()
 H, W, B, F = a.height, a.width, a.batch, a.frames
 if a.real:
@@ -19,7 +20,7 @@ else:  # background-like noise (40 +- 2), enough for timing
     frames = (torch.randn(F, H, W, device="cuda", generator=g) * 2 + 40).round().clamp(0, 255).to(torch.uint8)
 if a.bgr:
     frames = frames[:F // 2].unsqueeze(-1).expand(-1, -1, -1, 3).contiguous(); F = F // 2
-det = Detector(B, H, W, max_det=2048, threshold_variant=a.variant)
+det = Detector(B, H, W, max_det=2048, threshold_variant=a.variant, beside_batch_link=a.beside)
 for f0 in range(0, F, B): det.threshold(frames[f0:f0 + B])
 torch.cuda.synchronize()
 ts = []

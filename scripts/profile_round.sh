@@ -8,15 +8,16 @@ python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail 
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 > $O/ktrace.log 2>&1
 if [ -z "$SKIP_PMC" ]; then   # (SKIP_PMC=1: the threshold kernels have not changed since the committed counters)
-# (variant 1 = k_threshold_strip, the kernel of the pipeline and of the bench line; variant 0 = k_threshold_mfma)
+# (variant 0 = k_threshold_mfma, since round 4 the kernel of the pipeline and of the bench line, on the grid it takes there
+#  (--beside: 248 workgroups); variant 1 = k_threshold_strip)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_thr_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 1 > $O/pmc_thr_$c.log 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_mfma_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 > $O/pmc_mfma_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_mfma_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 --beside > $O/pmc_mfma_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_cal_$c -- $R/scripts/ubench/copy_calib > $O/pmc_cal_$c.log 2>&1
 done
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_thr_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 1 > $O/pmc_thr_SQ.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_mfma_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 > $O/pmc_mfma_SQ.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_mfma_SQ2 -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 > $O/pmc_mfma_SQ2.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_mfma_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 --beside > $O/pmc_mfma_SQ.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_mfma_SQ2 -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 --beside > $O/pmc_mfma_SQ2.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 O = "$O"
@@ -50,3 +51,13 @@ cat $O/kernel_stats.txt | cut -c1-150
 rocprofv3 --kernel-trace --output-format csv -d $O/kt4k -- python3 $R/bench.py --config 4 --steps 6 --cpu-sample 0 > $O/kt4k.log 2>&1
 python3 $R/scripts/timeline_4k.py $O/kt4k 60 > $O/timeline_4k.txt; rm -rf $O/kt4k; head -45 $O/timeline_4k.txt | cut -c1-150
 [ -f $R/scripts/var_stamps.so ] && YSMR_HIP_LIB=$R/scripts/var_stamps.so python3 $R/scripts/link_timeline.py > $O/link_timeline_4k.log 2>&1; cat $O/link_timeline_4k.log | grep -v amdgpu
+# round 4: what lies between two k_batch launches (the same kernel trace), the phases of the batch link and of the threshold
+# kernel's walk (stamps build), file to rows, the two-rank rehearsal on one device
+python3 $R/scripts/link_gaps.py $O/ktrace > $O/link_gaps.log 2>&1; cat $O/link_gaps.log
+if [ -f $R/scripts/var_stamps.so ]; then
+  YSMR_HIP_LIB=$R/scripts/var_stamps.so BL_WAVES=12 python3 $R/scripts/batch_stamps.py 500 768 2048 2>&1 | grep -v amdgpu > $O/batch_link_stamps.log; tail -14 $O/batch_link_stamps.log | cut -c1-170
+  YSMR_HIP_LIB=$R/scripts/var_stamps.so python3 $R/scripts/thr_stamps.py 2>&1 | grep -v amdgpu > $O/thr_stamps.log; cat $O/thr_stamps.log | cut -c1-170
+fi
+python3 $R/scripts/e2e_profile.py > $O/e2e_file_profile.log 2>&1; tail -12 $O/e2e_file_profile.log
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 $R/bench.py --gpus 2 --steps 10 --warmup 3 --dist-backend gloo --device-index 0 --cpu-sample 0 > $O/bench_gloo2.json 2> $O/bench_gloo2.err; cut -c1-260 $O/bench_gloo2.json
+rm -rf $O/ktrace/*/*kernel_trace.csv $O/ktrace_det/*/*kernel_trace.csv
