@@ -1,9 +1,9 @@
 // batch_link.h -- the link of a whole BATCH of frames in one launch (included by track.hip, inside its namespace).
 //
 // CentroidTracker.update (ysmr/tracker.py:93-230) + GaussianSumFIR.correct / predict (ysmr/gsff.py:204-347) + row
-// emission (ysmr/track_eval.py:313-316) for `batch` consecutive frames: ONE workgroup of 1024 threads on ONE compute
-// unit, a track per LANE, everything a frame needs of a track -- the filter bank's window sums, weights and estimates,
-// prediction, box, id, counters: 55 registers -- in the lane from the first frame of the batch to the last.
+// emission (ysmr/track_eval.py:313-316) for `batch` consecutive frames: ONE workgroup of BL_THREADS = 768 threads on ONE
+// compute unit, a track per LANE, everything a frame needs of a track -- the filter bank's window sums, weights and
+// estimates, prediction, box, id, counters: 55 registers -- in the lane from the first frame of the batch to the last.
 //
 //   detections   k_bgrid (one workgroup per frame, the whole batch at once, before this kernel) bins every frame's
 //                detections into a uniform grid of cells (counting sort) and leaves header | cell starts (u16) |
@@ -25,11 +25,12 @@
 //                sums S0_N = sum_{a<N} h[a], S1_N = sum_{a<N} a h[a].  A new measurement z turns them into
 //                S1' = S1 + S0 - N h[N-1], S0' = S0 + z - h[N-1]: six sums per coordinate in registers, updated with four
 //                operations each, and of the 31 measurements of history a frame touches FOUR: the one it appends and the
-//                three that leave the windows.  The history therefore lives in HBM, a ring of 32 frames x 1024 seats
+//                three that leave the windows.  The history therefore lives in HBM, a ring of 32 frames x 768 seats
 //                (every live track appends exactly one measurement per frame, so one head serves all seats and a ring
 //                position is one coalesced line per wave); the leaving entries are requested before the claims and used
-//                after them.  The sums are recomputed from the ring, exactly, at the start of every launch, so rounding
-//                drift is bounded by one batch (64 updates: ~1e-11 px, the size of a from-scratch sum's own rounding).
+//                after them.  The sums are recomputed from the ring, exactly, in every frame whose NUMBER is a multiple of
+//                BL_REFRESH = 64 (not at the start of a launch: the rows must not depend on how the frames were batched),
+//                so rounding drift is bounded by 64 updates: ~1e-11 px, the size of a from-scratch sum's own rounding.
 //   rows         one 40-byte ysmr_row per live lane at rows[base + rank], fire and forget.
 //
 // Three workgroup barriers per frame (after each atomic round, and at the end of the frame, where the next frame's
@@ -39,7 +40,7 @@
 //
 // Between launches the small state rests in HBM seat by seat (a seat keeps its track for the track's whole life; free
 // seats are flagged), next to the ring.  k_to_std / k_to_batch convert to and from the per-slot layout of k_frame /
-// k_link + k_track (ysmr_tracker_update, tables beyond this kernel's 1024 seats).
+// k_link + k_track (ysmr_tracker_update, tables beyond this kernel's 768 seats).
 #pragma once
 
 // (BL_* constants and struct BatchDev: track.hip, next to TrackerDev -- the host handle holds one)
