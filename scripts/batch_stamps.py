@@ -20,9 +20,21 @@ buf = (ctypes.c_ulonglong * (NW * 16))()
 names = ["dma issue", "search + key atomic", "barrier A", "clear next tables + id atomic", "barrier B", "claims / ageing / registration",
          "filter bank", "wait vmcnt(0)", "barrier D", "ranks + row"]
 acc = []
-for rep in range(6):
+# BESIDE=1: the stamped launch runs while another stream loops over the matrix-pipe threshold kernel on 248 workgroups, as
+# in the pipeline (which phase of a frame the memory system's load stretches)
+beside = os.environ.get("BESIDE") == "1"
+if beside:
+    from ysmr_amd.detect import Detector
+    side = torch.cuda.Stream()
+    det_b = Detector(B, H, W, max_det=md, beside_batch_link=True)
+    many = torch.from_numpy(SyntheticVideo(H, W, blobs, seed=1).frames(256)).cuda()
+for rep in range(12 if beside else 6):
     pipe.reset()
     pipe.trk.run(res0.det, res0.det_count, 0, pipe.rows, pipe.row_count)
+    torch.cuda.synchronize()
+    if beside:
+        with torch.cuda.stream(side):
+            for i in range(8): det_b.threshold(many[(i % 4) * B:(i % 4) * B + B])
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record(); pipe.trk.run(res1.det, res1.det_count, B, pipe.rows, pipe.row_count); t1.record()
     torch.cuda.synchronize()
@@ -32,7 +44,7 @@ for rep in range(6):
     acc.append(a)
     print("   fast path per wave:", (full[:, 11] - full[:, 1]).tolist(), " lanes left to the wave search:", full[:, 12].tolist())
     print(f"rep {rep}: launch pair {t0.elapsed_time(t1) * 1e3:.1f} us for {B} frames; frame (wave 0) {a[0, 10] - a[0, 0]} cycles")
-a = np.median(np.array(acc), axis=0)
+a = np.mean(np.array(acc), axis=0) if beside else np.median(np.array(acc), axis=0)
 d = np.diff(a, axis=1)
 print("%-44s" % "phase (cycles of s_memtime, 100 MHz? no: shader clock)", " ".join(f"w{w:<6d}" for w in range(NW)))
 for k, n in enumerate(names):
