@@ -184,6 +184,7 @@ def main():
             e.record(torch.cuda.current_stream(dev))
     torch.cuda.synchronize()
     pool_i = [0]
+    host_calls = {"detect_async": [], "link": [], "reset": []}   # seconds per call of the timed steps (where a slow host loses its time)
 
     def step(timed):
         # one clip per stream, fresh trackers; detection of batch b+1 (side stream) overlaps the link of
@@ -192,7 +193,9 @@ def main():
         t_host = time.perf_counter()
         for k in range(S):
             with torch.cuda.stream(link_streams[k]):
+                tc = time.perf_counter()
                 pipes[k].reset()
+                if timed: host_calls["reset"].append(time.perf_counter() - tc)
         for f0 in list(range(0, F, B)) + [None]:
             for k in range(S):
                 with torch.cuda.stream(link_streams[k]):
@@ -206,20 +209,41 @@ def main():
                         # link's are extra packets on their streams (1.5 % end to end when taken around every batch):
                         # every fourth batch is sampled
                         sampled = probe and (pool_i[0] % 4 == 1)
+                        tc = time.perf_counter()
                         nxt = (pipes[k].detect_async(clips[k][f0:f0 + B], thr_events if probe else None,
                                                      chain_events if (sampled and DIAG & 1) else None, events=evs,
                                                      frames_ready=False), f0, evs, sampled)   # (the clip is resident in HBM)
+                        if timed: host_calls["detect_async"].append(time.perf_counter() - tc)
                     if pending[k] is not None and not args.detect_only:
                         (slot, res, ready), p0, pevs, psampled = pending[k]
+                        tc = time.perf_counter()
                         pipes[k].link(slot, res, ready, p0, link_events if (psampled and DIAG & 2) else None, events=pevs,
                                       nxt=nxt[0] if nxt is not None else None)
+                        if timed: host_calls["link"].append(time.perf_counter() - tc)
                     pending[k] = nxt
         if timed:
             enqueue_s.append(time.perf_counter() - t_host)
 
+    # The warm-up steps ARE timed steps (same launches, same probes) whose records are thrown away: the first launch that
+    # carries timing events switches its hardware queue to profiling, once per queue, and on some hosts of this pool that
+    # one call blocks for 40 ms (scripts/host_probe.py, diagnostics.host_call_us: 86 us median, 42 ms maximum, inside
+    # the timed region, when warm-up ran without the probes: 159 k frames/s became 76-106 k on such a box)
+    # A full collection of CPython's garbage collector walks every tracked object of the process (torch, numpy, pandas
+    # modules: ~40 ms on this pool's hosts) and its trigger is an allocation count, so it fell INSIDE the timed region of
+    # some command lines and not of others: 159 k frames/s became 76-106 k (diagnostics.host_call_us showed one
+    # detect_async call of 42 ms among 80 of 86 us).  Everything alive now is moved out of the collector's sight
+    # (gc.freeze), as ysmr_amd.track_eval does around its frame loop; collections of what the steps allocate stay on.
+    # YSMR_BENCH_GC=1: leave the collector alone (the measurement of the above).
+    import gc
+    if os.environ.get("YSMR_BENCH_GC") != "1":
+        gc.collect()
+        gc.freeze()
     for _ in range(args.warmup):
-        step(False)
+        step(True)
     torch.cuda.synchronize()
+    for rec in (thr_events, chain_events, link_events, enqueue_s, *host_calls.values()):
+        rec.clear()
+    pool_i[0] = 0
     dist.barrier(info)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -305,6 +329,8 @@ def main():
                 "link_us_per_frame": stats_us([e0.elapsed_time(e1) * 1e3 / n for e0, e1, n, _ in link_events]),
                 "link_host_issue_us_per_frame": stats_us([h * 1e6 / n for _, _, n, h in link_events]),
                 "host_enqueue_ms_per_step": sum(enqueue_s) / len(enqueue_s) * 1e3 if enqueue_s else None,
+                # per call of the step loop: a host that blocks somewhere shows as a max far above the p50
+                "host_call_us": {k: stats_us([x * 1e6 for x in v]) for k, v in host_calls.items() if v},
                 "clocks": gpu_clocks(local_rank), "kernargs_in_device_memory": os.environ.get("HIP_FORCE_DEV_KERNARG") == "1",
                 "host_cpus": os.cpu_count(),
                 "cpus_usable": len(os.sched_getaffinity(0)), "pinned_to_gpu_numa_node": bool(pinned),

@@ -267,6 +267,39 @@ def test_detect_dense_noise_stresses_union_find(torch_cuda, oracle):
         _compare(oracle, frames, _detect_gpu(torch_cuda, frames, p, max_det=16384), p, max_det=16384)
 
 
+def test_residue_one_workgroup_per_frame(torch_cuda, oracle):
+    """Batches of 32 frames and more run the union-find passes with one workgroup per frame (k_residue_frames) instead of
+    the grid-barrier kernel: the three ways such a workgroup finds its pixels -- its part of the list gathered in LDS (a few
+    large islands per frame), the whole list re-read in every pass (one frame with more residue than the LDS list holds),
+    every pixel of the frame (the list itself overflowed) -- against the oracle, and the same frames through the
+    grid-barrier kernel (a batch of three)."""
+    from ysmr_amd.detect import threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    p = threshold_params(True, 5, 2.0)
+    rng = np.random.default_rng(14)
+    h, w = 150, 201
+    frames = SyntheticVideo(h, w, 14, seed=3).frames(32)
+    for f in range(32):                       # islands beyond a 16 x 16 window, touching pairs, one with a hole
+        y, x = 20 + (f * 3) % 60, 30 + (f * 7) % 100
+        frames[f, y:y + 24, x:x + 31] = 200
+        frames[f, y + 8:y + 12, x + 10:x + 16] = 40
+        frames[f, 110:118, 20 + f:60 + f] = 180
+    got = _detect_gpu(torch_cuda, frames, p, max_det=4096)
+    _compare(oracle, frames, got, p, max_det=4096)
+    few = _detect_gpu(torch_cuda, frames[:3], p, max_det=4096)
+    for k in ("labels", "mask", "det", "det_count", "anchors"):
+        np.testing.assert_array_equal(few[k], got[k][:3], err_msg=k)
+    # one frame of coarse blocks: ~10 k residue pixels in that frame (beyond the 8192 of the LDS list), the list still
+    # within its capacity of 1/8 of the batch's pixels
+    coarse = frames.copy()
+    blocks = (rng.random((h // 6 + 1, w // 6 + 1)) < 0.45)
+    coarse[5] = np.kron(blocks, np.ones((6, 6), dtype=np.uint8))[:h, :w] * np.uint8(190) + 30
+    _compare(oracle, coarse, _detect_gpu(torch_cuda, coarse, p, max_det=4096), p, max_det=4096)
+    # noise everywhere: the list overflows, every workgroup walks its frame
+    noise = rng.integers(0, 256, (32, 60, 81), dtype=np.uint8)
+    _compare(oracle, noise, _detect_gpu(torch_cuda, noise, p, max_det=8192), p, max_det=8192)
+
+
 def test_detect_nested_component_is_skipped(torch_cuda, oracle):
     from ysmr_amd.detect import threshold_params
     p = threshold_params(True, 5, 2.0)

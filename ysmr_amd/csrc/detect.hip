@@ -724,12 +724,25 @@ constexpr int SPARSE_BLOCKS = 768;  // resident grid of the list-driven passes (
 // The passes are bound by chains of dependent L2 round trips (union-find), so they want many
 // short threads: one lane per pixel, grid-stride.
 // (nb: the number of blocks that take part, see k_residue)
-#define FOR_LISTED_PIXELS(pl, g, nb, flat)                                                                       \
-    if (const uint32_t *idx_ = (pl).idx[0]; true)                                                                \
-        for (size_t cnt_ = (pl).hdr->count[0], dense_ = cnt_ > (pl).cap, ln_ = dense_ ? (g).total : cnt_,        \
-                    li_ = (size_t)blockIdx.x * 256 + threadIdx.x;                                                \
-             li_ < ln_; li_ += (size_t)(nb) * 256)                                                               \
-            if (const size_t flat = dense_ ? li_ : (size_t)idx_[li_]; true)
+// Where a pass takes its pixels from: entries `first, first + step, ...` of a list (the residue list in HBM, or one frame's
+// part of it gathered in LDS), optionally only those of one frame (a frame's workgroup reading the whole list), or -- `dense`,
+// the list overflowed -- every pixel from `dense_base` on.
+struct ResidueIter {
+    const uint32_t *idx;
+    size_t n, first, step, dense_base;
+    int only_frame;        // -1: any
+    bool dense;
+};
+__device__ __forceinline__ ResidueIter residue_iter_grid(const PixelList &pl, const Geo &g, unsigned nb)
+{
+    const size_t cnt = pl.hdr->count[0];
+    const bool dense = cnt > pl.cap;
+    return ResidueIter{pl.idx[0], dense ? g.total : cnt, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)nb * 256, 0, -1, dense};
+}
+#define FOR_LISTED_PIXELS(it, g, flat)                                                                                    \
+    for (size_t li_ = (it).first; li_ < (it).n; li_ += (it).step)                                                         \
+        if (const size_t flat = (it).dense ? (it).dense_base + li_ : (size_t)(it).idx[li_];                               \
+            (it).only_frame < 0 || flat / (g).HW == (size_t)(it).only_frame)
 
 struct CompTables {
     int32_t *nroots;   // [B * NR_STRIDE]: one counter per 128-byte line (same-line atomics serialise)
@@ -1210,10 +1223,9 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
 }
 
 // Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
-__device__ __forceinline__ void pass_union4(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const PixelList &pl,
-                                            unsigned nb)
+__device__ __forceinline__ void pass_union4(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const ResidueIter &it)
 {
-    FOR_LISTED_PIXELS(pl, g, nb, flat) {
+    FOR_LISTED_PIXELS(it, g, flat) {
         if (flat >= g.total || !(cls[flat] & 1u)) continue;
         uint32_t f, p; int y, x;
         locate(g, flat, f, p, y, x);
@@ -1234,9 +1246,9 @@ __device__ __forceinline__ void set_flag(uint8_t *cls, size_t flat)
 
 // Pass C: flag (bit2 on the root's class byte) every thresh-component that holds a marker pixel
 // or touches (4-neighbourhood) a marker pixel lying outside the mask.
-__device__ __forceinline__ void pass_flag(uint8_t *cls, uint32_t *labels, const Geo &g, const PixelList &pl, unsigned nb)
+__device__ __forceinline__ void pass_flag(uint8_t *cls, uint32_t *labels, const Geo &g, const ResidueIter &it)
 {
-    FOR_LISTED_PIXELS(pl, g, nb, flat) {
+    FOR_LISTED_PIXELS(it, g, flat) {
         {
             if (flat >= g.total) continue;
             uint32_t b = cls[flat];
@@ -1271,10 +1283,9 @@ __device__ __forceinline__ bool in_result(const uint8_t *cls_frame, const uint32
 }
 
 // Pass D: 8-connected components of R (what cv2.findContours traces).
-__device__ __forceinline__ void pass_union8(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const PixelList &pl,
-                                            unsigned nb)
+__device__ __forceinline__ void pass_union8(const uint8_t *__restrict__ cls, uint32_t *labels, const Geo &g, const ResidueIter &it)
 {
-    FOR_LISTED_PIXELS(pl, g, nb, flat) {
+    FOR_LISTED_PIXELS(it, g, flat) {
     {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
@@ -1308,9 +1319,9 @@ __device__ __forceinline__ void pass_union8(const uint8_t *__restrict__ cls, uin
 
 // Pass E: final labels (root + 1), final mask (cleared by k_clear beforehand), roots per frame.
 __device__ __forceinline__ void pass_flatten(const uint8_t *__restrict__ cls, uint32_t *labels, uint8_t *__restrict__ mask,
-                                             const Geo &g, const PixelList &pl, const CompTables &t, unsigned nb)
+                                             const Geo &g, const ResidueIter &it, const CompTables &t)
 {
-    FOR_LISTED_PIXELS(pl, g, nb, flat) {
+    FOR_LISTED_PIXELS(it, g, flat) {
         if (flat >= g.total) continue;
         uint32_t b = cls[flat];
         if (!(b & 3u)) continue;
@@ -1471,23 +1482,23 @@ constexpr uint32_t SLOT_TAG = 0x80000000u;
 // Per final-mask pixel: bounding box of its component; bit-quad counts for the Euler number
 // (E8 = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows, each window counted by its first set pixel).
 __device__ __forceinline__ void pass_bbox_euler(const uint8_t *__restrict__ cls, const uint32_t *labels, const Geo &g,
-                                                const PixelList &pl, const CompTables &t, unsigned nb)
+                                                const ResidueIter &it, const CompTables &t)
 {
     // The list keeps the pixels of a 16-pixel chunk on adjacent lanes, so a horizontal run of a
     // component sits on consecutive lanes: its lanes pool their y-extent candidates and quad counts
     // with ballots, and only the run's first lane issues those atomics.  (The loop is kept
     // wave-uniform for the ballots: lanes past the end of the list carry valid = false.)
-    const uint32_t *idx = pl.idx[0];
-    const size_t cnt = pl.hdr->count[0];
-    const bool dense = cnt > pl.cap;
-    const size_t ln = dense ? g.total : cnt;
+    const uint32_t *idx = it.idx;
+    const bool dense = it.dense;
+    const size_t ln = it.n;
     const int lane = threadIdx.x & 63;
-    const size_t stride = (size_t)nb * 256;
-    for (size_t base = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63); base < ln; base += stride) {
+    const size_t stride = it.step;
+    for (size_t base = it.first - (size_t)lane; base < ln; base += stride) {
         const size_t li = base + lane;
         bool valid = li < ln;
         size_t flat = 0;
-        if (valid) flat = dense ? li : (size_t)idx[li];
+        if (valid) flat = dense ? it.dense_base + li : (size_t)idx[li];
+        if (valid && it.only_frame >= 0) valid = flat / g.HW == (size_t)it.only_frame;
         uint32_t lab_i = 0;
         if (valid) valid = (cls[flat] & 3u) != 0;
         if (valid) { lab_i = labels[flat]; valid = lab_i != 0; }
@@ -1612,17 +1623,18 @@ __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels,
             for (int f = threadIdx.x; f < batch; f += 256) t.nroots[(size_t)f * NR_STRIDE] = 0;
         ok = grid_barrier(barrier, ++phase * nb, spin_limit);
     }
-    if (ok) pass_union4(cls, labels, g, pl, nb);
+    const ResidueIter it = residue_iter_grid(pl, g, nb);
+    if (ok) pass_union4(cls, labels, g, it);
     ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
-    if (ok) pass_flag(cls, labels, g, pl, nb);
+    if (ok) pass_flag(cls, labels, g, it);
     ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
-    if (ok) pass_union8(cls, labels, g, pl, nb);
+    if (ok) pass_union8(cls, labels, g, it);
     ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
-    if (ok) pass_flatten(cls, labels, mask, g, pl, t, nb);
+    if (ok) pass_flatten(cls, labels, mask, g, it, t);
     ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
     if (ok) pass_tag_roots(labels, g, t, batch, nb);
     ok = ok && grid_barrier(barrier, ++phase * nb, spin_limit);
-    if (ok) pass_bbox_euler(cls, labels, g, pl, t, nb);
+    if (ok) pass_bbox_euler(cls, labels, g, it, t);
     if (!ok && threadIdx.x == 0) {
         // The passes stopped half way: labels hold union-find parents, tables do not cover what was written.  The call's
         // results are void (status), and the header must not vouch for them either: dense = 1 makes the next call on
@@ -1632,6 +1644,89 @@ __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels,
         pl.hdr->fault = 0u;
         for (int f = 0; f < batch; ++f) atomicOr(&status[f], YSMR_DET_STALLED);
     }
+}
+
+// The same passes with ONE WORKGROUP PER FRAME (round 4): nothing about a frame's residue depends on another frame, so a
+// batch of many frames needs no grid barrier at all -- a frame's workgroup gathers its entries of the residue list into LDS
+// (in list order: pass_bbox_euler pools runs of adjacent entries) and runs the passes with workgroup barriers between them.
+// Five grid barriers among 128 blocks were 13 of k_residue's 16 us on the bench batch.  A frame with more entries than
+// the LDS list holds reads the whole list in every pass and keeps its own; an overflowed list (dense) walks the frame.
+// Batches of few frames keep k_residue (one workgroup would serve a whole 4K frame).
+#ifndef RESF_MIN_BATCH_N
+#define RESF_MIN_BATCH_N 32
+#endif
+constexpr int RESF_THREADS = 1024, RESF_CAP = 8192, RESF_MIN_BATCH = RESF_MIN_BATCH_N;
+__global__ __launch_bounds__(RESF_THREADS) void k_residue_frames(uint8_t *cls, uint32_t *labels, uint8_t *mask, Geo g, int batch,
+                                                                 PixelList pl, CompTables t, int32_t *status)
+{
+    DET_RING(5);
+    __shared__ uint32_t s_list[RESF_CAP];
+    __shared__ uint32_t s_wave[RESF_THREADS / 64];
+    const uint32_t listed = pl.hdr->count[0];   // (written by k_windows, the previous launch)
+    const bool fault = pl.hdr->fault == YSMR_WS_FAULT_RESIDUE_STALL;
+    if (listed == 0u && !fault) return;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (fault) {
+        // (the test's stalled barrier, include/ysmr_hip.h: this form has no barrier that could stall -- it reports what
+        // k_residue's bail-out reports, so that the caller's recovery is the same whichever kernel a batch size takes)
+        if (tid == 0) {
+            atomicOr(&status[f], YSMR_DET_STALLED);
+            if (f == 0) { pl.hdr->dense = 1u; pl.hdr->fault = 0u; }
+        }
+        return;
+    }
+    const bool dense = listed > pl.cap;
+    uint32_t n_own = 0;
+    if (!dense) {
+        for (uint32_t i0 = 0; i0 < listed; i0 += RESF_THREADS) {
+            const uint32_t i = i0 + (uint32_t)tid;
+            const uint32_t e = i < listed ? pl.idx[0][i] : 0u;
+            const bool mine = i < listed && e / g.HW == (uint32_t)f;
+            const unsigned long long b = __ballot(mine);
+            if (lane == 0) s_wave[wave] = (uint32_t)__popcll(b);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < RESF_THREADS / 64; ++w) { const uint32_t c = s_wave[w]; before += w < wave ? c : 0u; total += c; }
+            const uint32_t pos = n_own + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            if (mine && pos < (uint32_t)RESF_CAP) s_list[pos] = e;
+            n_own += total;
+            __syncthreads();
+        }
+        if (n_own == 0u) return;
+    }
+    ResidueIter it;
+    if (dense) it = ResidueIter{nullptr, (size_t)g.HW, (size_t)tid, (size_t)RESF_THREADS, (size_t)f * g.HW, -1, true};
+    else if (n_own <= (uint32_t)RESF_CAP) it = ResidueIter{s_list, (size_t)n_own, (size_t)tid, (size_t)RESF_THREADS, 0, -1, false};
+    else it = ResidueIter{pl.idx[0], (size_t)listed, (size_t)tid, (size_t)RESF_THREADS, 0, f, false};
+    if (dense) {
+        // (as in k_residue: everything k_windows settled in this frame is done again)
+        for (size_t p = (size_t)tid; p < (size_t)g.HW; p += RESF_THREADS) {
+            const size_t flat = (size_t)f * g.HW + p;
+            const uint32_t b = cls[flat];
+            if (b & 3u) {
+                labels[flat] = (uint32_t)p + 1u;
+                if (b & ~3u) cls[flat] = (uint8_t)(b & 3u);
+            }
+        }
+        if (tid == 0) t.nroots[(size_t)f * NR_STRIDE] = 0;
+        __syncthreads();
+    }
+    pass_union4(cls, labels, g, it);
+    __syncthreads();
+    pass_flag(cls, labels, g, it);
+    __syncthreads();
+    pass_union8(cls, labels, g, it);
+    __syncthreads();
+    pass_flatten(cls, labels, mask, g, it, t);
+    __syncthreads();
+    {   // pass_tag_roots for this frame
+        const int n = min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
+        for (int k = tid; k < n; k += RESF_THREADS)
+            labels[(size_t)f * g.HW + (uint32_t)t.roots[(size_t)f * t.max_det + k]] = SLOT_TAG | (uint32_t)k;
+    }
+    __syncthreads();
+    pass_bbox_euler(cls, labels, g, it, t);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2355,8 +2450,12 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
         hipLaunchKernelGGL(k_windows, dim3((unsigned)wblocks), tb, 0, st, cls_dev, labels, mask_dev, g,
                            batch, w.pixels, t);
     }
-    hipLaunchKernelGGL(k_residue, dim3(RESIDUE_BLOCKS), tb, 0, st, cls_dev, labels, mask_dev, g, batch, w.pixels, t, w.arena_used + 1,
-                       status_dev);
+    if (batch >= RESF_MIN_BATCH)
+        hipLaunchKernelGGL(k_residue_frames, dim3(batch), dim3(RESF_THREADS), 0, st, cls_dev, labels, mask_dev, g, batch, w.pixels, t,
+                           status_dev);
+    else
+        hipLaunchKernelGGL(k_residue, dim3(RESIDUE_BLOCKS), tb, 0, st, cls_dev, labels, mask_dev, g, batch, w.pixels, t, w.arena_used + 1,
+                           status_dev);
     YSMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rank, dim3(batch, (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) < 32 ? (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) : 32), dim3(RANK_THREADS), 0, st, t, labels, g.HW,
                        width, height, status_dev, w.pixels.hdr, w.n_holed, w.holed);

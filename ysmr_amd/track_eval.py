@@ -16,6 +16,7 @@ from __future__ import annotations
 import logging
 import os
 import threading
+import gc
 import time
 
 import numpy as np
@@ -353,6 +354,7 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
     sorted_rows = None
     feed = None
     verdict = "done"
+    froze = False
     t_start = t_frames = time.perf_counter()
     try:
         # Rows stay on the device for the whole video when they fit (capacity rows per frame is the
@@ -375,6 +377,12 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
         LAST_PASS_MARKS["pipeline built"] = time.perf_counter() - t_start
         feed = DeviceFrameFeed(video, pipe.B, pipe.device)
         LAST_PASS_MARKS["feed built"] = time.perf_counter() - t_start
+        # A full pass of CPython's garbage collector walks every tracked object of the process (~40 ms with torch, numpy
+        # and pandas loaded) and would stall the loop that keeps the GPU fed for as long as 50 batches take; what is alive
+        # now is moved out of its sight for the duration of the loop (collections of the loop's own garbage stay on).
+        froze = gc.get_freeze_count() == 0          # (not over a freeze of the caller's, or of another stream's thread)
+        if froze:
+            gc.freeze()
         for dev, f0, n_read, feed_slot in feed:
             LAST_PASS_MARKS.setdefault("first batch on the device", time.perf_counter() - t_start)
             nxt = (pipe.detect_async(dev), f0, n_read)
@@ -406,6 +414,9 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
             res = pipe.link(slot, r, ready, p0)
             frames_done = p0 + cnt
         LAST_PASS_MARKS["last batch issued"] = time.perf_counter() - t_start
+        if froze:
+            gc.unfreeze()
+            froze = False
         if res is not None:
             torch.cuda.synchronize(pipe.device)
             t_frames = time.perf_counter()
@@ -431,6 +442,8 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
         logger.critical("Device path failed for file {}: {}".format(video_path, exc))
         error_during_read = True
     finally:
+        if froze:
+            gc.unfreeze()
         if feed is not None:
             feed.close()
     return verdict, sorted_rows, frames_done, error_during_read, t_start, t_frames
