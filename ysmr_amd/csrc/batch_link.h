@@ -683,6 +683,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
             unsigned long long todo = __ballot(propose && !nr.done);
 #ifdef YSMR_STAMPS
             if (f == YSMR_BL_FRAME && lane == 0) g_bstamps[wave][12] = __popcll(todo);
+            if (lane == 0) { if (f == 0) { g_bstamps[wave][13] = 0; g_bstamps[wave][14] = 0; } g_bstamps[wave][13] += __popcll(todo); g_bstamps[wave][14] += todo ? 1 : 0; }
 #endif
             while (todo) {
                 const int l = __builtin_ctzll(todo);
