@@ -268,7 +268,7 @@ def test_detect_dense_noise_stresses_union_find(torch_cuda, oracle):
 
 
 def test_residue_one_workgroup_per_frame(torch_cuda, oracle):
-    """Batches of 32 frames and more run the union-find passes with one workgroup per frame (k_residue_frames) instead of
+    """Batches of eight frames and more run the union-find passes with one workgroup per frame (k_residue_frames) instead of
     the grid-barrier kernel: the three ways such a workgroup finds its pixels -- its part of the list gathered in LDS (a few
     large islands per frame), the whole list re-read in every pass (one frame with more residue than the LDS list holds),
     every pixel of the frame (the list itself overflowed) -- against the oracle, and the same frames through the
