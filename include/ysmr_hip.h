@@ -72,7 +72,12 @@ extern "C" {
  * workgroup, then cuts its rows for 31 workgroups per XCD instead of 32 -- whichever XCD the link sits on, none gets a
  * workgroup it cannot place before another has finished (same bytes). */
 #define YSMR_BESIDE_BATCH_LINK 8
-#define YSMR_CV_FLAVOUR_MASK 15
+/* ... and for the two-launch link of large tables (k_link + k_track, 4K: 5000 tracks): its launches want a fat workgroup and
+ * thousands of waves placed every ~30 us, so the matrix-pipe threshold kernel keeps to HALF the compute units (128 workgroups:
+ * twice as long itself, but 24.3 against 23.1 k frames/s end to end at 3840 x 2160 with the float32-chain kernel, and 21.7 k
+ * with the matrix-pipe kernel on every unit; same bytes). */
+#define YSMR_BESIDE_SPLIT_LINK 16
+#define YSMR_CV_FLAVOUR_MASK 31
 
 /* One output row: a live track in one frame (ysmr/track_eval.py:313-316,
  * CSV columns TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE). */

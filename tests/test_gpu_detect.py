@@ -808,4 +808,4 @@ def test_opencv_flavours(torch_cuda, oracle, version, flags):
             _, mean, sd, _ = lv.step(oracle.bgr2gray(frames[f], flags))
             assert d.mean_stats[f, 0].item() == mean and d.mean_stats[f, 1].item() == sd
     with pytest.raises(_lib.YsmrLibraryError):
-        Detector(1, 8, 8, cv_flavour=16).threshold(torch.zeros(1, 8, 8, dtype=torch.uint8, device="cuda"))
+        Detector(1, 8, 8, cv_flavour=32).threshold(torch.zeros(1, 8, 8, dtype=torch.uint8, device="cuda"))

@@ -25,6 +25,8 @@ CV_DEFAULT, CV_ANGLE_PRE451, CV_GRAY_3X = 0, 1, 2
 BESIDE_LINK = 4
 #: ... and for the one-launch-per-batch link, which holds one compute unit (YSMR_BESIDE_BATCH_LINK)
 BESIDE_BATCH_LINK = 8
+#: ... and for the two-launch link of large tables (YSMR_BESIDE_SPLIT_LINK): the matrix-pipe threshold kernel on half the units
+BESIDE_SPLIT_LINK = 16
 #: test hook in a detection workspace's header (include/ysmr_hip.h)
 WS_FAULT_OFFSET, WS_FAULT_RESIDUE_STALL = 32, 0xFA17057A
 

@@ -111,7 +111,7 @@ class Detector:
 
     def __init__(self, batch, height, width, max_det=2048, params: ThresholdParams | MeanGrayParams | None = None,
                  device="cuda:0", want_mask=True, mean_state: MeanGrayState | None = None, cv_flavour=0,
-                 threshold_variant=0, beside_batch_link=False):
+                 threshold_variant=0, beside_batch_link=False, beside_split_link=False):
         self.B, self.H, self.W, self.max_det = int(batch), int(height), int(width), int(max_det)
         #: which threshold kernel ``detect`` / ``threshold`` take (``ysmr_threshold_batch_variant``): 0 = the library's choice
         #: (the matrix-pipe kernel, which fills whole compute units); 1 = the float32-chain kernels, whose resident grid
@@ -120,7 +120,7 @@ class Detector:
         # which OpenCV release a1 / a6 follow (_lib.CV_*), plus the hint that a link runs beside: the labelling / geometry
         # kernels then keep to the resident grids that leave its workgroups their LDS
         self.cv_flavour = _lib.cv_flavour_of(cv_flavour) | (_lib.BESIDE_LINK if self.threshold_variant == 1 else 0) | \
-            (_lib.BESIDE_BATCH_LINK if beside_batch_link else 0)
+            (_lib.BESIDE_BATCH_LINK if beside_batch_link else 0) | (_lib.BESIDE_SPLIT_LINK if beside_split_link else 0)
         self.params = params or threshold_params(True, 5, 2.0)
         self.device = torch.device(device)
         L = _lib.lib()

@@ -98,7 +98,10 @@ class TrackingPipeline:
         # (a handle that links a whole batch with ONE launch -- one workgroup on one compute unit -- is nobody's neighbour:
         # detection then takes the matrix-pipe kernel and its full resident grids; beside the per-frame kernels, one-launch
         # or split (4K), it keeps round 3's choice: 21.0 k against 22.3 k frames/s at 4K with the matrix-pipe kernel)
-        beside_fused_link = bool(link) and not self.trk.batched
+        # (... except beside the SPLIT link of large tables, where the matrix-pipe kernel on half the compute units beats both:
+        # 24.3 k, profiles/r04_4k_thr_grid.log)
+        beside_split_link = bool(link) and not self.trk.batched and not self.trk.fused
+        beside_fused_link = bool(link) and not self.trk.batched and not beside_split_link
         #: the threshold kernel is issued on the LINK stream, between two batches' link chains, where it has the chip to
         #: itself (the labelling chain still runs beside the link, on the side stream)
         self.exclusive_threshold = False
@@ -109,7 +112,7 @@ class TrackingPipeline:
         self.det = [Detector(self.B, height, width, max_det=max_det, params=params, device=self.device,
                              mean_state=mean_state, cv_flavour=settings.get("opencv version"),
                              threshold_variant=1 if beside_fused_link else 0,
-                             beside_batch_link=bool(link) and self.trk.batched)
+                             beside_batch_link=bool(link) and self.trk.batched, beside_split_link=beside_split_link)
                     for _ in range(2)]
         self.capacity = int(capacity)
         self._link = bool(link)
