@@ -31,3 +31,6 @@ for k, n in enumerate(names):
 tot = (a[:, 12, 7] - a[:, 3, 0]) / 10.0
 print("%-44s" % "step", " ".join(f"{tot[w]:<6.0f}" for w in range(NW)))
 print("first stamp of step 0 to the last of step 14 (wave 0):", a[0, 14, 7] - a[0, 0, 0])
+rt0, mt0, rt1, mt1 = a[1, 18, 0], a[1, 18, 1], a[1, 19, 0], a[1, 19, 1]
+if rt1 > rt0:
+    print(f"shader clock over steps 3..13 of that workgroup: {(mt1 - mt0) / (rt1 - rt0) * 100:.0f} MHz ({mt1 - mt0:.0f} cycles in {(rt1 - rt0) / 100:.2f} us)")

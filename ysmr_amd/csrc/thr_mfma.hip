@@ -710,6 +710,15 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         for (int s = 0; s <= nblk; ++s) {
             int mine = 0;
             TMSTAMP(s, 0);
+#ifdef YSMR_STAMPS
+            // (the shader clock under this kernel's own load: s_memrealtime counts at a constant 100 MHz)
+            if (blockIdx.x == TM_ST_BLOCK && lane == 0 && wave == 0 && (s == 3 || s == 13)) {
+                unsigned long long rt;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
+                g_tm_stamps[1][s == 3 ? 18 : 19][0] = rt;
+                g_tm_stamps[1][s == 3 ? 18 : 19][1] = __builtin_amdgcn_s_memtime();
+            }
+#endif
             if (s + 2 <= nblk) mine = request_raw(s + 2);        // into the buffer the blur of step s has finished with
             TMSTAMP(s, 1);
             if (s >= 1) filter_step(s);
