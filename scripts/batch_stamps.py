@@ -44,6 +44,9 @@ for rep in range(12 if beside else 6):
     acc.append(a)
     print("   fast path per wave:", (full[:, 11] - full[:, 1]).tolist(), " lanes left to the wave search:", full[:, 12].tolist())
     print("   over the launch's frames: lanes left to the wave search per wave", full[:, 13].tolist(), "= %.2f per frame; frames in which a wave ran it:" % (full[:, 13].sum() / B), full[:, 14].tolist())
+    rt0, rt1, mt0, mt1 = int(full[0, 15]), int(full[1, 15]), int(full[2, 15]), int(full[3, 15])
+    if rt1 > rt0:
+        print(f"   shader clock over frames 8..56: {(mt1 - mt0) / (rt1 - rt0) * 100:.0f} MHz; {(rt1 - rt0) / 100 / 48:.2f} us and {(mt1 - mt0) / 48:.0f} cycles per frame")
     print(f"rep {rep}: launch pair {t0.elapsed_time(t1) * 1e3:.1f} us for {B} frames; frame (wave 0) {a[0, 10] - a[0, 0]} cycles")
 a = np.mean(np.array(acc), axis=0) if beside else np.median(np.array(acc), axis=0)
 d = np.diff(a, axis=1)

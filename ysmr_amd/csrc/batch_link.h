@@ -683,6 +683,13 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
             unsigned long long todo = __ballot(propose && !nr.done);
 #ifdef YSMR_STAMPS
             if (f == YSMR_BL_FRAME && lane == 0) g_bstamps[wave][12] = __popcll(todo);
+            // (the shader clock over frames 8 .. 56: s_memrealtime counts at a constant 100 MHz; column 15 of rows 0 .. 3)
+            if (wave == 0 && lane == 0 && (f == 8 || f == 56)) {
+                unsigned long long rt_;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory");
+                g_bstamps[f == 8 ? 0 : 1][15] = rt_;
+                g_bstamps[f == 8 ? 2 : 3][15] = __builtin_amdgcn_s_memtime();
+            }
             if (lane == 0) { if (f == 0) { g_bstamps[wave][13] = 0; g_bstamps[wave][14] = 0; } g_bstamps[wave][13] += __popcll(todo); g_bstamps[wave][14] += todo ? 1 : 0; }
 #endif
             while (todo) {
