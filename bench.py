@@ -74,7 +74,11 @@ def parse():
         args.batch = args.batch or 16
         args.max_det = args.capacity = 8192
         args.cpu_sample = min(args.cpu_sample, 8)
-    args.batch = args.batch or 64
+    # 256 frames per detection batch = per link launch (the whole 512-frame clip is resident anyway): the fixed costs of a
+    # batch -- the threshold kernel's item starts, the link launch's state in and out and the gap to the next launch, the host's
+    # calls -- are paid half / a quarter as often as at 128 / 64 (same box: 161.5 / 163.5 / 165 k frames/s, threshold kernel
+    # 0.214 / 0.248 / 0.265 of the roofline, host 1.0 / 0.5 / 0.24 ms per step; profiles/r04_batch_sizes.log)
+    args.batch = args.batch or 256
     return args
 
 
@@ -324,7 +328,11 @@ def main():
         # what the headline is made of, so that one line says which part was slow on this box: the link of a batch is one
         # launch on one compute unit (k_batch), frames strictly in order, so `value` ~ 1e6 / link.us_per_frame.avg as long
         # as detection (threshold + chain, on the other stream) hides behind it and the host keeps ahead
-        diag = {"threshold_us_per_batch": stats_us([m * 1e3 for m in ms]),
+        diag = {"frames_per_batch": B,
+                # (per 64 frames: what earlier rounds' lines, at 64 frames per batch, called "per batch")
+                "threshold_us_per_64_frames": sum(ms) / len(ms) * 1e3 * 64.0 / B,
+                "components_us_per_64_frames": (sum(e0.elapsed_time(e1) for e0, e1, _ in chain_events) / len(chain_events) * 1e3 * 64.0 / B) if chain_events else None,
+                "threshold_us_per_batch": stats_us([m * 1e3 for m in ms]),
                 "components_us_per_batch": stats_us([e0.elapsed_time(e1) * 1e3 for e0, e1, _ in chain_events]),
                 "link_us_per_frame": stats_us([e0.elapsed_time(e1) * 1e3 / n for e0, e1, n, _ in link_events]),
                 "link_host_issue_us_per_frame": stats_us([h * 1e6 / n for _, _, n, h in link_events]),

@@ -10,7 +10,7 @@ true = 580 * 2 ** 20
 rf = s["calib_FETCH_SIZE"] * 1024 / true          # counter bytes per true byte
 wf = s["calib_WRITE_SIZE"] * 1024 / true
 rd, wr = s["threshold_FETCH_SIZE"] * 1024 / rf, s["threshold_WRITE_SIZE"] * 1024 / wf
-B, H, W = 64, 922, 1228
+B, H, W = int(os.environ.get("PMC_BATCH", "256")), 922, 1228      # (the batch scripts/profile_round.sh passes to bench_threshold.py)
 out = {"kernel": "k_threshold_strip", "batch": B, "height": H, "width": W,
        "FETCH_SIZE_KB_raw": s["threshold_FETCH_SIZE"], "WRITE_SIZE_KB_raw": s["threshold_WRITE_SIZE"],
        "calibration": {"kernel": "copy_dword (scripts/ubench/copy_calib.hip): 580 MiB read + 580 MiB written, one dword per lane",

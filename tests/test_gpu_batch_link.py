@@ -46,7 +46,7 @@ def _run_frames(torch, trk, per_frame, batch, max_det, rows_cap, mode_switch=Non
 FIXTURES = [("tracker_small_gsff.npz", None), ("tracker_mid_gsff.npz", None), ("tracker_gap.npz", 5), ("tracker_2997.npz", 6)]
 
 
-@pytest.mark.parametrize("batch", [64, 7, 1])
+@pytest.mark.parametrize("batch", [256, 64, 7, 1])
 @pytest.mark.parametrize("name,max_gone", FIXTURES)
 def test_batch_link_matches_reference_fixture(torch_cuda, name, max_gone, batch):
     """The reference's own CentroidTracker outputs (tests/golden/gen_golden.py), frame by frame, from one launch per

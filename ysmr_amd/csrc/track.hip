@@ -82,7 +82,13 @@ constexpr int BL_THREADS = YSMR_BL_THREADS;      // seats: one track per lane
 constexpr int BL_WAVES = BL_THREADS / 64;
 constexpr int BL_HB = 32;             // ring of measurements per seat (hist_cap <= 32; a power of two)
 constexpr int BL_NF = 3;              // filters (n_f <= 3)
-constexpr int BL_MAX_BATCH = 64;      // frames per launch (the grid block is sized for it; longer batches are cut)
+#ifndef YSMR_BL_MAX_BATCH
+#define YSMR_BL_MAX_BATCH 256
+#endif
+constexpr int BL_MAX_BATCH = YSMR_BL_MAX_BATCH;      // frames per launch (the grid block is sized for it; longer batches are cut).
+                                                    // 256 since the end of round 4: a launch's fixed costs (state in and out, the gap to the next
+                                                    // launch) and the detection kernels' per-item costs are paid per BATCH (bench.py: 161.5 k frames/s
+                                                    // at 64 frames per batch, 163.5 k at 128, 165 k at 256)
 constexpr int BL_TABLE = 4096;        // CPython set model table, 32-bit slots (as FRAME_TABLE)
 constexpr int BL_SF64 = 3 * BL_NF + 2 + 4 * BL_NF;   // w, xa, xb, px, py, the window sums
 constexpr int BL_REFRESH = 64;        // frames between two exact recomputations of the window sums (a power of two)
