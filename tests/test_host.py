@@ -362,7 +362,7 @@ def test_bench_argument_presets(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
     assert (a.gpus, a.steps, a.warmup, a.height, a.width, a.blobs, a.batch, a.detect_only, a.adt) == \
-        (1, 5, 1, 922, 1228, 500, 64, False, 2.0)
+        (1, 5, 1, 922, 1228, 500, 256, False, 2.0)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "2", "--config", "4"])
     a = bench.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 3, 2)
