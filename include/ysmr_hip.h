@@ -277,7 +277,7 @@ int ysmr_tracker_link_mode(ysmr_tracker *t, int mode);
 /* Optional, for a handle that links a batch with one launch (a no-op for every other): that launch reads each frame's
  * detections binned into a uniform grid of cells, which ysmr_tracker_run works out in a launch of its own in front of the
  * link.  A caller that detects batch b+1 on one stream while batch b is linked on another can take that launch off the
- * link's chain: call this on the DETECTION stream behind the call that writes det_dev / det_count_dev (up to 64 frames),
+ * link's chain: call this on the DETECTION stream behind the call that writes det_dev / det_count_dev (up to 256 frames),
  * then ysmr_tracker_run with the same det_dev, det_count_dev and batch on the link stream once it has waited for the
  * detection stream as it must anyway.  slot (0 or 1) names which of two internal blocks to fill: a block must not be
  * prepared again before the ysmr_tracker_run that uses it has executed (two detectors taking turns use their own number).
