@@ -605,7 +605,7 @@ __host__ __device__ inline size_t bl_lds_bytes(int max_det)
 __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd, const float *__restrict__ det_all,
                                                       const int32_t *__restrict__ det_count, int batch, int frame0,
                                                       ysmr_row *rows, long long rows_capacity, long long *row_count,
-                                                      BlGains gt)
+                                                      const BlGains *gains)
 {
     __shared__ BlShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -819,7 +819,14 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         BLSTAMP(6);
         double o0 = z0, o1 = z1;
         if (S.alive) {
-            if (t.use_gsff) bl_gsff(S, t, bd, gt, tid, head, leave, z0, z1, fresh, o0, o1);
+            if (t.use_gsff) {
+                // (the twelve gain constants come out of the scalar cache in every frame: as kernel arguments they sat in 24
+                // scalar registers for the whole launch, and this kernel spilled 113 of them into vector lanes -- a tenth of a frame's
+                // vector instructions were v_readlane / v_writelane)
+                const BlGains *gq = gains;
+                asm volatile("" : "+s"(gq));
+                bl_gsff(S, t, bd, *gq, tid, head, leave, z0, z1, fresh, o0, o1);
+            }
             else { S.px = z0; S.py = z1; }
         }
         // ---- end of the frame: the next frame's detections have landed, the frame's counts are complete

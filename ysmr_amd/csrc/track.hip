@@ -139,6 +139,7 @@ struct ysmr_tracker {
     int link_mode = 0;             // ysmr_tracker_link_mode: 0 = the library's choice, 1 = one (or two) launches per frame
     size_t batch_lds = 0;
     BlGains bgains;
+    const BlGains *bgains_dev = nullptr;     // the same in device memory (behind the grid blocks): k_batch reads it frame by frame
     // ysmr_tracker_prepare: which batch each of the two caller-named grid blocks was binned for (block 2 is run's own)
     struct Prepared { const void *det = nullptr; const void *count = nullptr; int batch = 0; } prepared[2];
     bool use_batch() const { return batchable && link_mode == 0; }
@@ -2205,7 +2206,11 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
         const size_t per = t->batchable ? (size_t)bl_grid_dwords_max(max_det) * 4 : ysmr_tracker::grid_bytes_per_frame(max_det);
         const size_t blocks = t->batchable ? 3 : 1;      // (two for ysmr_tracker_prepare's callers, one for ysmr_tracker_run itself)
         if (t->batchable || !t->fused) {
-            e = hipMalloc(&t->grid_block, per * BL_MAX_BATCH * blocks);
+            e = hipMalloc(&t->grid_block, per * BL_MAX_BATCH * blocks + 256);
+            if (e == hipSuccess && t->batchable) {
+                t->bgains_dev = reinterpret_cast<const BlGains *>((char *)t->grid_block + per * BL_MAX_BATCH * blocks);
+                e = hipMemcpy((void *)t->bgains_dev, &t->bgains, sizeof(BlGains), hipMemcpyHostToDevice);
+            }
             if (e != hipSuccess) {
                 (void)hipFree(t->block);
                 delete t;
@@ -2354,7 +2359,7 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
                                    det_count_dev + f0, t->d.max_det, bd.grid, bd.grid_stride);
             hipLaunchKernelGGL(k_batch, dim3(1), dim3(BL_THREADS), t->batch_lds, (hipStream_t)stream, t->d, bd, det,
                                det_count_dev + f0, nb, first_frame_index + f0, rows_dev, (long long)rows_capacity,
-                               (long long *)row_count_dev, t->bgains);
+                               (long long *)row_count_dev, t->bgains_dev);
             YSMR_LAUNCH_CHECK();
         }
         return YSMR_OK;
