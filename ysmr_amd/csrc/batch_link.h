@@ -602,11 +602,37 @@ __host__ __device__ inline size_t bl_lds_bytes(int max_det)
     return 2 * 4 * (size_t)bl_grid_dwords_max(max_det) + 2 * 12 * (size_t)bl_md_padded(max_det) + 4 * BL_TABLE + 64;
 }
 
-__global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd, const float *__restrict__ det_all,
-                                                      const int32_t *__restrict__ det_count, int batch, int frame0,
-                                                      ysmr_row *rows, long long rows_capacity, long long *row_count,
-                                                      const BlGains *gains)
+// The kernel's arguments as ONE structure: the kernel argument segment then IS this structure, and an argument that one
+// phase of a frame needs (the row buffer, the detections' boxes, the error word, the state arrays at the end) is read
+// from it where it is needed -- one scalar load out of the scalar cache -- instead of sitting in scalar registers for the
+// whole launch: with everything passed and kept the usual way this kernel had 113 of them spilled into vector lanes.
+struct BlKernArgs {
+    TrackerDev t;
+    BatchDev bd;
+    const float *det_all;
+    const int32_t *det_count;
+    int batch, frame0;
+    ysmr_row *rows;
+    long long rows_capacity;
+    long long *row_count;
+    const BlGains *gains;
+};
+typedef const __attribute__((address_space(4))) BlKernArgs *BlKernArgsPtr;
+__device__ __forceinline__ BlKernArgsPtr bl_kernargs()
 {
+    BlKernArgsPtr p = (BlKernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));          // (opaque: a load through it is not merged with the preloaded arguments)
+    return p;
+}
+
+__global__ __launch_bounds__(BL_THREADS) void k_batch(BlKernArgs ka)
+{
+    const TrackerDev &t = ka.t;
+    const BatchDev &bd = ka.bd;
+    const int32_t *__restrict__ det_count = ka.det_count;
+    const int batch = ka.batch, frame0 = ka.frame0;
+    long long *row_count = ka.row_count;
+    const BlGains *gains = ka.gains;
     __shared__ BlShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -741,7 +767,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         bool fresh = false, died = false;
         if (mine) {
             z0 = (double)nr.zx; z1 = (double)nr.zy;
-            const float *d = det_all + ((size_t)f * md + nr.col) * 5;
+            const float *d = bl_kernargs()->det_all + ((size_t)f * md + nr.col) * 5;
             box[0] = d[2]; box[1] = d[3]; box[2] = d[4];
             S.gone = 0;
         } else if (S.alive && age) {
@@ -786,12 +812,12 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
                     if (cid_at(par)[c] == 0xFFFFFFFFu) unused[at++] = c;
                 __syncthreads();
                 int cnt_set = cpython_order_lds<BL_THREADS, BL_TABLE>(unused, total, m, sh.used[par], newcols, bl_u32(tab_off), list, sh.set_state);
-                if (cnt_set < 0) { if (tid == 0) atomicOr(t.err, ERR_TRACK_CAPACITY); cnt_set = 0; }
+                if (cnt_set < 0) { if (tid == 0) atomicOr(bl_kernargs()->t.err, ERR_TRACK_CAPACITY); cnt_set = 0; }
                 n_new_all = cnt_set;
             }
             n_new = n_new_all;
             if (n + n_new > seats) {
-                if (tid == 0) atomicOr(t.err, ERR_TRACK_CAPACITY);
+                if (tid == 0) atomicOr(bl_kernargs()->t.err, ERR_TRACK_CAPACITY);
                 n_new = seats - n;
             }
             // free lanes take the new tracks, in lane order
@@ -804,7 +830,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
             for (int k = 0; k < BL_WAVES; ++k) fr += k < wave ? sh.wave_cnt[1][k] : 0;
             if (free_lane && fr < n_new) {
                 const int c = newcols[fr];
-                const float *d = det_all + ((size_t)f * md + c) * 5;
+                const float *d = bl_kernargs()->det_all + ((size_t)f * md + c) * 5;
                 z0 = (double)d[0]; z1 = (double)d[1];
                 box[0] = d[2]; box[1] = d[3]; box[2] = d[4];
                 S.id = next_id + fr; S.rank = n + fr; S.gone = 0;
@@ -840,6 +866,9 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
             for (int k = 0; k < n_dead; ++k) S.rank -= sh.dead_id[par][k] < S.id;
         if (S.alive) { S.info[0] = box[0]; S.info[1] = box[1]; S.info[2] = box[2]; }   // (the claimed box: requested before the filter bank)
         const int n_live = n - n_dead + n_new;
+        const BlKernArgsPtr kr = bl_kernargs();
+        ysmr_row *rows = kr->rows;
+        const long long rows_capacity = kr->rows_capacity;
         if (S.alive && base + S.rank < rows_capacity) {      // track_eval.py:313-316
             ysmr_row rr;
             rr.frame = frame0 + f;
@@ -849,7 +878,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
             rr.disappeared = S.gone;
             rows[base + S.rank] = rr;
         }
-        if (tid == 0 && base + n_live > rows_capacity) atomicOr(t.err, ERR_ROWS_CAPACITY);
+        if (tid == 0 && base + n_live > rows_capacity) atomicOr(kr->t.err, ERR_ROWS_CAPACITY);
         base += n_live;
         n = n_live;
         next_id += n_new_all;
@@ -857,11 +886,17 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(TrackerDev t, BatchDev bd,
         BLSTAMP(10);
     }
     // ---- end of the batch: the small state goes back to HBM, seat by seat
-    if (tid < seats) {
-        bd.i32[5 * (size_t)bd.seat_cap + tid] = S.alive ? 1 : 0;
-        if (S.alive) bl_seat_store(S, bd, tid);
+    {
+        const BlKernArgsPtr ke = bl_kernargs();
+        BatchDev be;                       // (field by field: the structure lies in the constant address space)
+        be.ring = ke->bd.ring; be.f64 = ke->bd.f64; be.f32 = ke->bd.f32; be.i32 = ke->bd.i32; be.head = ke->bd.head;
+        be.grid = ke->bd.grid; be.grid_stride = ke->bd.grid_stride; be.seat_cap = ke->bd.seat_cap;
+        if (tid < seats) {
+            be.i32[5 * (size_t)be.seat_cap + tid] = S.alive ? 1 : 0;
+            if (S.alive) bl_seat_store(S, be, tid);
+        }
+        if (tid == 0) { *ke->t.n_tracks = n; *ke->t.next_id = next_id; *ke->row_count = base; *be.head = head; }
     }
-    if (tid == 0) { *t.n_tracks = n; *t.next_id = next_id; *row_count = base; *bd.head = head; }
 }
 
 // ---- conversions between the seat-major rest format and the per-slot layout of k_frame / k_link + k_track ----------

@@ -2357,9 +2357,11 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
             if (block == 2)
                 hipLaunchKernelGGL(k_bgrid, dim3(nb), dim3(BG_THREADS), t->bd.grid_stride, (hipStream_t)stream, det,
                                    det_count_dev + f0, t->d.max_det, bd.grid, bd.grid_stride);
-            hipLaunchKernelGGL(k_batch, dim3(1), dim3(BL_THREADS), t->batch_lds, (hipStream_t)stream, t->d, bd, det,
-                               det_count_dev + f0, nb, first_frame_index + f0, rows_dev, (long long)rows_capacity,
-                               (long long *)row_count_dev, t->bgains_dev);
+            BlKernArgs ka;
+            ka.t = t->d; ka.bd = bd; ka.det_all = det; ka.det_count = det_count_dev + f0; ka.batch = nb;
+            ka.frame0 = first_frame_index + f0; ka.rows = rows_dev; ka.rows_capacity = (long long)rows_capacity;
+            ka.row_count = (long long *)row_count_dev; ka.gains = t->bgains_dev;
+            hipLaunchKernelGGL(k_batch, dim3(1), dim3(BL_THREADS), t->batch_lds, (hipStream_t)stream, ka);
             YSMR_LAUNCH_CHECK();
         }
         return YSMR_OK;
