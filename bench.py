@@ -284,7 +284,8 @@ def main():
         avg_ms = sum(ms) / len(ms)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
-        thr_kernel = "k_threshold_strip" if pipe.det[0].threshold_variant == 1 else "k_threshold_mfma"
+        # (the matrix-pipe kernel serves gray frames whose width is a multiple of 4: thr_mfma.hip, ysmr_thr::supported)
+        thr_kernel = "k_threshold_strip" if (pipe.det[0].threshold_variant == 1 or args.channels != 1 or W % 4) else "k_threshold_mfma"
         pmc_name = "threshold_pmc.json" if thr_kernel == "k_threshold_strip" else "threshold_mfma_pmc.json"
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc) and not mean_gray:
