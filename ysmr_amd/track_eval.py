@@ -253,7 +253,8 @@ class TrackingPipeline:
 
 #: device-side limits when neither the call nor the settings dict name any; a video that exceeds them is
 #: re-run with doubled limits (up to LIMIT_MAX), so they only decide how much HBM the first attempt takes
-DEFAULT_BATCH, DEFAULT_MAX_DET, DEFAULT_CAPACITY, LIMIT_MAX = 64, 2048, 768, 32768
+DEFAULT_BATCH, DEFAULT_MAX_DET, DEFAULT_CAPACITY, LIMIT_MAX = 256, 2048, 768, 32768
+DEFAULT_BATCH_BYTES = 300e6
 
 
 def track_bacteria(video_path, settings=None, result_folder=None, batch=None, max_det=None, capacity=None,
@@ -319,7 +320,12 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
     local["threshold offset for detection"] = offset_on_entry
 
     frame_height, frame_width = video.height, video.width
-    batch = int(batch or settings.get("hip frames per batch") or DEFAULT_BATCH)
+    # frames per batch when nobody names a number: ~256 MB of frames, between 16 and 256 frames (256 at 1228 x 922, 32 at 4K).
+    # A batch's fixed costs -- one link launch, the detection kernels' starts, the reader's calls -- are paid per batch
+    # (a 1920-frame 1228 x 922 file: 114-119 ms at 64 frames per batch, 99 ms at 256, scripts/e2e_batches.py); three pinned
+    # staging buffers and two detectors' outputs of that many frames are what it costs in memory.
+    auto_batch = max(16, min(DEFAULT_BATCH, int(DEFAULT_BATCH_BYTES // max(1, frame_height * frame_width * (3 if video.channels == 3 else 1))) // 8 * 8))
+    batch = int(batch or settings.get("hip frames per batch") or auto_batch)
     max_det = int(max_det or settings.get("hip max detections per frame") or DEFAULT_MAX_DET)
     capacity = int(capacity or settings.get("hip max tracks") or DEFAULT_CAPACITY)
     while True:
