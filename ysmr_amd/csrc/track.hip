@@ -1010,8 +1010,11 @@ __device__ int cpython_unused_order(const TrackerDev &t, int m, int n_used, int 
 // ------------------------------------------------------------------------------------------
 // k_link: one workgroup
 // ------------------------------------------------------------------------------------------
-constexpr int LINK_THREADS = 1024;
-constexpr int LINK_ROWS = 8;       // rows per thread k_link keeps in registers for tables of more than 1024 rows
+#ifndef YSMR_LINK_THREADS
+#define YSMR_LINK_THREADS 1024
+#endif
+constexpr int LINK_THREADS = YSMR_LINK_THREADS;
+constexpr int LINK_ROWS = 8192 / LINK_THREADS;       // rows per thread k_link keeps in registers for tables of more than 1024 rows
 
 // LDS_ONLY: the two barriers wait for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier) -- __syncthreads also waits
 // for every global load and store the wave has in flight, a round trip to HBM each time; only for callers that order
@@ -1355,9 +1358,9 @@ __global__ __launch_bounds__(LINK_THREADS) void k_link(TrackerDev t, const DetT 
         for (int k = 0; k < LINK_ROWS; ++k) {
             const int r = tid + k * LINK_THREADS;
             int before = 0, all = 0;
-            static_assert(LINK_THREADS / 64 == 16, "four 16-byte reads per chunk");
+            static_assert((LINK_THREADS / 64) % 4 == 0, "16-byte reads of the waves' counts");
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
+            for (int q4 = 0; q4 < LINK_THREADS / 64 / 4; ++q4) {
                 const int4 c = reinterpret_cast<const int4 *>(s_keep[k])[q4];
                 const int cs[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
