@@ -375,6 +375,13 @@ def test_bench_argument_presets(monkeypatch):
     assert bench.parse().blobs == 50
 
 
+def test_frames_per_batch_follow_the_frame_size():
+    """track_bacteria's batch when neither the call nor the settings name one: ~300 MB of frames, 16 ... 256."""
+    from ysmr_amd.track_eval import auto_batch
+    assert auto_batch(922, 1228) == 256 and auto_batch(2160, 3840) == 32 and auto_batch(2160, 3840, 3) == 16
+    assert auto_batch(200, 260) == 256 and auto_batch(8000, 8000) == 16 and auto_batch(1080, 1920) == 144
+
+
 def test_ysmr_rejects_missing_paths_without_a_gpu(tmp_path, caplog):
     """ysmr(): settings come first, a missing file is reported per path and does not stop the others
     (main.py:292-313); nothing here touches the device."""

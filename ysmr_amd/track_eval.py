@@ -257,6 +257,13 @@ DEFAULT_BATCH, DEFAULT_MAX_DET, DEFAULT_CAPACITY, LIMIT_MAX = 256, 2048, 768, 32
 DEFAULT_BATCH_BYTES = 300e6
 
 
+def auto_batch(height, width, channels=1):
+    """Frames per batch for a video of this geometry when nobody names a number: about DEFAULT_BATCH_BYTES of frames, a
+    multiple of 8 between 16 and DEFAULT_BATCH."""
+    frame_bytes = max(1, int(height) * int(width) * (3 if channels == 3 else 1))
+    return max(16, min(DEFAULT_BATCH, int(DEFAULT_BATCH_BYTES // frame_bytes) // 8 * 8))
+
+
 def track_bacteria(video_path, settings=None, result_folder=None, batch=None, max_det=None, capacity=None,
                    device="cuda:0"):
     """Detect and track bright (or dark) spots in a video; write ``<name>_list.csv``.
@@ -324,8 +331,7 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
     # A batch's fixed costs -- one link launch, the detection kernels' starts, the reader's calls -- are paid per batch
     # (a 1920-frame 1228 x 922 file: 114-119 ms at 64 frames per batch, 99 ms at 256, scripts/e2e_batches.py); three pinned
     # staging buffers and two detectors' outputs of that many frames are what it costs in memory.
-    auto_batch = max(16, min(DEFAULT_BATCH, int(DEFAULT_BATCH_BYTES // max(1, frame_height * frame_width * (3 if video.channels == 3 else 1))) // 8 * 8))
-    batch = int(batch or settings.get("hip frames per batch") or auto_batch)
+    batch = int(batch or settings.get("hip frames per batch") or auto_batch(frame_height, frame_width, video.channels))
     max_det = int(max_det or settings.get("hip max detections per frame") or DEFAULT_MAX_DET)
     capacity = int(capacity or settings.get("hip max tracks") or DEFAULT_CAPACITY)
     while True:
