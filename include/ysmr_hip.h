@@ -42,7 +42,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   10
+#define YSMR_ABI_VERSION   11
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -323,6 +323,11 @@ int    ysmr_rows_format_csv(const ysmr_row *rows_host, long long n_rows, int wit
  * piece at its place in the file; *out_length (may be NULL) receives the number of bytes. */
 int    ysmr_rows_write_csv(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas,
                            int threads, const char *path, size_t *out_length);
+/* ... and, in the same pass, the seven DataFrame columns of ysmr_rows_columns below (ABI 11): the values the text is
+ * printed from are the values pandas would read back from it, worked out once for both consumers. */
+int    ysmr_rows_write_csv_columns(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas,
+                                   int threads, const char *path, size_t *out_length, uint32_t *track_id, uint32_t *t,
+                                   double *x, double *y, double *w, double *h, double *angle);
 
 /* HOST function: the seven DataFrame columns (dtypes of helper_file.py:881-889).
  * via_pandas (here and above): the reference does not keep the tracker's float64 values, it prints

@@ -555,3 +555,10 @@ def test_csv_written_by_the_formatting_threads_equals_the_one_buffer_form(tmp_pa
                 length = rows_to_csv_file(rows, str(path), header=header, via_pandas=via, threads=threads)
                 want = rows_to_csv_bytes(rows, header=header, via_pandas=via)
                 assert length == len(want) and path.read_bytes() == want
+                # ... and the one-pass form leaves the same file and the same DataFrame as the two separate calls
+                from ysmr_amd.helper_file import rows_to_csv_file_and_dataframe, rows_to_dataframe
+                path2 = tmp_path / f"u_{n}_{threads}_{header}_{via}.csv"
+                length2, df2 = rows_to_csv_file_and_dataframe(rows, str(path2), header=header, via_pandas=via, threads=threads)
+                assert length2 == len(want) and path2.read_bytes() == want
+                ref = rows_to_dataframe(rows, via_pandas=via)
+                assert df2.equals(ref) and list(df2.dtypes) == list(ref.dtypes)

@@ -261,7 +261,10 @@ char *put_u32(char *p, uint32_t v)
 constexpr size_t ROW_TEXT_MAX = 2 * 11 + 5 * 26 + 8;   // two uint32, five floats, separators
 const char CSV_HEADER[] = "TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE\n";   // helper_file.py:1451
 
-size_t format_range(const ysmr_row *rows, long long lo, long long hi, bool via_pandas, char *out)
+// (cols: the DataFrame's columns, filled in the same pass when asked for -- the values the csv is printed from ARE the
+//  values pandas would read back, and working them out once instead of once per consumer is a third of the tail's CPU time)
+struct ColumnSinks { uint32_t *track_id, *t; double *v[5]; };
+size_t format_range(const ysmr_row *rows, long long lo, long long hi, bool via_pandas, char *out, const ColumnSinks *cols = nullptr)
 {
     char *p = out;
     for (long long i = lo; i < hi; ++i) {
@@ -269,6 +272,10 @@ size_t format_range(const ysmr_row *rows, long long lo, long long hi, bool via_p
         double v[5] = {r.x, r.y, (double)r.w, (double)r.h, (double)r.angle};
         if (via_pandas)
             for (double &x : v) x = pandas_roundtrip(x);
+        if (cols) {
+            cols->track_id[i] = (uint32_t)r.track_id; cols->t[i] = (uint32_t)r.frame;
+            for (int k = 0; k < 5; ++k) cols->v[k][i] = v[k];
+        }
         p = put_u32(p, (uint32_t)r.track_id); *p++ = ',';
         p = put_u32(p, (uint32_t)r.frame); *p++ = ',';
         for (int k = 0; k < 5; ++k) { p = put_float(p, v[k]); *p++ = k == 4 ? '\n' : ','; }
@@ -370,8 +377,27 @@ int ysmr_rows_format_csv(const ysmr_row *rows_host, long long n_rows, int with_h
 // The same text straight into a file: every thread formats its range of rows into a buffer of its own, learns where its
 // piece goes once all pieces are sized, and writes it there itself (pwrite).  The one-buffer form above, written out by
 // the caller, spent more time packing the pieces (one memmove over 80 MB) and in ONE thread's write() than formatting.
+static int write_csv_impl(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas, int threads,
+                          const char *path, size_t *out_length, const ColumnSinks *cols);
+
 int ysmr_rows_write_csv(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas, int threads,
                         const char *path, size_t *out_length)
+{
+    return write_csv_impl(rows_host, n_rows, with_header, via_pandas, threads, path, out_length, nullptr);
+}
+
+int ysmr_rows_write_csv_columns(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas, int threads,
+                                const char *path, size_t *out_length, uint32_t *track_id, uint32_t *t, double *x, double *y,
+                                double *w, double *h, double *angle)
+{
+    if (n_rows && (!track_id || !t || !x || !y || !w || !h || !angle))
+        return ysmr::fail(YSMR_ERR_ARG, "all seven column pointers must be set");
+    const ColumnSinks cols{track_id, t, {x, y, w, h, angle}};
+    return write_csv_impl(rows_host, n_rows, with_header, via_pandas, threads, path, out_length, &cols);
+}
+
+static int write_csv_impl(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas, int threads,
+                          const char *path, size_t *out_length, const ColumnSinks *cols)
 {
     if (n_rows < 0 || (!rows_host && n_rows) || !path)
         return ysmr::fail(YSMR_ERR_ARG, "rows_host and path must be set");
@@ -398,7 +424,7 @@ int ysmr_rows_write_csv(const ysmr_row *rows_host, long long n_rows, int with_he
     auto work = [&](int t) {
         const long long lo = std::min<long long>((long long)t * per, n_rows), hi = std::min<long long>(lo + per, n_rows);
         piece[(size_t)t].reset(new (std::nothrow) char[(size_t)(hi - lo) * ROW_TEXT_MAX + 1]);
-        if (piece[(size_t)t]) used[(size_t)t] = format_range(rows_host, lo, hi, via_pandas != 0, piece[(size_t)t].get());
+        if (piece[(size_t)t]) used[(size_t)t] = format_range(rows_host, lo, hi, via_pandas != 0, piece[(size_t)t].get(), cols);
         else failed.store(1);
         {
             std::unique_lock<std::mutex> lk(mu);

@@ -375,6 +375,25 @@ def rows_to_csv_file(rows, path, header=True, via_pandas=True, threads=0):
     return n.value
 
 
+def rows_to_csv_file_and_dataframe(rows, path, header=True, via_pandas=True, threads=0):
+    """``rows_to_csv_file`` and ``rows_to_dataframe`` in ONE native pass (``ysmr_rows_write_csv_columns``): the values the csv is
+    printed from are the values pandas would read back from it -- worked out once for both.  Returns ``(bytes, DataFrame)``."""
+    import ctypes
+    import pandas as pd
+    from . import _lib
+    rows = np.ascontiguousarray(rows, dtype=_lib.ROW_DTYPE)
+    n = len(rows)
+    ids, t = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    cols = [np.empty(n, np.float64) for _ in range(5)]
+    length = ctypes.c_size_t(0)
+    _lib.check(_lib.lib().ysmr_rows_write_csv_columns(rows.ctypes.data, n, int(bool(header)), int(bool(via_pandas)), int(threads),
+                                                      os.fsencode(path), ctypes.byref(length), ids.ctypes.data, t.ctypes.data,
+                                                      *[c.ctypes.data for c in cols]), "ysmr_rows_write_csv_columns")
+    df = pd.DataFrame({"TRACK_ID": ids, "POSITION_T": t, "POSITION_X": cols[0], "POSITION_Y": cols[1],
+                       "WIDTH": cols[2], "HEIGHT": cols[3], "DEGREES_ANGLE": cols[4]})
+    return length.value, df
+
+
 def rows_to_dataframe(rows, via_pandas=True):
     """Rows (already sorted) -> the DataFrame ``get_data`` would have read back from the csv
     (dtypes of helper_file.py:881-889; ``via_pandas`` as in :func:`rows_to_csv_bytes`)."""

@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .detect import Detector, MeanGrayState, mean_gray_params, threshold_params
 from .frames import DeviceFrameFeed, open_video
-from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes, rows_to_csv_file,
+from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes, rows_to_csv_file, rows_to_csv_file_and_dataframe,
                           rows_to_dataframe, save_list)
 from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
@@ -489,23 +489,17 @@ def _finish(video_path, settings, logger, sorted_rows, frames_done, frame_count,
     n_rows_total = len(sorted_rows)
     last_id = int(alive_at_end.max()) if len(alive_at_end) else -1
     t_rows = time.perf_counter()
-    # the csv is formatted and written on a second thread while the DataFrame is built (both are native
-    # calls that release the GIL)
-    writer, write_error = None, []
+    # the csv and the DataFrame's columns come out of ONE native pass over the rows (the values the text is printed from are
+    # the values pandas would read back from it: worked out once, by the formatting threads themselves)
+    df_for_eval = None
     if not settings["delete .csv file after analysis"]:   # (else analyse() removes the file anyway, main.py:156)
-        def _write():
-            try:
-                rows_to_csv_file(sorted_rows, list_name)
-            except (OSError, _lib.YsmrLibraryError) as exc:
-                write_error.append(exc)
-        writer = threading.Thread(target=_write, name="ysmr-csv")
-        writer.start()
-    df_for_eval = rows_to_dataframe(sorted_rows)
+        try:
+            _, df_for_eval = rows_to_csv_file_and_dataframe(sorted_rows, list_name)
+        except (OSError, _lib.YsmrLibraryError) as exc:
+            logger.error("Could not write {}: {}".format(list_name, exc))
+    if df_for_eval is None:
+        df_for_eval = rows_to_dataframe(sorted_rows)
     t_df = time.perf_counter()
-    if writer is not None:
-        writer.join()
-        if write_error:
-            logger.error("Could not write {}: {}".format(list_name, write_error[0]))
     logger.debug("phases: frames {:.1f} ms, rows to host (sorted) {:.1f} ms, DataFrame {:.1f} ms, csv {:.1f} ms".format(
         (t_frames - t_start) * 1e3, (t_rows - t_frames) * 1e3, (t_df - t_rows) * 1e3, (time.perf_counter() - t_df) * 1e3))
     logger.info("objects: {}, frames: {} of {}, rows: {}, csv: {}".format(last_id + 1, frames_done, frame_count,
