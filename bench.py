@@ -221,8 +221,7 @@ def main():
                     if pending[k] is not None and not args.detect_only:
                         (slot, res, ready), p0, pevs, psampled = pending[k]
                         tc = time.perf_counter()
-                        pipes[k].link(slot, res, ready, p0, link_events if (psampled and DIAG & 2) else None, events=pevs,
-                                      nxt=nxt[0] if nxt is not None else None)
+                        pipes[k].link(slot, res, ready, p0, link_events if (psampled and DIAG & 2) else None, events=pevs)
                         if timed: host_calls["link"].append(time.perf_counter() - tc)
                     pending[k] = nxt
         if timed:

@@ -42,7 +42,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   11
+#define YSMR_ABI_VERSION   12
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -69,8 +69,8 @@ extern "C" {
 #define YSMR_BESIDE_LINK     4
 /* ... and the hint for a handle that links a whole batch with one launch (ysmr_tracker_batched): that launch holds ONE
  * compute unit for the length of the batch.  The matrix-pipe threshold kernel, which gives every compute unit one
- * workgroup, then cuts its rows for 31 workgroups per XCD instead of 32 -- whichever XCD the link sits on, none gets a
- * workgroup it cannot place before another has finished (same bytes). */
+ * workgroup, then cuts its rows for 248 workgroups (31 on each of the 8 XCDs) instead of 256 -- whichever XCD the link sits
+ * on, none gets a workgroup it cannot place before another has finished (same bytes). */
 #define YSMR_BESIDE_BATCH_LINK 8
 /* ... and for the two-launch link of large tables (k_link + k_track, 4K: 5000 tracks): its launches want a fat workgroup and
  * thousands of waves placed every ~30 us, so the matrix-pipe threshold kernel keeps to HALF the compute units (128 workgroups:
@@ -252,21 +252,18 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
  * to rows_dev (capacity rows_capacity) starting at *row_count_dev, which is advanced; rows of a
  * frame are contiguous and in ascending id order.  Overflow sets *row_count_dev past capacity
  * (rows beyond capacity are dropped); the host checks after synchronising. */
-/* ysmr_tracker_run with two more arguments, kept for callers written against ABI 9: after_det_dev f32 [max_det][5] /
- * after_count_dev i32 [1] named the frame that follows this call's last one, so that the last launch of a one-launch-per-
- * frame handle could find that frame's nearest detections too.  Since ABI 10 both are IGNORED (they may be NULL): the
- * shortcut read a counter its own launch writes, and the handles it paid for link a whole batch with one launch now. */
-int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
-                             int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev,
-                             const float *after_det_dev, const int32_t *after_count_dev);
-/* 1 when the handle links with one launch per frame (the case ysmr_tracker_run_chained serves), else 0 */
+/* 1 when the handle links with one launch per frame (k_frame), else 0 */
 int ysmr_tracker_fused(ysmr_tracker *t);
 
 /* How ysmr_tracker_run links a batch.  A handle whose configuration allows it -- tracking.ini's defaults do: up to three
- * filters with horizons of at most 31 frames, capacity <= 1024, max_det <= 2456 -- links a whole batch with ONE launch
+ * filters with horizons of at most 31 frames, capacity <= 768 (a track per lane of one 768-thread workgroup), max_det <= 2456
+ * -- links a whole batch with ONE launch
  * (one workgroup, a track per lane, the filter state in registers from the first frame to the last, the measurement
  * history in a ring in HBM); every other handle,
- * and ysmr_tracker_update, run one launch (or two, for large tables) per frame.  Same rows either way.
+ * and ysmr_tracker_update, run one launch (or two, for large tables) per frame.  The two paths emit the same frames, ids,
+ * counters, boxes and row order; the filtered positions agree within the parity tolerance (1e-9 px on well-conditioned rows),
+ * not bit for bit: the batch launch keeps running window sums and one reciprocal for the three weights where the per-frame
+ * kernels evaluate the FIR and three divisions.
  *   ysmr_tracker_batched    1 when ysmr_tracker_run takes the one-launch-per-batch path, else 0
  *   ysmr_tracker_link_mode  mode 0: the library's choice (default); 1: one launch per frame even where a batch launch
  *                           would serve (measurement and tests).  Takes effect with the next call; the track table is

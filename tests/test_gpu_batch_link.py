@@ -269,3 +269,121 @@ def test_prepared_batches_give_the_same_rows(torch_cuda):
         assert trk.info()[2] == 0
         out.append(rows_to_numpy(rows, int(count.item())).copy())
     assert len(out[0]) > 10000 and out[0].tobytes() == out[1].tobytes()
+
+
+def test_batch_link_with_all_twelve_waves_seated(torch_cuda, oracle):
+    """More than 704 live tracks for the whole clip (tests/link_clips.py: 720-754 of the 768 seats, deaths and births in
+    that state): every wave of k_batch holds tracks, so there is no helper wave and the frame's chores -- the next frame's
+    LDS-DMA, clearing its tables -- take their other branch (batch_link.h: helpers_from == BL_WAVES).  Frame 64, where
+    the window sums are re-summed from the ring, lies inside the second launch (batches of 48) and inside the only one
+    (one launch of 112 frames).  Against the oracle: ids, order, counters exact, positions to 1e-9."""
+    from link_clips import crowded_clip, oracle_rows
+    from ysmr_amd.tracker import DeviceTracker
+    kw = dict(max_disappeared=5.0, fps=30.0, n_min=0, n_max=30, n_f=3)
+    per_frame = crowded_clip()
+    ref, live, ot = oracle_rows(oracle, per_frame, use_gsff=True, shadows=2, **kw)
+    assert live.min() > 704 and live.max() <= 768
+    for batch in (48, 112):
+        trk = DeviceTracker(capacity=768, max_det=1024, **kw)
+        assert trk.batched
+        got = _run_frames(torch_cuda, trk, per_frame, batch, 1024, len(ref) + 8)
+        compare_rows(got, ref)
+        assert trk.info()[:2] == (int(live[-1]), ot.next_id)
+
+
+@pytest.mark.parametrize("stationary", [False, True])
+def test_batch_link_more_than_600_detections_per_frame(torch_cuda, oracle, stationary):
+    """~760 tracks and 620-760 detections per frame: k_bgrid bins them into 48 x 48 cells (other LDS offsets than every
+    other link test, whose frames hold at most 512), and bl_search_wave -- asked in every frame by the lost track far from
+    all detections -- scans them exactly, without its float pre-pass (m > 512).  ``stationary`` (GSFF off, blobs that do not
+    move): the planted EXACT ties -- two detections equidistant from a track (lowest column), two tracks equidistant from a
+    detection (lowest id) -- in frames 5, 6, 20."""
+    from link_clips import dense_detection_clip, oracle_rows
+    from ysmr_amd.tracker import DeviceTracker
+    kw = dict(max_disappeared=5.0, fps=30.0, n_min=0, n_max=30, n_f=3, use_gsff=not stationary)
+    per_frame = dense_detection_clip(stationary=stationary)
+    ref, live, ot = oracle_rows(oracle, per_frame, shadows=0 if stationary else 2, **kw)
+    assert min(len(d) for d, _ in per_frame) > 600 and live.max() <= 768
+    for batch in (40, 7):
+        trk = DeviceTracker(capacity=768, max_det=1024, **kw)
+        assert trk.batched
+        got = _run_frames(torch_cuda, trk, per_frame, batch, 1024, len(ref) + 8)
+        compare_rows(got, ref)
+        assert trk.info()[:2] == (int(live[-1]), ot.next_id)
+
+
+def test_batch_link_a_frame_of_1500_detections_overflows_cleanly(torch_cuda):
+    """1500 detections in one frame (64 cells per side: the largest grid block) against 768 seats: the error bit, 768
+    rows, nothing written out of bounds -- and after a reset the handle links again."""
+    torch = torch_cuda
+    from ysmr_amd import _lib
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    rng = np.random.default_rng(4)
+    trk = DeviceTracker(max_disappeared=3.0, fps=30.0, capacity=768, max_det=2048)
+    assert trk.batched
+    det = torch.zeros(2, 2048, 5, dtype=torch.float32, device="cuda")
+    xy = np.column_stack([rng.uniform(0, 3000, 1500), rng.uniform(0, 2000, 1500)]).astype(np.float32)
+    det[0, :1500, :2] = torch.from_numpy(xy).cuda()
+    det[1, :1400, :2] = torch.from_numpy(xy[:1400] + 0.5).cuda()
+    cnt = torch.tensor([1500, 1400], dtype=torch.int32, device="cuda")
+    guard = 64
+    rows = torch.full(((2 * 768 + guard) * _lib.ROW_DTYPE.itemsize,), 0xAB, dtype=torch.uint8, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    trk.run(det, cnt, 0, rows[:2 * 768 * _lib.ROW_DTYPE.itemsize], count)
+    torch.cuda.synchronize()
+    n, next_id, err = trk.info()
+    assert n == 768 and err & 1 and int(count.item()) <= 2 * 768
+    assert bool((rows[2 * 768 * _lib.ROW_DTYPE.itemsize:] == 0xAB).all())
+    trk.reset()
+    count.zero_()
+    det2 = torch.zeros(1, 2048, 5, dtype=torch.float32, device="cuda")
+    det2[0, :700, :2] = torch.from_numpy(xy[:700]).cuda()
+    trk.run(det2, torch.tensor([700], dtype=torch.int32, device="cuda"), 0, rows, count)
+    torch.cuda.synchronize()
+    got = rows_to_numpy(rows, int(count.item()))
+    assert len(got) == 700 and trk.info()[0] == 700
+    np.testing.assert_array_equal(got["track_id"], np.arange(700))
+    np.testing.assert_array_equal(got["x"], xy[:700, 0].astype(np.float64))
+
+
+def test_a_prepared_block_does_not_outlive_a_switch_to_the_per_frame_link(torch_cuda):
+    """ysmr_tracker_prepare remembers a binned block by the ADDRESSES of the detections it was made from.  A pipeline
+    that prepares a batch, is then switched to the per-frame link for it (where prepare is a no-op), refills the same
+    buffers without preparing them and switches back must not have its next batch linked with the old binning
+    (ADVICE r04): rows equal those of a tracker that never prepared anything."""
+    torch = torch_cuda
+    from ysmr_amd import _lib
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    rng = np.random.default_rng(12)
+    base = rng.uniform(0, 1000, (150, 2))
+
+    def batch_of(shift):
+        det = torch.zeros(8, 256, 5, dtype=torch.float32)
+        cnt = torch.zeros(8, dtype=torch.int32)
+        for i in range(8):
+            keep = rng.random(150) > 0.1
+            xy = (base + shift + rng.normal(0, 0.5, base.shape))[keep]
+            det[i, :len(xy), :2] = torch.from_numpy(xy.astype(np.float32))
+            det[i, :len(xy), 2:] = 3.0
+            cnt[i] = len(xy)
+        return det, cnt
+
+    batches = [batch_of(0.0), batch_of(2.0), batch_of(4.0)]
+    kw = dict(max_disappeared=4.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=256, max_det=256)
+    out = []
+    for prepared in (False, True):
+        trk = DeviceTracker(**kw)
+        det = torch.zeros(8, 256, 5, dtype=torch.float32, device="cuda")      # ONE pair of buffers, refilled per batch
+        cnt = torch.zeros(8, dtype=torch.int32, device="cuda")
+        rows = torch.empty(3 * 8 * 256 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        count = torch.zeros(1, dtype=torch.int64, device="cuda")
+        for b, (d, c) in enumerate(batches):
+            det.copy_(d); cnt.copy_(c)
+            if prepared and b == 0:
+                trk.prepare(det, cnt, slot=0)          # binned for batch 0 ...
+            trk.link_mode(1 if b < 2 else 0)           # ... which the per-frame kernels link, as they do batch 1
+            trk.run(det, cnt, 8 * b, rows, count)      # batch 2: a batch launch on the same addresses, other contents
+        torch.cuda.synchronize()
+        assert trk.info()[2] == 0
+        out.append(rows_to_numpy(rows, int(count.item())).copy())
+    assert len(out[0]) > 3000 and out[0].tobytes() == out[1].tobytes()

@@ -128,9 +128,18 @@ def test_threshold_matrix_pipe_distance(torch_cuda, oracle):
             assert np.array_equal(got, ref), f"{args} variant {variant}: " + _mismatch_report(got, ref)
 
 
+def _detect_all(torch, det, dev):
+    r = det.detect(dev)
+    torch.cuda.synchronize()
+    return [t.clone() for t in (r.cls, r.mask, r.labels, r.det_count, r.det, r.anchors, r.status)]
+
+
 def test_beside_link_hint_changes_no_byte(torch_cuda):
-    """YSMR_BESIDE_LINK (Detector(threshold_variant=1), what TrackingPipeline passes next to the one-launch link) only
-    picks kernels and resident grids: class map, labels, detections and counts are the same bytes as without it."""
+    """The scheduling hints of ``cv_flavour`` only pick kernels and resident grids: YSMR_BESIDE_LINK (the float32-chain
+    threshold kernel, smaller labelling grids: what TrackingPipeline passes next to the one-launch-per-frame link),
+    YSMR_BESIDE_BATCH_LINK (the matrix-pipe kernel on 248 workgroups, its rows cut into ranges of equal cost) and
+    YSMR_BESIDE_SPLIT_LINK (128 workgroups) leave class map, mask, label map, detections, anchors and counts the same
+    bytes as a call without them."""
     from ysmr_amd.detect import Detector, threshold_params
     from ysmr_amd.synth import SyntheticVideo
     from ysmr_amd import _lib
@@ -138,15 +147,64 @@ def test_beside_link_hint_changes_no_byte(torch_cuda):
     h, w = 922, 1228
     dev = torch.from_numpy(SyntheticVideo(h, w, 500, seed=2).frames(8)).cuda()
     out = []
-    for variant in (0, 1):
-        d = Detector(8, h, w, max_det=2048, params=threshold_params(True, 5, 2.0), threshold_variant=variant)
-        assert bool(d.cv_flavour & _lib.BESIDE_LINK) == (variant == 1)
-        r = d.detect(dev)
-        torch.cuda.synchronize()
-        out.append([t.clone() for t in (r.cls, r.labels, r.det_count, r.det, r.status)])
-    assert int(out[0][2].min()) > 300 and int(out[0][4].max()) == 0
-    for a, b in zip(*out):
+    for hint in (None, "link", "batch", "split"):
+        d = Detector(8, h, w, max_det=2048, params=threshold_params(True, 5, 2.0), threshold_variant=1 if hint == "link" else 0,
+                     beside_batch_link=hint == "batch", beside_split_link=hint == "split")
+        assert bool(d.cv_flavour & _lib.BESIDE_LINK) == (hint == "link")
+        assert bool(d.cv_flavour & _lib.BESIDE_BATCH_LINK) == (hint == "batch")
+        assert bool(d.cv_flavour & _lib.BESIDE_SPLIT_LINK) == (hint == "split")
+        out.append(_detect_all(torch, d, dev))
+    assert int(out[0][3].min()) > 300 and int(out[0][6].max()) == 0
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert torch.equal(a, b)
+
+
+def test_bench_launch_shape_256_frames_beside_the_batch_link(torch_cuda, oracle):
+    """The launch shape bench.py and track_bacteria really use: detection of 256 frames of
+    1228 x 922 in ONE call with YSMR_BESIDE_BATCH_LINK -- 248 workgroups of the matrix-pipe kernel, their rows cut into
+    unequal ranges by TM_START_ROWS, items that start in the middle of a frame -- gives, byte for byte, the class map, mask,
+    label map, detections and anchors of the default grid (256 workgroups, whole columns; its parity with the oracle on
+    64-frame calls is test_detect_bench_batch_frame_by_frame); a sample of its frames -- the first, the last, and those in
+    which the first workgroups' ranges end -- is also compared with the oracle directly."""
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    torch = torch_cuda
+    h, w, n = 922, 1228, 256
+    p = threshold_params(True, 5, 2.0)
+    frames = SyntheticVideo(h, w, 500, seed=6).frames(n)
+    dev = torch.from_numpy(frames).cuda()
+    plain = _detect_all(torch, Detector(n, h, w, max_det=2048, params=p), dev)
+    beside = _detect_all(torch, Detector(n, h, w, max_det=2048, params=p, beside_batch_link=True), dev)
+    assert int(plain[3].min()) > 400 and int(plain[6].max()) == 0
+    for a, b in zip(plain, beside):
         assert torch.equal(a, b)
+    got = dict(zip(("cls", "mask", "labels", "det_count", "det", "anchors", "status"), (t.cpu().numpy() for t in beside)))
+    for f in (0, 1, 8, 9, 16, 127, 255):       # (with 31 workgroups per XCD on 32 frames, a range ends inside frames 8 k + xcd)
+        one = {k: v[f:f + 1] for k, v in got.items()}
+        _compare(oracle, frames[f:f + 1], one, p, max_det=2048)
+
+
+def test_4k_launch_shape_16_frames_beside_the_split_link(torch_cuda, oracle):
+    """... and the shape of the 4K configuration: 16 frames of 3840 x 2160 with YSMR_BESIDE_SPLIT_LINK (the matrix-pipe
+    kernel on 128 workgroups, four column panels per frame) against the default grid, byte for byte, and two of its frames
+    against the oracle."""
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    torch = torch_cuda
+    h, w, n = 2160, 3840, 16
+    p = threshold_params(True, 5, 2.0)
+    frames = SyntheticVideo(h, w, 5000, seed=7).frames(n)
+    dev = torch.from_numpy(frames).cuda()
+    plain = _detect_all(torch, Detector(n, h, w, max_det=8192, params=p), dev)
+    beside = _detect_all(torch, Detector(n, h, w, max_det=8192, params=p, beside_split_link=True), dev)
+    assert int(plain[3].min()) > 4000 and int(plain[6].max()) == 0
+    for a, b in zip(plain, beside):
+        assert torch.equal(a, b)
+    got = dict(zip(("cls", "mask", "labels", "det_count", "det", "anchors", "status"), (t.cpu().numpy() for t in beside)))
+    for f in (0, 15):
+        one = {k: v[f:f + 1] for k, v in got.items()}
+        _compare(oracle, frames[f:f + 1], one, p, max_det=8192)
 
 
 def test_threshold_dispatch_sets_the_callers_events(torch_cuda, oracle):

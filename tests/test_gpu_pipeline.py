@@ -225,17 +225,16 @@ def test_resident_clip_needs_no_wait_behind_the_link():
                     dev.record_stream(pipe.side)
                     nxt = (pipe.detect_async(dev, frames_ready=ev), f0)
                 else:
-                    nxt = (pipe.detect_async(resident[f0:f0 + b], frames_ready=False if mode in ("resident", "chained") else None), f0)
+                    nxt = (pipe.detect_async(resident[f0:f0 + b], frames_ready=False if mode == "resident" else None), f0)
             if pending is not None:
                 (slot, res, ready), p0 = pending
-                # ("chained": the batch's last launch also finds the next batch's first row minima, ysmr_tracker_run_chained)
-                pipe.link(slot, res, ready, p0, nxt=nxt[0] if (mode == "chained" and nxt is not None) else None)
+                pipe.link(slot, res, ready, p0)
             pending = nxt
         return pipe.take_rows()
 
     ref = run("blanket")
     assert len(ref) > 1000
-    for mode in ("resident", "event", "chained"):
+    for mode in ("resident", "event"):
         got = run(mode)
         assert got.tobytes() == ref.tobytes(), mode
 
@@ -746,6 +745,26 @@ def test_video_denser_than_the_buffers_is_run_again_with_larger_ones(tmp_path, o
     df2 = analyse(str(path), settings=_settings(**{k: False for k in _OFFLINE_KEYS}), result_folder=str(tmp_path / "c"),
                   return_df=True, batch=24, max_det=64, capacity=96)
     assert df is not None and df.equals(res[0]) and df2.equals(res[0])
+
+
+def test_video_that_outgrows_the_batch_link_is_linked_per_frame_with_the_oracles_rows(tmp_path, oracle, caplog):
+    """More objects than the 768 seats of the one-launch-per-batch link: ~820 blobs at 1228 x 922
+    overflow capacity 768 in the first batch; track_bacteria runs the file again with capacity 1536 -- a handle the batch
+    link does not serve, i.e. on k_frame, one launch per frame -- and the table must be the oracle's."""
+    import logging
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import LAST_PIPELINE_FACTS, track_bacteria
+    frames = SyntheticVideo(922, 1228, 820, seed=13).frames(40)
+    path = tmp_path / "crowd.npy"
+    np.save(path, frames)
+    with caplog.at_level(logging.WARNING, logger="ysmr"):
+        res = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path), batch=16, max_det=1024, capacity=768)
+    assert res is not None
+    assert sum("running it again" in r.getMessage() for r in caplog.records) == 1
+    assert LAST_PIPELINE_FACTS == {"capacity": 1536, "max_det": 2048, "batched": False, "fused": True}
+    ref_rows, tr = oracle.track_frames(frames, fps=30.0, shadows=2)
+    assert max(np.bincount(np.array([r[0] for r in ref_rows], dtype=int))) > 768
+    compare_rows(_rows_from_df(res[0]), ref_rows)
 
 
 def test_no_live_track_in_the_last_frame_means_nothing_tracked(tmp_path, caplog):

@@ -562,3 +562,48 @@ def test_csv_written_by_the_formatting_threads_equals_the_one_buffer_form(tmp_pa
                 assert length2 == len(want) and path2.read_bytes() == want
                 ref = rows_to_dataframe(rows, via_pandas=via)
                 assert df2.equals(ref) and list(df2.dtypes) == list(ref.dtypes)
+
+
+def test_gc_freeze_is_counted_across_overlapping_passes():
+    """track_bacteria's frame loops hold the garbage collector's view of the heap frozen (a full collection is a 40-ms
+    stall of the loop that feeds the GPU).  Two stream threads per GPU worker overlap their passes: the first to finish
+    must not thaw the heap under the other, and a freeze of the caller's own is never undone."""
+    import gc
+    import threading
+    from ysmr_amd import track_eval as te
+    assert gc.get_freeze_count() == 0 and te._GC_HOLDERS == 0
+    first_in, second_in, first_out = threading.Event(), threading.Event(), threading.Event()
+    seen = {}
+
+    def first():
+        te._gc_hold()
+        first_in.set()
+        second_in.wait(10)
+        te._gc_release()                       # the other pass is still inside
+        seen["after_first_left"] = gc.get_freeze_count()
+        first_out.set()
+
+    def second():
+        first_in.wait(10)
+        te._gc_hold()
+        second_in.set()
+        first_out.wait(10)
+        seen["second_still_inside"] = gc.get_freeze_count()
+        te._gc_release()
+        seen["after_both"] = gc.get_freeze_count()
+
+    threads = [threading.Thread(target=first), threading.Thread(target=second)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(20)
+    assert seen["after_first_left"] > 0 and seen["second_still_inside"] > 0
+    assert seen["after_both"] == 0 and te._GC_HOLDERS == 0
+    # a caller's own freeze stays the caller's
+    gc.freeze()
+    try:
+        te._gc_hold()
+        te._gc_release()
+        assert gc.get_freeze_count() > 0
+    finally:
+        gc.unfreeze()

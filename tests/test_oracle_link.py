@@ -69,3 +69,24 @@ def test_tracker_matches_reference(oracle, name):
         assert tr.next_id == g["next_id"][f]
         assert sorted(claims) == sorted(map(tuple, g["claims"][coff[f]:coff[f + 1]].tolist())), f"frame {f}"
 
+
+
+def test_batch_link_clips_reach_the_states_their_gpu_tests_are_about(oracle):
+    """tests/link_clips.py builds the detection sequences of the batch link's GPU tests at the states where k_batch's code
+    paths change: more than 704 live tracks for >= 70 frames with deaths and births in that state (all
+    twelve waves seated), frames of more than 600 detections (48 cells per side, the wave search without its float
+    pre-pass).  Checked here, on the CPU, so that an edit of a generator cannot quietly move a test off its path."""
+    from link_clips import crowded_clip, dense_detection_clip, oracle_rows
+    kw = dict(max_disappeared=5.0, fps=30.0, n_min=0, n_max=30, n_f=3)
+    frames = crowded_clip()
+    rows, live, ot = oracle_rows(oracle, frames, use_gsff=True, **kw)
+    assert len(frames) >= 100 and live.min() >= 716 and live.max() <= 768           # seats 705.. of the twelfth wave in use throughout
+    assert ot.next_id - live[-1] >= 60                                               # deaths ...
+    births = [f for f in range(1, len(live)) if max(r[1] for r in rows if r[0] == f) > max(r[1] for r in rows if r[0] == f - 1)]
+    assert len(births) >= 5 and all(live[f - 1] >= 716 for f in births)             # ... and births in that state
+    assert any(32 < f < 96 for f in births)
+    for stationary in (False, True):
+        frames = dense_detection_clip(stationary=stationary)
+        rows, live, ot = oracle_rows(oracle, frames, use_gsff=not stationary, **kw)
+        m = np.array([len(d) for d, _ in frames])
+        assert live.max() <= 768 and live.min() > 704 and m.min() > 600 and m.max() <= 768

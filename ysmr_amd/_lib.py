@@ -49,12 +49,12 @@ def cv_flavour_of(version):
 ROW_DTYPE = np.dtype([("frame", "<i4"), ("track_id", "<i4"), ("x", "<f8"), ("y", "<f8"),
                       ("w", "<f4"), ("h", "<f4"), ("angle", "<f4"), ("disappeared", "<i4")])
 
-ABI_VERSION = 11   # YSMR_ABI_VERSION of include/ysmr_hip.h these argtypes were written against
+ABI_VERSION = 12   # YSMR_ABI_VERSION of include/ysmr_hip.h these argtypes were written against
 
 EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_detect_workspace_init",
            "ysmr_threshold_batch", "ysmr_threshold_batch_variant", "ysmr_threshold_timing", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
-           "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_run_chained", "ysmr_tracker_fused", "ysmr_tracker_batched", "ysmr_tracker_link_mode", "ysmr_tracker_prepare", "ysmr_tracker_peek",
+           "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_fused", "ysmr_tracker_batched", "ysmr_tracker_link_mode", "ysmr_tracker_prepare", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
            "ysmr_rows_format_csv", "ysmr_rows_write_csv", "ysmr_rows_write_csv_columns", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks",
            "ysmr_evaluate_workspace_bytes", "ysmr_evaluate_tracks", "ysmr_unpack_dib_batch", "ysmr_file_read")
@@ -143,7 +143,6 @@ def lib():
     L.ysmr_tracker_update.argtypes = [vp, vp, vp, ci, ci, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp]
     L.ysmr_tracker_peek.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ysmr_tracker_run.argtypes = [vp, vp, vp, vp, ci, ctypes.c_int32, vp, ctypes.c_int64, vp]
-    L.ysmr_tracker_run_chained.argtypes = [vp, vp, vp, vp, ci, ctypes.c_int32, vp, ctypes.c_int64, vp, vp, vp]
     L.ysmr_tracker_fused.argtypes = [vp]
     L.ysmr_tracker_batched.argtypes = [vp]
     L.ysmr_tracker_link_mode.argtypes = [vp, ci]

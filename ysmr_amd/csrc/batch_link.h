@@ -667,7 +667,10 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(BlKernArgs ka)
         S.alive = true;
     }
     __syncthreads();
-    if (lane == 0 && __ballot(S.alive)) atomicMax(&sh.top, 64 * (wave + 1));
+    {   // (the ballot outside the branch: under `lane == 0 &&` only lane 0 would vote)
+        const unsigned long long ba = __ballot(S.alive);
+        if (lane == 0 && ba) atomicMax(&sh.top, 64 * (wave + 1));
+    }
     __syncthreads();
     // The chores of a frame -- the next frame's LDS-DMA, clearing its tables -- go to the waves that hold no track, when
     // there are any: with 9 of 12 waves in use, three of them share one SIMD and set the frame's pace, and the idle waves

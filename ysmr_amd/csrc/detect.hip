@@ -1367,6 +1367,8 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *l
 {
     DET_RING(9);
     const int f = blockIdx.x;
+    // the test hook of the residue kernels (include/ysmr_hip.h) is good for one call: cleared here, behind the launch that read it
+    if (f == 0 && blockIdx.y == 0 && threadIdx.x == 0 && hdr->fault == YSMR_WS_FAULT_RESIDUE_STALL) hdr->fault = 0u;
     int n = t.nroots[(size_t)f * NR_STRIDE];
     if (n > t.max_det) {
         if (threadIdx.x == 0 && blockIdx.y == 0) {
@@ -1641,7 +1643,6 @@ __global__ __launch_bounds__(256) void k_residue(uint8_t *cls, uint32_t *labels,
         // these buffers clear everything -- label map, mask, counters and this barrier word -- instead of walking the
         // component boxes (k_clear; k_compact keeps the flag).
         pl.hdr->dense = 1u;
-        pl.hdr->fault = 0u;
         for (int f = 0; f < batch; ++f) atomicOr(&status[f], YSMR_DET_STALLED);
     }
 }
@@ -1671,7 +1672,8 @@ __global__ __launch_bounds__(RESF_THREADS) void k_residue_frames(uint8_t *cls, u
         // k_residue's bail-out reports, so that the caller's recovery is the same whichever kernel a batch size takes)
         if (tid == 0) {
             atomicOr(&status[f], YSMR_DET_STALLED);
-            if (f == 0) { pl.hdr->dense = 1u; pl.hdr->fault = 0u; }
+            if (f == 0) pl.hdr->dense = 1u;     // (the fault word itself is cleared by the NEXT kernel of the chain, k_rank:
+                                                // a workgroup of this launch that starts late must still see it)
         }
         return;
     }

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cerrno>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <vector>
 #include <unistd.h>
@@ -113,16 +114,32 @@ extern "C" int ysmr_file_read(int fd, void *dst, size_t n, long long offset, int
     auto piece = [&](size_t lo, size_t hi) {
         while (lo < hi) {
             const ssize_t got = ::pread(fd, (char *)dst + lo, hi - lo, (off_t)(offset + (long long)lo));
+            if (got < 0 && errno == EINTR) continue;
             if (got <= 0) { bad.store(got == 0 ? -1 : errno ? errno : -1); return; }
             lo += (size_t)got;
         }
     };
     if (nt == 1) piece(0, n);
     else {
+        // (a thread that cannot be started -- EAGAIN under a pids cgroup -- leaves its range to the caller's thread)
         std::vector<std::thread> pool;
-        for (int t = 0; t < nt; ++t) {
-            const size_t lo = (n * (size_t)t / nt) & ~(size_t)4095, hi = t + 1 == nt ? n : (n * (size_t)(t + 1) / nt) & ~(size_t)4095;
-            pool.emplace_back(piece, lo, hi);
+        auto range = [&](int t, size_t &lo, size_t &hi) {
+            lo = (n * (size_t)t / nt) & ~(size_t)4095;
+            hi = t + 1 == nt ? n : (n * (size_t)(t + 1) / nt) & ~(size_t)4095;
+        };
+        int started = 0;
+        try {
+            for (; started < nt - 1; ++started) {
+                size_t lo, hi;
+                range(started, lo, hi);
+                pool.emplace_back(piece, lo, hi);
+            }
+        } catch (const std::system_error &) {
+        }
+        for (int t = started; t < nt; ++t) {
+            size_t lo, hi;
+            range(t, lo, hi);
+            piece(lo, hi);
         }
         for (auto &th : pool) th.join();
     }

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <atomic>
 #include <condition_variable>
@@ -403,10 +404,12 @@ static int write_csv_impl(const ysmr_row *rows_host, long long n_rows, int with_
         return ysmr::fail(YSMR_ERR_ARG, "rows_host and path must be set");
     const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (fd < 0) return ysmr::fail(YSMR_ERR_ARG, "cannot open %s for writing: %s", path, std::strerror(errno));
-    auto write_all = [fd](const char *p, size_t n, off_t at) {
+    std::atomic<int> write_errno{0};
+    auto write_all = [fd, &write_errno](const char *p, size_t n, off_t at) {
         while (n) {
             const ssize_t w = ::pwrite(fd, p, n, at);
-            if (w <= 0) return false;
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) { write_errno.store(w < 0 ? errno : ENOSPC); return false; }     // (errno where it was set)
             p += w; n -= (size_t)w; at += w;
         }
         return true;
@@ -421,16 +424,20 @@ static int write_csv_impl(const ysmr_row *rows_host, long long n_rows, int with_
     std::atomic<int> sized{0}, failed{0};
     std::mutex mu;
     std::condition_variable cv;
-    auto work = [&](int t) {
+    // a piece is formatted, then -- once every piece knows its length -- written at its own offset by whoever formatted it
+    auto format_piece = [&](int t) {
         const long long lo = std::min<long long>((long long)t * per, n_rows), hi = std::min<long long>(lo + per, n_rows);
         piece[(size_t)t].reset(new (std::nothrow) char[(size_t)(hi - lo) * ROW_TEXT_MAX + 1]);
         if (piece[(size_t)t]) used[(size_t)t] = format_range(rows_host, lo, hi, via_pandas != 0, piece[(size_t)t].get(), cols);
         else failed.store(1);
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            if (sized.fetch_add(1) + 1 == nt) cv.notify_all();
-            else cv.wait(lk, [&] { return sized.load() == nt; });
-        }
+        std::unique_lock<std::mutex> lk(mu);
+        if (sized.fetch_add(1) + 1 == nt) cv.notify_all();
+    };
+    auto all_sized = [&]() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return sized.load() == nt; });
+    };
+    auto write_piece = [&](int t) {
         if (failed.load()) return;
         size_t at = head;
         for (int k = 0; k < t; ++k) at += used[(size_t)k];
@@ -438,17 +445,32 @@ static int write_csv_impl(const ysmr_row *rows_host, long long n_rows, int with_
         if (!write_all(piece[(size_t)t].get(), used[(size_t)t], (off_t)at)) failed.store(2);
         piece[(size_t)t].reset();
     };
-    if (nt == 1) work(0);
-    else {
+    {
+        // Threads that cannot be started (EAGAIN under a pids cgroup) leave their pieces to the caller's thread: every
+        // piece is formatted by somebody, so the wait above always ends (a throw out of emplace_back with
+        // workers already waiting ended in std::terminate inside a ctypes call).
         std::vector<std::thread> pool;
-        for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
+        int started = 0;
+        if (nt > 1) {
+            try {
+                for (; started < nt - 1; ++started)
+                    pool.emplace_back([&, started] { format_piece(started); all_sized(); write_piece(started); });
+            } catch (const std::system_error &) {
+            }
+        }
+        for (int t = started; t < nt; ++t) format_piece(t);
+        all_sized();
+        for (int t = started; t < nt; ++t) write_piece(t);
         for (auto &th : pool) th.join();
     }
     size_t len = head;
     for (size_t u : used) len += u;
     const int rc_close = ::close(fd);
+    const int close_errno = rc_close != 0 ? errno : 0;
+    if (failed.load() || rc_close != 0) ::unlink(path);            // (no truncated csv under the list's name)
     if (failed.load() == 1) return ysmr::fail(YSMR_ERR_CAPACITY, "out of memory formatting %lld rows", n_rows);
-    if (failed.load() == 2 || rc_close != 0) return ysmr::fail(YSMR_ERR_ARG, "writing %s failed: %s", path, std::strerror(errno));
+    if (failed.load() == 2 || rc_close != 0)
+        return ysmr::fail(YSMR_ERR_ARG, "writing %s failed: %s", path, std::strerror(failed.load() == 2 ? write_errno.load() : close_errno));
     if (out_length) *out_length = len;
     return YSMR_OK;
 }

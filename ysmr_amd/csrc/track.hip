@@ -2244,6 +2244,7 @@ int ysmr_tracker_reset(ysmr_tracker *t, void *stream)
     int n = t->d.capacity > t->d.max_det ? t->d.capacity : t->d.max_det;
     t->par = 0;
     t->rowmin_for = nullptr;
+    t->prepared[0] = t->prepared[1] = ysmr_tracker::Prepared();
     t->in_batch = t->use_batch();      // (an empty table is the same in both layouts)
     hipLaunchKernelGGL(k_tracker_reset, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d);
     YSMR_LAUNCH_CHECK();
@@ -2263,6 +2264,10 @@ int ysmr_tracker_destroy(ysmr_tracker *t)
 // where the state rests: the seat-major arrays of the batch link, or the per-slot layout of the per-frame kernels
 static int state_to_std(ysmr_tracker *t, hipStream_t st)
 {
+    // a binned block is matched by the addresses of its detections alone: once a frame is linked by the per-frame kernels
+    // (this function is in front of every such call) the caller may refill that buffer without preparing it again, and a
+    // later batch run must not take the old binning for the new contents
+    t->prepared[0] = t->prepared[1] = ysmr_tracker::Prepared();
     if (!t->in_batch) return YSMR_OK;
     hipLaunchKernelGGL(k_to_std, dim3((std::max(t->d.capacity, t->bd.seat_cap) + 255) / 256), dim3(256), 0, st, t->d, t->bd);
     YSMR_LAUNCH_CHECK();
@@ -2289,6 +2294,7 @@ int ysmr_tracker_link_mode(ysmr_tracker *t, int mode)
 {
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
     if (mode != 0 && mode != 1) return ysmr::fail(YSMR_ERR_ARG, "link mode must be 0 (the library's choice) or 1 (per-frame launches)");
+    if (t->link_mode != mode) t->prepared[0] = t->prepared[1] = ysmr_tracker::Prepared();
     t->link_mode = mode;       // (the state changes its layout at the next call that needs the other one)
     return YSMR_OK;
 }
@@ -2332,15 +2338,18 @@ int ysmr_tracker_update(ysmr_tracker *t, void *stream, const void *det_dev, int 
                                   n_new_dev, false, nullptr, nullptr);
 }
 
-int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
-                             int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev,
-                             const float *after_det_dev, const int32_t *after_count_dev)
+int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
+                     int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev)
 {
     if (!t) return ysmr::fail(YSMR_ERR_ARG, "tracker handle is NULL");
     if (!det_dev || !det_count_dev || !rows_dev || !row_count_dev || batch <= 0)
         return ysmr::fail(YSMR_ERR_ARG, "det_dev, det_count_dev, rows_dev, row_count_dev must be set and batch > 0");
-    if ((after_det_dev == nullptr) != (after_count_dev == nullptr))
-        return ysmr::fail(YSMR_ERR_ARG, "after_det_dev and after_count_dev go together");
+    // (ysmr_tracker_run_chained, which also took the NEXT call's first frame, left the ABI with version 12: its look-ahead
+    // had been ignored since version 10 -- a launch that had the next call's first row minima ready had to take its first
+    // output row from *row_count_dev, the word its own first workgroup advances, ADVICE r03 -- and a batch-link handle
+    // links a batch with ONE launch, so there is nothing to chain.)
+    const float *after_det_dev = nullptr;
+    const int32_t *after_count_dev = nullptr;
     if (t->use_batch()) {
         // one launch links the batch (cut to the BL_MAX_BATCH frames the grid block holds); `after` has nothing to save here
         if (int rc = state_to_batch(t, (hipStream_t)stream)) return rc;
@@ -2370,12 +2379,6 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
         return YSMR_OK;
     }
     if (int rc = state_to_std(t, (hipStream_t)stream)) return rc;
-    // `after` is accepted and ignored since ABI 10.  A launch that had the next call's first row minima ready had to take
-    // its first output row from *row_count_dev -- the word its own first workgroup advances, with nothing ordering the
-    // other workgroups' reads before that write once the grid no longer fits the chip -- and recognised "the next call" by
-    // the address of its detections alone.  What it saved was one of a batch's 65 launches (+0.6 % at best); the handles
-    // that this mattered for now link a batch with ONE launch.
-    after_det_dev = nullptr; after_count_dev = nullptr;
     // the previous call may have left this call's first row minima behind (it was told this frame comes next)
     const bool have_rowmin = t->fused && t->rowmin_for != nullptr && t->rowmin_for == (const void *)det_dev;
     t->rowmin_for = nullptr;
@@ -2389,8 +2392,8 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
         if (batch > t->grid_frames) {      // (the grid block was sized by ysmr_tracker_create: longer batches go in pieces)
             for (int f0 = 0; f0 < batch; f0 += t->grid_frames) {
                 const int nb = batch - f0 < t->grid_frames ? batch - f0 : t->grid_frames;
-                if (int rc = ysmr_tracker_run_chained(t, stream, det_dev + (size_t)f0 * t->d.max_det * 5, det_count_dev + f0, nb,
-                                                      first_frame_index + f0, rows_dev, rows_capacity, row_count_dev, nullptr, nullptr))
+                if (int rc = ysmr_tracker_run(t, stream, det_dev + (size_t)f0 * t->d.max_det * 5, det_count_dev + f0, nb,
+                                              first_frame_index + f0, rows_dev, rows_capacity, row_count_dev))
                     return rc;
             }
             return YSMR_OK;
@@ -2414,13 +2417,6 @@ int ysmr_tracker_run_chained(ysmr_tracker *t, void *stream, const float *det_dev
     }
     if (after_det_dev) t->rowmin_for = (const void *)after_det_dev;
     return YSMR_OK;
-}
-
-int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const int32_t *det_count_dev, int batch,
-                     int32_t first_frame_index, ysmr_row *rows_dev, int64_t rows_capacity, int64_t *row_count_dev)
-{
-    return ysmr_tracker_run_chained(t, stream, det_dev, det_count_dev, batch, first_frame_index, rows_dev, rows_capacity,
-                                    row_count_dev, nullptr, nullptr);
 }
 
 int ysmr_tracker_fused(ysmr_tracker *t) { return t && t->fused && !t->use_batch() ? 1 : 0; }

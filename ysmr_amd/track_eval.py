@@ -33,6 +33,8 @@ __all__ = ["track_bacteria", "TrackingPipeline", "select_tracks", "evaluate_trac
 
 #: where the wall time of the last _device_pass went, in seconds since it began (diagnostics: scripts/e2e_profile.py)
 LAST_PASS_MARKS = {}
+#: which device buffers and which link path the last _device_pass ran with (the re-run of a video too dense for its first attempt)
+LAST_PIPELINE_FACTS = {}
 
 #: most rows kept on the device for one video (40 B each); longer tables are moved to the host in between
 ROW_BUDGET_MAX = 32 << 20
@@ -201,12 +203,10 @@ class TrackingPipeline:
         self.row_count.zero_()
 
     @_on_own_device
-    def link(self, slot, res, ready, first_frame, link_events=None, events=None, nxt=None):
+    def link(self, slot, res, ready, first_frame, link_events=None, events=None):
         """Link one detected batch on the current stream; rows accumulate in self.rows.
         ``link_events``: list that receives a (start, stop, frames, host_seconds) record around the batch's
-        launches -- HIP events on the link stream, and how long the host took to issue them.
-        ``nxt``: accepted and ignored (round 3 let a batch's last per-frame launch look ahead into the next batch: ABI 10
-        dropped that, include/ysmr_hip.h)."""
+        launches -- HIP events on the link stream, and how long the host took to issue them."""
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ready)
         n = int(res.det_count.shape[0])
@@ -352,6 +352,33 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
                    list_name, fps_of_file, frame_height, frame_width, t_start, t_frames)
 
 
+_GC_LOCK = threading.Lock()
+_GC_HOLDERS = 0          # frame loops of this process that currently want the heap frozen
+_GC_OURS = False         # the freeze in force is this module's (not the caller's own)
+
+
+def _gc_hold():
+    """The first frame loop of the process freezes the collector's view of the heap, unless the caller already has
+    (``gc.get_freeze_count() != 0``: that freeze is theirs and stays theirs); later loops only count themselves in."""
+    global _GC_HOLDERS, _GC_OURS
+    with _GC_LOCK:
+        if _GC_HOLDERS == 0:
+            _GC_OURS = gc.get_freeze_count() == 0
+            if _GC_OURS:
+                gc.freeze()
+        _GC_HOLDERS += 1
+
+
+def _gc_release():
+    """... and only the last one to leave thaws it (two stream threads per GPU worker overlap their passes)."""
+    global _GC_HOLDERS, _GC_OURS
+    with _GC_LOCK:
+        _GC_HOLDERS -= 1
+        if _GC_HOLDERS == 0 and _GC_OURS:
+            gc.unfreeze()
+            _GC_OURS = False
+
+
 def _persist_chunk(list_name, rows, first):
     """'hip persist rows': the rows of one full device buffer, in the order they were tracked, appended to the list
     file -- what save_list (helper_file.py:1403-1478) does every 'list save length interval' rows."""
@@ -382,6 +409,8 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
         row_budget = max(row_budget, 2 * batch * capacity, int(settings["list save length interval"]))
         pipe = TrackingPipeline(frame_height, frame_width, fps_of_file, local, batch=batch, max_det=max_det,
                                 capacity=capacity, device=device, rows_per_flush=row_budget)
+        LAST_PIPELINE_FACTS.clear()
+        LAST_PIPELINE_FACTS.update(capacity=int(capacity), max_det=int(max_det), batched=bool(pipe.trk.batched), fused=bool(pipe.trk.fused))
         chunks = []
         pending = None
         res = None
@@ -395,9 +424,10 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
         # A full pass of CPython's garbage collector walks every tracked object of the process (~40 ms with torch, numpy
         # and pandas loaded) and would stall the loop that keeps the GPU fed for as long as 50 batches take; what is alive
         # now is moved out of its sight for the duration of the loop (collections of the loop's own garbage stay on).
-        froze = gc.get_freeze_count() == 0          # (not over a freeze of the caller's, or of another stream's thread)
-        if froze:
-            gc.freeze()
+        # (a count under a lock: with two stream threads per GPU worker the first pass to finish must not thaw the heap
+        # under the other's loop)
+        _gc_hold()
+        froze = True
         for dev, f0, n_read, feed_slot in feed:
             LAST_PASS_MARKS.setdefault("first batch on the device", time.perf_counter() - t_start)
             nxt = (pipe.detect_async(dev), f0, n_read)
@@ -411,7 +441,7 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
                     if persist_to:
                         _persist_chunk(persist_to, chunks[-1], len(chunks) == 1)
                     rows_upper = 0
-                res = pipe.link(slot, r, ready, p0, nxt=nxt[0])
+                res = pipe.link(slot, r, ready, p0)
                 rows_upper += cnt * pipe.capacity
                 frames_done = p0 + cnt
                 if not checked_early:           # a video too dense for the buffers is found out after its
@@ -430,7 +460,7 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
             frames_done = p0 + cnt
         LAST_PASS_MARKS["last batch issued"] = time.perf_counter() - t_start
         if froze:
-            gc.unfreeze()
+            _gc_release()
             froze = False
         if res is not None:
             torch.cuda.synchronize(pipe.device)
@@ -458,7 +488,7 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
         error_during_read = True
     finally:
         if froze:
-            gc.unfreeze()
+            _gc_release()
         if feed is not None:
             feed.close()
     return verdict, sorted_rows, frames_done, error_during_read, t_start, t_frames

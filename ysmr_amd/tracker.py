@@ -77,18 +77,16 @@ class DeviceTracker:
         _lib.check(rc, "ysmr_tracker_update")
 
     @_on_own_device
-    def run(self, det, det_count, first_frame, rows, row_count, after=None):
+    def run(self, det, det_count, first_frame, rows, row_count):
         """Frames [first_frame, first_frame + B): det f32 [B,max_det,5], det_count i32 [B] on device;
-        rows: uint8 buffer viewed as ysmr_row[]; row_count: int64 device scalar (advanced).
-        ``after``: ignored since ABI 10 (``ysmr_tracker_run_chained``)."""
+        rows: uint8 buffer viewed as ysmr_row[]; row_count: int64 device scalar (advanced)."""
         b = det_count.numel()
         if det.shape[1] != self.max_det:
             raise ValueError("det must be [B, max_det, 5] with the tracker's max_det")
-        a_det, a_cnt = (None, None) if after is None else (after[0].data_ptr(), after[1].data_ptr())
-        rc = _lib.lib().ysmr_tracker_run_chained(self._handle, _lib.stream_ptr(self.device), det.data_ptr(),
-                                                 det_count.data_ptr(), b, int(first_frame), rows.data_ptr(),
-                                                 rows.numel() // _lib.ROW_DTYPE.itemsize, row_count.data_ptr(), a_det, a_cnt)
-        _lib.check(rc, "ysmr_tracker_run_chained")
+        rc = _lib.lib().ysmr_tracker_run(self._handle, _lib.stream_ptr(self.device), det.data_ptr(),
+                                         det_count.data_ptr(), b, int(first_frame), rows.data_ptr(),
+                                         rows.numel() // _lib.ROW_DTYPE.itemsize, row_count.data_ptr())
+        _lib.check(rc, "ysmr_tracker_run")
 
     @_on_own_device
     def prepare(self, det, det_count, slot):
