@@ -12,7 +12,7 @@ det = Detector(B, H, W, max_det=2048)
 for f0 in range(0, F, B): det.threshold(frames[f0:f0 + B])
 torch.cuda.synchronize()
 L = _lib.lib()
-NW, NS, NK = 16, 20, 8
+NW, NS, NK = int(os.environ.get("TM_WAVES", "16")), 20, 8
 buf = (ctypes.c_ulonglong * (NW * NS * NK))()
 acc = []
 for rep in range(5):

@@ -12,6 +12,7 @@ struct Params {
     int inv, use_high, t_low, t_high;
     // x = S * (theta - v) * sign + 127.5 saturates to byte 0 / 255 outside EPS of the level theta (v = mean - blurred)
     float x_mul, neg_x_mul, lo_add, hi_minus_lo;
+    float col_scale, row_scale;   // the Gaussian's taps enter as f16(col_scale w) (columns) and f16(row_scale w) (rows: x_mul / col_scale)
     int start_rows;        // the cost of starting an item, in rows of the walk (how the rows are cut into ranges)
     uint32_t lo_bits;      // class bits taken from the first level's byte (both when there is one level)
     float kw[6];           // the Gaussian's distinct weights k[0..5] (k[i] == k[10 - i]), cv2's float32 values
@@ -20,8 +21,8 @@ struct Params {
 // geometry / arguments the kernel serves (everything else stays on k_threshold_strip / k_threshold)
 bool supported(int H, int W, int channels, int t_low, int t_high, int use_high);
 
-// variant: 0 = shipped (EPS = 1/256), 1 = EPS = 1/512 (diagnostic: half the margin), 2 = every pixel through the
-// exact path (diagnostic)
+// variant: 0 = shipped (EPS = 127 / S for the largest admissible scale S: 0.050 gray levels with cv2's taps), 1 = half that
+// scale (diagnostic: twice the EPS, twice the list of undecided pixels), 2 = every pixel through the exact path (diagnostic)
 // ev_start / ev_stop (either may be null): events the dispatch itself updates (hipExtLaunchKernel)
 int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H, int W, int inv, int t_low, int t_high,
            int use_high, const float *gauss11, int blocks_wanted, int variant, hipEvent_t ev_start = nullptr,
