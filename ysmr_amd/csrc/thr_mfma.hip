@@ -89,6 +89,18 @@ constexpr int TM_RAW_PITCH = 16 * TM_RAW_CHUNKS;
 constexpr int TM_RAW_PIECES = (TM_ROWS * TM_RAW_CHUNKS + 63) / 64;       // 1 KiB DMA pieces per step
 constexpr int TM_PIECES_PER_WAVE = (TM_RAW_PIECES + TM_WAVES - 1) / TM_WAVES;
 constexpr int TM_OUT_PITCH = 16 * TM_PER_WAVE;               // bytes per row of a wave's class-byte staging
+#ifndef TM_DMA_AFTER_BLOCK_N
+#define TM_DMA_AFTER_BLOCK_N 2
+#endif
+constexpr int TM_DMA_AFTER_BLOCK = TM_DMA_AFTER_BLOCK_N;     // the second half of the waves request their rows behind this block of the filter (-1: at the start, like the first half)
+#ifndef TM_STORE_AT_START_N
+#define TM_STORE_AT_START_N 1
+#endif
+constexpr bool TM_STORE_AT_START = TM_STORE_AT_START_N != 0;  // a step's class bytes leave at the start of the next step (0: behind its filter, round 4)
+#ifndef TM_BLUR_GROUP_N
+#define TM_BLUR_GROUP_N 1
+#endif
+constexpr int TM_BLUR_GROUP = TM_BLUR_GROUP_N;               // blocks of the blur a wave takes through its phases together (1: one chain per block)
 #ifndef TM_LIST_CAP_N
 #define TM_LIST_CAP_N 248
 #endif
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
     // conversion at 1024 + x, where f16 counts in ones, leaves 1024 + ((S + 8) >> 4).
     i32x4 K_ROW = {0x6600, 0x6600, 0x6600, 0x6600};
     f32x4 K_COL = {768.5f, 768.5f, 768.5f, 768.5f};
-    f32x4 K_LO = {P.lo_add, P.lo_add, P.lo_add, P.lo_add};
+    f32x4 K_LO = {P.k_first, P.k_first, P.k_first, P.k_first};
     asm volatile("" : "+v"(K_ROW), "+v"(K_COL), "+v"(K_LO));   // (opaque: not rematerialised as four moves per use)
     const half8_t BID = as_half8(bid[0], bid[1], bid[2], bid[3]);
     const half8_t TBh = as_half8(tbh[0], tbh[1], tbh[2], tbh[3]);
@@ -459,7 +471,11 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                         off = (uint32_t)clampi(r0 + r, 0, H - 1) * (uint32_t)W + (uint32_t)max(col, 0);
                     }
                     if (rq_on[k])
+#ifdef TM_NT_LOADS
+                        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(off), "s"(frame) : "memory");
+#else
                         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(off), "s"(frame) : "memory");
+#endif
                 }
             }
             if (wave == TM_WAVES - 1) {   // the lightest wave waits for these sixteen-plus-sixteen chunks at once
@@ -488,6 +504,8 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         for (int bi = 0; bi < TM_PER_WAVE; ++bi)
 #pragma unroll
             for (int k = 0; k < 4; ++k) hst[bi][k] = 0x64006400u;
+        const bool blur_left = edge_l && u0 == 0;
+        const bool blur_right = edge_r && ((PW + 7) >> 4) >= u0 && ((PW + 7) >> 4) < u0 + TM_PER_WAVE && ((PW + 7) >> 4) <= ntiles;
         auto blur_step = [&](int j, auto par_tag, auto sums_tag) __attribute__((always_inline)) {
 #ifdef TM_DBG_NOBLUR
             return;
@@ -518,6 +536,69 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             const int lo = opaque_lane(lane), l16o = lo & 15, qo = lo >> 4;
             const uint8_t *rawp = raw + l16o * 16 * nch + 16 * u0 + 16 * qo;
             uint2 *cellp = reinterpret_cast<uint2 *>(&L.tile[16 * u0 + l16o][16 * PAR + 4 * qo]);
+            if constexpr (TM_BLUR_GROUP > 1) {
+                // Blocks in groups of TM_BLUR_GROUP, phase by phase in straight-line code: the LDS reads, the row products, the column
+                // products, the conversions of the group's blocks back to back, then their (guarded) writes.  One block at a time is
+                // a chain of LDS latency, two MFMA latencies and three waits that the compiler cannot overlap with the next block's
+                // (each sits behind its own wave-uniform test): a wave's five blocks took 2 100 - 2 800 cycles where their
+                // instructions issue in ~450, and four such waves do not fill a SIMD (profiles/r05_thr_stamps_*.log).  Blocks beyond
+                // the panel (the last wave's) are computed like the others -- their reads stay inside LDS, nobody uses the result --
+                // only their tile writes are held back.
+                const half2_t bias = {(_Float16)1152.0f, (_Float16)1152.0f};
+#pragma unroll
+                for (int g0 = 0; g0 < TM_PER_WAVE; g0 += TM_BLUR_GROUP) {
+                    constexpr int G = TM_BLUR_GROUP;
+                    u32x4 a[G];
+                    i32x4 ch[G];
+                    f32x4 y[G];
+                    uint32_t b01[G], b23[G];
+#pragma unroll
+                    for (int b = 0; b < G; ++b)
+                        if (g0 + b < TM_PER_WAVE) a[b] = *reinterpret_cast<const u32x4 *>(rawp + 16 * (g0 + b));
+#pragma unroll
+                    for (int b = 0; b < G; ++b)
+                        if (g0 + b < TM_PER_WAVE) {
+                            a[b] ^= 0x80808080u;
+                            ch[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a[b]), THI, K_ROW, 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int b = 0; b < G; ++b)
+                        if (g0 + b < TM_PER_WAVE) {
+                            const int bi = g0 + b;
+                            hst[bi][2 * PAR] = ((uint32_t)ch[b][1] << 16) | (uint32_t)ch[b][0];
+                            hst[bi][2 * PAR + 1] = ((uint32_t)ch[b][3] << 16) | (uint32_t)ch[b][2];
+                            if (!SUMS_ONLY)
+                                y[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(TV, as_half8(hst[bi][0], hst[bi][1], hst[bi][2], hst[bi][3]), K_COL, 0, 0, 0);
+                        }
+                    if (!SUMS_ONLY) {
+#pragma unroll
+                        for (int b = 0; b < G; ++b)
+                            if (g0 + b < TM_PER_WAVE) {
+                                b01[b] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(y[b][0], y[b][1])) - bias);
+                                b23[b] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(y[b][2], y[b][3])) - bias);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);       // (the writes and their tests behind the arithmetic of the whole group)
+#pragma unroll
+                        for (int b = 0; b < G; ++b)
+                            if (g0 + b < TM_PER_WAVE) {
+                                const int bi = g0 + b, u = u0 + bi;
+                                uint2 *cell = cellp + bi * (16 * TM_COL_PITCH / 4);
+                                if (u <= ntiles && (!edge_r || 16 * u <= PW + 7)) *cell = make_uint2(b01[b], b23[b]);
+                                if (edge_l && u == 0) {                          // wave-uniform
+                                    if (l16o == 8)
+#pragma unroll
+                                        for (int e = 1; e <= 8; ++e) cell[-e * (TM_COL_PITCH / 4)] = make_uint2(b01[b], b23[b]);
+                                }
+                                if (edge_r && u == (PW + 7) >> 4) {              // wave-uniform: the block of column W - 1
+                                    if (l16o == ((PW + 7) & 15))
+                                        for (int e = 1; PW + 7 + e < 16 * ntiles + 16; ++e) cell[e * (TM_COL_PITCH / 4)] = make_uint2(b01[b], b23[b]);
+                                }
+                            }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);           // (one group's registers at a time)
+                }
+                return;
+            }
 #pragma unroll
             for (int bi = 0; bi < TM_PER_WAVE; ++bi) {
                 const int u = u0 + bi;
@@ -538,25 +619,34 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                         // (positions beyond column W - 1 in the block of that column are rewritten by the lane that holds it, below:
                         // a wave's LDS accesses complete in order; a block wholly beyond it -- wave-uniform -- stays away)
                         if (!edge_r || 16 * u <= PW + 7) *cell = make_uint2(b01, b23);
-                        // the Gaussian's REPLICATE border: columns < 0 repeat column 0 (position 8), columns >= W column W - 1
-                        if (edge_l && u == 0) {                          // wave-uniform
-                            if (l16o == 8)
-#pragma unroll
-                                for (int e = 1; e <= 8; ++e) cell[-e * (TM_COL_PITCH / 4)] = make_uint2(b01, b23);
-                        }
-                        if (edge_r && u == (PW + 7) >> 4) {              // wave-uniform: the block of column W - 1
-                            if (l16o == ((PW + 7) & 15))
-                                for (int e = 1; PW + 7 + e < 16 * ntiles + 16; ++e) cell[e * (TM_COL_PITCH / 4)] = make_uint2(b01, b23);
-                        }
                     }
                 }
                 if (bi & 1) __builtin_amdgcn_sched_barrier(0);   // (two blocks in flight are enough; all five cost registers)
             }
+            // the Gaussian's REPLICATE border: columns < 0 repeat column 0 (position 8), columns >= W column W - 1.  Behind the
+            // blocks, for the one or two waves of a panel that hold an image edge (round 4 tested every block of every wave for
+            // both edges: two v_readlane, a v_cmp and a dozen scalar instructions per block): the lane that holds the edge column
+            // reads back what it has just written (a wave's LDS accesses complete in order) and copies it outward.
+            if (!SUMS_ONLY && blur_left) {                               // wave-uniform
+                if (l16o == 8) {
+                    const uint2 v = *cellp;
+#pragma unroll
+                    for (int e = 1; e <= 8; ++e) cellp[-e * (TM_COL_PITCH / 4)] = v;
+                }
+            }
+            if (!SUMS_ONLY && blur_right) {                              // wave-uniform: the block of column W - 1 is this wave's
+                if (l16o == ((PW + 7) & 15)) {
+                    uint2 *cell = cellp + (((PW + 7) >> 4) - u0) * (16 * TM_COL_PITCH / 4);
+                    const uint2 v = *cell;
+                    for (int e = 1; PW + 7 + e < 16 * ntiles + 16; ++e) cell[e * (TM_COL_PITCH / 4)] = v;
+                }
+            }
         };
 
         // ---- filter: output rows of step s - 1 = window rows 8 .. 23 (window rows 0..15: tile block s - 1, 16..31: block s) ---
-        auto filter_step = [&](int s) __attribute__((always_inline)) {
+        auto filter_step = [&](int s, bool late_dma, int &mine) __attribute__((always_inline)) {
 #ifdef TM_DBG_NOFILTER
+            if (late_dma) mine = request_raw(s + 2);
             return;
 #endif
             const int oy = it.y0 + TM_ROWS * (s - 1);            // first output row
@@ -585,7 +675,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 if (bi >= 1) {
                     const int t = u - 1, ti = bi - 1;
                     if (t < ntiles) {   // wave-uniform
-                        // x_lo = x_mul (mean - b) + lo_add: the taps carry x_mul, the accumulator starts at lo_add - x_mul (b - 128)
+                        // x = X (mean - b - theta_1): the taps carry X, the accumulator starts at -X theta_1 - X (b - 128)
                         // (the centre pixels: columns 16t + l16 = positions 16t + 8 + l16, this lane's window rows)
                         const half8_t Ab = *reinterpret_cast<const half8_t *>(colp + (16 * ti + 8) * TM_COL_PITCH);
                         const half8_t XH = as_half8(xh[0], xh[1], xh[2], xh[3]);
@@ -596,31 +686,35 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                         f32x4 c2 = K_LO;
                         c2[0] += (float)XH[0] + (float)Ab[0]; c2[1] += (float)XH[2]; c2[2] += (float)XH[4]; c2[3] += (float)XH[6];
 #endif
-                        // c2[r] = x_lo at output COLUMN 16t + 4q + r, row l16; x saturates to byte 0x00 / 0xFF when the mean is
-                        // farther than EPS from the level, on the side that clears / sets the bit; x_hi = x_lo + (hi_add - lo_add)
-                        uint32_t pk_lo = 0, pk_hi = 0;
+                        // c2[r] = x at output COLUMN 16t + 4q + r, row l16: x = X (v - theta_1) for the FIRST level, the one whose clear bit
+                        // implies the other's (launch()); negative <=> the level's class bit is set.  v_cvt_pk_bf8_f32 packs two x into two
+                        // bytes sign | 5 exponent bits | 2 mantissa bits: bit 7 IS the class bit, and bit 6 -- the exponent's top bit --
+                        // is set exactly when |x| rounds to 2 or more, i.e. when v is EPS = 1.875 / |X| or more away from the level
+                        // (decided).  Two instructions per four pixels (round 4: eight v_cvt_pk_u8_f32 and four adds for the two levels).
+                        uint32_t f1 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(c2[0], c2[1], 0, false);
+                        f1 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(c2[2], c2[3], (int)f1, true);
+                        // Most tiles hold background only: every pixel of every lane decided and clear at the first level, hence at
+                        // the second -- class 0, nothing to list -- and the second level is not evaluated at all (wave-uniform)
+                        uint32_t cb = 0u;
+                        const bool calm = (f1 & 0xC0C0C0C0u) == 0x40404040u;
+                        if (EPS_MODE == 2 || __builtin_amdgcn_ballot_w64(!calm) != 0ull) {
+                            uint32_t f2 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(c2[0] + P.d2, c2[1] + P.d2, 0, false);
+                            f2 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(c2[2] + P.d2, c2[3] + P.d2, (int)f2, true);
+                            cb = ((f1 >> P.sh1) & P.k1) | ((f2 >> P.sh2) & P.k2);
+                            // (the levels are dozens of x-units apart: at most one of a pixel's two bytes is undecided)
+                            uint32_t amb = ~(f1 & f2) & 0x40404040u;
+                            if (EPS_MODE == 2) amb = 0x40404040u;          // diagnostic build: every pixel takes the exact path
+                            if (__builtin_expect(__builtin_amdgcn_ballot_w64(amb != 0u) != 0ull, 0)) {
+                                const int lc = opaque_lane(lane), l16 = lc & 15, q = lc >> 4;      // (cold)
+                                const int y = oy + l16;
+                                if (amb != 0u && y < it.y1) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            pk_lo = __builtin_amdgcn_cvt_pk_u8_f32(c2[r], r, pk_lo);
-                            pk_hi = __builtin_amdgcn_cvt_pk_u8_f32(c2[r] + P.hi_minus_lo, r, pk_hi);
-                        }
-                        // decided bytes are 0x00 / 0xFF: the class bits are bit 0 of pk_lo and bit 1 of pk_hi.  The levels are at
-                        // least 2^16 x-units apart, so at most one of the two bytes of a pixel is undecided, and then their XOR
-                        // is neither 0x00 nor 0xFF either: some bit differs from its upper neighbour inside the byte
-                        const uint32_t cb = (pk_lo & P.lo_bits) | (pk_hi & 0x02020202u);
-                        const uint32_t z = pk_lo ^ pk_hi;
-                        uint32_t amb = (z ^ (z >> 1)) & 0x7F7F7F7Fu;
-                        if (EPS_MODE == 2) amb = 0x01010101u;          // diagnostic build: every pixel takes the exact path
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(amb != 0u) != 0ull, 0)) {
-                            const int lc = opaque_lane(lane), l16 = lc & 15, q = lc >> 4;      // (cold)
-                            const int y = oy + l16;
-                            if (amb != 0u && y < it.y1) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int x = it.x0 + 16 * t + 4 * q + r;
-                                    if (((amb >> (8 * r)) & 0xFFu) && x < it.x1) {
-                                        const uint32_t slot = atomicAdd(&L.n_list, 1u);
-                                        if (slot < (uint32_t)TM_LIST_CAP) { L.list[slot] = ((uint32_t)y << 16) | (uint32_t)x; L.list_f[slot] = (uint16_t)it.f; }
+                                    for (int r = 0; r < 4; ++r) {
+                                        const int x = it.x0 + 16 * t + 4 * q + r;
+                                        if (((amb >> (8 * r)) & 0xFFu) && x < it.x1) {
+                                            const uint32_t slot = atomicAdd(&L.n_list, 1u);
+                                            if (slot < (uint32_t)TM_LIST_CAP) { L.list[slot] = ((uint32_t)y << 16) | (uint32_t)x; L.list_f[slot] = (uint16_t)it.f; }
+                                        }
                                     }
                                 }
                             }
@@ -629,6 +723,10 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                         *reinterpret_cast<uint32_t *>(wout + 16 * ti) = cb;
                     }
                 }
+                // The second half of the waves (two per SIMD) ask for the gray rows of step s + 2 HERE, in the middle of their tiles,
+                // the first half at the step's start: sixteen waves' LDS-DMA instructions at one point of the step queue for ~600
+                // cycles each while every SIMD waits for its first wave to get through (profiles/r04_thr_stamps.log)
+                if (bi == TM_DMA_AFTER_BLOCK && late_dma) mine = request_raw(s + 2);     // (wave-uniform)
                 if (bi & 1) __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -672,7 +770,11 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
 #endif
                 if (full) {
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(wout + st_lds[k]);
+#ifdef TM_NT_STORES
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(base + st_g[k]));
+#else
                     __builtin_memcpy(base + st_g[k], &v, 16);
+#endif
                 }
                 if (__builtin_amdgcn_ballot_w64(part) != 0ull) {
                     if (part) {
@@ -705,6 +807,17 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         };
+#if !defined(TM_PRIO_FLAT) && !defined(TM_PRIO4) && !defined(TM_PRIO4R)
+        // The second-dispatched half of the waves (two per SIMD) issues ahead of the first: with equal priorities the four waves
+        // of a SIMD reach every memory instruction and every barrier of a step together; with two of them preferred the pairs
+        // drift half a phase apart and one pair's stalls meet the other pair's arithmetic (241 -> 228 us per 256 frames;
+        // four levels or the older half preferred: 232 / 245, profiles/r05_ab_thr_priority.log)
+        if (wave >= TM_WAVES / 2) __builtin_amdgcn_s_setprio(1);
+#elif defined(TM_PRIO4)
+        if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1); else if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2); else if ((wave >> 2) == 3) __builtin_amdgcn_s_setprio(3);
+#elif defined(TM_PRIO4R)
+        if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(1); else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(2); else if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(3);
+#endif
         request_raw(-1);
         request_raw(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -725,13 +838,20 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 g_tm_stamps[1][s == 3 ? 18 : 19][1] = __builtin_amdgcn_s_memtime();
             }
 #endif
-            if (s + 2 <= nblk) mine = request_raw(s + 2);        // into the buffer the blur of step s has finished with
+            // The class bytes of step s - 1 leave at the START of step s (they wait in the wave's staging rows, which only this
+            // step's tiles overwrite): a wave that stalls on its store instructions here stalls while the other waves of its SIMD
+            // have tiles to filter; behind the filter (round 4) the stall of the LAST wave to finish was the phase's last 540 - 880
+            // cycles, with every other wave already at the barrier (profiles/r05_thr_stamps_*.log).
+            if (TM_STORE_AT_START && s >= 2) store_step(s - 1);
+            // (into the buffer the blur of step s has finished with; half of the waves ask later, inside filter_step)
+            const bool late_dma = TM_DMA_AFTER_BLOCK >= 0 && s >= 1 && s + 2 <= nblk && wave >= TM_WAVES / 2;
+            if (s + 2 <= nblk && !late_dma) mine = request_raw(s + 2);
             TMSTAMP(s, 1);
-            if (s >= 1) filter_step(s);
+            if (s >= 1) filter_step(s, late_dma, mine);
             TMSTAMP(s, 2);
             wait_all_but(__builtin_amdgcn_readfirstlane(mine));  // the rows of step s + 1 have landed (and every older store)
             TMSTAMP(s, 3);
-            if (s >= 1) store_step(s);
+            if (!TM_STORE_AT_START && s >= 1) store_step(s);
             TMSTAMP(s, 4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             TMSTAMP(s, 5);
@@ -740,6 +860,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             TMSTAMP(s, 7);
         }
+        if (TM_STORE_AT_START && nblk >= 1) store_step(nblk);
 
         // ---- an item whose ambiguous pixels outgrew the list (a frame made to sit on the levels): all of it again, exactly ----
         const uint32_t n_now = L.n_list;
@@ -799,7 +920,8 @@ namespace {
 //   cv2 itself    its float32 chain is within 22 x 2^-24 x 255 of the real mean; its taps sum to 1 within 1e-8
 // s and S are free: s is searched so that the eleven scaled weights lie close to f16 values (dc = 3.1e-5 at s = 0.9945 for
 // cv2's sigma-2 kernel, against 2.1e-4 at s = 1), S -- an f16 value itself, it is a tap of the accumulator's preset --
-// likewise, the largest whose 126.5 / S covers 1.1 x the bound: S = 2520, bound 0.0426, EPS = 127 / S = 0.0504 gray levels
+// likewise, the largest whose 1.875 / S (where the bf8 conversion of x sets its exponent's top bit) covers 1.1 x the bound:
+// S = 39.375, bound 0.0423, EPS = 1.875 / S = 0.0476 gray levels
 // (scripts/sim/thr_single_f16.py is the same arithmetic in numpy, with the counts of undecided pixels it leaves).
 struct Scales { double s, S, bound; };
 
@@ -848,9 +970,9 @@ Scales choose_scales(const float *gauss6)
         if (score < best_score) { best_score = score; best.s = s; }
     }
     if (best.s > 0.0)
-        for (int S = 3400; S >= 256; S -= 2) {       // even: f16 holds every even integer below 4096, and the diagnostic variant halves it
-            const double E = walk_bound(w, best.s, (double)S);
-            if (1.1 * E <= 126.5 / S) { best.S = S; best.bound = E; break; }
+        for (int k = 64 * 16; k >= 4 * 16; --k) {    // multiples of 1/16 below 64: f16 values, and so are their halves (the diagnostic variant)
+            const double S = k / 16.0, E = walk_bound(w, best.s, S);
+            if (1.1 * E <= 1.875 / S) { best.S = S; best.bound = E; break; }
         }
     std::memcpy(key, gauss6, sizeof(key));
     cached = best;
@@ -879,20 +1001,26 @@ int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H
     const int blocks = blocks_wanted > 0 ? blocks_wanted : 256 * (int)((160 * 1024) / sizeof(Lds));   // every CU full
     P.inv = inv; P.use_high = use_high; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
     for (int i = 0; i < 6; ++i) P.kw[i] = gauss11[i];
-    // v = mean - b.  BINARY: bit = (b - m > t) <=> v < -t - 0.5;  INV: bit = (b - m <= t) <=> v > -t - 0.5 (ties: exact path).
-    // x = sign * S * (theta - v) + 127.5 converts to byte 0x00 / 0xFF exactly when v is 127 / S or more away from theta:
-    // S is the largest scale whose 126.5 / S still covers the error bound of the walk's arithmetic with a tenth to spare
-    // (choose_scales: EPS = 0.050 for cv2's sigma-2 taps; variant 1, diagnostic: half that scale, twice the list)
+    // v = mean - b.  BINARY: bit = (b - m > t) <=> v < theta = -t - 0.5;  INV: bit = (b - m <= t) <=> v > theta (ties: exact path).
+    // x = X (v - theta) with X = +S (BINARY) / -S (INV) is negative exactly where the bit is set, and |x| >= 1.875 -- where its
+    // bf8 conversion has the exponent's top bit set -- exactly when v is 1.875 / S or more away from theta: S is the largest scale
+    // whose 1.875 / S still covers the error bound of the walk's arithmetic with a tenth to spare (choose_scales: S = 39.375,
+    // EPS = 0.0476 gray levels for cv2's sigma-2 taps; variant 1, diagnostic: half that scale, twice the list).
+    // The FIRST level is the one whose clear, decided bit implies the other's: the larger theta for BINARY, the smaller for INV;
+    // a tile in which it fires nowhere is class 0 throughout and never evaluates the second.  One level: the second = the first.
     const Scales sc = choose_scales(gauss11);
     if (!(sc.S > 0.0)) return ysmr::fail(YSMR_ERR_ARG, "the matrix-pipe threshold kernel found no admissible scale for these taps");
-    const float S = (float)(variant == 1 ? sc.S / 2 : sc.S), sgn = inv ? -1.0f : 1.0f;
+    const double S = variant == 1 ? sc.S / 2 : sc.S, X = inv ? -S : S;
+    const double th_lo = -(double)t_low - 0.5, th_hi = use_high ? -(double)t_high - 0.5 : th_lo;
+    const bool lo_first = inv ? th_lo <= th_hi : th_lo >= th_hi;
+    const double th1 = lo_first ? th_lo : th_hi, th2 = lo_first ? th_hi : th_lo;
     P.col_scale = (float)sc.s;
-    P.row_scale = (float)((double)(-sgn * S) / sc.s);
-    P.x_mul = -sgn * S; P.neg_x_mul = sgn * S;
-    P.lo_add = sgn * S * (-(float)t_low - 0.5f) + 127.5f;
-    // one level: the second byte is always 0x00 and both class bits come from the first
-    P.hi_minus_lo = use_high ? sgn * S * (float)(t_low - t_high) : -1e30f;
-    P.lo_bits = use_high ? 0x01010101u : 0x03030303u;
+    P.row_scale = (float)(X / sc.s);
+    P.neg_x_mul = (float)-X;
+    P.k_first = (float)(-X * th1);
+    P.d2 = (float)(X * (th1 - th2));
+    P.sh1 = lo_first ? 7 : 6; P.k1 = lo_first ? 0x01010101u : 0x02020202u;
+    P.sh2 = lo_first ? 6 : 7; P.k2 = lo_first ? 0x02020202u : 0x01010101u;
     // (no workgroup with fewer than 32 rows: an item re-filters 16 halo rows)
     long long grid = std::max<long long>(1, std::min<long long>((long long)batch * P.panels * H / 32, blocks));
     P.by_xcd = (batch % 8 == 0 && grid % 8 == 0) ? 1 : 0;
