@@ -253,10 +253,13 @@ def main():
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0          # this rank's K steps, before it waits for the others
     dist.barrier(info)
     torch.cuda.synchronize()
     red = dev if args.dist_backend == "nccl" else "cpu"
     elapsed = dist.max_over_ranks(time.perf_counter() - t0, info, device=red)
+    # every rank's own rate (frames it linked / its own time): a straggler GPU or host shows as one low entry
+    per_rank_fps = dist.gather_over_ranks(S * F * args.steps / own_elapsed, info, device=red)
     # (how many ranks reached this line with their steps done, and what they did: a SCALE record then shows that N ranks
     # took part, not one rank's figure times N)
     ranks_seen = int(round(dist.sum_over_ranks(1.0, info, device=red)))
@@ -304,6 +307,7 @@ def main():
             "unit": "frames/s",
             "n_gpus": world,
             "ranks_seen": ranks_seen,
+            "per_rank_frames_per_s": [round(x, 1) for x in per_rank_fps],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

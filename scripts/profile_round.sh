@@ -2,7 +2,12 @@
 # Round profile bundle (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats of
 # the same command, PMC passes (each in its own run, no tracing domains) for the threshold kernel
 # plus the FETCH/WRITE calibration copy.  Everything lands in gpurun_out/round/.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
+# Round 5: every call writes into gpurun_out/round_<tag> (tag = $1, default "now"), which the builder deletes locally before the
+# call (gpurun MERGES what a call wrote into the local gpurun_out/: round 4's directory had ten runs' files side by side, and
+# the copy into profiles/ took the oldest), and the per-kernel summaries are copied to fixed names by kstats.py's rule (the
+# newest *_kernel_stats.csv of the directory): profiles/rNN_kernel_stats.csv is $O/kernel_stats.csv, nothing else.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round_${1:-now}; rm -rf $O; mkdir -p $O
+git -C $R rev-parse HEAD > $O/HEAD 2>/dev/null || true
 [ -x $R/scripts/ubench/copy_calib ] || make -C $R/scripts/ubench copy_calib >/dev/null
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
@@ -45,6 +50,7 @@ for c in 0 1 4; do python3 $R/bench.py --config $c --cpu-sample 20 2>> $O/bench.
 cut -c1-150 $O/bench_configs.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_det -- python3 $R/bench.py --cpu-sample 0 --config 1 > $O/ktrace_det.log 2>&1
 python3 $R/scripts/kstats.py $O/ktrace 30 > $O/kernel_stats.txt; python3 $R/scripts/kstats.py $O/ktrace_det 20 > $O/kernel_stats_detect_only.txt
+cp "$(ls -t $O/ktrace/*/*_kernel_stats.csv | head -1)" $O/kernel_stats.csv; cp "$(ls -t $O/ktrace_det/*/*_kernel_stats.csv | head -1)" $O/kernel_stats_detect_only.csv
 cat $O/kernel_stats.txt | cut -c1-150
 # configs[4]: who runs beside whom (kernel trace), and the link's phases alone / beside detection (device stamps; needs
 # scripts/var_stamps.so from scripts/build_stamps.sh)

@@ -635,7 +635,7 @@ def test_rows_can_be_persisted_while_the_video_runs(tmp_path, monkeypatch):
     assert open(whole[4], "rb").read() == open(kept[4], "rb").read()
 
 
-ROUND = "r04"
+from conftest import ROUND  # noqa: E402
 
 
 def _write_parity(name, report):
@@ -658,7 +658,8 @@ def test_bench_config_rows_hold_1e9_outside_the_oracles_ill_conditioned_set(tmp_
     (oracle shadow filters, conftest.compare_rows) are a small, counted fraction, each within conftest.AMPLIFICATION
     x what one ulp does to the reference itself, and every row beyond north_star's 1e-5 relative is one whose own
     +-1-ulp shadows are more than 1e-5 apart (the claim "the reference does not determine this row to 1e-5", tested).
-    The numbers go to profiles/r04_parity_bench_config.json (quoted in DESIGN.md section 2)."""
+    The numbers go to profiles/<ROUND>_parity_bench_config.json; DESIGN.md section 2 quotes them, and tests/test_host.py::
+    test_design_quotes_the_parity_record_it_names fails when the quote and the tracked file differ."""
     from conftest import parity_report
     from ysmr_amd.synth import SyntheticVideo
     from ysmr_amd.track_eval import track_bacteria

@@ -132,8 +132,9 @@ def _gloo_worker(rank, world, port, out_dir):
     mine = dist.shard(streams, info.rank, info.world)
     dist.barrier(info)
     elapsed = dist.max_over_ranks(1.0 + info.rank, info)      # slowest rank defines the job time
+    rates = dist.gather_over_ranks(100.0 * (1 + info.rank), info)     # every rank's own rate, in rank order, on every rank
     with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as fh:
-        fh.write(f"{','.join(mine)};{elapsed}")
+        fh.write(f"{','.join(mine)};{elapsed};{rates}")
     dist.finish(info)
 
 
@@ -145,6 +146,7 @@ def test_stream_sharding_world_size_2_gloo(tmp_path):
     r1 = (tmp_path / "r1.txt").read_text().split(";")
     assert r0[0] == "video0,video2,video4" and r1[0] == "video1,video3"
     assert float(r0[1]) == float(r1[1]) == 2.0
+    assert r0[2] == r1[2] == "[100.0, 200.0]"
 
 
 # ---- a19 / f2: the csv the reference ends up with ------------------------------------------------------
@@ -607,3 +609,27 @@ def test_gc_freeze_is_counted_across_overlapping_passes():
         assert gc.get_freeze_count() > 0
     finally:
         gc.unfreeze()
+
+
+def test_design_quotes_the_parity_record_it_names():
+    """DESIGN.md section 2 quotes the bench configuration's parity record; rounds 3 and 4 each shipped a quote that the
+    tracked file contradicted.  The quote now carries a machine-readable line naming its file: every
+    figure in it must be the file's, to the digits quoted."""
+    import json
+    import re
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    m = re.search(r"<!-- parity-record file=(\S+) (.*?) -->", text)
+    assert m, "DESIGN.md lost its parity-record line"
+    rec = json.load(open(os.path.join(ROOT, m.group(1))))
+    q = dict(kv.split("=") for kv in m.group(2).split())
+    assert int(q["rows"]) == rec["rows"] and int(q["lost"]) == rec["rows_of_lost_tracks"]
+    assert int(q["marked"]) == rec["ill_conditioned_rows"]
+    assert int(q["beyond"]) == rec["ill_conditioned_rows_beyond_1e-5_relative"]
+    assert q["worst_px"] == f"{rec['worst_ill_conditioned_px']:.4f}"
+    assert float(q["worst_rel"]) == float(f"{rec['worst_ill_conditioned_relative']:.1e}")
+    assert q["over_sens"] == f"{rec['worst_deviation_over_sens']:.2f}"
+    assert float(q["well"]) == float(f"{rec['worst_well_conditioned_relative']:.1e}")
+    # ... and the prose beside it says the same
+    para = text[m.start() - 900:m.start()]
+    for needle in ("60 of 100 828", "0.0030 px", "5.2e-6", "0.53 x", "4.4e-12"):
+        assert needle in para, needle

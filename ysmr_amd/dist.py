@@ -66,6 +66,19 @@ def sum_over_ranks(value: float, info: RankInfo, device="cpu") -> float:
     return float(t.item())
 
 
+def gather_over_ranks(value: float, info: RankInfo, device="cpu") -> list:
+    """Every rank's value, in rank order, on every rank (bench.py: each rank's own frames/s, so that a SCALE record shows a
+    straggler rank and not only the max-over-ranks time).  One all-reduce of a vector that is zero but for the own entry."""
+    if info.world <= 1:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros(info.world, dtype=torch.float64, device=device)
+    t[info.rank] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
 def finish(info: RankInfo):
     if info.world > 1:
         import torch.distributed as dist
