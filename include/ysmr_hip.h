@@ -42,7 +42,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   12
+#define YSMR_ABI_VERSION   13
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -325,6 +325,21 @@ int    ysmr_rows_write_csv(const ysmr_row *rows_host, long long n_rows, int with
 int    ysmr_rows_write_csv_columns(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas,
                                    int threads, const char *path, size_t *out_length, uint32_t *track_id, uint32_t *t,
                                    double *x, double *y, double *w, double *h, double *angle);
+
+/* HOST functions (ABI 13): the same csv and columns worked out WHILE the video runs.  Rows go in as the link emits them -- any
+ * number of ysmr_rows_stream_push calls with host rows in any order; a call copies its rows and returns, the stream's threads
+ * format them meanwhile -- and ysmr_rows_stream_finish orders what has been pushed by (TRACK_ID, POSITION_T) (a row's place is
+ * offset[id] + frame - first_frame[id] for the tracker's tables, whose ids are never reused and whose tracks have a row in every
+ * frame of their life; any other table is sorted), writes the csv to `path` (NULL: no file) and fills the seven columns (all
+ * NULL: none): byte for byte what ysmr_rows_sort + ysmr_rows_write_csv_columns give for the same rows (track_eval.py:393,
+ * helper_file.py:1538-1574).  One handle per video, used from one thread at a time. */
+typedef struct ysmr_rows_stream ysmr_rows_stream;
+int    ysmr_rows_stream_create(int threads, int via_pandas, ysmr_rows_stream **out);
+int    ysmr_rows_stream_push(ysmr_rows_stream *s, const ysmr_row *rows_host, long long n_rows);
+long long ysmr_rows_stream_count(ysmr_rows_stream *s);   /* rows pushed so far (-1: NULL handle) */
+int    ysmr_rows_stream_finish(ysmr_rows_stream *s, int with_header, const char *path, size_t *out_length,
+                               uint32_t *track_id, uint32_t *t, double *x, double *y, double *w, double *h, double *angle);
+int    ysmr_rows_stream_destroy(ysmr_rows_stream *s);
 
 /* HOST function: the seven DataFrame columns (dtypes of helper_file.py:881-889).
  * via_pandas (here and above): the reference does not keep the tracker's float64 values, it prints

@@ -768,6 +768,28 @@ def test_video_that_outgrows_the_batch_link_is_linked_per_frame_with_the_oracles
     compare_rows(_rows_from_df(res[0]), ref_rows)
 
 
+def test_rows_printed_while_the_video_runs_leave_the_same_file_and_table(tmp_path):
+    """'hip stream rows' = True (``_RowDrain`` + ``ysmr_rows_stream_*``: every batch's rows leave the device behind its link
+    launch and are printed while later batches run; their order is worked out at the end) against the default, serial
+    tail: the same csv byte for byte, the same DataFrame -- also when the device row buffer is small enough to be started
+    over in mid-video."""
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(300, 400, 60, seed=17).frames(96)
+    path = tmp_path / "clip.npy"
+    np.save(path, frames)
+    for name in "abc":
+        (tmp_path / name).mkdir()
+    want = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path / "a"), batch=16)
+    assert want is not None
+    want_bytes = open(want[4], "rb").read()
+    for name, extra in (("b", {}), ("c", {"list save length interval": 1})):      # (c: the smallest row buffer, 2 batches' worth)
+        got = track_bacteria(str(path), settings=_settings(**{"hip stream rows": True}, **extra), result_folder=str(tmp_path / name),
+                             batch=16, capacity=128)
+        assert got is not None and got[0].equals(want[0]) and list(got[0].dtypes) == list(want[0].dtypes)
+        assert open(got[4], "rb").read() == want_bytes
+
+
 def test_no_live_track_in_the_last_frame_means_nothing_tracked(tmp_path, caplog):
     """track_eval.py:387-392: the reference asks the LAST frame's tracker output for its last object id, so a
     video that ends on more than a second of empty frames 'did not track any objects' (the list is on disk)."""

@@ -633,3 +633,61 @@ def test_design_quotes_the_parity_record_it_names():
     para = text[m.start() - 900:m.start()]
     for needle in ("60 of 100 828", "0.0030 px", "5.2e-6", "0.53 x", "4.4e-12"):
         assert needle in para, needle
+
+
+def _tracker_like_rows(n_frames, n_tracks, seed):
+    """Rows as the link emits them: frame-major, ids ascending within a frame; tracks are born and die, ids never return."""
+    from ysmr_amd import _lib
+    rng = np.random.default_rng(seed)
+    born = np.sort(rng.integers(0, max(1, n_frames - 2), n_tracks)); born[: n_tracks // 3] = 0
+    born.sort()
+    life = rng.integers(1, n_frames, n_tracks)
+    out = []
+    for f in range(n_frames):
+        ids = np.nonzero((born <= f) & (f < born + life))[0]
+        r = np.zeros(len(ids), _lib.ROW_DTYPE)
+        r["frame"], r["track_id"] = f, ids
+        r["x"], r["y"] = rng.uniform(-5, 1300, len(ids)), rng.uniform(0, 1000, len(ids))
+        r["w"], r["h"], r["angle"] = rng.uniform(0, 30, len(ids)), rng.uniform(0, 30, len(ids)), rng.uniform(0, 90, len(ids))
+        gone = rng.random(len(ids)) < 0.1
+        for k in ("w", "h", "angle"):
+            r[k][gone] = 0
+        r["disappeared"] = gone
+        out.append(r)
+    return np.concatenate(out)
+
+
+def test_row_stream_equals_sorting_then_writing(tmp_path):
+    """``ysmr_rows_stream_*`` (ABI 13): rows pushed batch by batch in the order the link emits them, formatted while later
+    batches arrive, ordered at the end -- the csv and the DataFrame are those of sorting the whole table by
+    (TRACK_ID, POSITION_T) and writing it in one go (``rows_to_csv_file_and_dataframe``), byte for byte: for the tracker's
+    tables (a row's place from its id and frame alone), for tables that break the tracker's invariants (gaps, duplicate
+    (id, frame) pairs, ids that were never issued: the stable-sort fallback), with and without file and header."""
+    from ysmr_amd import _lib
+    from ysmr_amd.helper_file import RowStream, rows_to_csv_file_and_dataframe
+    cases = {"empty": np.zeros(0, _lib.ROW_DTYPE), "small": _tracker_like_rows(9, 5, 1), "large": _tracker_like_rows(160, 900, 2)}
+    irregular = _tracker_like_rows(40, 60, 3)
+    irregular = np.concatenate([irregular[::2], irregular[5:9], irregular[-1:]])      # gaps, duplicates
+    irregular["track_id"][3] = 100000                                                    # an id far beyond the row count
+    cases["irregular"] = irregular
+    for name, rows in cases.items():
+        order = np.lexsort((rows["frame"], rows["track_id"])) if name != "irregular" else np.argsort(
+            rows["track_id"].astype(np.int64) << 32 | rows["frame"].astype(np.int64), kind="stable")
+        for via in (True, False):
+            want_path = tmp_path / f"want_{name}_{via}.csv"
+            want_len, want_df = rows_to_csv_file_and_dataframe(rows[order], str(want_path), via_pandas=via)
+            for pieces, header, with_file in ((1, True, True), (7, True, True), (7, False, True), (3, True, False)):
+                st = RowStream(via_pandas=via, threads=3)
+                for part in np.array_split(rows, pieces):
+                    st.push(part)
+                assert len(st) == len(rows)
+                path = tmp_path / f"got_{name}_{via}_{pieces}_{header}.csv"
+                path.write_bytes(b"stale " * 50)
+                length, df = st.finish(str(path) if with_file else None, header=header)
+                st.close()
+                assert df.equals(want_df) and list(df.dtypes) == list(want_df.dtypes), (name, via, pieces)
+                if with_file:
+                    want = want_path.read_bytes()
+                    if not header:
+                        want = want[want.index(b"\n") + 1:]
+                    assert length == len(want) and path.read_bytes() == want, (name, via, pieces, header)

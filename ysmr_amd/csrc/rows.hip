@@ -10,6 +10,9 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -253,6 +256,19 @@ double pandas_roundtrip(double v)
     return pandas_parse(buf, end);
 }
 
+// text of the value pandas reads back from v's text, written at p; *v becomes that value.  Four values in five come back
+// unchanged: their first text is the final one, and printing a float is the expensive half of a row (round 5: a third of
+// the formatting time)
+char *put_float_via_pandas(char *p, double *v)
+{
+    if (!std::isfinite(*v)) return put_float(p, *v);
+    char *end = put_float(p, *v);
+    const double back = pandas_parse(p, end);
+    if (back == *v && !(back == 0.0 && std::signbit(back) != std::signbit(*v))) return end;
+    *v = back;
+    return put_float(p, back);
+}
+
 char *put_u32(char *p, uint32_t v)
 {
     auto r = std::to_chars(p, p + 12, v);
@@ -271,15 +287,13 @@ size_t format_range(const ysmr_row *rows, long long lo, long long hi, bool via_p
     for (long long i = lo; i < hi; ++i) {
         const ysmr_row &r = rows[i];
         double v[5] = {r.x, r.y, (double)r.w, (double)r.h, (double)r.angle};
-        if (via_pandas)
-            for (double &x : v) x = pandas_roundtrip(x);
+        p = put_u32(p, (uint32_t)r.track_id); *p++ = ',';
+        p = put_u32(p, (uint32_t)r.frame); *p++ = ',';
+        for (int k = 0; k < 5; ++k) { p = via_pandas ? put_float_via_pandas(p, &v[k]) : put_float(p, v[k]); *p++ = k == 4 ? '\n' : ','; }
         if (cols) {
             cols->track_id[i] = (uint32_t)r.track_id; cols->t[i] = (uint32_t)r.frame;
             for (int k = 0; k < 5; ++k) cols->v[k][i] = v[k];
         }
-        p = put_u32(p, (uint32_t)r.track_id); *p++ = ',';
-        p = put_u32(p, (uint32_t)r.frame); *p++ = ',';
-        for (int k = 0; k < 5; ++k) { p = put_float(p, v[k]); *p++ = k == 4 ? '\n' : ','; }
     }
     return (size_t)(p - out);
 }
@@ -472,6 +486,317 @@ static int write_csv_impl(const ysmr_row *rows_host, long long n_rows, int with_
     if (failed.load() == 2 || rc_close != 0)
         return ysmr::fail(YSMR_ERR_ARG, "writing %s failed: %s", path, std::strerror(failed.load() == 2 ? write_errno.load() : close_errno));
     if (out_length) *out_length = len;
+    return YSMR_OK;
+}
+
+// ---- the same csv and columns, worked out WHILE the video runs (ABI 13) -----------------------------------------------
+// track_bacteria's tail -- rows to the host, 27 ms of formatting, the csv -- used to start when the last frame was linked
+// (39 of a 1920-frame file's 97 ms).  A row's text and the value pandas reads back from it do not depend on any
+// other row, only its PLACE in the file does: the stream takes each batch's rows as the link emits them (frame-major),
+// formats them on its own threads while later batches run, and at the end only orders what it has -- a row's place is
+// offset[id] + frame - first_frame[id], the tracker's invariant that ysmr_rows_sort uses on the device; tables without it go
+// through a stable sort -- and gathers lines and columns into the file and the caller's arrays.
+// One cache line per row: what the ordered table needs of it -- its key, the five values the text was printed from (read back
+// through pandas' parser), and where its line lies.  (A first version kept the rows, the values as five arrays and the line
+// ends per task: ordering 971 k rows then cost 57 ms, seven random cache lines per row.)
+struct alignas(64) StreamRec {
+    uint32_t id, frame;
+    double v[5];
+    const char *text;
+    uint16_t len;
+};
+static_assert(sizeof(StreamRec) == 64, "one line per row");
+struct StreamTask {
+    long long lo = 0, hi = 0;                   // records [lo, hi) of the chunk
+    std::unique_ptr<char[]> text;               // their lines, back to back
+};
+struct StreamChunk {
+    std::unique_ptr<StreamRec[]> rec;
+    long long n = 0;
+    std::vector<StreamTask> tasks;
+    const ysmr_row *src = nullptr;              // the caller's rows while push() is running
+};
+}  // extern "C"
+
+struct ysmr_rows_stream {
+    int via_pandas = 1;
+    std::vector<std::thread> pool;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_idle;
+    std::vector<std::pair<StreamChunk *, int>> queue;      // (chunk, task index) waiting for a thread
+    size_t queue_head = 0;
+    int busy = 0;
+    bool closing = false, failed = false;
+    std::vector<std::unique_ptr<StreamChunk>> chunks;
+    long long n_rows = 0;
+    std::vector<uint32_t> count, first;                    // per id: rows, first frame (kept up to date by push)
+
+    void work()
+    {
+        for (;;) {
+            std::pair<StreamChunk *, int> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return closing || queue_head < queue.size(); });
+                if (queue_head >= queue.size()) return;          // closing, nothing left
+                job = queue[queue_head++];
+                ++busy;
+            }
+            StreamChunk &c = *job.first;
+            StreamTask &t = c.tasks[(size_t)job.second];
+            bool ok = true;
+            try {
+                std::unique_ptr<char[]> big(new char[(size_t)(t.hi - t.lo) * ROW_TEXT_MAX + 1]);
+                std::vector<uint32_t> start((size_t)(t.hi - t.lo) + 1);
+                char *p = big.get();
+                for (long long i = t.lo; i < t.hi; ++i) {
+                    StreamRec &r = c.rec[(size_t)i];
+                    start[(size_t)(i - t.lo)] = (uint32_t)(p - big.get());
+                    p = put_u32(p, r.id); *p++ = ',';
+                    p = put_u32(p, r.frame); *p++ = ',';
+                    for (int k = 0; k < 5; ++k) { p = via_pandas ? put_float_via_pandas(p, &r.v[k]) : put_float(p, r.v[k]); *p++ = k == 4 ? '\n' : ','; }
+                }
+                const size_t used = (size_t)(p - big.get());
+                start[(size_t)(t.hi - t.lo)] = (uint32_t)used;
+                t.text.reset(new char[used ? used : 1]);                 // (the worst-case buffer is 4 x what the lines take)
+                std::memcpy(t.text.get(), big.get(), used);
+                for (long long i = t.lo; i < t.hi; ++i) {
+                    StreamRec &r = c.rec[(size_t)i];
+                    r.text = t.text.get() + start[(size_t)(i - t.lo)];
+                    r.len = (uint16_t)(start[(size_t)(i - t.lo) + 1] - start[(size_t)(i - t.lo)]);
+                }
+            } catch (const std::bad_alloc &) {
+                ok = false;
+            }
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (!ok) failed = true;
+                --busy;
+                if (busy == 0 && queue_head >= queue.size()) cv_idle.notify_all();
+            }
+        }
+    }
+};
+
+extern "C" {
+
+int ysmr_rows_stream_create(int threads, int via_pandas, ysmr_rows_stream **out)
+{
+    if (!out) return ysmr::fail(YSMR_ERR_ARG, "out must not be NULL");
+    *out = nullptr;
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, 64));
+    auto *s = new (std::nothrow) ysmr_rows_stream();
+    if (!s) return ysmr::fail(YSMR_ERR_CAPACITY, "out of memory");
+    s->via_pandas = via_pandas != 0;
+    try {
+        for (int t = 0; t < nt; ++t) s->pool.emplace_back([s] { s->work(); });
+    } catch (const std::system_error &) {
+        // (fewer threads than asked for is fine; none at all is not)
+    }
+    if (s->pool.empty()) { delete s; return ysmr::fail(YSMR_ERR_HIP, "cannot start a formatting thread"); }
+    *out = s;
+    return YSMR_OK;
+}
+
+int ysmr_rows_stream_push(ysmr_rows_stream *s, const ysmr_row *rows_host, long long n)
+{
+    if (!s) return ysmr::fail(YSMR_ERR_ARG, "stream handle is NULL");
+    if (n < 0 || (n && !rows_host)) return ysmr::fail(YSMR_ERR_ARG, "rows_host must be set");
+    if (n == 0) return YSMR_OK;
+    std::unique_ptr<StreamChunk> c;
+    try {
+        c.reset(new StreamChunk());
+        c->rec.reset(new StreamRec[(size_t)n]);
+        c->n = n;
+        const long long per = std::max<long long>(2048, (n + (long long)s->pool.size() - 1) / (long long)s->pool.size());
+        for (long long lo = 0; lo < n; lo += per) {
+            c->tasks.emplace_back();
+            c->tasks.back().lo = lo; c->tasks.back().hi = std::min(n, lo + per);
+        }
+        // the keys and the values leave the caller's buffer here (it is free when this call returns); rows per id and first
+        // frames are kept as the rows come in, so that ordering them at the end starts from finished tables
+        for (long long i = 0; i < n; ++i) {
+            const ysmr_row &r = rows_host[i];
+            StreamRec &q = c->rec[(size_t)i];
+            q.id = (uint32_t)r.track_id; q.frame = (uint32_t)r.frame;
+            q.v[0] = r.x; q.v[1] = r.y; q.v[2] = (double)r.w; q.v[3] = (double)r.h; q.v[4] = (double)r.angle;
+            q.text = nullptr; q.len = 0;
+            if (q.id >= s->count.size()) {
+                const size_t want = std::max<size_t>((size_t)q.id + 1, s->count.size() * 2);
+                if ((size_t)q.id > (size_t)0x0FFFFFFF) return ysmr::fail(YSMR_ERR_ARG, "track id %u out of range", q.id);
+                s->count.resize(want, 0u); s->first.resize(want, 0xFFFFFFFFu);
+            }
+            ++s->count[q.id];
+            if (q.frame < s->first[q.id]) s->first[q.id] = q.frame;
+        }
+    } catch (const std::bad_alloc &) {
+        return ysmr::fail(YSMR_ERR_CAPACITY, "out of memory taking %lld rows", n);
+    }
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->n_rows += n;
+        StreamChunk *raw = c.get();
+        s->chunks.push_back(std::move(c));
+        for (int t = 0; t < (int)raw->tasks.size(); ++t) s->queue.emplace_back(raw, t);
+    }
+    s->cv_work.notify_all();
+    return YSMR_OK;
+}
+
+long long ysmr_rows_stream_count(ysmr_rows_stream *s)
+{
+    if (!s) return -1;
+    std::unique_lock<std::mutex> lk(s->mu);
+    return s->n_rows;
+}
+
+int ysmr_rows_stream_finish(ysmr_rows_stream *s, int with_header, const char *path, size_t *out_length, uint32_t *track_id,
+                            uint32_t *t, double *x, double *y, double *w, double *h, double *angle)
+{
+    if (!s) return ysmr::fail(YSMR_ERR_ARG, "stream handle is NULL");
+#ifdef YSMR_TUNING
+    const bool dbg = getenv("YSMR_STREAM_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) { if (dbg) { const double t = now(); fprintf(stderr, "[rows stream] %s: %.2f ms\n", what, t - t_prev); t_prev = t; } };
+#else
+    auto lap = [](const char *) {};
+#endif
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv_idle.wait(lk, [&] { return s->busy == 0 && s->queue_head >= s->queue.size(); });
+        if (s->failed) return ysmr::fail(YSMR_ERR_CAPACITY, "out of memory formatting rows");
+    }
+    lap("waited for the formatting threads");
+    const long long N = s->n_rows;
+    const bool want_cols = track_id || t || x || y || w || h || angle;
+    if (want_cols && N && !(track_id && t && x && y && w && h && angle))
+        return ysmr::fail(YSMR_ERR_ARG, "all seven column pointers must be set, or none");
+    if (N > 0x7FFFFFFFll) return ysmr::fail(YSMR_ERR_ARG, "more than 2^31 - 1 rows");
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(s->pool.size(), (size_t)(N / 4096 + 1)));
+    auto in_parallel = [&](int parts, auto &&fn) {        // fn(k) for k in 0..parts-1, on up to nt threads (the caller's included)
+        std::atomic<int> next{0};
+        auto loop = [&] { for (int k; (k = next.fetch_add(1)) < parts;) fn(k); };
+        std::vector<std::thread> th;
+        try {
+            for (int q = 0; q < std::min(nt, parts) - 1; ++q) th.emplace_back(loop);
+        } catch (const std::system_error &) {
+        }
+        loop();
+        for (auto &q : th) q.join();
+    };
+    // where every row goes: offset[id] + frame - first_frame[id].  N rows into N places: the map is a bijection exactly when no
+    // place stays empty, so the threads fill `src` without looking at each other and the gaps are counted afterwards.
+    std::vector<const StreamRec *> src;
+    std::vector<uint16_t> len_at;
+    try {
+        std::vector<uint32_t> offset(s->count.size() + 1, 0u);
+        for (size_t i = 0; i < s->count.size(); ++i) offset[i + 1] = offset[i] + s->count[i];
+        src.assign((size_t)N, nullptr);
+        len_at.assign((size_t)N, 0);
+        std::atomic<int> irregular{0};
+        std::vector<std::pair<const StreamChunk *, const StreamTask *>> all_tasks;
+        for (auto &c : s->chunks)
+            for (auto &tk : c->tasks) all_tasks.emplace_back(c.get(), &tk);
+        in_parallel((int)all_tasks.size(), [&](int k) {
+            const StreamChunk &c = *all_tasks[(size_t)k].first;
+            const StreamTask &tk = *all_tasks[(size_t)k].second;
+            for (long long i = tk.lo; i < tk.hi; ++i) {
+                const StreamRec &r = c.rec[(size_t)i];
+                const uint32_t d = r.frame - s->first[r.id];
+                if (d >= s->count[r.id]) { irregular.store(1); continue; }
+                src[offset[r.id] + d] = &r;
+                len_at[offset[r.id] + d] = r.len;
+            }
+        });
+        if (!irregular.load())
+            for (long long d = 0; d < N; ++d)
+                if (!src[(size_t)d]) { irregular.store(1); break; }
+        if (irregular.load()) {      // gaps or duplicates (rows a caller assembled): a stable sort by (TRACK_ID, POSITION_T)
+            size_t at = 0;
+            for (auto &c : s->chunks)
+                for (long long i = 0; i < c->n; ++i) src[at++] = &c->rec[(size_t)i];
+            std::stable_sort(src.begin(), src.end(), [](const StreamRec *a, const StreamRec *b) {
+                return a->id != b->id ? a->id < b->id : a->frame < b->frame;
+            });
+            for (long long d = 0; d < N; ++d) len_at[(size_t)d] = src[(size_t)d]->len;
+        }
+    } catch (const std::bad_alloc &) {
+        return ysmr::fail(YSMR_ERR_CAPACITY, "out of memory ordering %lld rows", N);
+    }
+    lap("places");
+    const size_t head = with_header ? sizeof(CSV_HEADER) - 1 : 0;
+    int fd = -1;
+    if (path) {
+        fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0) return ysmr::fail(YSMR_ERR_ARG, "cannot open %s for writing: %s", path, std::strerror(errno));
+    }
+    lap("file opened (truncated)");
+    // pieces of the ordered table: size them (the lengths lie in table order), then every thread gathers the lines and columns of
+    // its pieces -- one cache line of record and the line's text per row -- and writes each piece at its offset
+    const int parts = (int)std::max<long long>(1, std::min<long long>(4LL * nt, N / 2048 + 1));
+    const long long per = (N + parts - 1) / parts;
+    std::vector<size_t> bytes((size_t)parts, 0), at((size_t)parts + 1, head);
+    for (int k = 0; k < parts; ++k) {
+        const long long lo = std::min<long long>((long long)k * per, N), hi = std::min<long long>(lo + per, N);
+        size_t sum = 0;
+        for (long long d = lo; d < hi; ++d) sum += len_at[(size_t)d];
+        bytes[(size_t)k] = sum;
+        at[(size_t)k + 1] = at[(size_t)k] + sum;
+    }
+    lap("pieces sized");
+    std::atomic<int> bad{0}, write_errno{0};
+    auto write_all = [&](const char *p, size_t n, off_t off) {
+        while (n) {
+            const ssize_t wr = ::pwrite(fd, p, n, off);
+            if (wr < 0 && errno == EINTR) continue;
+            if (wr <= 0) { write_errno.store(wr < 0 ? errno : ENOSPC); bad.store(2); return; }
+            p += wr; n -= (size_t)wr; off += wr;
+        }
+    };
+    in_parallel(parts, [&](int k) {
+        const long long lo = std::min<long long>((long long)k * per, N), hi = std::min<long long>(lo + per, N);
+        std::unique_ptr<char[]> buf(path ? new (std::nothrow) char[bytes[(size_t)k] + 1] : nullptr);
+        if (path && !buf) { bad.store(1); return; }
+        char *o = buf.get();
+        for (long long d = lo; d < hi; ++d) {
+            const StreamRec &r = *src[(size_t)d];
+            if (d + 8 < hi) { __builtin_prefetch(src[(size_t)d + 8]); __builtin_prefetch(src[(size_t)d + 4]->text); }
+            if (path) { std::memcpy(o, r.text, r.len); o += r.len; }
+            if (want_cols) {
+                track_id[d] = r.id; t[d] = r.frame;
+                x[d] = r.v[0]; y[d] = r.v[1]; w[d] = r.v[2]; h[d] = r.v[3]; angle[d] = r.v[4];
+            }
+        }
+        if (!path) return;
+        if (k == 0 && head) write_all(CSV_HEADER, head, 0);
+        write_all(buf.get(), bytes[(size_t)k], (off_t)at[(size_t)k]);
+    });
+    lap("gathered and written");
+    if (fd >= 0) {
+        const int rc_close = ::close(fd);
+        if (rc_close != 0 && !bad.load()) { write_errno.store(errno); bad.store(2); }
+        if (bad.load()) ::unlink(path);
+    }
+    lap("closed");
+    if (bad.load() == 1) return ysmr::fail(YSMR_ERR_CAPACITY, "out of memory assembling %lld rows", N);
+    if (bad.load() == 2) return ysmr::fail(YSMR_ERR_ARG, "writing %s failed: %s", path, std::strerror(write_errno.load()));
+    if (out_length) *out_length = at[(size_t)parts];
+    return YSMR_OK;
+}
+
+int ysmr_rows_stream_destroy(ysmr_rows_stream *s)
+{
+    if (!s) return YSMR_OK;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->closing = true;
+        s->queue_head = s->queue.size();         // (whatever is still queued is dropped)
+    }
+    s->cv_work.notify_all();
+    for (auto &th : s->pool) th.join();
+    delete s;
     return YSMR_OK;
 }
 

@@ -394,6 +394,60 @@ def rows_to_csv_file_and_dataframe(rows, path, header=True, via_pandas=True, thr
     return length.value, df
 
 
+class RowStream:
+    """``ysmr_rows_stream_*``: the csv and the DataFrame worked out while the video runs.  ``push`` rows (a structured
+    ``_lib.ROW_DTYPE`` array, or a raw pointer and a count) as the link emits them; ``finish`` orders them by
+    (TRACK_ID, POSITION_T), writes ``path`` (None: no file) and returns ``(bytes, DataFrame)`` -- what
+    ``rows_to_csv_file_and_dataframe`` returns for the same rows in sorted order."""
+
+    def __init__(self, via_pandas=True, threads=0):
+        import ctypes
+        from . import _lib
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().ysmr_rows_stream_create(int(threads), int(bool(via_pandas)), ctypes.byref(self._h)),
+                   "ysmr_rows_stream_create")
+
+    def push(self, rows, n=None):
+        from . import _lib
+        if n is None:
+            rows = np.ascontiguousarray(rows, dtype=_lib.ROW_DTYPE)
+            ptr, n = rows.ctypes.data, len(rows)
+        else:
+            ptr = int(rows)
+        _lib.check(_lib.lib().ysmr_rows_stream_push(self._h, ptr, int(n)), "ysmr_rows_stream_push")
+
+    def __len__(self):
+        from . import _lib
+        return int(_lib.lib().ysmr_rows_stream_count(self._h))
+
+    def finish(self, path=None, header=True):
+        import ctypes
+        import pandas as pd
+        from . import _lib
+        n = len(self)
+        ids, t = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        cols = [np.empty(n, np.float64) for _ in range(5)]
+        length = ctypes.c_size_t(0)
+        _lib.check(_lib.lib().ysmr_rows_stream_finish(self._h, int(bool(header)), None if path is None else os.fsencode(path),
+                                                      ctypes.byref(length), ids.ctypes.data, t.ctypes.data,
+                                                      *[c.ctypes.data for c in cols]), "ysmr_rows_stream_finish")
+        df = pd.DataFrame({"TRACK_ID": ids, "POSITION_T": t, "POSITION_X": cols[0], "POSITION_Y": cols[1],
+                           "WIDTH": cols[2], "HEIGHT": cols[3], "DEGREES_ANGLE": cols[4]})
+        return length.value, df
+
+    def close(self):
+        from . import _lib
+        if self._h:
+            _lib.lib().ysmr_rows_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def rows_to_dataframe(rows, via_pandas=True):
     """Rows (already sorted) -> the DataFrame ``get_data`` would have read back from the csv
     (dtypes of helper_file.py:881-889; ``via_pandas`` as in :func:`rows_to_csv_bytes`)."""

@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .detect import Detector, MeanGrayState, mean_gray_params, threshold_params
 from .frames import DeviceFrameFeed, open_video
-from .helper_file import (COLOR_BGR2GRAY, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes, rows_to_csv_file, rows_to_csv_file_and_dataframe,
+from .helper_file import (COLOR_BGR2GRAY, RowStream, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes, rows_to_csv_file, rows_to_csv_file_and_dataframe,
                           rows_to_dataframe, save_list)
 from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
@@ -352,6 +352,104 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
                    list_name, fps_of_file, frame_height, frame_width, t_start, t_frames)
 
 
+def usable_cpus():
+    """CPUs this process may really use: its affinity mask, cut by the cgroup's quota (a box of this pool shows 256 CPUs and
+    grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                quota, period = int(fq.read()), int(fp.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+class _RowDrain:
+    """The tail of a video, taken off its end (39 of a 1920-frame file's 97 ms came after the last frame, all
+    serial): a thread that, batch by batch, waits for the batch's link launch, brings the rows it added to the device buffer
+    to the host through pinned memory on a stream of its own, and hands them to a ``RowStream`` (``ysmr_rows_stream_*``),
+    whose threads print them while later batches run.  A row's text does not depend on any other row; its place in the file
+    -- by (TRACK_ID, POSITION_T) -- is worked out once, at the end."""
+
+    def __init__(self, pipe, threads=None):
+        import queue
+        self.pipe = pipe
+        self.rows_cap = pipe.rows.numel() // _lib.ROW_DTYPE.itemsize
+        self.stream = RowStream(via_pandas=True, threads=threads or int(os.environ.get("YSMR_STREAM_THREADS", 0)) or max(2, min(12, usable_cpus() // 2)))
+        self.copy_stream = torch.cuda.Stream(device=pipe.device)
+        self.count_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.staging = torch.empty(min(self.rows_cap, pipe.B * pipe.capacity) * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+        self.taken = 0
+        self.error = None
+        self.q = queue.Queue()
+        self.thread = threading.Thread(target=self._run, name="ysmr-row-drain", daemon=True)
+        self.thread.start()
+
+    def submit(self, linked_event):
+        """``linked_event``: recorded on the link stream behind the batch's launch."""
+        self.q.put(linked_event)
+
+    def _run(self):
+        size = _lib.ROW_DTYPE.itemsize
+        with torch.cuda.device(self.pipe.device):
+            while True:
+                ev = self.q.get()
+                try:
+                    if ev is None:
+                        return
+                    if self.error is not None:
+                        continue
+                    ev.synchronize()
+                    with torch.cuda.stream(self.copy_stream):
+                        self.count_host.copy_(self.pipe.row_count, non_blocking=True)
+                        self.copy_stream.synchronize()
+                        n = int(self.count_host.item())
+                        if n > self.rows_cap:
+                            raise _lib.YsmrLibraryError(f"row buffer overflow: {n} rows > capacity {self.rows_cap}")
+                        per = self.staging.numel() // size
+                        while self.taken < n:
+                            k = min(n - self.taken, per)
+                            self.staging[:k * size].copy_(self.pipe.rows[self.taken * size:(self.taken + k) * size], non_blocking=True)
+                            self.copy_stream.synchronize()
+                            self.stream.push(self.staging.data_ptr(), k)
+                            self.taken += k
+                except Exception as exc:           # (kept for the caller's thread: finish() / wait_idle() raise it)
+                    self.error = exc
+                finally:
+                    self.q.task_done()
+
+    def wait_idle(self):
+        """Every batch submitted so far is in the stream (the device buffer may be reused from its start)."""
+        self.q.join()
+        if self.error is not None:
+            raise self.error
+
+    def restart_buffer(self):
+        self.taken = 0
+
+    def finish(self):
+        """-> the RowStream holding every row of the video (its threads may still be printing the last batch)."""
+        self.q.put(None)
+        self.thread.join()
+        if self.error is not None:
+            self.stream.close()
+            raise self.error
+        return self.stream
+
+    def abort(self):
+        self.q.put(None)
+        self.thread.join()
+        self.stream.close()
+
+
 _GC_LOCK = threading.Lock()
 _GC_HOLDERS = 0          # frame loops of this process that currently want the heap frozen
 _GC_OURS = False         # the freeze in force is this module's (not the caller's own)
@@ -379,6 +477,13 @@ def _gc_release():
             _GC_OURS = False
 
 
+def _linked_event(device):
+    """An event of its own behind a batch's link launch (the pipeline's per-slot events are recorded again two batches on)."""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return ev
+
+
 def _persist_chunk(list_name, rows, first):
     """'hip persist rows': the rows of one full device buffer, in the order they were tracked, appended to the list
     file -- what save_list (helper_file.py:1403-1478) does every 'list save length interval' rows."""
@@ -397,6 +502,7 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
     feed = None
     verdict = "done"
     froze = False
+    drain = None
     t_start = t_frames = time.perf_counter()
     try:
         # Rows stay on the device for the whole video when they fit (capacity rows per frame is the
@@ -421,6 +527,12 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
         LAST_PASS_MARKS["pipeline built"] = time.perf_counter() - t_start
         feed = DeviceFrameFeed(video, pipe.B, pipe.device)
         LAST_PASS_MARKS["feed built"] = time.perf_counter() - t_start
+        # (rows leave for the host and are printed batch by batch, while later batches run -- unless they are to be appended
+        # to the list file in the order they were tracked, 'hip persist rows', which is the older, serial path)
+        # ('hip stream rows', default off: measured on a 16-CPU box the overlap LOSES -- 107-154 ms against the serial tail's 98 for a
+        # 1920-frame file, profiles/r05_e2e_stream_threads.log: the loop's one host copy per byte of video and the printing of
+        # 971 k rows are 0.43 core-seconds each, and side by side they only slow each other down)
+        drain = _RowDrain(pipe) if (persist_to is None and settings.get("hip stream rows", False)) else None
         # A full pass of CPython's garbage collector walks every tracked object of the process (~40 ms with torch, numpy
         # and pandas loaded) and would stall the loop that keeps the GPU fed for as long as 50 batches take; what is alive
         # now is moved out of its sight for the duration of the loop (collections of the loop's own garbage stay on).
@@ -437,11 +549,18 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
                 if rows_upper + cnt * pipe.capacity > row_capacity:
                     if res is not None:
                         pipe.check(res)
-                    chunks.append(pipe.take_rows())
-                    if persist_to:
-                        _persist_chunk(persist_to, chunks[-1], len(chunks) == 1)
+                    if drain is not None:       # everything linked so far is with the stream: the buffer starts over
+                        drain.wait_idle()
+                        pipe.row_count.zero_()
+                        drain.restart_buffer()
+                    else:
+                        chunks.append(pipe.take_rows())
+                        if persist_to:
+                            _persist_chunk(persist_to, chunks[-1], len(chunks) == 1)
                     rows_upper = 0
                 res = pipe.link(slot, r, ready, p0)
+                if drain is not None:
+                    drain.submit(_linked_event(pipe.device))
                 rows_upper += cnt * pipe.capacity
                 frames_done = p0 + cnt
                 if not checked_early:           # a video too dense for the buffers is found out after its
@@ -453,10 +572,17 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
             if rows_upper + cnt * pipe.capacity > row_capacity:
                 if res is not None:
                     pipe.check(res)
-                chunks.append(pipe.take_rows())
-                if persist_to:
-                    _persist_chunk(persist_to, chunks[-1], len(chunks) == 1)
+                if drain is not None:
+                    drain.wait_idle()
+                    pipe.row_count.zero_()
+                    drain.restart_buffer()
+                else:
+                    chunks.append(pipe.take_rows())
+                    if persist_to:
+                        _persist_chunk(persist_to, chunks[-1], len(chunks) == 1)
             res = pipe.link(slot, r, ready, p0)
+            if drain is not None:
+                drain.submit(_linked_event(pipe.device))
             frames_done = p0 + cnt
         LAST_PASS_MARKS["last batch issued"] = time.perf_counter() - t_start
         if froze:
@@ -467,7 +593,11 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
             t_frames = time.perf_counter()
             LAST_PASS_MARKS["last batch linked"] = t_frames - t_start
             pipe.check(res)
-            if chunks:      # did not fit: gather on the host, order on the device in one go
+            if drain is not None:
+                sorted_rows = drain.finish()       # (a RowStream: _finish orders and writes it)
+                drain = None
+                LAST_PASS_MARKS["last rows with the stream"] = time.perf_counter() - t_start
+            elif chunks:      # did not fit: gather on the host, order on the device in one go
                 chunks.append(pipe.take_rows())
                 everything = np.concatenate(chunks)
                 on_dev = torch.from_numpy(everything.view(np.uint8)).to(pipe.device)
@@ -491,6 +621,8 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
             _gc_release()
         if feed is not None:
             feed.close()
+        if drain is not None:       # (an attempt that ended early: its rows go nowhere)
+            drain.abort()
     return verdict, sorted_rows, frames_done, error_during_read, t_start, t_frames
 
 
@@ -505,31 +637,51 @@ def _finish(video_path, settings, logger, sorted_rows, frames_done, frame_count,
             logger.info("Restoring old list: {}".format(list_name))
         except OSError as exc:
             logger.error("Could not restore {}: {!r}".format(list_name, exc.args))
+    stream = sorted_rows if isinstance(sorted_rows, RowStream) else None
     if sorted_rows is None or len(sorted_rows) == 0:
+        if stream is not None:
+            stream.close()
         logger.warning("Did not track any objects. File: {}".format(video_path))
         return None
     # track_eval.py:387-392 asks the LAST frame's tracker output for its last object id: a video whose final
     # frame has no live track (nothing seen for more than a second) "did not track any objects" upstream,
     # whatever the earlier frames held -- and the unsorted list stays on disk.  Same verdict here (the list
     # is written, ordered, before returning).
-    alive_at_end = sorted_rows["track_id"][sorted_rows["frame"] == frames_done - 1]
     # track_eval.py:393: sort_list(file_path=list_name, save_file=not settings['delete .csv ...']) re-reads
     # the csv with pandas, sorts it and rewrites it; the same DataFrame and the same bytes come
     # straight from the rows here (helper_file.rows_to_dataframe / rows_to_csv_bytes).
-    n_rows_total = len(sorted_rows)
-    last_id = int(alive_at_end.max()) if len(alive_at_end) else -1
     t_rows = time.perf_counter()
-    # the csv and the DataFrame's columns come out of ONE native pass over the rows (the values the text is printed from are
-    # the values pandas would read back from it: worked out once, by the formatting threads themselves)
     df_for_eval = None
-    if not settings["delete .csv file after analysis"]:   # (else analyse() removes the file anyway, main.py:156)
+    keep_file = not settings["delete .csv file after analysis"]   # (else analyse() removes the file anyway, main.py:156)
+    if stream is not None:
+        # the rows were printed while the video ran (_RowDrain): what is left is their order, the file, the columns
+        n_rows_total = len(stream)
         try:
-            _, df_for_eval = rows_to_csv_file_and_dataframe(sorted_rows, list_name)
-        except (OSError, _lib.YsmrLibraryError) as exc:
-            logger.error("Could not write {}: {}".format(list_name, exc))
-    if df_for_eval is None:
-        df_for_eval = rows_to_dataframe(sorted_rows)
+            try:
+                _, df_for_eval = stream.finish(list_name if keep_file else None)
+            except (OSError, _lib.YsmrLibraryError) as exc:
+                if not keep_file:
+                    raise
+                logger.error("Could not write {}: {}".format(list_name, exc))
+                _, df_for_eval = stream.finish(None)
+        finally:
+            stream.close()
+        alive_at_end = df_for_eval["TRACK_ID"].to_numpy()[df_for_eval["POSITION_T"].to_numpy() == frames_done - 1]
+    else:
+        alive_at_end = sorted_rows["track_id"][sorted_rows["frame"] == frames_done - 1]
+        n_rows_total = len(sorted_rows)
+        # the csv and the DataFrame's columns come out of ONE native pass over the rows (the values the text is printed from are
+        # the values pandas would read back from it: worked out once, by the formatting threads themselves)
+        if keep_file:
+            try:
+                _, df_for_eval = rows_to_csv_file_and_dataframe(sorted_rows, list_name)
+            except (OSError, _lib.YsmrLibraryError) as exc:
+                logger.error("Could not write {}: {}".format(list_name, exc))
+        if df_for_eval is None:
+            df_for_eval = rows_to_dataframe(sorted_rows)
+    last_id = int(alive_at_end.max()) if len(alive_at_end) else -1
     t_df = time.perf_counter()
+    LAST_PASS_MARKS["csv and DataFrame done"] = t_df - t_start
     logger.debug("phases: frames {:.1f} ms, rows to host (sorted) {:.1f} ms, DataFrame {:.1f} ms, csv {:.1f} ms".format(
         (t_frames - t_start) * 1e3, (t_rows - t_frames) * 1e3, (t_df - t_rows) * 1e3, (time.perf_counter() - t_df) * 1e3))
     logger.info("objects: {}, frames: {} of {}, rows: {}, csv: {}".format(last_id + 1, frames_done, frame_count,
