@@ -20,7 +20,7 @@ for rep in range(5):
     L.ysmr_debug_read_thr_stamps(buf)
     acc.append(np.array(buf[:], dtype=np.int64).reshape(NW, NS, NK))
 a = np.median(np.array(acc), axis=0)          # [wave][step][stamp]
-names = ["request rows (DMA issue)", "filter (column + row pass, classify)", "wait for the rows of the next step", "class-map stores",
+names = ["stores of the previous step + DMA issue", "filter (column + row pass, classify)", "wait for the rows of the next step", "(class-map stores: at the step's start since r05)",
          "barrier 1", "blur of the next block", "barrier 2"]
 steps = range(3, 13)                            # steady state
 d = np.diff(a[:, steps, :], axis=2).mean(axis=1)     # [wave][phase]
