@@ -95,21 +95,21 @@ def main():
         print("column scale s: best by 128 dc + rho:", best[:5], "  s = 1 - 2^-10:", taps_error(w, 1 - 2.0 ** -10))
         s = best[0][1]
         cand = []
-        for S in np.arange(400.0, 2048.0, 1.0):      # S itself must be an f16 (the preset's tap): integers below 2048 are
+        for S in np.arange(16.0, 64.0, 1 / 32.0):    # S itself must be an f16 (the preset's tap): multiples of 1/32 below 64 are
             cand.append((taps_error(w, S / s), S))
         cand.sort()
         print("classification scale S: smallest row-tap error:", cand[:8])
-    s = args.s or 0.9995
-    S = args.S or 1024.0
+    s = args.s or 0.9945          # what choose_scales (thr_mfma.hip) picks for these taps
+    S = args.S or 39.375
     E, parts = bound(w, s, S)
-    print(f"s = {s}, S = {S}: bound {E:.5f}  parts {parts}   EPS by the byte range = 127.5 / S = {127.5 / S:.5f}")
+    print(f"s = {s}, S = {S}: bound {E:.5f}  parts {parts}   EPS where the bf8 conversion decides = 1.875 / S = {1.875 / S:.5f}")
     from ysmr_amd.synth import SyntheticVideo
     rng = np.random.default_rng(0)
     levels = (-5.5, -7.5)
     for name, frames in (("bench clip, 3 frames", SyntheticVideo(922, 1228, 500, seed=0).frames(3)),
                          ("4K dense, 1 frame", SyntheticVideo(2160, 3840, 5000, seed=0).frames(1)),
                          ("uniform noise 400x1228", rng.integers(0, 256, (1, 400, 1228), dtype=np.uint8))):
-        for eps in sorted({127.5 / S, 1 / 256}):
+        for eps in sorted({1.875 / S, 1 / 256}):
             n, worst = count(frames, w, s, S, eps, levels)
             print(f"{name}: EPS {eps:.5f}: undecided pixels per frame {n}; worst |model - real| {worst:.5f}")
 

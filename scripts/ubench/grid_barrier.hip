@@ -53,6 +53,33 @@ __global__ void k_tree(unsigned *ctr, int iters, unsigned long long *out, int *e
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = rt() - t0;
 }
+// Round 5 (the 4K link's paper): a barrier among FEW workgroups -- 7 or 8, what 5 000 tracks at 768 seats
+// need -- placed on ONE XCD (launch 8 x as many and let blockIdx % 8 != 0 leave: round-robin dealing puts the rest on one XCD,
+// for speed only), with the fences a link frame needs (release before the arrive, acquire after the wait) or with none (the
+// frame's exchange done through agent-scope atomics themselves), 768 threads per workgroup like k_batch.
+template <bool FENCES, bool ONE_XCD>
+__global__ void k_few(unsigned *ctr, int iters, unsigned long long *out, int *err, unsigned members)
+{
+    if (ONE_XCD && (blockIdx.x & 7u) != 0u) return;
+    const unsigned long long t0 = rt();
+    for (int it = 1; it <= iters; ++it) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (threadIdx.x == 0) {
+            if (FENCES) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (ld(ctr) < (unsigned)it * members) {
+                if (++spins > 4000000u) { atomicOr(err, 1); break; }
+            }
+            if (FENCES) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = rt() - t0;
+}
+
 int main()
 {
     unsigned *ctr; unsigned long long *out, h; int *err, herr;
@@ -66,6 +93,21 @@ int main()
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost);
             printf("%3d blocks %s: %.2f us per barrier%s\n", blocks, tree ? "tree" : "flat", h * 0.01 / iters, herr ? "  (TIMEOUT)" : "");
+        }
+    }
+    for (unsigned members : {2u, 4u, 7u, 8u}) {
+        for (int mode = 0; mode < 4; ++mode) {
+            const bool fences = mode & 1, one = mode & 2;
+            (void)hipMemset(ctr, 0, 4096); (void)hipMemset(err, 0, 4);
+            const unsigned grid = one ? 8 * members : members;
+            if (fences && one) hipLaunchKernelGGL((k_few<true, true>), grid, 768, 0, 0, ctr, iters, out, err, members);
+            else if (fences) hipLaunchKernelGGL((k_few<true, false>), grid, 768, 0, 0, ctr, iters, out, err, members);
+            else if (one) hipLaunchKernelGGL((k_few<false, true>), grid, 768, 0, 0, ctr, iters, out, err, members);
+            else hipLaunchKernelGGL((k_few<false, false>), grid, 768, 0, 0, ctr, iters, out, err, members);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost);
+            printf("%u workgroups of 768 threads, %s, %s: %.2f us per barrier%s\n", members, one ? "one XCD" : "dealt over the XCDs",
+                   fences ? "release + acquire fences" : "counter only", h * 0.01 / iters, herr ? "  (TIMEOUT)" : "");
         }
     }
     return 0;

@@ -6,46 +6,49 @@
 //         column pass = symmetric form), REPLICATE border
 //   m   = round-half-even(acc);  thresh = (b - m > t_low), markers = (b - m > t_high)   [INV: <=]
 // The two class bits only depend on where acc lies relative to b - t - 0.5.  This kernel evaluates
-//   v = mean - b   with |v - (acc - b)| < EPS   (a bound, below)
-// on the matrix pipe and decides every pixel whose v is farther than EPS from both levels; the few that are not (a few
-// per 100 000 pixels) are listed and recomputed with cv2's exact float32 chain at the end of the work item, from the
-// frame in global memory.  Results are bit for bit those of k_threshold / k_threshold_strip (detect.hip), which remain
-// the path for BGR input and odd geometries.
+//   v = mean - b   with |v - (acc - b)| < EPS   (a bound worked out on the host: choose_scales / walk_bound below)
+// on the matrix pipe and decides every pixel whose v is farther than EPS from both levels; the others (a few dozen per frame)
+// are listed and recomputed with cv2's exact float32 chain at the end of the workgroup, from the frame in global memory.
+// Results are bit for bit those of k_threshold / k_threshold_strip (detect.hip), which remain the path for BGR input and odd
+// geometries.
 //
 // Why the matrix pipe: the float32-chain kernel is bound by vector-instruction issue (~34 instructions per pixel), and
-// so was a first version of this kernel that still did the 3x3 blur with SWAR integer arithmetic (profiles/
-// r03_thr_mfma_by_deletion.log: blur 31 us, filter 33 us of 92).  Here every multiply-add is an MFMA:
+// so was a first version of this kernel that still did the 3x3 blur with SWAR integer arithmetic.  Here every multiply-add
+// is an MFMA (5.2 per 16 x 16 tile since round 5; 8.8 in round 4, when every tap and the intermediate were f16 hi + lo pairs):
 //   blur, row direction     v_mfma_i32_16x16x64_i8: the gray BYTES as they lie in LDS (XOR 0x80 makes them signed) times
 //                           a banded (1, 2, 1) matrix; the accumulator starts at 0x6400 + 512, so a result IS the f16
 //                           bit pattern of 1024 + sum -- two results pack into an f16 pair with one v_lshl_or
 //   blur, column direction  v_mfma_f32_16x16x32_f16 over the previous and this 16-row block of those sums (kept in
 //                           registers: the accumulator layout is the next product's B operand); exact integers;
-//                           (sum + 8) >> 4 is one fma and a round-toward-zero conversion at 1024 + x
+//                           (sum + 8) >> 4 is folded into the taps and a round-toward-zero conversion at 1024 + x;
+//                           the tile then holds b - 128: centred, so that the Gaussian's f16 taps meet |b - 128| <= 128
 //   Gaussian, columns       the blurred tile lives in LDS as [column][row] f16, so the operand is a 16-byte read;
-//                           taps as f16 hi + lo: 2 MFMA per 16-column block; result split into f16 hi + lo in registers
-//   Gaussian, rows          3 MFMA per 16x16 output tile over two neighbouring blocks; the taps carry the classification's
-//                           scale and the accumulator starts at lo_add - scale * b, so the result is the byte-range value x
-// which leaves about 50 vector instructions per 256 pixels: conversions, the hi/lo split, the classification.
+//                           ONE f16 per tap (the taps scaled by a host-chosen s near 1 at which all eleven lie close to f16
+//                           values); the result ONE f16, rounded to nearest (v_cvt_pk_f16_f32)
+//   Gaussian, rows          1 MFMA per 16x16 output tile over two neighbouring blocks, transposed (a lane ends up with four
+//                           consecutive columns of one row: a dword of class bytes); the taps carry the classification's
+//                           scale X, the accumulator starts at -X theta_1 - X (b - 128) (one more product: tile x scaled
+//                           shifted identity), so the result is x = X (mean - b - theta_1)
+//   classification          v_cvt_pk_bf8_f32 of x: the byte's sign bit IS the class bit and its exponent's top bit says
+//                           |x| >= 2, i.e. decided; the second level only in tiles where the first fires somewhere
+// which leaves about 45 vector instructions per 256 pixels (round 4: 62): the blur's XOR / pack / conversions, two conversions
+// of the intermediate, the classification, addresses and control.
 //
 // Memory skeleton (scripts/ubench/skeleton.hip): a 1024-thread workgroup owns a band of rows of one frame over a
 // column panel (the whole width up to 1232 columns) and walks down in steps of 16 rows: whole rows come in by
 // LDS-DMA (global_load_lds_dwordx4, no registers), the class map leaves as 16-byte stores.  Per step:
-//   DMA    gray rows of step s+2                                       -> s_raw[s & 1]
-//   filter output rows of step s-1 from the tile blocks of steps s-1 and s -> class bytes -> wave-private staging -> stores
+//   stores class bytes of step s-1 (they waited in the wave's staging rows)
+//   DMA    gray rows of step s+2                                       -> s_raw[s & 1]   (half of the waves: between two tiles)
+//   filter output rows of step s-1 from the tile blocks of steps s-1 and s -> class bytes -> wave-private staging
 //   barrier
 //   blur   step s+1: s_raw[(s+1) & 1] -> tile block (s+1) & 1
 //   barrier
 //
-// Error bound (EPS = 1/256 = 3.9e-3): the blurred pixels are exact; each tap enters as f16 hi + lo with a residual below
-// 2^-11 |lo| (< 3e-8 of the weight's scale; x 255 x 11 taps, two passes: < 2e-4); a column-filtered value enters the row pass
-// as rtz-f16 hi + rtz-f16 lo (residual < 2^-10 x 2^-3 = 1.2e-4; the taps sum to 1); the dropped lo x lo product is below
-// 3.2e-4 x 0.125 = 4e-5; float32 accumulation inside the five chained MFMAs (32 products each) costs at most
-// 5 x 32 x 2^-24 x 255 = 2.4e-3 if every partial sum were rounded on its own and all errors lined up, and 5 x 2^-24 x 255
-// = 8e-5 with one rounding per MFMA; cv2's own chain is within 22 x 2^-24 x 255 = 3.3e-4 of the real mean: 3.1e-3 in all if
-// every worst case held at once, which EPS covers (round 3 shipped 1/512, covered by measurement only).  MEASURED
-// (tests/test_gpu_detect.py::test_threshold_matrix_pipe_distance): with EPS = 1/2048 (round 3; 1/512 since) the kernel still reproduces the
-// oracle byte for byte on 3.9 M pixels of uniform noise, and an earlier build that decided everything but exact ties
-// differed in 3 of them -- a distance of about 2e-5, a hundredth of EPS.
+// Error bound: the comment at walk_bound() (bottom of this file): 0.0423 gray levels for cv2's sigma-2 taps with any image,
+// of which 0.031 is the f16 rounding of the intermediate (half an ulp at |v1| < 128); EPS = 1.875 / 39.375 = 0.0476.
+// MEASURED: tests/test_gpu_detect.py (47 cases, every geometry class, noise and synthetic video, the bench's and the 4K launch
+// shapes) byte for byte against the oracle; scripts/sim/thr_single_f16.py models the same arithmetic in numpy: worst
+// |model - real| 0.037 on the bench clip, ~35 undecided pixels per 1.13-Mpx frame (4 at round 4's EPS = 1/256).
 #include "common.h"
 #include "thr_mfma.h"
 #include <hip/hip_ext.h>
@@ -906,12 +909,12 @@ extern "C" int ysmr_debug_read_thr_stamps(unsigned long long *out) { return (int
 namespace {
 
 // ---- the scales of the walk's arithmetic and its error bound (host) ------------------------------------------------
-// The walk evaluates  x = x_mul (mean - b) + lo_add  with ONE f16 per tap and ONE f16 for the column-filtered value:
+// The walk evaluates  x = X (mean - b - theta_1), X = +-S,  with ONE f16 per tap and ONE f16 for the column-filtered value:
 //   tile          b - 128, exact integers in [-128, 127]
 //   column pass   v1 = sum_j f16(s w_j) (b_j - 128)            float32 accumulation of exact products
 //   intermediate  h = f16(v1), round to nearest                 |h - v1| <= 2^-5 while |v1| < 128
-//   row pass      x = sum_i f16(x_mul / s  w_i) h_i + [lo_add - x_mul (b - 128)]
-// against the real number  x_mul (sum_ij w_i w_j b_ij - b) + lo_add.  In gray levels (divide by |x_mul| = S):
+//   row pass      x = sum_i f16(X / s  w_i) h_i + [-X theta_1 - X (b - 128)]
+// against the real number  X (sum_ij w_i w_j b_ij - b - theta_1).  In gray levels (divide by S):
 //   column taps   |sum_j (f16(s w_j) / s - w_j) (b_j - 128)|            <= 128 dc,   dc = sum_j |f16(s w_j) / s - w_j|
 //   intermediate  (1 / s) sum_i w_i |h_i - v1_i|                        <= 2^-5 / s  (needs s 128 (1 + dc) sum w < 128)
 //   row taps      |sum_i (f16(S / s w_i) / S - w_i / s) h_i|, |h_i| <= 128   <= 128 dr / s,   dr = sum_i |f16(S / s w_i) s / S - w_i|
