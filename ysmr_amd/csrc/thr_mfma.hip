@@ -96,6 +96,10 @@ constexpr int TM_OUT_PITCH = 16 * TM_PER_WAVE;               // bytes per row of
 #define TM_DMA_AFTER_BLOCK_N 2
 #endif
 constexpr int TM_DMA_AFTER_BLOCK = TM_DMA_AFTER_BLOCK_N;     // the second half of the waves request their rows behind this block of the filter (-1: at the start, like the first half)
+#ifndef TM_STORE_ROWS_N
+#define TM_STORE_ROWS_N 0
+#endif
+constexpr bool TM_STORE_ROWS = TM_STORE_ROWS_N != 0;          // whole rows leave behind the step's first barrier (20 store instructions per step instead of 32)
 #ifndef TM_STORE_AT_START_N
 #define TM_STORE_AT_START_N 1
 #endif
@@ -735,19 +739,32 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         };
         // the wave's 16 rows x 80 bytes leave as 16-byte pieces: piece = (row, 16 columns)
         // (which 16-byte piece of its 16 rows x 80 bytes a lane stores does not change along the walk either)
-        constexpr int ST_ITERS = (TM_ROWS * TM_PER_WAVE + 63) / 64;
+        // TM_STORE_ROWS (round 5, an experiment switch): the step's sixteen WHOLE rows leave behind the step's first barrier,
+        // where every wave's staging bytes are visible to every wave: 16 x 77 sixteen-byte pieces in row order = 20 store
+        // instructions per step for the workgroup instead of the 32 that sixteen waves' private 16 x 80-byte blocks take
+        // (two each, the second a quarter full), each writing 1 KB of ONE row.
+        constexpr int ST_ITERS = TM_STORE_ROWS ? (TM_ROWS * TM_MAX_TILES + 64 * TM_WAVES - 1) / (64 * TM_WAVES) : (TM_ROWS * TM_PER_WAVE + 63) / 64;
         int st_lds[ST_ITERS], st_g[ST_ITERS];
         bool st_full[ST_ITERS], st_part[ST_ITERS];
         auto st_piece = [&](int k, int &r, int &x) __attribute__((always_inline)) {
-            const int pc = lane + 64 * k;
-            r = pc / TM_PER_WAVE;
-            x = it.x0 + 16 * u0 + 16 * (pc - r * TM_PER_WAVE);
+            if (TM_STORE_ROWS) {
+                const int pc = lane + 64 * (wave + TM_WAVES * k);        // piece = (row, 16-byte chunk of the panel's row)
+                r = pc / ntiles;
+                x = it.x0 + 16 * (pc - r * ntiles);
+            } else {
+                const int pc = lane + 64 * k;
+                r = pc / TM_PER_WAVE;
+                x = it.x0 + 16 * u0 + 16 * (pc - r * TM_PER_WAVE);
+            }
         };
 #pragma unroll
         for (int k = 0; k < ST_ITERS; ++k) {
             int r, x;
             st_piece(k, r, x);
-            st_lds[k] = r * TM_OUT_PITCH + (x - it.x0 - 16 * u0);
+            if (TM_STORE_ROWS) {
+                const int chunk = (x - it.x0) >> 4;                      // whose staging block: wave chunk / 5, tile chunk % 5
+                st_lds[k] = (chunk / TM_PER_WAVE) * (TM_ROWS * TM_OUT_PITCH) + r * TM_OUT_PITCH + 16 * (chunk % TM_PER_WAVE);
+            } else st_lds[k] = r * TM_OUT_PITCH + (x - it.x0 - 16 * u0);
             st_g[k] = r * W + x;
             st_full[k] = r < TM_ROWS && it.x1 - x >= 16;
             st_part[k] = r < TM_ROWS && it.x1 - x > 0 && it.x1 - x < 16;      // (4, 8 or 12 bytes left in the row)
@@ -757,7 +774,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             return;
 #endif
             const int oy = it.y0 + TM_ROWS * (s - 1);
-            const uint8_t *wout = reinterpret_cast<const uint8_t *>(L.out[wave]);
+            const uint8_t *wout = reinterpret_cast<const uint8_t *>(TM_STORE_ROWS ? L.out[0] : L.out[wave]);
             const int rows = min(TM_ROWS, it.y1 - oy);                         // (below 16 in an item's last step only)
             uint8_t *base = dst + (size_t)oy * W;                              // (wave-uniform)
 #pragma unroll
@@ -845,7 +862,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             // step's tiles overwrite): a wave that stalls on its store instructions here stalls while the other waves of its SIMD
             // have tiles to filter; behind the filter (round 4) the stall of the LAST wave to finish was the phase's last 540 - 880
             // cycles, with every other wave already at the barrier (profiles/r05_thr_stamps_*.log).
-            if (TM_STORE_AT_START && s >= 2) store_step(s - 1);
+            if (!TM_STORE_ROWS && TM_STORE_AT_START && s >= 2) store_step(s - 1);
             // (into the buffer the blur of step s has finished with; half of the waves ask later, inside filter_step)
             const bool late_dma = TM_DMA_AFTER_BLOCK >= 0 && s >= 1 && s + 2 <= nblk && wave >= TM_WAVES / 2;
             if (s + 2 <= nblk && !late_dma) mine = request_raw(s + 2);
@@ -854,16 +871,17 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             TMSTAMP(s, 2);
             wait_all_but(__builtin_amdgcn_readfirstlane(mine));  // the rows of step s + 1 have landed (and every older store)
             TMSTAMP(s, 3);
-            if (!TM_STORE_AT_START && s >= 1) store_step(s);
+            if (!TM_STORE_ROWS && !TM_STORE_AT_START && s >= 1) store_step(s);
             TMSTAMP(s, 4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (TM_STORE_ROWS && s >= 1) store_step(s);        // (every wave's class bytes of the step are in LDS: whole rows leave)
             TMSTAMP(s, 5);
             if (s + 1 <= nblk) blur_any(s + 1);           // overwrites the tile block of step s - 1
             TMSTAMP(s, 6);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             TMSTAMP(s, 7);
         }
-        if (TM_STORE_AT_START && nblk >= 1) store_step(nblk);
+        if (!TM_STORE_ROWS && TM_STORE_AT_START && nblk >= 1) store_step(nblk);
 
         // ---- an item whose ambiguous pixels outgrew the list (a frame made to sit on the levels): all of it again, exactly ----
         const uint32_t n_now = L.n_list;
