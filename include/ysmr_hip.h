@@ -73,9 +73,9 @@ extern "C" {
  * on, none gets a workgroup it cannot place before another has finished (same bytes). */
 #define YSMR_BESIDE_BATCH_LINK 8
 /* ... and for the two-launch link of large tables (k_link + k_track, 4K: 5000 tracks): its launches want a fat workgroup and
- * thousands of waves placed every ~30 us, so the matrix-pipe threshold kernel keeps to HALF the compute units (128 workgroups:
- * twice as long itself, but 24.3 against 23.1 k frames/s end to end at 3840 x 2160 with the float32-chain kernel, and 21.7 k
- * with the matrix-pipe kernel on every unit; same bytes). */
+ * thousands of waves placed every ~30 us, so the matrix-pipe threshold kernel keeps to 160 of the 256 compute units (round 5's
+ * kernel at 3840 x 2160: 24.2 k frames/s end to end on 128 or 160 workgroups, 23.7 k on 192, 21.9 k on 248 -- and a threshold
+ * fraction of 0.13 / 0.16 / 0.19 / 0.23, profiles/r05_sweep_4k_thr_grid.log; same bytes). */
 #define YSMR_BESIDE_SPLIT_LINK 16
 #define YSMR_CV_FLAVOUR_MASK 31
 

@@ -138,7 +138,7 @@ def test_beside_link_hint_changes_no_byte(torch_cuda):
     """The scheduling hints of ``cv_flavour`` only pick kernels and resident grids: YSMR_BESIDE_LINK (the float32-chain
     threshold kernel, smaller labelling grids: what TrackingPipeline passes next to the one-launch-per-frame link),
     YSMR_BESIDE_BATCH_LINK (the matrix-pipe kernel on 248 workgroups, its rows cut into ranges of equal cost) and
-    YSMR_BESIDE_SPLIT_LINK (128 workgroups) leave class map, mask, label map, detections, anchors and counts the same
+    YSMR_BESIDE_SPLIT_LINK (160 workgroups) leave class map, mask, label map, detections, anchors and counts the same
     bytes as a call without them."""
     from ysmr_amd.detect import Detector, threshold_params
     from ysmr_amd.synth import SyntheticVideo
@@ -187,7 +187,7 @@ def test_bench_launch_shape_256_frames_beside_the_batch_link(torch_cuda, oracle)
 
 def test_4k_launch_shape_16_frames_beside_the_split_link(torch_cuda, oracle):
     """... and the shape of the 4K configuration: 16 frames of 3840 x 2160 with YSMR_BESIDE_SPLIT_LINK (the matrix-pipe
-    kernel on 128 workgroups, four column panels per frame) against the default grid, byte for byte, and two of its frames
+    kernel on 160 workgroups, four column panels per frame) against the default grid, byte for byte, and two of its frames
     against the oracle."""
     from ysmr_amd.detect import Detector, threshold_params
     from ysmr_amd.synth import SyntheticVideo

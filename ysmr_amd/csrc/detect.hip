@@ -2317,7 +2317,7 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
     const bool timed = ev0 || ev1;
     if (variant != 1 && ysmr_thr::supported(H, W, channels, t_low, t_high, use_high))
         return ysmr_thr::launch(st, frames, cls, batch, H, W, inv, t_low, t_high, use_high, gk.k,
-                                knobs().thr_blocks > 0 ? knobs().thr_blocks : ((cv_flavour & YSMR_BESIDE_BATCH_LINK) ? 248 : ((cv_flavour & YSMR_BESIDE_SPLIT_LINK) ? 128 : 0)),
+                                knobs().thr_blocks > 0 ? knobs().thr_blocks : ((cv_flavour & YSMR_BESIDE_BATCH_LINK) ? 248 : ((cv_flavour & YSMR_BESIDE_SPLIT_LINK) ? 160 : 0)),
                                 variant >= 2 ? variant - 1 : 0, ev0, ev1);
     if (variant >= 2) return ysmr::fail(YSMR_ERR_ARG, "the matrix-pipe threshold kernel does not serve this geometry");
     const int t_gap = use_high ? (t_high > t_low ? t_high - t_low : t_low - t_high) : 0;
