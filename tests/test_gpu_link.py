@@ -275,3 +275,51 @@ def test_capacity_beyond_the_lds_tables(torch_cuda, oracle):
             got = np.concatenate(parts)
         assert trk.info()[2] == 0
         compare_rows(got, ref_rows)
+
+
+def test_split_link_lane_per_track_over_ring_wraps_and_refreshes(torch_cuda, oracle):
+    """Tables of more than 768 tracks link with two launches per frame, the second with a track per LANE (batch_link.h:
+    k_track_lanes): filter state seat-major by slot, a 32-entry ring, window sums rebuilt every 64th frame.  140 frames of
+    ~900 moving tracks with dropout (tracks lost, dropped and their slots taken by new ids) cross the ring's wrap four
+    times and the refresh twice; batches of 16 and of 1 against the oracle (tracker.py:113-240)."""
+    torch = torch_cuda
+    from ysmr_amd import _lib
+    from ysmr_amd.tracker import DeviceTracker, rows_to_numpy
+    rng = np.random.default_rng(11)
+    n_frames, cap = 140, 2048
+    base = rng.uniform(0, 3800, (900, 2))
+    vel = rng.normal(0, 0.6, base.shape)
+    frames = []
+    for f in range(n_frames):
+        keep = rng.random(len(base)) > 0.04
+        if f % 37 == 36:
+            keep[rng.integers(0, len(base), 60)] = False          # a burst of losses
+        xy = base[keep] + rng.normal(0, 0.3, (int(keep.sum()), 2))
+        whd = np.column_stack([rng.uniform(1, 9, len(xy)), rng.uniform(1, 9, len(xy)), rng.uniform(0, 90, len(xy))])
+        frames.append(np.column_stack([xy, whd]).astype(np.float32))
+        base += vel
+        if f % 20 == 19:                                          # some leave for good, others appear
+            gone = rng.integers(0, len(base), 25)
+            base[gone] = rng.uniform(0, 3800, (25, 2))
+    ot = oracle.OracleTracker(max_disappeared=4.0, fps=30.0, n_min=0, n_max=30, n_f=3, shadows=2)
+    ref_rows = []
+    for f, d in enumerate(frames):
+        ids, xy, info, _ = ot.update(oracle.det_to_rects(d))
+        ref_rows += [(f, tid, float(xy[i][0]), float(xy[i][1]), *map(float, info[i]), float(ot.last_sens[i]))
+                     for i, tid in enumerate(ids)]
+    for batch in (16, 1):
+        trk = DeviceTracker(max_disappeared=4.0, fps=30.0, n_min=0, n_max=30, n_f=3, capacity=cap, max_det=cap)
+        assert not trk.batched
+        rows = torch.empty(n_frames * 1100 * _lib.ROW_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        count = torch.zeros(1, dtype=torch.int64, device="cuda")
+        for b0 in range(0, n_frames, batch):
+            part = frames[b0:b0 + batch]
+            det = torch.zeros(len(part), cap, 5, dtype=torch.float32, device="cuda")
+            cnt = torch.zeros(len(part), dtype=torch.int32, device="cuda")
+            for k, d in enumerate(part):
+                det[k, :len(d)] = torch.from_numpy(d).cuda()
+                cnt[k] = len(d)
+            trk.run(det, cnt, b0, rows, count)
+        got = rows_to_numpy(rows, int(count.item()))
+        assert trk.info()[2] == 0
+        compare_rows(got, ref_rows)

@@ -902,6 +902,203 @@ __global__ __launch_bounds__(BL_THREADS) void k_batch(BlKernArgs ka)
     }
 }
 
+// ---- the split link's second kernel with a track per LANE (round 5) ------------------------------------------------
+// Tables beyond k_batch's 768 seats (4K: ~5 000 tracks) link with two launches per frame: k_link DECIDES (one workgroup), then
+// every track applies its claim, runs its filter bank, writes its row and finds its nearest detection of the next frame.  That
+// second kernel was k_track, a WAVE per track: 5 000 waves every frame, whose tail waits for wave slots that the detection
+// kernels of the next batch hold (12 us alone, 19 beside them: profiles/r04_timeline_4k.txt).  k_track_lanes does the same per
+// LANE with the batch link's arithmetic: the filter bank as window sums over an HBM ring (bl_gsff: four operations per filter
+// and coordinate, four ring entries per frame), the state seat-major by SLOT (a track keeps its slot for life), the row
+// minimum from the 3 x 3 cells of the next frame's grid around the prediction in exact float64, then from the 5 x 5 for the
+// lanes that leaves open -- 20 workgroups of 256 lanes instead of 1 250 of four waves.  What neither settles (a prediction
+// farther from every detection than the block reaches, or more candidates than slots) goes to the wave, one lane at a time,
+// through k_track's own rowmin_grid / rowmin_wave.
+// Measured (profiles/r05_link_4k_lanes.log): as fast as k_track, not faster -- 21 us per launch beside detection,
+// 14.7 with no lane falling through.  The kernel is a chain of dependent rounds of loads at 1.5-2 us each (data k_link wrote on
+// another XCD, HBM busy with the next batch's detection), six of them; arithmetic and gathers are ~2 us.  Hence the order of
+// the loads below: whatever hangs on the row or on the slot alone is requested in the first round that can, and before stores.
+// A handle that can (three filters of <= 31 frames, affine gains) keeps its filter state in this layout from the start:
+// ysmr_tracker_update, ysmr_tracker_run and the peeks need no conversion; rec / hist of the per-slot layout stay unused.
+// bd.i32 row 0 holds the id the slot's filter state belongs to (-1: none): a slot whose track id differs is a new track.
+
+// nearest detection of (px, py) among the (2 REACH + 1)^2 cells around it, exactly (rowmin_grid's rules: smallest squared
+// distance; the lowest column among the equal ROUNDED distances); false: the block does not settle it (nothing in it, something
+// outside it could be nearer, or it holds more than SLOTS candidates).  Two rounds of loads -- the bounds of the block's row-runs,
+// then every candidate's centre and column at once into registers, the runs laid end to end over the slots: a loop that fetched
+// a candidate per iteration was a chain of round trips (the first build of k_track_lanes: 26-36 us per launch).
+template <int REACH, int SLOTS>
+__device__ __forceinline__ bool bl_rowmin_lane(const DetGrid &g, const GridHdr &gh, double px, double py, int m, double &d_min, int &arg)
+{
+    constexpr int ROWS = 2 * REACH + 1;
+    const double x0 = (double)gh.x0, y0 = (double)gh.y0, cell = (double)gh.cell, inv = (double)gh.inv;
+    int cx = (int)floor((px - x0) * inv), cy = (int)floor((py - y0) * inv);
+    cx = cx < 0 ? 0 : (cx > GRID_N - 1 ? GRID_N - 1 : cx);
+    cy = cy < 0 ? 0 : (cy > GRID_N - 1 ? GRID_N - 1 : cy);
+    const int xl = max(cx - REACH, 0), xh = min(cx + REACH, GRID_N - 1), yl = max(cy - REACH, 0), yh = min(cy + REACH, GRID_N - 1);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    int a[ROWS], e[ROWS + 1];        // first entry of each row's run; the runs laid end to end: run r takes slots e[r] .. e[r + 1] - 1
+    e[0] = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int iy = min(yl + r, GRID_N - 1);
+        a[r] = g.start[iy * GRID_N + xl];
+        const int b = g.start[iy * GRID_N + xh + 1];
+        e[r + 1] = e[r] + (yl + r > yh ? 0 : b - a[r]);
+    }
+    const int n_all = e[ROWS];
+    float2 c[SLOTS];
+    int col[SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        int q = a[0] + k;
+#pragma unroll
+        for (int r = 1; r < ROWS; ++r) q = k >= e[r] ? a[r] + (k - e[r]) : q;
+        q = min(q, m - 1);                              // (a slot behind the runs reads some entry and is masked below)
+        c[k] = g.xy[q];
+        col[k] = g.items[q];
+    }
+    double sq[SLOTS], s_min = inf;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const double dx = px - (double)c[k].x;
+        const double dy = py - (double)c[k].y;
+        double v = dx * dx;
+        v = v + dy * dy;
+        sq[k] = k < n_all ? v : inf;
+        s_min = __builtin_fmin(sq[k], s_min);
+    }
+    const bool fits = n_all <= SLOTS;
+    // distance from the prediction to the outside of the block; a side on the edge of the grid has nothing beyond it
+    double bound = inf;
+    if (cx - REACH > 0) bound = fmin(bound, px - (x0 + (cx - REACH) * cell));
+    if (cx + REACH < GRID_N - 1) bound = fmin(bound, (x0 + (cx + REACH + 1) * cell) - px);
+    if (cy - REACH > 0) bound = fmin(bound, py - (y0 + (cy - REACH) * cell));
+    if (cy + REACH < GRID_N - 1) bound = fmin(bound, (y0 + (cy + REACH + 1) * cell) - py);
+    bound -= 1e-3 * cell;       // (cells were assigned in float arithmetic)
+    if (!fits || !(s_min < inf)) return false;
+    if (!(bound == inf || (bound > 0.0 && bound * bound > s_min * (1.0 + 1e-9)))) return false;
+    const double near_limit = s_min + s_min * 0x1p-48;
+    d_min = sqrt(s_min);
+    int cand = 0x7FFFFFFF;
+    bool inexact = false;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const bool near = sq[k] <= near_limit;
+        cand = near ? min(cand, col[k]) : cand;
+        inexact = inexact || (near && sq[k] != s_min);
+    }
+    if (inexact) {              // some s differs from min s by a few ulps: compare the rounded roots
+        cand = 0x7FFFFFFF;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if (sq[k] <= near_limit && sqrt(sq[k]) == d_min) cand = min(cand, col[k]);
+    }
+    arg = cand;
+    return true;
+}
+
+constexpr int TL_THREADS = 256;
+template <typename DetT>
+__global__ __launch_bounds__(TL_THREADS) void k_track_lanes(TrackerDev t, BatchDev bd, const BlGains *gains, int head, int frame,
+                                                            ysmr_row *rows, long long rows_capacity, const DetT *__restrict__ det,
+                                                            const DetT *__restrict__ next_det, const int32_t *next_m_dev,
+                                                            DetGrid next_grid)
+{
+    const int cap = t.capacity, nf = t.n_f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = blockIdx.x * TL_THREADS + tid;                       // table row
+    const int n_live = *t.n_tracks, claims_by_row = t.n_tracks[4];
+    const int m_next = next_det ? det_count(-1, next_m_dev, t.max_det, nullptr) : 0;
+    const GridHdr gh = grid_hdr(next_grid);
+    // (the row's slot and claim are requested beside the counts that say whether the row is live, not after them: every round of
+    // dependent loads is 1-2 us here, the data having been written by k_link on another XCD a moment ago)
+    const int i_safe = min(i, cap - 1);
+    const int slot = t.order[i_safe];
+    const int c_row = t.claim_row[i_safe];
+    const bool live = i < n_live;
+    double p0 = 0.0, p1 = 0.0;
+    bool to_wave = false;
+    if (live) {
+        const int c = claims_by_row ? c_row : t.claim_slot[slot];
+        // (everything the row needs that hangs on the slot alone, requested now: a load issued after the seat's stores would wait for them)
+        const int id = t.id[slot], gone = t.gone[slot];
+        const long long base = t.row_base[0];
+        // the measurement: the detection k_link let this track claim (position and box stored here), or the position it has
+        double z0, z1;
+        float bw, bh, ba;
+        if (c >= 0) {
+            const DetT *d = det + (size_t)c * 5;
+            z0 = (double)d[0]; z1 = (double)d[1];
+            bw = (float)d[2]; bh = (float)d[3]; ba = (float)d[4];
+            t.info[slot] = bw; t.info[cap + slot] = bh; t.info[2 * cap + slot] = ba;
+        } else {
+            z0 = t.pos[slot]; z1 = t.pos[cap + slot];
+            bw = t.info[slot]; bh = t.info[cap + slot]; ba = t.info[2 * cap + slot];
+        }
+        double o0 = z0, o1 = z1;
+        p0 = z0; p1 = z1;
+        if (t.use_gsff) {
+            // (the seat and the ring entries are requested whatever the slot holds -- in the same round of loads as the id that says
+            // whether they are this track's; a new track's are blanked afterwards)
+            BlSeat S;
+            bl_seat_load(S, bd, slot);
+            const int hn[BL_NF] = {t.n_i[0], nf > 1 ? t.n_i[1] : 1, nf > 2 ? t.n_i[2] : 1};
+            double2 leave[BL_NF];
+#pragma unroll
+            for (int k = 0; k < BL_NF; ++k) leave[k] = k < nf ? bl_ring_load(bd, (head - hn[k]) & (BL_HB - 1), slot) : make_double2(0.0, 0.0);
+            const bool fresh = S.id != id;
+            if (fresh) bl_seat_blank(S);
+            else if ((frame & (BL_REFRESH - 1)) == 0)          // (on the frame NUMBER, as k_batch: rows must not depend on the batching)
+                bl_sums_from_ring(S, bd, slot, head, t.n_i[0], nf > 1 ? t.n_i[1] : 0, nf > 2 ? t.n_i[2] : 0);
+            bl_gsff(S, t, bd, *gains, slot, head, leave, z0, z1, fresh, o0, o1);
+            p0 = S.px; p1 = S.py;
+            S.id = id;
+            bl_seat_store(S, bd, slot);
+        }
+        t.pos[slot] = p0; t.pos[cap + slot] = p1;      // CentroidTracker.objects[id]: the prediction (tracker.py:225), or the raw centroid
+        {
+            t.row_gone[i] = gone;
+            if (rows && base + i < rows_capacity) {
+                ysmr_row r;
+                r.frame = frame;
+                r.track_id = id;
+                r.x = o0; r.y = o1;
+                r.w = bw; r.h = bh; r.angle = ba;
+                r.disappeared = gone;
+                rows[base + i] = r;
+            }
+        }
+        to_wave = m_next > 0;
+    }
+    // nearest detection of the NEXT frame (tracker.py:151-163): the 3 x 3 cells around the prediction; for the lanes they do not
+    // settle (lost tracks, mostly: nothing near the prediction) the 5 x 5; the whole wave for what is left
+    if (next_grid.start) {
+        double d_min = 0.0;
+        int arg = 0;
+        if (to_wave && bl_rowmin_lane<1, 16>(next_grid, gh, p0, p1, m_next, d_min, arg)) { t.row_min[i] = d_min; t.row_arg[i] = arg; to_wave = false; }
+#ifndef TL_ONE_PASS
+        if (__ballot(to_wave) != 0ull) {
+            if (to_wave && bl_rowmin_lane<2, 32>(next_grid, gh, p0, p1, m_next, d_min, arg)) { t.row_min[i] = d_min; t.row_arg[i] = arg; to_wave = false; }
+        }
+#endif
+    }
+    // the lanes whose 3 x 3 cells did not settle it, one after the other, by the whole wave (k_track's own search)
+    unsigned long long todo = __ballot(to_wave);
+#ifdef TL_NOFALLBACK
+    todo = 0ull;       // (tuning build: what the lanes alone cost; results are wrong)
+#endif
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int row_l = blockIdx.x * TL_THREADS + (tid & ~63) + l;
+        const double qx = lane_value(p0, l), qy = lane_value(p1, l);
+        if (next_grid.start && rowmin_grid(t, row_l, qx, qy, next_det, next_grid, lane, gh)) continue;
+        DetChunk<DetT> first;
+        load_chunk(first, next_det, m_next, 0, lane);
+        rowmin_wave(t, row_l, qx, qy, next_det, m_next, lane, first);
+    }
+}
+
 // ---- conversions between the seat-major rest format and the per-slot layout of k_frame / k_link + k_track ----------
 // (a: the CURRENT parity view of the per-slot state; table row r takes seat r)
 __global__ void k_to_batch(TrackerDev a, BatchDev bd)

@@ -142,6 +142,10 @@ struct ysmr_tracker {
     const BlGains *bgains_dev = nullptr;     // the same in device memory (behind the grid blocks): k_batch reads it frame by frame
     // ysmr_tracker_prepare: which batch each of the two caller-named grid blocks was binned for (block 2 is run's own)
     struct Prepared { const void *det = nullptr; const void *count = nullptr; int batch = 0; } prepared[2];
+    // split link with a track per lane (batch_link.h: k_track_lanes): the filter state of a non-fused handle lives seat-major by
+    // slot in `bd` from the start; the ring's head is kept here (every live track appends one measurement per frame)
+    bool lanes = false;
+    int lanes_head = 0;
     bool use_batch() const { return batchable && link_mode == 0; }
     DetGrid grid(int f) const
     {
@@ -2015,7 +2019,11 @@ int launch_update_t(ysmr_tracker *t, hipStream_t st, const DetT *det, int m, con
         else
             hipLaunchKernelGGL((k_link<DetT, false>), dim3(1), dim3(LINK_THREADS), 0, st, d, det, m, m_dev, frame, rows,
                                rows_capacity, row_count, n_rows, claim, n_before, new_cols, n_new);
-        if (d.n_f <= 3)
+        if (t->lanes) {
+            hipLaunchKernelGGL(k_track_lanes<DetT>, dim3((d.capacity + TL_THREADS - 1) / TL_THREADS), dim3(TL_THREADS), 0, st, d, t->bd,
+                               t->bgains_dev, t->lanes_head, frame, rows, rows_capacity, det, next_det, next_m_dev, next_grid);
+            t->lanes_head = (t->lanes_head + 1) & (BL_HB - 1);
+        } else if (d.n_f <= 3)
             hipLaunchKernelGGL((k_track<DetT, 3>), wgrid, dim3(256), 0, st, d, frame, rows, rows_capacity, det, next_det, -1,
                                next_m_dev, next_grid);
         else
@@ -2118,7 +2126,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     const size_t o_scal1 = take(sizeof(int) * 16), o_order1 = take(sizeof(int) * cap), o_gone1 = take(sizeof(int) * cap);
     const size_t o_rmin1 = take(sizeof(double) * cap), o_rarg1 = take(sizeof(int) * cap);
     // the batch link's rest format (seat-major) and its gain table
-    const size_t seat_cap = BL_THREADS;
+    const size_t seat_cap = capacity > BL_THREADS ? (size_t)capacity : (size_t)BL_THREADS;     // (k_batch: 768 seats; k_track_lanes: a seat per slot)
     const size_t o_ring = take(sizeof(double2) * BL_HB * seat_cap);
     const size_t o_b64 = take(sizeof(double) * BL_SF64 * seat_cap), o_b32 = take(sizeof(float) * 3 * seat_cap);
     const size_t o_bi = take(sizeof(int) * 6 * seat_cap);
@@ -2189,28 +2197,35 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
     if (t->batchable &&
         hipFuncSetAttribute((const void *)k_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->batch_lds) != hipSuccess)
         t->batchable = false;
+    // ... and the two-launch link of larger tables runs its per-track half with a track per LANE (k_track_lanes) under the same
+    // conditions on the filter bank (tuning builds: YSMR_LINK_MODE=waves keeps k_track, a wave per track, for A/B runs)
+    t->lanes = !t->fused && d.n_f <= BL_NF && d.hist_cap <= BL_HB && (!use_gsff || d.gains_decoupled) &&
+               !(mode_env && !strcmp(mode_env, "waves"));
     // the gains as the batch kernel takes them: affine in the age of a measurement (batch_link.h: bl_fir)
     std::memset(&t->bgains, 0, sizeof(t->bgains));
-    if (use_gsff && t->batchable)
-        for (int f = 0; f < d.n_f && t->batchable; ++f) {
+    if (use_gsff && (t->batchable || t->lanes)) {
+        bool affine = true;
+        for (int f = 0; f < d.n_f && affine; ++f) {
             const int N = d.n_i[f];
             const double *g = t->gains_host.data() + d.gain_off[f];
-            for (int c = 0; c < 2 && t->batchable; ++c) {
+            for (int c = 0; c < 2 && affine; ++c) {
                 auto gain = [&](int a) { return c ? g[2 * N + 2 * (N - 1 - a) + 1] : g[2 * (N - 1 - a)]; };   // age a, row c
                 const double alpha = gain(0), beta = N > 1 ? gain(0) - gain(1) : 0.0;
                 for (int a = 0; a < N; ++a)
-                    if (std::fabs(gain(a) - (alpha - beta * a)) > 1e-14 * std::fabs(alpha)) t->batchable = false;
+                    if (std::fabs(gain(a) - (alpha - beta * a)) > 1e-14 * std::fabs(alpha)) affine = false;
                 t->bgains.alpha[f][c] = alpha;
                 t->bgains.beta[f][c] = beta;
             }
         }
+        if (!affine) t->batchable = t->lanes = false;
+    }
     // the per-frame grids of a batch: sized here, once, for BL_MAX_BATCH frames (longer batches are cut to that)
     {
         const size_t per = t->batchable ? (size_t)bl_grid_dwords_max(max_det) * 4 : ysmr_tracker::grid_bytes_per_frame(max_det);
         const size_t blocks = t->batchable ? 3 : 1;      // (two for ysmr_tracker_prepare's callers, one for ysmr_tracker_run itself)
         if (t->batchable || !t->fused) {
             e = hipMalloc(&t->grid_block, per * BL_MAX_BATCH * blocks + 256);
-            if (e == hipSuccess && t->batchable) {
+            if (e == hipSuccess && (t->batchable || t->lanes)) {
                 t->bgains_dev = reinterpret_cast<const BlGains *>((char *)t->grid_block + per * BL_MAX_BATCH * blocks);
                 e = hipMemcpy((void *)t->bgains_dev, &t->bgains, sizeof(BlGains), hipMemcpyHostToDevice);
             }
@@ -2225,6 +2240,7 @@ int ysmr_tracker_create(double max_disappeared, double fps, int n_min, double n_
         }
     }
     e = hipMemset(t->block, 0, off);
+    if (e == hipSuccess && t->lanes) e = hipMemset(t->bd.i32, 0xFF, sizeof(int) * seat_cap);     // no slot's filter state belongs to a track yet
     if (e == hipSuccess && gain_doubles)
         e = hipMemcpy(b + o_gain, t->gains_host.data(), sizeof(double) * gain_doubles, hipMemcpyHostToDevice);
 
@@ -2245,6 +2261,10 @@ int ysmr_tracker_reset(ysmr_tracker *t, void *stream)
     t->par = 0;
     t->rowmin_for = nullptr;
     t->prepared[0] = t->prepared[1] = ysmr_tracker::Prepared();
+    if (t->lanes) {                    // (ids start over: a slot's old filter state must not pass for the new track 0's)
+        YSMR_HIP_CHECK(hipMemsetAsync(t->bd.i32, 0xFF, sizeof(int) * (size_t)t->bd.seat_cap, (hipStream_t)stream));
+        t->lanes_head = 0;
+    }
     t->in_batch = t->use_batch();      // (an empty table is the same in both layouts)
     hipLaunchKernelGGL(k_tracker_reset, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d);
     YSMR_LAUNCH_CHECK();
