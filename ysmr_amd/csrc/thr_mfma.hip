@@ -66,6 +66,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef TM_MEM_WAVE_N
+#define TM_MEM_WAVE_N 0
+#endif
+// Round 5, an experiment switch (-DTM_MEM_WAVE_N=1; parity-tested, NOT the default: it measures the same 230 us per 256 frames
+// as the default within 2 %, profiles/r05_ab_thr_memory_wave.log).  ONE wave of the sixteen, at priority 3 and with no tiles
+// of its own, issues every global memory instruction of the walk -- a step's gray rows as 32 LDS-DMA requests addressed on the
+// scalar unit, a step's class rows as 24 stores out of sixteen dense staging rows, the two chunks that straddle a row's ends
+// dword by dword through a side buffer -- and the other fifteen issue none.  Built because with every wave issuing its share the
+// 53 one-KB instructions of a step cost each wave 700 - 1 500 cycles of a 7 665-cycle step; what it showed is that those cycles were
+// not the limit: with the memory wave off the critical path of both phases (stamps: it waits at both barriers) the fifteen
+// others' filter and blur phases stretch to fill the step.
+constexpr bool TM_MEM_WAVE = TM_MEM_WAVE_N != 0;
 #ifndef TM_WAVES_N
 #define TM_WAVES_N 16
 #endif
@@ -81,7 +93,10 @@ constexpr int TM_ROWS = 16;                                  // rows per step (o
 constexpr int TM_MAX_PANEL = TM_MAX_PANEL_N;                 // columns per panel, a multiple of 16 (1232: 77 tiles of 16)
 constexpr int TM_MAX_TILES = TM_MAX_PANEL / 16;              // output tiles t: columns 16t .. 16t + 15 of the panel
 constexpr int TM_MAX_BLOCKS = TM_MAX_TILES + 1;              // tile column blocks u: columns 16u - 8 .. 16u + 7
-constexpr int TM_PER_WAVE = (TM_MAX_BLOCKS + TM_WAVES - 1) / TM_WAVES;   // blocks (and tiles) per wave: 5
+// blocks (and tiles) per wave: 5 -- with the memory wave, which has none: fifteen waves of five and one more for the three that share
+// the memory wave's SIMD (waves 3, 7, 11: 18 blocks beside the memory wave, 20 on the other SIMDs)
+constexpr int TM_PER_WAVE = (TM_MAX_BLOCKS + TM_WAVES - 1) / TM_WAVES + (TM_MEM_WAVE ? 1 : 0);
+static_assert(!TM_MEM_WAVE || (TM_WAVES == 16 && 5 * 15 + 3 >= TM_MAX_BLOCKS), "the memory wave's split of the blocks");
 constexpr int TM_POS = 16 * TM_MAX_BLOCKS;                   // tile positions: p = column - x0 + 8
 #ifndef TM_COL_PITCH_N
 #define TM_COL_PITCH_N 40
@@ -298,12 +313,15 @@ __device__ __forceinline__ uint32_t exact_class_wave(const uint8_t *frame, const
 struct Lds {
     _Float16 tile[TM_POS][TM_COL_PITCH];                 // blurred pixels [column position][row of a 2 x 16-row ring]
     uint8_t raw[2][TM_ROWS * TM_RAW_PITCH];              // gray rows of a step: row r, columns x0 - 24 ... at r * 16 * (chunks per row)
-    uint32_t out[TM_WAVES][TM_ROWS * TM_OUT_PITCH / 4];  // a wave's class bytes of a step
+    // a wave's class bytes of a step; with the memory wave: the step's sixteen dense rows of 16 ntiles bytes (read as one array)
+    uint32_t out[TM_WAVES][TM_MEM_WAVE ? TM_ROWS * 16 * TM_MAX_TILES / 4 / TM_WAVES : TM_ROWS * TM_OUT_PITCH / 4];
+    uint8_t side[TM_MEM_WAVE ? 2 : 1][512];              // the memory wave: the two 16-row x 16-byte chunks that straddle a row's ends, as they come from memory
     uint32_t list[TM_LIST_CAP];                          // ambiguous pixels: y << 16 | x ...
     uint16_t list_f[TM_LIST_CAP];                        // ... and their frame (the list is worked off once per workgroup)
     uint32_t n_list;
 };
 static_assert(sizeof(Lds) <= 160 * 1024, "LDS of one CU");
+static_assert(!TM_MEM_WAVE || (TM_ROWS * 16 * TM_MAX_TILES / 4) % TM_WAVES == 0, "the dense staging rows as TM_WAVES equal parts");
 static_assert(sizeof(Lds::out) >= 256 * (TM_THREADS / 16), "the exact path's windows live in the class-byte staging");
 static_assert(sizeof(Lds::out) >= 768 * TM_WAVES, "and so does the wave-per-pixel form's scratch");
 
@@ -311,7 +329,7 @@ static_assert(sizeof(Lds::out) >= 768 * TM_WAVES, "and so does the wave-per-pixe
 __device__ __forceinline__ uint32_t small_f16(int w) { return w == 0 ? 0u : w == 1 ? 0x2C00u : w == 2 ? 0x3000u : w == 3 ? 0x3200u : 0x3400u; }
 
 template <int EPS_MODE>
-__global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__restrict__ frames, uint8_t *__restrict__ cls,
+__global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_threshold_mfma(const uint8_t *__restrict__ frames, uint8_t *__restrict__ cls,
                                                                ysmr_thr::Params P)
 {
     extern __shared__ __align__(16) uint8_t lds_bytes[];
@@ -425,11 +443,13 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         const uint8_t *frame = frames + (size_t)it.f * H * W;
         uint8_t *dst = cls + (size_t)it.f * H * W;
         const int PW = it.x1 - it.x0;                       // a multiple of 4
-        const int ntiles = (PW + 15) >> 4;                  // output tiles; column blocks u = 0 .. ntiles
+        int ntiles = (PW + 15) >> 4;                        // output tiles; column blocks u = 0 .. ntiles (not const: TM_FRESH below)
         const int nch = ntiles + 4;                         // gray chunks per row
         const int nblk = (it.y1 - it.y0 + TM_ROWS - 1) / TM_ROWS;
         const bool edge_l = it.x0 == 0, edge_r = it.x1 == W;
-        const int u0 = wave * TM_PER_WAVE;                  // this wave's blocks u0 .. u0 + 4 and tiles t = u0 .. u0 + 4
+        // this wave's blocks u0 .. u0 + cnt - 1 and tiles t = u0 .. u0 + cnt - 1
+        int u0 = TM_MEM_WAVE ? 5 * wave + (wave > 3) + (wave > 7) + (wave > 11) : wave * TM_PER_WAVE;
+        int cnt = TM_MEM_WAVE ? (wave == TM_WAVES - 1 ? 0 : 5 + ((wave & 3) == 3)) : TM_PER_WAVE;
         // blurred block j holds rows yb(j) .. + 15; it is made of gray blocks j - 1 and j (rows yb(j) + 1 ...)
         auto yb = [&](int j) { return it.y0 - 8 + TM_ROWS * j; };
 
@@ -441,7 +461,23 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         // neighbours: column -1 := column 1, column W := column W - 2 -- the banded matrix of the row pass is the same everywhere.
         const int part_c = lane < 16 ? 1 : (W - (it.x0 - 24)) >> 4;
         const int part_col = it.x0 - 24 + 16 * part_c;
-        const bool part_on = wave == TM_WAVES - 1 && lane < 32 && part_c < nch && (lane < 16 ? edge_l : edge_r);
+        const bool part_lane = lane < 32 && part_c < nch && (lane < 16 ? edge_l : edge_r);
+        auto part_load = [&](int j, u32x4 &v, uint32_t &last4) __attribute__((always_inline)) {
+            const uint8_t *row = frame + (size_t)clampi(yb(j) + 1 + (lane & 15), 0, H - 1) * W;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const uint32_t *>(row + clampi(part_col + 4 * i, 0, W - 4));
+            last4 = *reinterpret_cast<const uint32_t *>(row + W - 4);
+        };
+        auto part_write = [&](int j, u32x4 v, uint32_t last4) __attribute__((always_inline)) {
+            if (lane < 16) {
+                v[1] = (v[1] & 0x00FFFFFFu) | ((v[2] << 16) & 0xFF000000u);           // column -1 := column 1
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (part_col + 4 * i == W) v[i] = (v[i] & 0xFFFFFF00u) | ((last4 >> 16) & 0xFFu);   // column W := column W - 2
+            }
+            *reinterpret_cast<u32x4 *>(&L.raw[j & 1][(lane & 15) * 16 * nch + 16 * part_c]) = v;   // (rows lie 16 nch bytes apart: the DMA's chunk order)
+        };
         // What a lane fetches does not change along the walk: chunk (r, c) of every 16-row block -- worked out once per item.
         uint32_t rq_off[TM_PIECES_PER_WAVE];               // r W + column, for blocks that lie inside the image
         bool rq_on[TM_PIECES_PER_WAVE];
@@ -486,24 +522,104 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 }
             }
             if (wave == TM_WAVES - 1) {   // the lightest wave waits for these sixteen-plus-sixteen chunks at once
-                if (part_on) {
-                    const uint8_t *row = frame + (size_t)clampi(r0 + (lane & 15), 0, H - 1) * W;
+                if (part_lane) {
                     u32x4 v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const uint32_t *>(row + clampi(part_col + 4 * i, 0, W - 4));
-                    if (lane < 16) {
-                        v[1] = (v[1] & 0x00FFFFFFu) | ((v[2] << 16) & 0xFF000000u);           // column -1 := column 1
-                    } else {
-                        const uint32_t last4 = *reinterpret_cast<const uint32_t *>(row + W - 4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (part_col + 4 * i == W) v[i] = (v[i] & 0xFFFFFF00u) | ((last4 >> 16) & 0xFFu);   // column W := column W - 2
-                    }
-                    *reinterpret_cast<u32x4 *>(&L.raw[j & 1][(lane & 15) * 16 * nch + 16 * part_c]) = v;   // (rows lie 16 nch bytes apart: the DMA's chunk order)
+                    uint32_t last4;
+                    part_load(j, v, last4);
+                    part_write(j, v, last4);
                 }
             }
             return rq_n;
         };
+
+        // The memory wave's form: block j row by row, addressed on the SCALAR unit -- a row's chunks 64 g .. 64 g + 63 are one
+        // instruction whose lanes read 16 lane bytes behind a scalar base (the clamped row, the panel's first gray column) under an
+        // execution mask that leaves out the chunks beyond the image's ends; two scalar additions, m0 and the request per piece,
+        // no vector arithmetic.  (The first build walked 64-chunk pieces across the rows with per-lane arithmetic, ~30
+        // instructions and three branches per piece: 250 cycles apiece, 5 300 per step -- profiles/r05_thr_stamps_memory_wave.log.)
+        const int c_lo = it.x0 >= 24 ? 0 : (24 - it.x0 + 15) >> 4;                          // first chunk that lies inside the row
+        const int c_hi = min(nch - 1, (W - 16 - (it.x0 - 24)) >> 4);                       // last one
+        auto lane_mask = [](int lo, int hi) -> uint64_t {                                   // lanes lo .. hi of 0 .. 63 (scalar)
+            lo = lo < 0 ? 0 : lo; hi = hi > 63 ? 63 : hi;
+            if (lo > hi) return 0ull;
+            const uint64_t upto = hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull);
+            return upto & ~((1ull << lo) - 1ull);
+        };
+        auto dma_piece = [&](uint64_t mask, uint32_t m0v, const uint8_t *sbase, uint32_t lane16) __attribute__((always_inline)) {
+            uint64_t saved;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %3, %4\n\ts_mov_b64 exec, %0"
+                         : "=&s"(saved) : "s"(mask), "s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(lane16), "s"(sbase) : "memory");
+        };
+        // sixteen consecutive rows inside the image: the request, the next row's LDS address (m0 += the row pitch), the next row's
+        // offset (a lane's += W) -- three instructions per piece under one execution mask
+        auto dma_rows16 = [&](uint64_t mask, uint32_t m0v, const uint8_t *sbase, uint32_t voff) __attribute__((always_inline)) {
+            uint64_t saved;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\ts_mov_b32 m0, %3\n\t"
+                         ".rept 16\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_add_u32 m0, m0, %6\n\tv_add_u32 %1, %5, %1\n\t.endr\n\t"
+                         "s_mov_b64 exec, %0"
+                         : "=&s"(saved), "+v"(voff) : "s"(mask), "s"(m0v), "s"(sbase), "s"(W), "s"(16 * nch) : "memory", "scc");
+        };
+        const int part_cr = (W - (it.x0 - 24)) >> 4;        // the chunk that holds column W (edge_r)
+        const bool side_l = edge_l && 1 < nch, side_r = edge_r && part_cr < nch;
+        auto request_all = [&](int j) __attribute__((always_inline)) -> int {
+#ifdef TM_DBG_NOLOAD
+            return 0;
+#endif
+            const int r0 = yb(j) + 1;
+            const bool inside = r0 >= 0 && r0 + TM_ROWS <= H;                  // (wave-uniform)
+            const uint32_t lds0 = (uint32_t)(uintptr_t)&L.raw[j & 1][0];
+            const uint64_t dma_mask0 = lane_mask(c_lo, c_hi), dma_mask1 = lane_mask(c_lo - 64, c_hi - 64);
+            const int lo = opaque_lane(lane);
+            const uint32_t lane16 = 16u * (uint32_t)lo;
+            int n = 0;
+            if (inside) {
+                const uint8_t *sbase = frame + (ptrdiff_t)r0 * W + (it.x0 - 24);
+                if (dma_mask0 != 0ull) { dma_rows16(dma_mask0, lds0, sbase, lane16); n += TM_ROWS; }
+                if (dma_mask1 != 0ull) { dma_rows16(dma_mask1, lds0 + 1024u, sbase + 1024, lane16); n += TM_ROWS; }
+            } else {
+#pragma unroll 1
+                for (int r = 0; r < TM_ROWS; ++r) {
+                    const uint8_t *sbase = frame + (ptrdiff_t)clampi(r0 + r, 0, H - 1) * W + (it.x0 - 24);     // rows above / below the image repeat its first / last row
+                    if (dma_mask0 != 0ull) { dma_piece(dma_mask0, lds0 + (uint32_t)(r * 16 * nch), sbase, lane16); ++n; }
+                    if (dma_mask1 != 0ull) { dma_piece(dma_mask1, lds0 + (uint32_t)(r * 16 * nch) + 1024u, sbase + 1024, lane16); ++n; }
+                }
+            }
+            // the chunks that straddle the row's ends: dword by dword (clamped into the row) into the side buffer, lane = 4 row + dword
+            if (side_l || side_r) {   // wave-uniform
+                const uint32_t rowoff = (uint32_t)clampi(r0 + (lo >> 2), 0, H - 1) * (uint32_t)W;
+                if (side_l) {
+                    const uint32_t off = rowoff + (uint32_t)clampi(it.x0 - 8 + 4 * (lo & 3), 0, W - 4);
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"((uint32_t)(uintptr_t)&L.side[j & 1][0]), "v"(off), "s"(frame) : "memory");
+                    ++n;
+                }
+                if (side_r) {
+                    const uint32_t off = rowoff + (uint32_t)clampi(it.x0 - 24 + 16 * part_cr + 4 * (lo & 3), 0, W - 4);
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"((uint32_t)(uintptr_t)&L.side[j & 1][256]), "v"(off), "s"(frame) : "memory");
+                    ++n;
+                }
+            }
+            return n;
+        };
+        // ... and, once they have landed: the blur's REFLECT_101 neighbours patched in (as part_write), into the rows' chunks
+        auto side_patch = [&](int j) __attribute__((always_inline)) {
+            if (part_lane) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(&L.side[j & 1][(lane < 16 ? 0 : 256) + 16 * (lane & 15)]);
+                uint32_t last4 = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) last4 = part_col + 4 * i == W ? v[i] : last4;      // (the dword asked for at column W was clamped to W - 4)
+                part_write(j, v, last4);
+            }
+        };
+        auto wait_all_but_n = [&](int n) __attribute__((always_inline)) {    // n: wave-uniform, at most 32 (two pieces per row)
+            switch (n) {
+#define TM_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+                TM_W(1) TM_W(2) TM_W(3) TM_W(4) TM_W(5) TM_W(6) TM_W(7) TM_W(8) TM_W(9) TM_W(10) TM_W(11) TM_W(12) TM_W(13) TM_W(14) TM_W(15) TM_W(16)
+                TM_W(17) TM_W(18) TM_W(19) TM_W(20) TM_W(21) TM_W(22) TM_W(23) TM_W(24) TM_W(25) TM_W(26) TM_W(27) TM_W(28) TM_W(29) TM_W(30) TM_W(31) TM_W(32)
+#undef TM_W
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        };
+        static_assert(TM_RAW_CHUNKS <= 128, "two pieces per gray row");
 
         // ---- blur: gray block j -> row sums (kept for two steps) -> tile block j ------------------------------------------
         uint32_t hst[TM_PER_WAVE][4];
@@ -512,7 +628,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
 #pragma unroll
             for (int k = 0; k < 4; ++k) hst[bi][k] = 0x64006400u;
         const bool blur_left = edge_l && u0 == 0;
-        const bool blur_right = edge_r && ((PW + 7) >> 4) >= u0 && ((PW + 7) >> 4) < u0 + TM_PER_WAVE && ((PW + 7) >> 4) <= ntiles;
+        const bool blur_right = edge_r && ((PW + 7) >> 4) >= u0 && ((PW + 7) >> 4) < u0 + cnt && ((PW + 7) >> 4) <= ntiles;
         auto blur_step = [&](int j, auto par_tag, auto sums_tag) __attribute__((always_inline)) {
 #ifdef TM_DBG_NOBLUR
             return;
@@ -609,7 +725,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
 #pragma unroll
             for (int bi = 0; bi < TM_PER_WAVE; ++bi) {
                 const int u = u0 + bi;
-                if (u <= ntiles) {   // wave-uniform
+                if (u <= ntiles && bi < cnt) {   // wave-uniform
                     u32x4 a = *reinterpret_cast<const u32x4 *>(rawp + 16 * bi);
                     a ^= 0x80808080u;
                     const i32x4 ch = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), THI, K_ROW, 0, 0, 0);
@@ -658,7 +774,9 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
 #endif
             const int oy = it.y0 + TM_ROWS * (s - 1);            // first output row
             const int lo = opaque_lane(lane), l16o = lo & 15, qo = lo >> 4;
-            uint8_t *wout = reinterpret_cast<uint8_t *>(L.out[wave]) + l16o * TM_OUT_PITCH + 4 * qo;      // this lane's dword of a tile's staging rows
+            // this lane's dword of a tile's staging rows (a block per wave; with the memory wave: dense rows of the whole panel)
+            uint8_t *wout = TM_MEM_WAVE ? reinterpret_cast<uint8_t *>(L.out) + l16o * (16 * ntiles) + 16 * u0 + 4 * qo
+                                        : reinterpret_cast<uint8_t *>(L.out[wave]) + l16o * TM_OUT_PITCH + 4 * qo;
             // window rows 8q .. 8q + 7 of this lane's column (A operand of the column pass), from the wave's first block on
             const _Float16 *colp = &L.tile[16 * u0 + l16o][(qo >> 1 ? (s & 1) : ((s - 1) & 1)) * 16 + 8 * (qo & 1)];
             uint32_t xh[4] = {0, 0, 0, 0};
@@ -667,7 +785,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
             for (int bi = 0; bi <= TM_PER_WAVE; ++bi) {
                 const int u = u0 + bi;                            // column block: positions 16u .. 16u + 15
                 const int hsel = bi & 1;
-                if (bi == 0 ? u < ntiles : u - 1 < ntiles) {      // some tile of this wave uses the block (wave-uniform)
+                if ((bi == 0 ? u < ntiles : u - 1 < ntiles) && bi <= cnt && cnt > 0) {      // some tile of this wave uses the block (wave-uniform)
                     const half8_t A = *reinterpret_cast<const half8_t *>(colp + 16 * bi * TM_COL_PITCH);
                     f32x4 cv = {0.f, 0.f, 0.f, 0.f};
 #ifndef TM_DBG_NOMFMA
@@ -681,7 +799,7 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 }
                 if (bi >= 1) {
                     const int t = u - 1, ti = bi - 1;
-                    if (t < ntiles) {   // wave-uniform
+                    if (t < ntiles && ti < cnt) {   // wave-uniform
                         // x = X (mean - b - theta_1): the taps carry X, the accumulator starts at -X theta_1 - X (b - 128)
                         // (the centre pixels: columns 16t + l16 = positions 16t + 8 + l16, this lane's window rows)
                         const half8_t Ab = *reinterpret_cast<const half8_t *>(colp + (16 * ti + 8) * TM_COL_PITCH);
@@ -810,6 +928,92 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
                 }
             }
         };
+        // The memory wave's form.  In this mode the class bytes of a step are staged as sixteen DENSE rows of 16 ntiles bytes (not a block
+        // per wave), and leave row by row behind scalar bases: chunks 0 .. 63 of a row as one 1-KB instruction, the rows' tails
+        // (chunks 64 .. and the 4-, 8- or 12-byte end of a row whose length is no multiple of 16) several rows per instruction.
+        const int stage_pitch = 16 * ntiles;
+        const int n_full = PW >> 4, rem = PW & 15;                         // whole 16-byte chunks of a row; bytes behind them
+        const int head = min(64, n_full);
+        const int tail_c0 = n_full > 64 ? 64 : n_full, tail_n = (n_full > 64 ? n_full - 64 : 0) + (rem ? 1 : 0);    // at most 14 chunks
+        static_assert(TM_MAX_TILES - 64 + 1 <= 16, "a row's tail");
+        auto store_rows = [&](int s) __attribute__((always_inline)) {
+#if defined(TM_DBG_NOFILTER) || defined(TM_DBG_NOSTORE)
+            return;
+#endif
+            const int oy = it.y0 + TM_ROWS * (s - 1);
+            const int rows = min(TM_ROWS, it.y1 - oy);                         // (below 16 in an item's last step only)
+            uint8_t *base = dst + (size_t)oy * W + it.x0;                      // (wave-uniform)
+            const uint8_t *stage = reinterpret_cast<const uint8_t *>(L.out);
+            const uint32_t l16b = 16u * (uint32_t)opaque_lane(lane);
+            // heads.  A full step of a panel of 64 chunks or more: eight rows at a time in straight-line code -- eight LDS reads (a
+            // lane's address += the staging pitch), then the eight stores as their data arrives (a lane's offset += W); 16 bytes
+            // per lane behind a scalar base.  (The compiler's version of the loop below gave every store a basic block of its own,
+            // two v_readlane for a spilled row base and a 64-bit address add: 130 cycles per store at priority 3.)
+            if (head == 64 && rows == TM_ROWS) {   // wave-uniform
+                uint32_t la = (uint32_t)(uintptr_t)stage + l16b, go = l16b;
+#pragma unroll
+                for (int r0 = 0; r0 < TM_ROWS; r0 += 8) {
+                    u32x4 t0, t1, t2, t3, t4, t5, t6, t7;
+                    asm volatile("ds_read_b128 %0, %8\n\tv_add_u32 %8, %10, %8\n\tds_read_b128 %1, %8\n\tv_add_u32 %8, %10, %8\n\t"
+                                 "ds_read_b128 %2, %8\n\tv_add_u32 %8, %10, %8\n\tds_read_b128 %3, %8\n\tv_add_u32 %8, %10, %8\n\t"
+                                 "ds_read_b128 %4, %8\n\tv_add_u32 %8, %10, %8\n\tds_read_b128 %5, %8\n\tv_add_u32 %8, %10, %8\n\t"
+                                 "ds_read_b128 %6, %8\n\tv_add_u32 %8, %10, %8\n\tds_read_b128 %7, %8\n\tv_add_u32 %8, %10, %8\n\t"
+                                 "s_waitcnt lgkmcnt(7)\n\tglobal_store_dwordx4 %9, %0, %11\n\tv_add_u32 %9, %12, %9\n\t"
+                                 "s_waitcnt lgkmcnt(6)\n\tglobal_store_dwordx4 %9, %1, %11\n\tv_add_u32 %9, %12, %9\n\t"
+                                 "s_waitcnt lgkmcnt(5)\n\tglobal_store_dwordx4 %9, %2, %11\n\tv_add_u32 %9, %12, %9\n\t"
+                                 "s_waitcnt lgkmcnt(4)\n\tglobal_store_dwordx4 %9, %3, %11\n\tv_add_u32 %9, %12, %9\n\t"
+                                 "s_waitcnt lgkmcnt(3)\n\tglobal_store_dwordx4 %9, %4, %11\n\tv_add_u32 %9, %12, %9\n\t"
+                                 "s_waitcnt lgkmcnt(2)\n\tglobal_store_dwordx4 %9, %5, %11\n\tv_add_u32 %9, %12, %9\n\t"
+                                 "s_waitcnt lgkmcnt(1)\n\tglobal_store_dwordx4 %9, %6, %11\n\tv_add_u32 %9, %12, %9\n\t"
+                                 "s_waitcnt lgkmcnt(0)\n\tglobal_store_dwordx4 %9, %7, %11\n\tv_add_u32 %9, %12, %9"
+                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "+v"(la), "+v"(go)
+                                 : "s"(stage_pitch), "s"(base), "s"(W)
+                                 : "memory");
+                }
+            } else {
+#pragma unroll 1
+                for (int r0 = 0; r0 < TM_ROWS; r0 += 4) {
+                    u32x4 v[4];
+                    if (lane < head) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const u32x4 *>(stage + (r0 + e) * stage_pitch + l16b);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (r0 + e < rows) __builtin_memcpy(base + (size_t)(r0 + e) * W + l16b, &v[e], 16);       // (wave-uniform test)
+                    }
+                }
+            }
+            // tails: at most four instructions' worth of rows (64 / tail_n >= 4 rows each), their reads first
+            if (tail_n) {   // wave-uniform
+                // rows per tail instruction: 64 / tail_n, by table (tail_n <= 16)
+                const int tail_rows = tail_n <= 4 ? TM_ROWS : (int)((0x4444556789AC0000ull >> (4 * (tail_n - 1))) & 15ull);
+                const uint32_t tail_recip = (uint32_t)(65536.0f / (float)tail_n) + 2u;       // lane / tail_n for lanes < 64
+                const int tr = (int)(((uint32_t)lane * tail_recip) >> 16), ti = lane - tr * tail_n;
+                const bool t_on = tr < tail_rows;
+                const bool t_part = rem != 0 && ti == tail_n - 1;
+                const uint32_t t_lds = (uint32_t)(tr * stage_pitch + 16 * (tail_c0 + ti)), t_g = (uint32_t)(tr * W + 16 * (tail_c0 + ti));
+                u32x4 v[4];
+                if (t_on) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k * tail_rows < rows) v[k] = *reinterpret_cast<const u32x4 *>(stage + k * tail_rows * stage_pitch + t_lds);   // (wave-uniform test; the last lanes' rows may lie beyond the step's: not stored)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int g0 = k * tail_rows;
+                        if (g0 < rows && g0 + tr < rows) {
+                            uint8_t *g = base + (size_t)g0 * W + t_g;
+                            if (!t_part) __builtin_memcpy(g, &v[k], 16);
+                            else {
+                                uint32_t *g4 = reinterpret_cast<uint32_t *>(g);
+                                g4[0] = v[k][0];
+                                if (rem >= 8) g4[1] = v[k][1];
+                                if (rem >= 12) g4[2] = v[k][2];
+                            }
+                        }
+                    }
+                }
+            }
+        };
         auto blur_any = [&](int j) __attribute__((always_inline)) {
             if (j & 1) blur_step(j, std::integral_constant<int, 1>{}, std::false_type{});
             else blur_step(j, std::integral_constant<int, 0>{}, std::false_type{});
@@ -846,42 +1050,83 @@ __global__ __launch_bounds__(TM_THREADS) void k_threshold_mfma(const uint8_t *__
         if (nblk >= 1) request_raw(1);
         blur_any(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        for (int s = 0; s <= nblk; ++s) {
-            int mine = 0;
-            TMSTAMP(s, 0);
-#ifdef YSMR_STAMPS
-            // (the shader clock under this kernel's own load: s_memrealtime counts at a constant 100 MHz)
-            if (blockIdx.x == TM_ST_BLOCK && lane == 0 && wave == 0 && (s == 3 || s == 13)) {
-                unsigned long long rt;
-                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
-                g_tm_stamps[1][s == 3 ? 18 : 19][0] = rt;
-                g_tm_stamps[1][s == 3 ? 18 : 19][1] = __builtin_amdgcn_s_memtime();
-            }
+        if constexpr (TM_MEM_WAVE) {
+            const bool is_mem = wave == TM_WAVES - 1;
+            // The memory wave issues AHEAD of the others: at equal priority each of its instructions waits its turn behind three
+            // waves' MFMAs -- 260 - 1 000 cycles per memory instruction beside busy waves, 20 - 40 at priority 3
+            // (scripts/ubench/vmem_issue.hip, profiles/r05_vmem_issue.log)
+#ifndef TM_MEM_PRIO_FLAT
+            if (is_mem) __builtin_amdgcn_s_setprio(3);
 #endif
-            // The class bytes of step s - 1 leave at the START of step s (they wait in the wave's staging rows, which only this
-            // step's tiles overwrite): a wave that stalls on its store instructions here stalls while the other waves of its SIMD
-            // have tiles to filter; behind the filter (round 4) the stall of the LAST wave to finish was the phase's last 540 - 880
-            // cycles, with every other wave already at the barrier (profiles/r05_thr_stamps_*.log).
-            if (!TM_STORE_ROWS && TM_STORE_AT_START && s >= 2) store_step(s - 1);
-            // (into the buffer the blur of step s has finished with; half of the waves ask later, inside filter_step)
-            const bool late_dma = TM_DMA_AFTER_BLOCK >= 0 && s >= 1 && s + 2 <= nblk && wave >= TM_WAVES / 2;
-            if (s + 2 <= nblk && !late_dma) mine = request_raw(s + 2);
-            TMSTAMP(s, 1);
-            if (s >= 1) filter_step(s, late_dma, mine);
-            TMSTAMP(s, 2);
-            wait_all_but(__builtin_amdgcn_readfirstlane(mine));  // the rows of step s + 1 have landed (and every older store)
-            TMSTAMP(s, 3);
-            if (!TM_STORE_ROWS && !TM_STORE_AT_START && s >= 1) store_step(s);
-            TMSTAMP(s, 4);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (TM_STORE_ROWS && s >= 1) store_step(s);        // (every wave's class bytes of the step are in LDS: whole rows leave)
-            TMSTAMP(s, 5);
-            if (s + 1 <= nblk) blur_any(s + 1);           // overwrites the tile block of step s - 1
-            TMSTAMP(s, 6);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            TMSTAMP(s, 7);
+            for (int s = 0; s <= nblk; ++s) {
+                int n_dma = 0, unused = 0;
+#ifndef TM_NO_FRESH
+                // The per-block tests (is this block / tile inside the panel, is it this wave's) are scalar comparisons of these three.
+                // Left to itself the compiler works all of them out once per item and keeps each as a 64-bit mask: dozens of scalar
+                // register pairs, spilled to vector-register lanes and fetched with two v_readlane per test inside the walk.  Opaque here,
+                // they are compared where they are used (two scalar instructions, no storage).
+                asm volatile("" : "+s"(ntiles), "+s"(cnt), "+s"(u0));
+#endif
+                TMSTAMP(s, 0);
+                if (is_mem && s + 2 <= nblk) n_dma = request_all(s + 2);       // (into the buffer the blur of step s has finished with)
+                TMSTAMP(s, 1);
+                if (s >= 1 && cnt > 0) filter_step(s, false, unused);
+                TMSTAMP(s, 2);
+                // the rows of step s + 1 have landed, and every older store has retired (vmcnt counts in issue order)
+                if (is_mem) {
+                    wait_all_but_n(n_dma);
+                    if (s >= 1 && s + 1 <= nblk) side_patch(s + 1);
+                }
+                TMSTAMP(s, 3);
+                TMSTAMP(s, 4);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // (every wave's class bytes of the step are in LDS: the rows leave, and stay in flight through the next filter)
+                if (is_mem && s >= 1) store_rows(s);
+                TMSTAMP(s, 5);
+                if (s + 1 <= nblk && cnt > 0) blur_any(s + 1);           // overwrites the tile block of step s - 1
+                TMSTAMP(s, 6);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                TMSTAMP(s, 7);
+            }
+        } else {
+        for (int s = 0; s <= nblk; ++s) {
+                int mine = 0;
+                TMSTAMP(s, 0);
+    #ifdef YSMR_STAMPS
+                // (the shader clock under this kernel's own load: s_memrealtime counts at a constant 100 MHz)
+                if (blockIdx.x == TM_ST_BLOCK && lane == 0 && wave == 0 && (s == 3 || s == 13)) {
+                    unsigned long long rt;
+                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
+                    g_tm_stamps[1][s == 3 ? 18 : 19][0] = rt;
+                    g_tm_stamps[1][s == 3 ? 18 : 19][1] = __builtin_amdgcn_s_memtime();
+                }
+    #endif
+                // The class bytes of step s - 1 leave at the START of step s (they wait in the wave's staging rows, which only this
+                // step's tiles overwrite): a wave that stalls on its store instructions here stalls while the other waves of its SIMD
+                // have tiles to filter; behind the filter (round 4) the stall of the LAST wave to finish was the phase's last 540 - 880
+                // cycles, with every other wave already at the barrier (profiles/r05_thr_stamps_*.log).
+                if (!TM_STORE_ROWS && TM_STORE_AT_START && s >= 2) store_step(s - 1);
+                // (into the buffer the blur of step s has finished with; half of the waves ask later, inside filter_step)
+                const bool late_dma = TM_DMA_AFTER_BLOCK >= 0 && s >= 1 && s + 2 <= nblk && wave >= TM_WAVES / 2;
+                if (s + 2 <= nblk && !late_dma) mine = request_raw(s + 2);
+                TMSTAMP(s, 1);
+                if (s >= 1) filter_step(s, late_dma, mine);
+                TMSTAMP(s, 2);
+                wait_all_but(__builtin_amdgcn_readfirstlane(mine));  // the rows of step s + 1 have landed (and every older store)
+                TMSTAMP(s, 3);
+                if (!TM_STORE_ROWS && !TM_STORE_AT_START && s >= 1) store_step(s);
+                TMSTAMP(s, 4);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (TM_STORE_ROWS && s >= 1) store_step(s);        // (every wave's class bytes of the step are in LDS: whole rows leave)
+                TMSTAMP(s, 5);
+                if (s + 1 <= nblk) blur_any(s + 1);           // overwrites the tile block of step s - 1
+                TMSTAMP(s, 6);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                TMSTAMP(s, 7);
+            }
+            if (!TM_STORE_ROWS && TM_STORE_AT_START && nblk >= 1) store_step(nblk);
+    
         }
-        if (!TM_STORE_ROWS && TM_STORE_AT_START && nblk >= 1) store_step(nblk);
 
         // ---- an item whose ambiguous pixels outgrew the list (a frame made to sit on the levels): all of it again, exactly ----
         const uint32_t n_now = L.n_list;
@@ -1019,7 +1264,10 @@ int launch(hipStream_t st, const uint8_t *frames, uint8_t *cls, int batch, int H
     P.panels = (W + TM_MAX_PANEL - 1) / TM_MAX_PANEL;
     P.panel_w = ((W + P.panels - 1) / P.panels + 15) & ~15;
     P.panels = (W + P.panel_w - 1) / P.panel_w;
-    const int blocks = blocks_wanted > 0 ? blocks_wanted : 256 * (int)((160 * 1024) / sizeof(Lds));   // every CU full
+    // every CU full; a build whose workgroups are small enough for several per compute unit (TM_WAVES_N = 8 with narrow panels: an
+    // experiment of round 5) takes the caller's figure as compute units
+    const int per_cu = (int)((160 * 1024) / sizeof(Lds));
+    const int blocks = (blocks_wanted > 0 ? blocks_wanted : 256) * per_cu;
     P.inv = inv; P.use_high = use_high; P.t_low = t_low; P.t_high = use_high ? t_high : t_low;
     for (int i = 0; i < 6; ++i) P.kw[i] = gauss11[i];
     // v = mean - b.  BINARY: bit = (b - m > t) <=> v < theta = -t - 0.5;  INV: bit = (b - m <= t) <=> v > theta (ties: exact path).
