@@ -123,6 +123,12 @@ constexpr bool TM_STORE_AT_START = TM_STORE_AT_START_N != 0;  // a step's class 
 #define TM_BLUR_GROUP_N 1
 #endif
 constexpr int TM_BLUR_GROUP = TM_BLUR_GROUP_N;               // blocks of the blur a wave takes through its phases together (1: one chain per block)
+#ifndef TM_PREFETCH_N
+#define TM_PREFETCH_N 1
+#endif
+// the walk's LDS reads (the filter's column and centre operands, the blur's gray bytes) an iteration ahead of their use, outside the
+// wave-uniform tests that fence every block: 232 -> 224 us per 256 frames (profiles/r05_ab_thr_prefetch.log)
+constexpr bool TM_PREFETCH = TM_PREFETCH_N != 0;
 #ifndef TM_LIST_CAP_N
 #define TM_LIST_CAP_N 248
 #endif
@@ -722,11 +728,15 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 }
                 return;
             }
+            u32x4 a_pre = {};
+            if (TM_PREFETCH) a_pre = *reinterpret_cast<const u32x4 *>(rawp);
 #pragma unroll
             for (int bi = 0; bi < TM_PER_WAVE; ++bi) {
                 const int u = u0 + bi;
+                const u32x4 a_now = a_pre;
+                if (TM_PREFETCH && bi + 1 < TM_PER_WAVE) a_pre = *reinterpret_cast<const u32x4 *>(rawp + 16 * (bi + 1));   // (the next block's gray bytes, whether it exists or not)
                 if (u <= ntiles && bi < cnt) {   // wave-uniform
-                    u32x4 a = *reinterpret_cast<const u32x4 *>(rawp + 16 * bi);
+                    u32x4 a = TM_PREFETCH ? a_now : *reinterpret_cast<const u32x4 *>(rawp + 16 * bi);
                     a ^= 0x80808080u;
                     const i32x4 ch = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), THI, K_ROW, 0, 0, 0);
                     hst[bi][2 * PAR] = ((uint32_t)ch[1] << 16) | (uint32_t)ch[0];
@@ -781,12 +791,21 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             const _Float16 *colp = &L.tile[16 * u0 + l16o][(qo >> 1 ? (s & 1) : ((s - 1) & 1)) * 16 + 8 * (qo & 1)];
             uint32_t xh[4] = {0, 0, 0, 0};
             const half8_t THh[2] = {as_half8(thh[0], thh[1], thh[2], thh[3]), as_half8(thh[2], thh[3], thh[0], thh[1])};
+            // TM_PREFETCH: the two LDS reads of an iteration -- the next block's column, the next tile's centre pixels -- are issued an
+            // iteration ahead, whatever the tests below say (a block beyond the panel reads LDS bytes nobody uses)
+            half8_t A_pre = {}, Ab_pre = {};
+            if (TM_PREFETCH) A_pre = *reinterpret_cast<const half8_t *>(colp);
 #pragma unroll
             for (int bi = 0; bi <= TM_PER_WAVE; ++bi) {
                 const int u = u0 + bi;                            // column block: positions 16u .. 16u + 15
                 const int hsel = bi & 1;
+                const half8_t A_now = A_pre, Ab_now = Ab_pre;
+                if (TM_PREFETCH && bi < TM_PER_WAVE) {
+                    A_pre = *reinterpret_cast<const half8_t *>(colp + 16 * (bi + 1) * TM_COL_PITCH);
+                    Ab_pre = *reinterpret_cast<const half8_t *>(colp + (16 * bi + 8) * TM_COL_PITCH);
+                }
                 if ((bi == 0 ? u < ntiles : u - 1 < ntiles) && bi <= cnt && cnt > 0) {      // some tile of this wave uses the block (wave-uniform)
-                    const half8_t A = *reinterpret_cast<const half8_t *>(colp + 16 * bi * TM_COL_PITCH);
+                    const half8_t A = TM_PREFETCH ? A_now : *reinterpret_cast<const half8_t *>(colp + 16 * bi * TM_COL_PITCH);
                     f32x4 cv = {0.f, 0.f, 0.f, 0.f};
 #ifndef TM_DBG_NOMFMA
                     cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, TBh, cv, 0, 0, 0);
@@ -802,9 +821,10 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     if (t < ntiles && ti < cnt) {   // wave-uniform
                         // x = X (mean - b - theta_1): the taps carry X, the accumulator starts at -X theta_1 - X (b - 128)
                         // (the centre pixels: columns 16t + l16 = positions 16t + 8 + l16, this lane's window rows)
-                        const half8_t Ab = *reinterpret_cast<const half8_t *>(colp + (16 * ti + 8) * TM_COL_PITCH);
+                        const half8_t Ab = TM_PREFETCH ? Ab_now : *reinterpret_cast<const half8_t *>(colp + (16 * ti + 8) * TM_COL_PITCH);
                         const half8_t XH = as_half8(xh[0], xh[1], xh[2], xh[3]);
 #ifndef TM_DBG_NOMFMA
+                        // (the preset ahead of the block's column pass, two independent MFMAs in flight: 232 against 226 us, dropped)
                         f32x4 c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ab, BID, K_LO, 0, 0, 0);
                         c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(THh[hsel], XH, c2, 0, 0, 0);
 #else
