@@ -1872,6 +1872,8 @@ __device__ __forceinline__ void chain_push(const HullStore &s, Chain &c, int x, 
 
 #define YSMR_PI 3.1415926535897932384626433832795
 
+// vectors_ready: vx / vy / il of every edge are in the store already (k_geometry's lanes work them out side by side)
+template <bool VECTORS_READY = false>
 __device__ void min_area_rect_hull(const HullStore &s, int n, float *rect)
 {
     float cx = 0.f, cy = 0.f, bw = 0.f, bh = 0.f, ang = 0.f;
@@ -1889,10 +1891,12 @@ __device__ void min_area_rect_hull(const HullStore &s, int n, float *rect)
             if (pty < bottom_y) { bottom_y = pty; bottom = i; }
             int nx = (i + 1 < n) ? i + 1 : 0;
             float qx = s.px(nx), qy = s.py(nx);
-            double dx = (double)qx - (double)ptx, dy = (double)qy - (double)pty;
-            s.vx(i) = (float)dx;
-            s.vy(i) = (float)dy;
-            s.il(i) = (float)(1. / sqrt(dx * dx + dy * dy));
+            if (!VECTORS_READY) {
+                double dx = (double)qx - (double)ptx, dy = (double)qy - (double)pty;
+                s.vx(i) = (float)dx;
+                s.vy(i) = (float)dy;
+                s.il(i) = (float)(1. / sqrt(dx * dx + dy * dy));
+            }
             ptx = qx; pty = qy;
         }
         float orientation = 0.f;
@@ -2071,13 +2075,64 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
     }
     __syncthreads();
     GEOSTAMP(2);
-    if (!live || sub != 0) return;
-
-    HullStore s;
+    if (!live) return;
     if (narrow) {
+        // Round 5: the two monotone chains side by side -- lane 0 of the group the max-y side (columns right -> left, within a
+        // column bottom first then top) into the point columns of the store, lane 1 the min-y side (left -> right, top then
+        // bottom) into the store's vector columns, which nobody needs yet -- then all eight lanes move the second chain behind the
+        // first and work out the edge vectors (a float64 square root and a division per edge, which lane 0 used to do one after the
+        // other), and lane 0 runs the calipers.  The same points, the same arithmetic, in the same places as the serial form.
+        HullStore s;
         s.base = lds + grp * GEO_LDS_STRIDE;
         s.stride = 1;
-    } else {
+        const int lane = threadIdx.x & 63, g0 = lane & ~(GEO_GROUP - 1);
+        int n_mine = 0;
+        if (sub < 2) {
+            HullStore sc = s;
+            if (sub == 1) sc.base = s.base + 2;               // px / py of this view are the store's vx / vy
+            Chain c{0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < bwid; ++k) {
+                const int col = sub == 0 ? bwid - 1 - k : k;
+                const int top = s_top[grp][col], bot = s_bot[grp][col];
+                if (top < 0) continue;
+                chain_push(sc, c, minx + col, sub == 0 ? bot : top);
+                chain_push(sc, c, minx + col, sub == 0 ? top : bot);
+            }
+            n_mine = c.n;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nu = __shfl(n_mine, g0), nl = __shfl(n_mine, g0 + 1);
+        // the min-y side starts at the max-y side's last point (the lexicographically first pixel): its points 1 .. nl - 1 follow
+        for (int j = 1 + sub; j < nl; j += GEO_GROUP) {
+            const float x = s.vx(j), y = s.vy(j);
+            s.px(nu - 1 + j) = x;
+            s.py(nu - 1 + j) = y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // drop the closing point (== point 0) unless the hull is a single point
+        int hn = nu - 1 + nl - 1;
+        if (hn < 1) hn = 1;
+        for (int i = sub; i < hn; i += GEO_GROUP) {
+            const int nx = (i + 1 < hn) ? i + 1 : 0;
+            const float ptx = s.px(i), pty = s.py(i), qx = s.px(nx), qy = s.py(nx);
+            const double dx = (double)qx - (double)ptx, dy = (double)qy - (double)pty;
+            s.vx(i) = (float)dx;
+            s.vy(i) = (float)dy;
+            s.il(i) = (float)(1. / sqrt(dx * dx + dy * dy));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        GEOSTAMP(3);
+        if (sub == 0) min_area_rect_hull<true>(s, hn, det_tmp + o * 5);
+        GEOSTAMP(4);
+        return;
+    }
+    if (sub != 0) return;
+
+    HullStore s;
+    {
         uint32_t need = (uint32_t)(2 * bwid + 3) * 5u;
         uint32_t off = atomicAdd(arena_used, need);
         if (off + need > arena_floats) {
@@ -2093,8 +2148,7 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
     Chain up{0, 0, 0, 0, 0, 0};
     for (int x = maxx; x >= minx; --x) {
         int top, bot;
-        if (narrow) { top = s_top[grp][x - minx]; bot = s_bot[grp][x - minx]; }
-        else column_extent(L, W, x, miny, maxy, want, top, bot);
+        column_extent(L, W, x, miny, maxy, want, top, bot);
         if (top < 0) continue;
         chain_push(s, up, x, bot);
         chain_push(s, up, x, top);
@@ -2103,8 +2157,7 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
     Chain lo{up.n - 1, up.n - 1, 0, 0, 0, 0};
     for (int x = minx; x <= maxx; ++x) {
         int top, bot;
-        if (narrow) { top = s_top[grp][x - minx]; bot = s_bot[grp][x - minx]; }
-        else column_extent(L, W, x, miny, maxy, want, top, bot);
+        column_extent(L, W, x, miny, maxy, want, top, bot);
         if (top < 0) continue;
         chain_push(s, lo, x, top);
         chain_push(s, lo, x, bot);
