@@ -2043,14 +2043,19 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
     __shared__ int s_top[GEO_COMPS][GEO_COLS], s_bot[GEO_COMPS][GEO_COLS];
     GEOSTAMP(0);
     const int grp = threadIdx.x / GEO_GROUP, sub = threadIdx.x % GEO_GROUP;
-    bool live = k < min(t.nroots[(size_t)f * NR_STRIDE], t.max_det);
-    const size_t o = live ? (size_t)f * t.max_det + k : 0;
-    if (live) live = !t.nested[o];
+    // (the component's table entries are requested beside the count that says whether rank k exists, not behind it: the
+    // kernel is a chain of round trips per component, and this was one of them)
+    const size_t o = (size_t)f * t.max_det + min(k, t.max_det - 1);
+    const int n_f = t.nroots[(size_t)f * NR_STRIDE];
+    const bool nested = t.nested[o] != 0;
+    const int order = t.order[o];
+    const int4 box = *reinterpret_cast<const int4 *>(t.bbox + o * 4);
+    const bool live = k < min(n_f, t.max_det) && !nested;
     uint32_t want = 0;
     int minx = 0, maxx = -1, miny = 0, maxy = -1;
     if (live) {
-        want = (uint32_t)t.order[o] + 1u;
-        minx = t.bbox[o * 4 + 0]; maxx = t.bbox[o * 4 + 1]; miny = t.bbox[o * 4 + 2]; maxy = t.bbox[o * 4 + 3];
+        want = (uint32_t)order + 1u;
+        minx = box.x; maxx = box.y; miny = box.z; maxy = box.w;
     }
     const int bwid = maxx - minx + 1;
     const uint32_t *L = labels + (size_t)(live ? f : 0) * g.HW;
@@ -2073,7 +2078,10 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
             }
         }
     }
-    __syncthreads();
+    // (a group's columns are written and read by lanes of ONE wave, like its hull store: no workgroup barrier anywhere in this
+    // kernel -- a wave does not wait for the tallest box of the other three's components)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     GEOSTAMP(2);
     if (!live) return;
     if (narrow) {
@@ -2187,7 +2195,8 @@ __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__rest
         const int kb = (int)(it / batch), f = (int)(it - (long long)kb * batch);
         geometry_group(labels, g, t, f, kb * GEO_COMPS + threadIdx.x / GEO_GROUP, det_tmp, arena, arena_floats,
                        arena_used, status);
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (this item's LDS reads before the next item's writes, wave by wave)
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
