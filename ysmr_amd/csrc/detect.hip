@@ -1985,15 +1985,16 @@ extern "C" int ysmr_debug_read_geo_stamps(unsigned long long *out) { return (int
 #define GEOSTAMP(k) do {} while (0)
 #endif
 
-// 8 lanes per component: lane `sub` scans columns minx+sub and minx+sub+8 of the bounding box for the top-most
-// and bottom-most pixel of the component (the only hull candidates of a column; all loads are independent, so
-// two columns cost one round trip), lane 0 then builds the chains from the (top, bottom) pairs and runs the
-// calipers.  The kernel is bound by that serial chain (~15 us per component), i.e. by how many components are
-// in flight: 8 lanes instead of 16 per component hold twice as many per resident wave (32 k at 4 blocks per
-// CU: the benchmark batch in one round instead of two).  Components wider than GEO_COLS columns take the
-// serial path with arena storage.
+// GEO_GROUP lanes per component: lane `sub` scans columns minx+sub and minx+sub+GEO_GROUP of the bounding box (then the next
+// two, for boxes wider than 2 GEO_GROUP) for the top-most and bottom-most pixel of the component (the only hull candidates of a
+// column; all loads are independent, so two columns cost one round trip); lanes 0 and 1 then build the two chains from the
+// (top, bottom) pairs side by side, all lanes the edge vectors, lane 0 runs the calipers.  The kernel is bound by that chain of
+// dependent steps per component, i.e. by how many components are in flight: 16 -> 8 lanes per component took it from 61 to 41 us
+// per 64 frames (round 2), 8 -> 4 (round 5, with the chains on two lanes: 64 components per block, 53 KB of LDS, three blocks per
+// unit) the labelling chain from 366-380 to 344-349 us per 256 frames.  Components wider than GEO_COLS columns take the serial
+// path with arena storage.
 #ifndef GEO_GROUP_N
-#define GEO_GROUP_N 8
+#define GEO_GROUP_N 4
 #endif
 constexpr int GEO_GROUP = GEO_GROUP_N;
 constexpr int GEO_COLS = 16;
