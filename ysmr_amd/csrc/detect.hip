@@ -876,7 +876,10 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
 // the class bit of four pixels), and read by the 16 windows of the tile.
 // ------------------------------------------------------------------------------------------
 constexpr int WIN_CORE = 32, WIN_MARGIN = 16;
-constexpr int WIN_GROUP = 4;                                     // cores per work item, side by side
+#ifndef WIN_GROUP_N
+#define WIN_GROUP_N 8
+#endif
+constexpr int WIN_GROUP = WIN_GROUP_N;                           // cores per work item, side by side (4, or 8: round 5)
 constexpr int WIN_HALVES = 2 * (WIN_GROUP + 1);                  // 16-pixel half-words per staged row (5 dwords, odd: lanes = rows hit 32 banks)
 // Resident grid: 4 blocks per CU.  The kernel's own time hardly depends on it (1536 .. 2560 blocks: 62 .. 66 us), but
 // every block holds 10 KB of LDS, and with 8 per CU only one of k_frame's 59 KB blocks fits next to them
@@ -1138,13 +1141,14 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
         const int f = (int)(it / per_frame) * f_mul + f_add, rem = (int)(it % per_frame);
         const int Y0 = rem / groups_x * WIN_CORE, X0 = rem % groups_x * SPAN;
         uint8_t *cf = cls + (size_t)f * g.HW;
-        static_assert(ROUNDS % 2 == 0, "two half-batches of loads");
+        constexpr int PARTS = WIN_GROUP == 4 ? 2 : 3, PER_PART = ROUNDS / PARTS;
+        static_assert(ROUNDS % PARTS == 0, "equal part-batches of loads");
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {   // (all ten loads in flight at once cost 40 VGPRs and a wave per SIMD)
-        uint4 v[ROUNDS / 2];
+        for (int half = 0; half < PARTS; ++half) {   // (all ten loads in flight at once cost 40 VGPRs and a wave per SIMD)
+        uint4 v[PER_PART];
 #pragma unroll
-        for (int jj = 0; jj < ROUNDS / 2; ++jj) {
-            const int j = jj + half * (ROUNDS / 2);
+        for (int jj = 0; jj < PER_PART; ++jj) {
+            const int j = jj + half * PER_PART;
             const int q = lane + 64 * j, r = q / WIN_HALVES, c = q - r * WIN_HALVES;
             const int y = Y0 - WIN_MARGIN + r, xs = X0 - WIN_MARGIN + 16 * c;
             uint4 &vj = v[jj];
@@ -1175,8 +1179,8 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
             }
         }
 #pragma unroll
-        for (int jj = 0; jj < ROUNDS / 2; ++jj) {
-            const int j = jj + half * (ROUNDS / 2);
+        for (int jj = 0; jj < PER_PART; ++jj) {
+            const int j = jj + half * PER_PART;
             const uint4 &vj = v[jj];
             const uint32_t m = 0x01010101u, lo = 0x08040201u, hi = 0x80402010u;   // v_dot4_u32_u8: 4 class bits -> a nibble
             const uint32_t t0 = __builtin_amdgcn_udot4(vj.x & m, lo, __builtin_amdgcn_udot4(vj.y & m, hi, 0u, false), false);
@@ -1189,26 +1193,35 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's LDS writes before its LDS reads
         __builtin_amdgcn_wave_barrier();
-        uint32_t tw[WIN_GROUP + 1], mw[WIN_GROUP + 1];
+        uint32_t tw[WIN_GROUP == 4 ? WIN_GROUP + 1 : 1], mw[WIN_GROUP == 4 ? WIN_GROUP + 1 : 1];
+        if constexpr (WIN_GROUP == 4) {
 #pragma unroll
-        for (int k = 0; k <= WIN_GROUP; ++k) {
-            tw[k] = reinterpret_cast<const uint32_t *>(st)[lane * (WIN_GROUP + 1) + k];
-            mw[k] = reinterpret_cast<const uint32_t *>(sm)[lane * (WIN_GROUP + 1) + k];
+            for (int k = 0; k <= WIN_GROUP; ++k) {
+                tw[k] = reinterpret_cast<const uint32_t *>(st)[lane * (WIN_GROUP + 1) + k];
+                mw[k] = reinterpret_cast<const uint32_t *>(sm)[lane * (WIN_GROUP + 1) + k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... and the reads before the next item's writes
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... and the reads before the next item's writes
-        __builtin_amdgcn_wave_barrier();
         WindowOut o;
         o.cls = cf; o.labels = labels + (size_t)f * g.HW; o.mask = mask ? mask + (size_t)f * g.HW : nullptr;
         o.W = W; o.H = H; o.wy0 = Y0 - WIN_MARGIN;
         o.fbase = (uint32_t)((size_t)f * g.HW);
-        static_assert(WIN_GROUP == 4, "the word selection below is written out for four cores");
+        static_assert(WIN_GROUP == 4 || WIN_GROUP == 8, "four cores (words in registers, picked by selects) or eight (words read from LDS core by core)");
 #pragma unroll 1
         for (int cx = 0; cx < WIN_GROUP; ++cx) {   // (one copy of the window code: the words are picked by selects)
             if (X0 + cx * WIN_CORE >= W) break;   // core outside the frame
-            const uint32_t t_lo = cx == 0 ? tw[0] : cx == 1 ? tw[1] : cx == 2 ? tw[2] : tw[3];
-            const uint32_t t_hi = cx == 0 ? tw[1] : cx == 1 ? tw[2] : cx == 2 ? tw[3] : tw[4];
-            const uint32_t m_lo = cx == 0 ? mw[0] : cx == 1 ? mw[1] : cx == 2 ? mw[2] : mw[3];
-            const uint32_t m_hi = cx == 0 ? mw[1] : cx == 1 ? mw[2] : cx == 2 ? mw[3] : mw[4];
+            uint32_t t_lo, t_hi, m_lo, m_hi;
+            if constexpr (WIN_GROUP == 4) {
+                t_lo = cx == 0 ? tw[0] : cx == 1 ? tw[1] : cx == 2 ? tw[2] : tw[3];
+                t_hi = cx == 0 ? tw[1] : cx == 1 ? tw[2] : cx == 2 ? tw[3] : tw[4];
+                m_lo = cx == 0 ? mw[0] : cx == 1 ? mw[1] : cx == 2 ? mw[2] : mw[3];
+                m_hi = cx == 0 ? mw[1] : cx == 1 ? mw[2] : cx == 2 ? mw[3] : mw[4];
+            } else {
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(st) + lane * (WIN_GROUP + 1) + cx;
+                const uint32_t *mp = reinterpret_cast<const uint32_t *>(sm) + lane * (WIN_GROUP + 1) + cx;
+                t_lo = tp[0]; t_hi = tp[1]; m_lo = mp[0]; m_hi = mp[1];
+            }
             const uint64_t T = (uint64_t)t_lo | ((uint64_t)t_hi << 32), M = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
             const uint64_t core_rows = (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) ? 0x0000FFFFFFFF0000ull : 0ull;
             if (__ballot(((T | M) & core_rows) != 0ull) == 0ull) continue;
@@ -1218,6 +1231,10 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
 #else
             window_islands(T, M, o, lane, f, cf, pl, t);
 #endif
+        }
+        if constexpr (WIN_GROUP != 4) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the cores' reads of the words before the next item's writes
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
