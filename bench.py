@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=512, help="distinct frames per clip (512 x 1.13 MB > 256 MiB L3)")
+    ap.add_argument("--frames", type=int, default=None, help="distinct frames per clip (default: two batches, 496 x 1.13 MB > 256 MiB L3)")
     ap.add_argument("--batch", type=int, default=None, help="frames per detection launch")
     ap.add_argument("--height", type=int, default=922)
     ap.add_argument("--width", type=int, default=1228)
@@ -78,7 +78,13 @@ def parse():
     # batch -- the threshold kernel's item starts, the link launch's state in and out and the gap to the next launch, the host's
     # calls -- are paid half / a quarter as often as at 128 / 64 (same box: 161.5 / 163.5 / 165 k frames/s, threshold kernel
     # 0.214 / 0.248 / 0.265 of the roofline, host 1.0 / 0.5 / 0.24 ms per step; profiles/r04_batch_sizes.log)
-    args.batch = args.batch or 256
+    # Round 5: as many frames as the threshold kernel has workgroups beside the batch link (248: ysmr_threshold_workgroups) -- every
+    # workgroup takes one whole frame and starts one item; 256 frames on 248 workgroups start two each (0.344 instead of 0.327 of
+    # the roofline, same frames/s: profiles/r05_batch_248.log).  Detection only: 256 workgroups, 256 frames.
+    if not args.batch:
+        from ysmr_amd import _lib
+        args.batch = 256 if args.detect_only else int(_lib.lib().ysmr_threshold_workgroups(_lib.BESIDE_BATCH_LINK))
+    args.frames = args.frames or 2 * args.batch
     return args
 
 

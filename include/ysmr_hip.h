@@ -42,7 +42,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   13
+#define YSMR_ABI_VERSION   14
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -147,6 +147,13 @@ int ysmr_threshold_batch(void *stream, const uint8_t *frames_dev, int batch, int
  * Events recorded on the stream before and after the call also count the dispatch gaps on both sides (~10 us of a
  * 100 us kernel).  Not used by the mean-gray call. */
 int ysmr_threshold_timing(void *start_event, void *stop_event);
+/* How many workgroups the matrix-pipe threshold kernel cuts a batch's rows for under these hints (256: one per compute
+ * unit; 248 beside the one-launch batch link; 160 beside the two-launch link) -- what a caller needs to size its batches:
+ * with as many frames per batch as workgroups (of one panel each: frames up to 1232 columns wide) every workgroup takes ONE
+ * whole frame and starts one item, where 256 frames on 248 workgroups start two (the kernel is 5 % faster per frame that way:
+ * 0.344 instead of 0.327 of the roofline, profiles/r05_batch_248.log).  ABI 14.  No reference counterpart (the reference
+ * thresholds frame by frame, track_eval.py:180-208). */
+int ysmr_threshold_workgroups(int cv_flavour);
 
 /* The same call with the kernel named (test and measurement aid; the results are the same bytes whichever is taken).
  * Gray frames of at least 18 rows and 64 columns (width a multiple of 4) are served by a kernel that evaluates the

@@ -23,6 +23,7 @@ out = {"kernel": "k_threshold_strip", "batch": B, "height": H, "width": W,
 json.dump(out, open(os.path.join(root, "profiles", "threshold_pmc.json"), "w"), indent=1)
 print(f"k_threshold_strip: read {rd / 1e6:.1f} MB + written {wr / 1e6:.1f} MB = {(rd + wr) / (2 * B * H * W):.2f} x algorithmic")
 if s.get("mfma_FETCH_SIZE") is not None:
+    B = int(os.environ.get("PMC_BATCH_MFMA", "248"))     # (the matrix-pipe kernel's launches: bench.py's batch beside the batch link)
     rd, wr = s["mfma_FETCH_SIZE"] * 1024 / rf, s["mfma_WRITE_SIZE"] * 1024 / wf
     out = {"kernel": "k_threshold_mfma", "batch": B, "height": H, "width": W, "FETCH_SIZE_KB_raw": s["mfma_FETCH_SIZE"],
            "WRITE_SIZE_KB_raw": s["mfma_WRITE_SIZE"], "calibration": out["calibration"],

@@ -160,8 +160,11 @@ def test_beside_link_hint_changes_no_byte(torch_cuda):
             assert torch.equal(a, b)
 
 
-def test_bench_launch_shape_256_frames_beside_the_batch_link(torch_cuda, oracle):
-    """The launch shape bench.py and track_bacteria really use: detection of 256 frames of
+@pytest.mark.parametrize("n", [256, 248])
+def test_bench_launch_shape_256_frames_beside_the_batch_link(torch_cuda, oracle, n):
+    """(n = 248, since round 5 what bench.py and track_bacteria launch: as many frames as workgroups, a whole frame each; n = 256,
+    round 4's shape and any caller's who names that batch: ranges that end inside frames.)
+    The launch shape bench.py and track_bacteria really use: detection of 256 frames of
     1228 x 922 in ONE call with YSMR_BESIDE_BATCH_LINK -- 248 workgroups of the matrix-pipe kernel, their rows cut into
     unequal ranges by TM_START_ROWS, items that start in the middle of a frame -- gives, byte for byte, the class map, mask,
     label map, detections and anchors of the default grid (256 workgroups, whole columns; its parity with the oracle on
@@ -170,7 +173,7 @@ def test_bench_launch_shape_256_frames_beside_the_batch_link(torch_cuda, oracle)
     from ysmr_amd.detect import Detector, threshold_params
     from ysmr_amd.synth import SyntheticVideo
     torch = torch_cuda
-    h, w, n = 922, 1228, 256
+    h, w = 922, 1228
     p = threshold_params(True, 5, 2.0)
     frames = SyntheticVideo(h, w, 500, seed=6).frames(n)
     dev = torch.from_numpy(frames).cuda()
@@ -180,7 +183,7 @@ def test_bench_launch_shape_256_frames_beside_the_batch_link(torch_cuda, oracle)
     for a, b in zip(plain, beside):
         assert torch.equal(a, b)
     got = dict(zip(("cls", "mask", "labels", "det_count", "det", "anchors", "status"), (t.cpu().numpy() for t in beside)))
-    for f in (0, 1, 8, 9, 16, 127, 255):       # (with 31 workgroups per XCD on 32 frames, a range ends inside frames 8 k + xcd)
+    for f in (0, 1, 8, 9, 16, 127, n - 1):     # (with 31 workgroups per XCD on 32 frames, a range ends inside frames 8 k + xcd)
         one = {k: v[f:f + 1] for k, v in got.items()}
         _compare(oracle, frames[f:f + 1], one, p, max_det=2048)
 

@@ -363,8 +363,9 @@ def test_bench_argument_presets(monkeypatch):
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert (a.gpus, a.steps, a.warmup, a.height, a.width, a.blobs, a.batch, a.detect_only, a.adt) == \
-        (1, 5, 1, 922, 1228, 500, 256, False, 2.0)
+    # (248 frames per batch: one per workgroup of the threshold kernel beside the batch link; two batches per step)
+    assert (a.gpus, a.steps, a.warmup, a.height, a.width, a.blobs, a.batch, a.frames, a.detect_only, a.adt) == \
+        (1, 5, 1, 922, 1228, 500, 248, 496, False, 2.0)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "2", "--config", "4"])
     a = bench.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 3, 2)
@@ -372,7 +373,8 @@ def test_bench_argument_presets(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "4", "--batch", "8"])
     assert bench.parse().batch == 8
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "1"])
-    assert bench.parse().detect_only
+    a = bench.parse()
+    assert a.detect_only and (a.batch, a.frames) == (256, 512)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "0"])
     assert bench.parse().blobs == 50
 
@@ -380,8 +382,9 @@ def test_bench_argument_presets(monkeypatch):
 def test_frames_per_batch_follow_the_frame_size():
     """track_bacteria's batch when neither the call nor the settings name one: ~300 MB of frames, 16 ... 256."""
     from ysmr_amd.track_eval import auto_batch
-    assert auto_batch(922, 1228) == 256 and auto_batch(2160, 3840) == 32 and auto_batch(2160, 3840, 3) == 16
-    assert auto_batch(200, 260) == 256 and auto_batch(8000, 8000) == 16 and auto_batch(1080, 1920) == 144
+    # (248 = ysmr_threshold_workgroups beside the batch link: a frame per workgroup, not 256 frames on 248 workgroups)
+    assert auto_batch(922, 1228) == 248 and auto_batch(2160, 3840) == 32 and auto_batch(2160, 3840, 3) == 16
+    assert auto_batch(200, 260) == 248 and auto_batch(8000, 8000) == 16 and auto_batch(1080, 1920) == 144
 
 
 def test_ysmr_rejects_missing_paths_without_a_gpu(tmp_path, caplog):

@@ -49,10 +49,10 @@ def cv_flavour_of(version):
 ROW_DTYPE = np.dtype([("frame", "<i4"), ("track_id", "<i4"), ("x", "<f8"), ("y", "<f8"),
                       ("w", "<f4"), ("h", "<f4"), ("angle", "<f4"), ("disappeared", "<i4")])
 
-ABI_VERSION = 13   # YSMR_ABI_VERSION of include/ysmr_hip.h these argtypes were written against
+ABI_VERSION = 14   # YSMR_ABI_VERSION of include/ysmr_hip.h these argtypes were written against
 
 EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_detect_workspace_init",
-           "ysmr_threshold_batch", "ysmr_threshold_batch_variant", "ysmr_threshold_timing", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
+           "ysmr_threshold_batch", "ysmr_threshold_batch_variant", "ysmr_threshold_timing", "ysmr_threshold_workgroups", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_fused", "ysmr_tracker_batched", "ysmr_tracker_link_mode", "ysmr_tracker_prepare", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
@@ -130,6 +130,7 @@ def lib():
     L.ysmr_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci]
     L.ysmr_threshold_batch_variant.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci]
     L.ysmr_threshold_timing.argtypes = [vp, vp]
+    L.ysmr_threshold_workgroups.argtypes = [ctypes.c_int]
     L.ysmr_mean_threshold_state_bytes.argtypes = [ci]
     L.ysmr_mean_threshold_state_bytes.restype = ctypes.c_size_t
     L.ysmr_mean_threshold_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, cd, ci, vp, vp, vp, vp, ci]

@@ -2382,6 +2382,13 @@ const Knobs &knobs()
     return k;
 }
 
+// workgroups of the matrix-pipe threshold kernel under the caller's hints (0: one per compute unit, thr_mfma's own choice)
+static int threshold_workgroups(int cv_flavour)
+{
+    return (cv_flavour & YSMR_BESIDE_BATCH_LINK) ? 248 : ((cv_flavour & YSMR_BESIDE_SPLIT_LINK) ? 160 : 0);
+}
+
+
 thread_local hipEvent_t t_thr_events[2] = {nullptr, nullptr};   // ysmr_threshold_timing -> the next launch_threshold of this thread
 
 // variant: 0 = the shipped choice of kernel; 1 = strip / tile kernels only (bit-exact float32 chain for every pixel);
@@ -2397,7 +2404,7 @@ int launch_threshold(hipStream_t st, const uint8_t *frames, int batch, int H, in
     const bool timed = ev0 || ev1;
     if (variant != 1 && ysmr_thr::supported(H, W, channels, t_low, t_high, use_high))
         return ysmr_thr::launch(st, frames, cls, batch, H, W, inv, t_low, t_high, use_high, gk.k,
-                                knobs().thr_blocks > 0 ? knobs().thr_blocks : ((cv_flavour & YSMR_BESIDE_BATCH_LINK) ? 248 : ((cv_flavour & YSMR_BESIDE_SPLIT_LINK) ? 160 : 0)),
+                                knobs().thr_blocks > 0 ? knobs().thr_blocks : threshold_workgroups(cv_flavour),
                                 variant >= 2 ? variant - 1 : 0, ev0, ev1);
     if (variant >= 2) return ysmr::fail(YSMR_ERR_ARG, "the matrix-pipe threshold kernel does not serve this geometry");
     const int t_gap = use_high ? (t_high > t_low ? t_high - t_low : t_low - t_high) : 0;
@@ -2481,6 +2488,12 @@ int ysmr_threshold_timing(void *start_event, void *stop_event)
     t_thr_events[0] = (hipEvent_t)start_event;
     t_thr_events[1] = (hipEvent_t)stop_event;
     return YSMR_OK;
+}
+
+int ysmr_threshold_workgroups(int cv_flavour)
+{
+    const int n = threshold_workgroups(cv_flavour);
+    return n > 0 ? n : 256;
 }
 
 int ysmr_threshold_batch_variant(void *stream, const uint8_t *frames_dev, int batch, int height, int width, int channels,
