@@ -81,6 +81,12 @@ def parse():
     # Round 5: as many frames as the threshold kernel has workgroups beside the batch link (248: ysmr_threshold_workgroups) -- every
     # workgroup takes one whole frame and starts one item; 256 frames on 248 workgroups start two each (0.344 instead of 0.327 of
     # the roofline, same frames/s: profiles/r05_batch_248.log).  Detection only: 256 workgroups, 256 frames.
+    # (resolve_batch, called once the library may be loaded: parse() must not touch it -- main() builds it in a child process first)
+    return args
+
+
+def resolve_batch(args):
+    """Frames per detection batch and per clip when the command line names none (see parse())."""
     if not args.batch:
         from ysmr_amd import _lib
         args.batch = 256 if args.detect_only else int(_lib.lib().ysmr_threshold_workgroups(_lib.BESIDE_BATCH_LINK))
@@ -165,6 +171,7 @@ def main():
     from ysmr_amd.synth import SyntheticVideo
     from ysmr_amd.track_eval import TrackingPipeline
 
+    resolve_batch(args)
     F, B, H, W, S = args.frames, args.batch, args.height, args.width, max(1, args.streams_per_gpu)
     fps_video = 30.0
     settings = default_settings()                    # tracking.ini defaults: offset 5, adt 2.0, GSFF 10/20/30

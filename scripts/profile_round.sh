@@ -17,12 +17,12 @@ if [ -z "$SKIP_PMC" ]; then   # (SKIP_PMC=1: the threshold kernels have not chan
 #  (--beside: 248 workgroups, and since the end of round 5 248 frames per launch: a frame per workgroup); variant 1 = k_threshold_strip, 256 frames)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_thr_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 1 --batch 256 > $O/pmc_thr_$c.log 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_mfma_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 --beside --batch 248 > $O/pmc_mfma_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_mfma_$c -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 --beside --batch 248 --frames 496 > $O/pmc_mfma_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_cal_$c -- $R/scripts/ubench/copy_calib > $O/pmc_cal_$c.log 2>&1
 done
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_thr_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 1 --batch 256 > $O/pmc_thr_SQ.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_mfma_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 --beside --batch 248 > $O/pmc_mfma_SQ.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_mfma_SQ2 -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 --beside --batch 248 > $O/pmc_mfma_SQ2.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_mfma_SQ -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 --beside --batch 248 --frames 496 > $O/pmc_mfma_SQ.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_mfma_SQ2 -- python3 $R/scripts/bench_threshold.py --reps 1 --real --variant 0 --beside --batch 248 --frames 496 > $O/pmc_mfma_SQ2.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 O = "$O"

@@ -363,6 +363,8 @@ def test_bench_argument_presets(monkeypatch):
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
+    assert a.batch is None and a.frames is None          # (parse() does not load the library: main() builds it first)
+    a = bench.resolve_batch(a)
     # (248 frames per batch: one per workgroup of the threshold kernel beside the batch link; two batches per step)
     assert (a.gpus, a.steps, a.warmup, a.height, a.width, a.blobs, a.batch, a.frames, a.detect_only, a.adt) == \
         (1, 5, 1, 922, 1228, 500, 248, 496, False, 2.0)
@@ -373,7 +375,7 @@ def test_bench_argument_presets(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "4", "--batch", "8"])
     assert bench.parse().batch == 8
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "1"])
-    a = bench.parse()
+    a = bench.resolve_batch(bench.parse())
     assert a.detect_only and (a.batch, a.frames) == (256, 512)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "0"])
     assert bench.parse().blobs == 50
