@@ -42,7 +42,7 @@ extern "C" {
 #define YSMR_ERR_CAPACITY  3   /* a fixed-capacity buffer would overflow (tracks, workspace) */
 #define YSMR_ERR_STATE     4   /* handle used in the wrong state */
 
-#define YSMR_ABI_VERSION   14
+#define YSMR_ABI_VERSION   15
 
 /* per-frame detection status bits (status_dev) */
 #define YSMR_DET_OVERFLOW  1   /* more components than max_det: detections truncated */
@@ -332,6 +332,25 @@ int    ysmr_rows_write_csv(const ysmr_row *rows_host, long long n_rows, int with
 int    ysmr_rows_write_csv_columns(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas,
                                    int threads, const char *path, size_t *out_length, uint32_t *track_id, uint32_t *t,
                                    double *x, double *y, double *w, double *h, double *angle);
+
+/* DEVICE function (ABI 15): the same csv text and the same seven columns worked out ON THE DEVICE from rows that are already there
+ * in order (ysmr_rows_sort's output) -- a thread prints a row (shortest round-trip digits by Burger & Dybvig's free-format
+ * algorithm in 128-bit fixed point, CPython's layout, pandas' float converter, csrc/fmt.h), a scan places the rows, a second
+ * launch packs them behind the header.  Asynchronous on `stream`.  csv_capacity >= ysmr_rows_csv_bound(n_rows, with_header);
+ * *csv_length_dev receives the number of bytes; *unserved_dev counts the rows that hold a value the device form does not print
+ * (NaN, infinities, |v| outside 2^-20 .. 2^24 other than zero: not something a track produces) -- if it is not 0 the text and
+ * columns are incomplete and the caller takes ysmr_rows_write_csv_columns for the table.  Byte for byte and bit for bit what
+ * that host function gives otherwise (track_eval.py:393, helper_file.py:1403-1478, 860-905, 1366-1400). */
+size_t ysmr_rows_format_device_workspace_bytes(long long n_rows);
+int    ysmr_rows_format_device(void *stream, const ysmr_row *rows_dev, long long n_rows, int with_header, int via_pandas,
+                               void *workspace_dev, size_t workspace_bytes, char *csv_dev, size_t csv_capacity,
+                               unsigned long long *csv_length_dev, uint32_t *track_id_dev, uint32_t *t_dev, double *x_dev,
+                               double *y_dev, double *w_dev, double *h_dev, double *angle_dev, uint32_t *unserved_dev);
+/* HOST function: the device form's arithmetic (csrc/fmt.h) run on the host a row at a time -- what the CPU tests compare with
+ * ysmr_rows_format_csv (std::to_chars) on millions of values.  columns5: five arrays of n_rows doubles, one behind the other
+ * (may be NULL); *unserved as above (such rows are left out of the text). */
+int    ysmr_rows_format_csv_devicelike(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas, char *out,
+                                       size_t out_capacity, size_t *out_length, double *columns5, long long *unserved);
 
 /* HOST functions (ABI 13): the same csv and columns worked out WHILE the video runs.  Rows go in as the link emits them -- any
  * number of ysmr_rows_stream_push calls with host rows in any order; a call copies its rows and returns, the stream's threads

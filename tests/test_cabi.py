@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ysmr_abi_version() == int(re.search(r"#define YSMR_ABI_VERSION\s+(\d+)", header).group(1)) == 14
+    assert lib.ysmr_abi_version() == int(re.search(r"#define YSMR_ABI_VERSION\s+(\d+)", header).group(1)) == 15
 
 
 def test_row_struct_layout():

@@ -790,6 +790,62 @@ def test_rows_printed_while_the_video_runs_leave_the_same_file_and_table(tmp_pat
         assert open(got[4], "rb").read() == want_bytes
 
 
+def test_rows_printed_on_the_device_leave_the_same_file_and_table(tmp_path):
+    """Round 5: ``track_bacteria`` prints its ordered rows on the device (``ysmr_rows_format_device``: csv text and the
+    DataFrame's columns, csrc/fmt.h) -- against the host path ('hip print rows on device' = False, ``ysmr_rows_write_csv_columns``):
+    the same csv byte for byte, the same DataFrame bit for bit (helper_file.py:1403-1478, 860-905, 1366-1400)."""
+    from ysmr_amd.synth import SyntheticVideo
+    from ysmr_amd.track_eval import track_bacteria
+    frames = SyntheticVideo(300, 400, 60, seed=18).frames(96)
+    path = tmp_path / "clip.npy"
+    np.save(path, frames)
+    for name in "ab":
+        (tmp_path / name).mkdir()
+    want = track_bacteria(str(path), settings=_settings(**{"hip print rows on device": False}), result_folder=str(tmp_path / "a"), batch=16)
+    got = track_bacteria(str(path), settings=_settings(), result_folder=str(tmp_path / "b"), batch=16)
+    assert want is not None and got is not None
+    assert got[0].equals(want[0]) and list(got[0].dtypes) == list(want[0].dtypes) and len(got[0]) > 3000
+    for c in ("POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE"):
+        np.testing.assert_array_equal(got[0][c].to_numpy().view(np.uint64), want[0][c].to_numpy().view(np.uint64))
+    assert open(got[4], "rb").read() == open(want[4], "rb").read()
+
+
+def test_device_formatter_against_the_host_formatter_on_a_large_table(tmp_path):
+    """``ysmr_rows_format_device`` on 400 000 rows of mixed values (uniform, float32-widened: ties, halves, negative, zeros, the
+    neighbours of powers of two) against ``ysmr_rows_write_csv_columns``: file and columns identical; a table with a NaN is
+    declined (``None``: the caller takes the host path), an empty table is its header."""
+    import torch
+    from ysmr_amd import _lib
+    from ysmr_amd.helper_file import rows_device_to_csv_file_and_dataframe, rows_to_csv_file_and_dataframe
+    rng = np.random.default_rng(33)
+    n = 400000
+    rows = np.zeros(n, _lib.ROW_DTYPE)
+    rows["track_id"] = np.arange(n) // 200
+    rows["frame"] = np.arange(n) % 200
+    powers = np.ldexp(1.0, np.arange(-20, 24))
+    edge = np.concatenate([powers, np.nextafter(powers, 0)[1:], np.nextafter(powers, np.inf), [0.0, -0.0, 0.1, 0.5, 1e-5, 123456.789]])
+    rows["x"] = np.where(rng.random(n) < 0.5, rng.uniform(-5, 1300, n), rng.uniform(0, 4000, n).astype(np.float32).astype(np.float64))
+    rows["x"][:len(edge)] = edge
+    rows["y"] = rng.integers(0, 4000, n) + rng.choice([0, 0.5, 0.25, 0.125, 0.1, 0.3], n)
+    rows["w"], rows["h"] = rng.uniform(0, 40, n).astype(np.float32), rng.uniform(0, 40, n).astype(np.float32)
+    rows["angle"] = rng.uniform(-90, 90, n).astype(np.float32)
+    dev = torch.from_numpy(rows.view(np.uint8).copy()).cuda()
+    for via in (True, False):
+        a, b = tmp_path / "host.csv", tmp_path / "device.csv"
+        len_h, df_h = rows_to_csv_file_and_dataframe(rows, str(a), via_pandas=via)
+        made = rows_device_to_csv_file_and_dataframe(dev, n, str(b), via_pandas=via)
+        assert made is not None and made[0] == len_h
+        assert a.read_bytes() == b.read_bytes()
+        assert made[1].equals(df_h) and list(made[1].dtypes) == list(df_h.dtypes)
+        for c in ("POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE"):
+            np.testing.assert_array_equal(made[1][c].to_numpy().view(np.uint64), df_h[c].to_numpy().view(np.uint64))
+    rows["y"][12345] = np.nan
+    assert rows_device_to_csv_file_and_dataframe(torch.from_numpy(rows.view(np.uint8).copy()).cuda(), n, None) is None
+    empty = rows_device_to_csv_file_and_dataframe(dev, 0, str(tmp_path / "empty.csv"))
+    assert empty is not None and len(empty[1]) == 0
+    assert (tmp_path / "empty.csv").read_bytes() == b"TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE\n"
+
+
 def test_no_live_track_in_the_last_frame_means_nothing_tracked(tmp_path, caplog):
     """track_eval.py:387-392: the reference asks the LAST frame's tracker output for its last object id, so a
     video that ends on more than a second of empty frames 'did not track any objects' (the list is on disk)."""

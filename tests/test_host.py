@@ -696,3 +696,53 @@ def test_row_stream_equals_sorting_then_writing(tmp_path):
                     if not header:
                         want = want[want.index(b"\n") + 1:]
                     assert length == len(want) and path.read_bytes() == want, (name, via, pieces, header)
+
+
+def _devicelike(rows, header, via_pandas):
+    import ctypes
+    from ysmr_amd import _lib
+    L = _lib.lib()
+    n = len(rows)
+    cap = int(L.ysmr_rows_csv_bound(n, int(header)))
+    out = np.empty(cap, np.uint8)
+    cols = np.empty((5, n), np.float64)
+    length, bad = ctypes.c_size_t(0), ctypes.c_longlong(0)
+    _lib.check(L.ysmr_rows_format_csv_devicelike(rows.ctypes.data, n, int(header), int(via_pandas), out.ctypes.data, cap,
+                                                 ctypes.byref(length), cols.ctypes.data, ctypes.byref(bad)), "devicelike")
+    return out[:length.value].tobytes(), cols, int(bad.value)
+
+
+def test_device_formatter_arithmetic_equals_the_host_formatter():
+    """csrc/fmt.h -- the shortest round-trip digits of Burger & Dybvig's free-format algorithm in 128-bit fixed point, CPython's
+    layout, pandas' float converter: what ysmr_rows_format_device runs per thread -- on the HOST against ysmr_rows_format_csv
+    (std::to_chars + the pandas restatement, itself pinned against pandas above): the same bytes and the same column values,
+    on uniform values, values spread over the served exponents, float32 values widened to float64 (their exact expansions end
+    in a 5: real ties, to the even digit), halves and tenths, negative values, zeros, the neighbours of every power of two;
+    values outside 2^-20 .. 2^24, NaN and infinities are counted as unserved and their rows left out
+    (helper_file.py:1403-1478, 860-905, 1366-1400)."""
+    from ysmr_amd.helper_file import rows_to_csv_bytes, rows_to_dataframe
+    rng = np.random.default_rng(12)
+    n = 150000
+    powers = np.ldexp(1.0, np.arange(-20, 24))
+    pools = [rng.uniform(0, 1300, n), rng.uniform(0, 1, n) * 10.0 ** rng.integers(-5, 7, n),
+             np.ldexp(rng.uniform(0.5, 1, n), rng.integers(-19, 24, n)), rng.uniform(0, 4000, n).astype(np.float32).astype(np.float64),
+             rng.integers(0, 4000, n) + rng.choice([0, 0.5, 0.25, 0.125, 0.1, 0.3], n), -rng.uniform(0, 100, n),
+             np.resize(np.concatenate([powers, np.nextafter(powers, 0), np.nextafter(powers, np.inf), 1.5 * powers, [0.0, -0.0]]), n)]
+    for k, pool in enumerate(pools):
+        rows = _random_rows(n, 20 + k)
+        x = pool.copy()
+        x[(np.abs(x) < 2.0 ** -20) & (x != 0)] = 1.0          # (the served range; the unserved cases are below)
+        x[np.abs(x) >= 2.0 ** 24] = 2.0
+        rows["x"], rows["y"] = x, x[::-1]
+        for via_pandas in (False, True):
+            text, cols, bad = _devicelike(rows, True, via_pandas)
+            assert bad == 0
+            assert text == rows_to_csv_bytes(rows, header=True, via_pandas=via_pandas, threads=4), (k, via_pandas)
+            if via_pandas:
+                df = rows_to_dataframe(rows)
+                for j, name in enumerate(("POSITION_X", "POSITION_Y", "WIDTH", "HEIGHT", "DEGREES_ANGLE")):
+                    np.testing.assert_array_equal(cols[j].view(np.uint64), df[name].to_numpy().view(np.uint64))
+    rows = _random_rows(1000, 3)
+    rows["x"][:6] = [np.nan, np.inf, -np.inf, 1e-9, 2.0 ** 24, 5e-324]
+    text, _, bad = _devicelike(rows, False, True)
+    assert bad == 6 and text == rows_to_csv_bytes(rows[6:], header=False, via_pandas=True)

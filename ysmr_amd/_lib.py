@@ -49,14 +49,14 @@ def cv_flavour_of(version):
 ROW_DTYPE = np.dtype([("frame", "<i4"), ("track_id", "<i4"), ("x", "<f8"), ("y", "<f8"),
                       ("w", "<f4"), ("h", "<f4"), ("angle", "<f4"), ("disappeared", "<i4")])
 
-ABI_VERSION = 14   # YSMR_ABI_VERSION of include/ysmr_hip.h these argtypes were written against
+ABI_VERSION = 15   # YSMR_ABI_VERSION of include/ysmr_hip.h these argtypes were written against
 
 EXPORTS = ("ysmr_abi_version", "ysmr_last_error", "ysmr_detect_workspace_bytes", "ysmr_detect_workspace_init",
            "ysmr_threshold_batch", "ysmr_threshold_batch_variant", "ysmr_threshold_timing", "ysmr_threshold_workgroups", "ysmr_mean_threshold_state_bytes", "ysmr_mean_threshold_batch",
            "ysmr_components_batch", "ysmr_detect_batch", "ysmr_gsff_gains", "ysmr_tracker_create", "ysmr_tracker_destroy",
            "ysmr_tracker_reset", "ysmr_tracker_update", "ysmr_tracker_run", "ysmr_tracker_fused", "ysmr_tracker_batched", "ysmr_tracker_link_mode", "ysmr_tracker_prepare", "ysmr_tracker_peek",
            "ysmr_tracker_info", "ysmr_rows_sort_workspace_bytes", "ysmr_rows_sort", "ysmr_rows_csv_bound",
-           "ysmr_rows_format_csv", "ysmr_rows_write_csv", "ysmr_rows_write_csv_columns", "ysmr_rows_stream_create", "ysmr_rows_stream_push", "ysmr_rows_stream_count", "ysmr_rows_stream_finish", "ysmr_rows_stream_destroy", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks",
+           "ysmr_rows_format_csv", "ysmr_rows_write_csv", "ysmr_rows_write_csv_columns", "ysmr_rows_format_device_workspace_bytes", "ysmr_rows_format_device", "ysmr_rows_format_csv_devicelike", "ysmr_rows_stream_create", "ysmr_rows_stream_push", "ysmr_rows_stream_count", "ysmr_rows_stream_finish", "ysmr_rows_stream_destroy", "ysmr_rows_columns", "ysmr_select_workspace_bytes", "ysmr_select_tracks",
            "ysmr_evaluate_workspace_bytes", "ysmr_evaluate_tracks", "ysmr_unpack_dib_batch", "ysmr_file_read")
 
 SELECT_OK, SELECT_TOO_SHORT, SELECT_TOO_SHORT_CLEANED, SELECT_NONE = 0, 1, 2, 3
@@ -159,6 +159,11 @@ def lib():
     L.ysmr_file_read.argtypes = [ci, vp, ctypes.c_size_t, ctypes.c_longlong, ci]
     L.ysmr_rows_write_csv.argtypes = [vp, ctypes.c_longlong, ci, ci, ci, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
     L.ysmr_rows_write_csv_columns.argtypes = [vp, ctypes.c_longlong, ci, ci, ci, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)] + [vp] * 7
+    L.ysmr_rows_format_device_workspace_bytes.argtypes = [ctypes.c_longlong]
+    L.ysmr_rows_format_device_workspace_bytes.restype = ctypes.c_size_t
+    L.ysmr_rows_format_device.argtypes = [vp, vp, ctypes.c_longlong, ci, ci, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp] + [vp] * 7 + [vp]
+    L.ysmr_rows_format_csv_devicelike.argtypes = [vp, ctypes.c_longlong, ci, ci, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), vp,
+                                                  ctypes.POINTER(ctypes.c_longlong)]
     L.ysmr_rows_stream_create.argtypes = [ci, ci, ctypes.POINTER(vp)]
     L.ysmr_rows_stream_push.argtypes = [vp, vp, ctypes.c_longlong]
     L.ysmr_rows_stream_count.argtypes = [vp]

@@ -30,6 +30,7 @@
 
 #include "common.h"
 #include "prim.h"
+#include "fmt.h"
 
 namespace {
 
@@ -296,6 +297,77 @@ size_t format_range(const ysmr_row *rows, long long lo, long long hi, bool via_p
         }
     }
     return (size_t)(p - out);
+}
+
+
+// ---- the same text and columns on the DEVICE (round 5: file -> rows; fmt.h) ------------------------------------------
+// A thread per row prints it into a slot of ROW_TEXT_MAX bytes (and the DataFrame's columns: the values pandas reads back),
+// an inclusive scan of the lengths places the rows, a second kernel packs them behind the header.  A row that holds a value
+// fmt.h does not serve (NaN, infinities, |v| outside 2^-20 .. 2^24 other than zero) is counted in *unserved: the caller then
+// takes the host path for the whole table (tracks do not produce such values; tests do).
+__device__ const char FMT_HEADER[] = "TRACK_ID,POSITION_T,POSITION_X,POSITION_Y,WIDTH,HEIGHT,DEGREES_ANGLE\n";
+struct DevColumns { uint32_t *track_id, *t; double *v[5]; };
+
+__device__ __forceinline__ uint32_t fmt_row(const ysmr_row &r, bool via_pandas, char *out, double (&v)[5], bool &ok)
+{
+    char *p = out;
+    p = ysmr_fmt::put_u32(p, (uint32_t)r.track_id); *p++ = ',';
+    p = ysmr_fmt::put_u32(p, (uint32_t)r.frame); *p++ = ',';
+    v[0] = r.x; v[1] = r.y; v[2] = (double)r.w; v[3] = (double)r.h; v[4] = (double)r.angle;
+#pragma unroll 1
+    for (int k = 0; k < 5; ++k) { p = ysmr_fmt::put_value(p, &v[k], via_pandas, ok); *p++ = k == 4 ? '\n' : ','; }
+    return (uint32_t)(p - out);
+}
+
+__global__ __launch_bounds__(256) void k_fmt_rows(const ysmr_row *__restrict__ rows, long long n, int via_pandas, char *slots,
+                                                  uint32_t *len, DevColumns cols, uint32_t *unserved)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const ysmr_row r = rows[i];
+        double v[5];
+        bool ok = true;
+        const uint32_t l = fmt_row(r, via_pandas != 0, slots + (size_t)i * ROW_TEXT_MAX, v, ok);
+        len[i] = ok ? l : 0u;
+        if (!ok) atomicAdd(unserved, 1u);
+        cols.track_id[i] = (uint32_t)r.track_id; cols.t[i] = (uint32_t)r.frame;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cols.v[k][i] = v[k];
+    }
+}
+
+// (a wave per 64 rows: lane b of a row's turn copies byte b, b + 64, ... -- coalesced writes into the packed text)
+__global__ __launch_bounds__(256) void k_fmt_pack(const char *__restrict__ slots, const uint32_t *__restrict__ len,
+                                                  const uint32_t *__restrict__ incl, long long n, int with_header, char *csv,
+                                                  unsigned long long *csv_length)
+{
+    const int head = with_header ? (int)sizeof(FMT_HEADER) - 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x < head) csv[threadIdx.x] = FMT_HEADER[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *csv_length = (unsigned long long)head + (n ? incl[n - 1] : 0u);
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4, wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (long long i0 = wave * 64; i0 < n; i0 += waves * 64) {
+        const long long mine = i0 + lane;
+        const uint32_t l_mine = mine < n ? len[mine] : 0u, e_mine = mine < n ? incl[mine] : 0u;
+        for (int k = 0; k < 64 && i0 + k < n; ++k) {
+            const uint32_t l = (uint32_t)__shfl((int)l_mine, k), at = (uint32_t)__shfl((int)e_mine, k) - l;
+            const char *src = slots + (size_t)(i0 + k) * ROW_TEXT_MAX;
+            for (uint32_t b = (uint32_t)lane; b < l; b += 64u) csv[(size_t)head + at + b] = src[b];
+        }
+    }
+}
+
+struct FmtLayout { size_t slots, len, incl, temp, total; };
+FmtLayout fmt_layout(long long n)
+{
+    FmtLayout L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off = ysmr::align_up(off + bytes, 256); return at; };
+    L.slots = take((size_t)n * ROW_TEXT_MAX);
+    L.len = take(sizeof(uint32_t) * (size_t)n);
+    L.incl = take(sizeof(uint32_t) * (size_t)n);
+    L.temp = take(sizeof(uint32_t) * ysmr::prim::scan_temp_words((size_t)n));
+    L.total = off;
+    return L;
 }
 
 }  // namespace
@@ -827,6 +899,78 @@ int ysmr_rows_columns(const ysmr_row *rows_host, long long n_rows, int via_panda
         pool.emplace_back(work, lo, hi);
     }
     for (auto &th : pool) th.join();
+    return YSMR_OK;
+}
+
+
+// ---- the device formatter ----------------------------------------------------------------------------------------------
+size_t ysmr_rows_format_device_workspace_bytes(long long n_rows)
+{
+    if (n_rows <= 0 || n_rows > 0x7FFFFFFFll / (long long)ROW_TEXT_MAX) return 0;
+    return fmt_layout(n_rows).total;
+}
+
+int ysmr_rows_format_device(void *stream, const ysmr_row *rows_dev, long long n_rows, int with_header, int via_pandas,
+                            void *workspace_dev, size_t workspace_bytes, char *csv_dev, size_t csv_capacity,
+                            unsigned long long *csv_length_dev, uint32_t *track_id_dev, uint32_t *t_dev, double *x_dev,
+                            double *y_dev, double *w_dev, double *h_dev, double *angle_dev, uint32_t *unserved_dev)
+{
+    if (n_rows < 0 || n_rows > 0x7FFFFFFFll / (long long)ROW_TEXT_MAX)
+        return ysmr::fail(YSMR_ERR_ARG, "n_rows must be in 0..%lld, got %lld", 0x7FFFFFFFll / (long long)ROW_TEXT_MAX, n_rows);
+    if (!csv_dev || !csv_length_dev || !unserved_dev || (n_rows && (!rows_dev || !workspace_dev || !track_id_dev || !t_dev || !x_dev ||
+                                                                     !y_dev || !w_dev || !h_dev || !angle_dev)))
+        return ysmr::fail(YSMR_ERR_ARG, "rows_dev, workspace_dev, csv_dev, csv_length_dev, the seven columns and unserved_dev must be set");
+    if (csv_capacity < ysmr_rows_csv_bound(n_rows, with_header))
+        return ysmr::fail(YSMR_ERR_CAPACITY, "csv buffer too small: %zu < %zu bytes", csv_capacity, ysmr_rows_csv_bound(n_rows, with_header));
+    hipStream_t st = (hipStream_t)stream;
+    YSMR_HIP_CHECK(hipMemsetAsync(unserved_dev, 0, sizeof(uint32_t), st));
+    FmtLayout L{};
+    if (n_rows) {
+        L = fmt_layout(n_rows);
+        if (workspace_bytes < L.total)
+            return ysmr::fail(YSMR_ERR_CAPACITY, "format workspace too small: %zu < %zu bytes", workspace_bytes, L.total);
+    }
+    char *w = (char *)workspace_dev;
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((n_rows + 255) / 256, 2048));
+    if (n_rows) {
+        const DevColumns cols{track_id_dev, t_dev, {x_dev, y_dev, w_dev, h_dev, angle_dev}};
+        hipLaunchKernelGGL(k_fmt_rows, dim3(grid), dim3(256), 0, st, rows_dev, n_rows, via_pandas, w + L.slots, (uint32_t *)(w + L.len),
+                           cols, unserved_dev);
+        ysmr::prim::inclusive_scan_u32(st, (const uint32_t *)(w + L.len), (uint32_t *)(w + L.incl), (size_t)n_rows,
+                                       (uint32_t *)(w + L.temp));
+    }
+    hipLaunchKernelGGL(k_fmt_pack, dim3(grid), dim3(256), 0, st, w + L.slots, (const uint32_t *)(w + L.len), (const uint32_t *)(w + L.incl),
+                       n_rows, with_header, csv_dev, csv_length_dev);
+    YSMR_LAUNCH_CHECK();
+    return YSMR_OK;
+}
+
+// the device formatter's arithmetic (fmt.h) on the HOST, a row at a time: what the CPU tests compare with ysmr_rows_format_csv
+// (std::to_chars + the pandas restatement) on millions of values; *unserved counts the rows fmt.h leaves to the host path
+int ysmr_rows_format_csv_devicelike(const ysmr_row *rows_host, long long n_rows, int with_header, int via_pandas, char *out,
+                                    size_t out_capacity, size_t *out_length, double *columns5, long long *unserved)
+{
+    if (n_rows < 0 || (!rows_host && n_rows) || !out || !out_length || !unserved)
+        return ysmr::fail(YSMR_ERR_ARG, "rows_host, out, out_length and unserved must be set");
+    if (out_capacity < ysmr_rows_csv_bound(n_rows, with_header))
+        return ysmr::fail(YSMR_ERR_CAPACITY, "csv buffer too small: %zu < %zu bytes", out_capacity, ysmr_rows_csv_bound(n_rows, with_header));
+    char *p = out;
+    if (with_header) { std::memcpy(p, CSV_HEADER, sizeof(CSV_HEADER) - 1); p += sizeof(CSV_HEADER) - 1; }
+    long long bad = 0;
+    for (long long i = 0; i < n_rows; ++i) {
+        const ysmr_row &r = rows_host[i];
+        double v[5] = {r.x, r.y, (double)r.w, (double)r.h, (double)r.angle};
+        char *q = p;
+        q = ysmr_fmt::put_u32(q, (uint32_t)r.track_id); *q++ = ',';
+        q = ysmr_fmt::put_u32(q, (uint32_t)r.frame); *q++ = ',';
+        bool ok = true;
+        for (int k = 0; k < 5; ++k) { q = ysmr_fmt::put_value(q, &v[k], via_pandas != 0, ok); *q++ = k == 4 ? '\n' : ','; }
+        if (ok) p = q; else ++bad;
+        if (columns5)
+            for (int k = 0; k < 5; ++k) columns5[(size_t)k * (size_t)n_rows + (size_t)i] = v[k];
+    }
+    *out_length = (size_t)(p - out);
+    *unserved = bad;
     return YSMR_OK;
 }
 

@@ -394,6 +394,113 @@ def rows_to_csv_file_and_dataframe(rows, path, header=True, via_pandas=True, thr
     return length.value, df
 
 
+#: pinned staging of the device formatter's results, kept between videos (pinning 100 MB costs more than the copies)
+_PINNED = {}
+#: (diagnostics) seconds since the call began at which the last rows_device_to_csv_file_and_dataframe reached its steps
+LAST_DEVICE_ROWS_MARKS = {}
+
+
+def _pinned(name, nbytes):
+    import torch
+    buf = _PINNED.get(name)
+    if buf is None or buf.numel() < nbytes:
+        buf = _PINNED[name] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, pin_memory=True)
+    return buf[:nbytes]
+
+
+def rows_device_to_csv_file_and_dataframe(rows_u8, n, path, header=True, via_pandas=True):
+    """``rows_to_csv_file_and_dataframe`` for rows that are on the DEVICE, in order (``tracker.sort_rows``): text and columns are
+    worked out there (``ysmr_rows_format_device``), copied over and the text written to ``path`` (None: no file).  Returns
+    ``(bytes, DataFrame)``, or ``None`` when the table holds a value the device form does not print (NaN, infinities,
+    magnitudes outside 2^-20 .. 2^24): the caller then takes the host path (helper_file.py:1403-1478, 860-905, 1366-1400)."""
+    import time
+    import pandas as pd
+    import torch
+    from . import _lib
+    t0 = time.perf_counter()
+    marks = LAST_DEVICE_ROWS_MARKS
+    marks.clear()
+    L = _lib.lib()
+    n = int(n)
+    dev = rows_u8.device
+    cap = int(L.ysmr_rows_csv_bound(n, int(bool(header))))
+    ws_bytes = int(L.ysmr_rows_format_device_workspace_bytes(n)) if n else 0
+    with torch.cuda.device(dev):
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        csv = torch.empty(cap, dtype=torch.uint8, device=dev)
+        meta = torch.zeros(2, dtype=torch.int64, device=dev)          # csv length; unserved rows (low 32 bits)
+        # the seven columns in one buffer: TRACK_ID, POSITION_T (uint32), then the five float64 columns
+        colbuf = torch.empty(max(n, 1) * 48, dtype=torch.uint8, device=dev)
+        base = colbuf.data_ptr()
+        _lib.check(L.ysmr_rows_format_device(_lib.stream_ptr(dev), rows_u8.data_ptr(), n, int(bool(header)), int(bool(via_pandas)),
+                                             ws.data_ptr(), ws_bytes, csv.data_ptr(), cap, meta.data_ptr(), base, base + 4 * n,
+                                             *[base + 8 * n + 8 * n * k for k in range(5)], meta[1:].data_ptr()), "ysmr_rows_format_device")
+        host_cols = _pinned("columns", 48 * n)
+        host_cols.copy_(colbuf[:48 * n], non_blocking=True)
+        length, unserved = (int(v) for v in meta.cpu())
+        marks["formatted"] = time.perf_counter() - t0
+        if unserved & 0xFFFFFFFF:
+            torch.cuda.current_stream(dev).synchronize()
+            return None
+        text = _pinned("text", length)
+        text.copy_(csv[:length], non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+    marks["copied"] = time.perf_counter() - t0
+    # the file is written by a thread of its own (the kernel's copy into the page cache: no GIL) while this one builds the table
+    writer, failure = None, []
+    if path is not None:
+        import threading
+
+        def write():
+            try:
+                _write_file(path, text.numpy())
+            except OSError as exc:
+                failure.append(exc)
+        writer = threading.Thread(target=write)
+        writer.start()
+    hc = host_cols.numpy()
+    ids_h, t_h = hc[:4 * n].view(np.uint32), hc[4 * n:8 * n].view(np.uint32)
+    cols_h = hc[8 * n:48 * n].view(np.float64).reshape(5, n)
+    # (the DataFrame copies its columns into its own blocks: the pinned staging is free for the next video)
+    df = pd.DataFrame({"TRACK_ID": ids_h, "POSITION_T": t_h, "POSITION_X": cols_h[0], "POSITION_Y": cols_h[1],
+                       "WIDTH": cols_h[2], "HEIGHT": cols_h[3], "DEGREES_ANGLE": cols_h[4]})
+    marks["frame"] = time.perf_counter() - t0
+    if writer is not None:
+        writer.join()
+        if failure:
+            raise failure[0]
+    marks["written"] = time.perf_counter() - t0
+    return length, df
+
+
+def _write_file(path, data):
+    """``data`` (a uint8 array) to ``path`` (created or truncated).  One writer: buffered writes to ONE file take the inode's lock
+    one at a time, so eight threads writing a piece each were no faster than one (60 MB: 13.5 against 14.0 ms,
+    scripts/file_write_probe.py); reserving the blocks first is (11 ms)."""
+    n = len(data)
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+    try:
+        if n >= (1 << 20):
+            try:
+                os.posix_fallocate(fd, 0, n)
+            except OSError:
+                pass                    # (a file system without it: the writes extend the file)
+        view, at = memoryview(data), 0
+        while at < n:
+            at += os.pwrite(fd, view[at:at + (64 << 20)], at)
+    except OSError:
+        os.close(fd)
+        fd = -1
+        try:
+            os.unlink(path)             # (as the native writer: no partial file is left behind)
+        except OSError:
+            pass
+        raise
+    finally:
+        if fd >= 0:
+            os.close(fd)
+
+
 class RowStream:
     """``ysmr_rows_stream_*``: the csv and the DataFrame worked out while the video runs.  ``push`` rows (a structured
     ``_lib.ROW_DTYPE`` array, or a raw pointer and a count) as the link emits them; ``finish`` orders them by

@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .detect import Detector, MeanGrayState, mean_gray_params, threshold_params
 from .frames import DeviceFrameFeed, open_video
-from .helper_file import (COLOR_BGR2GRAY, RowStream, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes, rows_to_csv_file, rows_to_csv_file_and_dataframe,
+from .helper_file import (COLOR_BGR2GRAY, RowStream, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes, rows_to_csv_file, rows_to_csv_file_and_dataframe, rows_device_to_csv_file_and_dataframe,
                           rows_to_dataframe, save_list)
 from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
@@ -60,6 +60,19 @@ def _on_own_device(method):
         with _lib.on(self.device):
             return method(self, *args, **kwargs)
     return wrapped
+
+
+class DeviceRows:
+    """A video's rows, ordered, still on the device (``TrackingPipeline.take_rows_device``)."""
+
+    def __init__(self, rows_u8, count):
+        self.rows_u8, self.count = rows_u8, int(count)
+
+    def __len__(self):
+        return self.count
+
+    def to_numpy(self):
+        return rows_to_numpy(self.rows_u8, self.count)
 
 
 class TrackingPipeline:
@@ -240,6 +253,19 @@ class TrackingPipeline:
         rows = rows_to_numpy(sort_rows(self.rows, n) if sort else self.rows, n)   # (a fresh host array)
         self.row_count.zero_()
         return rows
+
+    @_on_own_device
+    def take_rows_device(self):
+        """Synchronise, order the accumulated rows by (TRACK_ID, POSITION_T) on the device (``sort_list``,
+        helper_file.py:1538-1574), LEAVE them there and reset the row buffer: ``DeviceRows`` for ``_finish``, which prints them
+        on the device too."""
+        n = int(self.row_count.item())
+        cap = self.rows.numel() // _lib.ROW_DTYPE.itemsize
+        if n > cap:
+            raise _lib.YsmrLibraryError(f"row buffer overflow: {n} rows > capacity {cap}")
+        out = DeviceRows(sort_rows(self.rows, n), n)
+        self.row_count.zero_()
+        return out
 
     @_on_own_device
     def check(self, res):
@@ -606,6 +632,8 @@ def _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_
                 everything = np.concatenate(chunks)
                 on_dev = torch.from_numpy(everything.view(np.uint8)).to(pipe.device)
                 sorted_rows = rows_to_numpy(sort_rows(on_dev, len(everything)), len(everything))
+            elif settings.get("hip print rows on device", True):
+                sorted_rows = pipe.take_rows_device()      # (_finish prints them there: ysmr_rows_format_device)
             else:
                 sorted_rows = pipe.take_rows(sort=True)
         # the reference reads until cap.read() fails and accepts that only where the container said it would end, or
@@ -642,6 +670,7 @@ def _finish(video_path, settings, logger, sorted_rows, frames_done, frame_count,
         except OSError as exc:
             logger.error("Could not restore {}: {!r}".format(list_name, exc.args))
     stream = sorted_rows if isinstance(sorted_rows, RowStream) else None
+    on_device = sorted_rows if isinstance(sorted_rows, DeviceRows) else None
     if sorted_rows is None or len(sorted_rows) == 0:
         if stream is not None:
             stream.close()
@@ -671,7 +700,26 @@ def _finish(video_path, settings, logger, sorted_rows, frames_done, frame_count,
         finally:
             stream.close()
         alive_at_end = df_for_eval["TRACK_ID"].to_numpy()[df_for_eval["POSITION_T"].to_numpy() == frames_done - 1]
-    else:
+    if on_device is not None:
+        # Round 5: text and columns come from the device, where the ordered rows are (shortest digits, CPython's layout, pandas'
+        # reading: csrc/fmt.h) -- the host copies them over and writes the file.  A table with a value the device form does not
+        # print (none that a track produces) is brought over and takes the host path below.
+        n_rows_total = len(on_device)
+        made = None
+        try:
+            made = rows_device_to_csv_file_and_dataframe(on_device.rows_u8, n_rows_total, list_name if keep_file else None)
+        except OSError as exc:
+            if not keep_file:
+                raise
+            logger.error("Could not write {}: {}".format(list_name, exc))
+            made = rows_device_to_csv_file_and_dataframe(on_device.rows_u8, n_rows_total, None)
+        if made is None:
+            sorted_rows = on_device.to_numpy()
+            on_device = None
+        else:
+            df_for_eval = made[1]
+            alive_at_end = df_for_eval["TRACK_ID"].to_numpy()[df_for_eval["POSITION_T"].to_numpy() == frames_done - 1]
+    if stream is None and on_device is None:
         alive_at_end = sorted_rows["track_id"][sorted_rows["frame"] == frames_done - 1]
         n_rows_total = len(sorted_rows)
         # the csv and the DataFrame's columns come out of ONE native pass over the rows (the values the text is printed from are
