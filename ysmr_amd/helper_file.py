@@ -394,17 +394,20 @@ def rows_to_csv_file_and_dataframe(rows, path, header=True, via_pandas=True, thr
     return length.value, df
 
 
-#: pinned staging of the device formatter's results, kept between videos (pinning 100 MB costs more than the copies)
-_PINNED = {}
+#: pinned staging of the device formatter's results, kept between videos (pinning 100 MB costs more than the copies) -- per THREAD:
+#: a GPU worker runs two stream threads whose tails may overlap
+import threading as _threading
+_PINNED = _threading.local()
 #: (diagnostics) seconds since the call began at which the last rows_device_to_csv_file_and_dataframe reached its steps
 LAST_DEVICE_ROWS_MARKS = {}
 
 
 def _pinned(name, nbytes):
     import torch
-    buf = _PINNED.get(name)
+    held = _PINNED.__dict__.setdefault("buffers", {})
+    buf = held.get(name)
     if buf is None or buf.numel() < nbytes:
-        buf = _PINNED[name] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, pin_memory=True)
+        buf = held[name] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, pin_memory=True)
     return buf[:nbytes]
 
 
