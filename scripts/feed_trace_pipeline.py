@@ -6,7 +6,7 @@ from ysmr_amd import frames as fr
 from ysmr_amd.helper_file import default_settings
 from ysmr_amd.synth import SyntheticVideo
 from ysmr_amd.track_eval import TrackingPipeline
-F, B = 960, 64
+F, B = (int(sys.argv[1]) if len(sys.argv) > 1 else 960), (int(sys.argv[2]) if len(sys.argv) > 2 else 64)
 d = tempfile.mkdtemp(dir="/tmp")
 path = os.path.join(d, "clip.npy"); np.save(path, SyntheticVideo(922, 1228, 500, seed=0).frames(F))
 v = fr.NpyVideo(path)
