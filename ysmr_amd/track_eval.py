@@ -308,6 +308,9 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
     Optional settings key 'hip persist rows' (default False): keep at most 'list save length interval' rows on the
     device and append every full buffer to ``<name>_list.csv`` as the reference does (helper_file.py:1403-1478), so
     that an interrupted run leaves the rows tracked so far; the file is rewritten in order at the end either way.
+    Optional settings key 'hip print rows on device' (default True): the ordered rows' csv text and DataFrame columns are worked
+    out on the device (``ysmr_rows_format_device``); False: on the host's threads (``ysmr_rows_write_csv_columns``) -- the same
+    bytes and bits either way.  'hip stream rows' (default False): the host's threads print the rows while the video runs.
     """
     logger = logging.getLogger("ysmr").getChild(__name__)
     settings = get_configs(settings)
