@@ -102,6 +102,17 @@ constexpr int TM_POS = 16 * TM_MAX_BLOCKS;                   // tile positions: 
 #define TM_COL_PITCH_N 40
 #endif
 constexpr int TM_COL_PITCH = TM_COL_PITCH_N;                             // f16 per tile column: 32 rows + 8 (80 bytes: 16 columns hit 16 x 4 banks)
+#ifndef TM_PLANES_N
+#define TM_PLANES_N 1
+#endif
+// Round 5 (end): the tile as four PLANES, one per octet of its 32 rows -- plane o holds rows 8 o .. 8 o + 7 of EVERY column position,
+// 16 bytes apiece, one position behind the other (a plane is 1248 x 16 = 19 968 bytes, a multiple of 256).  A lane's MFMA operand
+// (8 consecutive rows of one column) is still one 16-byte read, and now the sixteen lanes the LDS serves together -- eight columns of
+// one octet and eight of the next: MI355X_MICROARCH.md's ds_read_b128 groups -- fall on 64 different banks: 4 cycles per read
+// where the 80-byte columns took 8 (SQ_LDS_BANK_CONFLICT was 45 % of the LDS-active cycles, scripts/sim/lds_banks.py), and the tile
+// is 80 KB instead of 100.
+constexpr bool TM_PLANES = TM_PLANES_N != 0;
+constexpr int TM_POS_PITCH = TM_PLANES ? 8 : TM_COL_PITCH;               // f16 from a column position to the next
 constexpr int TM_RAW_CHUNKS = TM_MAX_TILES + 4;              // 16-byte chunks per gray row: columns x0 - 24 ...
 constexpr int TM_RAW_PITCH = 16 * TM_RAW_CHUNKS;
 constexpr int TM_RAW_PIECES = (TM_ROWS * TM_RAW_CHUNKS + 63) / 64;       // 1 KiB DMA pieces per step
@@ -317,7 +328,12 @@ __device__ __forceinline__ uint32_t exact_class_wave(const uint8_t *frame, const
 }
 
 struct Lds {
-    _Float16 tile[TM_POS][TM_COL_PITCH];                 // blurred pixels [column position][row of a 2 x 16-row ring]
+    // blurred pixels: [column position][row of a 2 x 16-row ring] at TM_COL_PITCH, or four planes [row octet][column position][8 rows]
+    _Float16 tile[TM_PLANES ? 4 * TM_POS * 8 : TM_POS * TM_COL_PITCH];
+    __device__ __forceinline__ _Float16 *at(int pos, int row)       // row: a multiple of 4 here (operands are 8 rows, the blur writes 4)
+    {
+        return TM_PLANES ? &tile[(row >> 3) * (TM_POS * 8) + pos * 8 + (row & 7)] : &tile[pos * TM_COL_PITCH + row];
+    }
     uint8_t raw[2][TM_ROWS * TM_RAW_PITCH];              // gray rows of a step: row r, columns x0 - 24 ... at r * 16 * (chunks per row)
     // a wave's class bytes of a step; with the memory wave: the step's sixteen dense rows of 16 ntiles bytes (read as one array)
     uint32_t out[TM_WAVES][TM_MEM_WAVE ? TM_ROWS * 16 * TM_MAX_TILES / 4 / TM_WAVES : TM_ROWS * TM_OUT_PITCH / 4];
@@ -664,7 +680,7 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             const half8_t TV = as_half8(tvv[0], tvv[1], tvv[2], tvv[3]);
             const int lo = opaque_lane(lane), l16o = lo & 15, qo = lo >> 4;
             const uint8_t *rawp = raw + l16o * 16 * nch + 16 * u0 + 16 * qo;
-            uint2 *cellp = reinterpret_cast<uint2 *>(&L.tile[16 * u0 + l16o][16 * PAR + 4 * qo]);
+            uint2 *cellp = reinterpret_cast<uint2 *>(L.at(16 * u0 + l16o, 16 * PAR + 4 * qo));
             if constexpr (TM_BLUR_GROUP > 1) {
                 // Blocks in groups of TM_BLUR_GROUP, phase by phase in straight-line code: the LDS reads, the row products, the column
                 // products, the conversions of the group's blocks back to back, then their (guarded) writes.  One block at a time is
@@ -711,16 +727,16 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                         for (int b = 0; b < G; ++b)
                             if (g0 + b < TM_PER_WAVE) {
                                 const int bi = g0 + b, u = u0 + bi;
-                                uint2 *cell = cellp + bi * (16 * TM_COL_PITCH / 4);
+                                uint2 *cell = cellp + bi * (16 * TM_POS_PITCH / 4);
                                 if (u <= ntiles && (!edge_r || 16 * u <= PW + 7)) *cell = make_uint2(b01[b], b23[b]);
                                 if (edge_l && u == 0) {                          // wave-uniform
                                     if (l16o == 8)
 #pragma unroll
-                                        for (int e = 1; e <= 8; ++e) cell[-e * (TM_COL_PITCH / 4)] = make_uint2(b01[b], b23[b]);
+                                        for (int e = 1; e <= 8; ++e) cell[-e * (TM_POS_PITCH / 4)] = make_uint2(b01[b], b23[b]);
                                 }
                                 if (edge_r && u == (PW + 7) >> 4) {              // wave-uniform: the block of column W - 1
                                     if (l16o == ((PW + 7) & 15))
-                                        for (int e = 1; PW + 7 + e < 16 * ntiles + 16; ++e) cell[e * (TM_COL_PITCH / 4)] = make_uint2(b01[b], b23[b]);
+                                        for (int e = 1; PW + 7 + e < 16 * ntiles + 16; ++e) cell[e * (TM_POS_PITCH / 4)] = make_uint2(b01[b], b23[b]);
                                 }
                             }
                     }
@@ -748,7 +764,7 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                         const half2_t bias = {(_Float16)1152.0f, (_Float16)1152.0f};
                         const uint32_t b01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(y[0], y[1])) - bias);
                         const uint32_t b23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, pkrtz(y[2], y[3])) - bias);
-                        uint2 *cell = cellp + bi * (16 * TM_COL_PITCH / 4);
+                        uint2 *cell = cellp + bi * (16 * TM_POS_PITCH / 4);
                         // (positions beyond column W - 1 in the block of that column are rewritten by the lane that holds it, below:
                         // a wave's LDS accesses complete in order; a block wholly beyond it -- wave-uniform -- stays away)
                         if (!edge_r || 16 * u <= PW + 7) *cell = make_uint2(b01, b23);
@@ -764,14 +780,14 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 if (l16o == 8) {
                     const uint2 v = *cellp;
 #pragma unroll
-                    for (int e = 1; e <= 8; ++e) cellp[-e * (TM_COL_PITCH / 4)] = v;
+                    for (int e = 1; e <= 8; ++e) cellp[-e * (TM_POS_PITCH / 4)] = v;
                 }
             }
             if (!SUMS_ONLY && blur_right) {                              // wave-uniform: the block of column W - 1 is this wave's
                 if (l16o == ((PW + 7) & 15)) {
-                    uint2 *cell = cellp + (((PW + 7) >> 4) - u0) * (16 * TM_COL_PITCH / 4);
+                    uint2 *cell = cellp + (((PW + 7) >> 4) - u0) * (16 * TM_POS_PITCH / 4);
                     const uint2 v = *cell;
-                    for (int e = 1; PW + 7 + e < 16 * ntiles + 16; ++e) cell[e * (TM_COL_PITCH / 4)] = v;
+                    for (int e = 1; PW + 7 + e < 16 * ntiles + 16; ++e) cell[e * (TM_POS_PITCH / 4)] = v;
                 }
             }
         };
@@ -788,7 +804,7 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             uint8_t *wout = TM_MEM_WAVE ? reinterpret_cast<uint8_t *>(L.out) + l16o * (16 * ntiles) + 16 * u0 + 4 * qo
                                         : reinterpret_cast<uint8_t *>(L.out[wave]) + l16o * TM_OUT_PITCH + 4 * qo;
             // window rows 8q .. 8q + 7 of this lane's column (A operand of the column pass), from the wave's first block on
-            const _Float16 *colp = &L.tile[16 * u0 + l16o][(qo >> 1 ? (s & 1) : ((s - 1) & 1)) * 16 + 8 * (qo & 1)];
+            const _Float16 *colp = L.at(16 * u0 + l16o, (qo >> 1 ? (s & 1) : ((s - 1) & 1)) * 16 + 8 * (qo & 1));
             uint32_t xh[4] = {0, 0, 0, 0};
             const half8_t THh[2] = {as_half8(thh[0], thh[1], thh[2], thh[3]), as_half8(thh[2], thh[3], thh[0], thh[1])};
             // TM_PREFETCH: the two LDS reads of an iteration -- the next block's column, the next tile's centre pixels -- are issued an
@@ -801,11 +817,11 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 const int hsel = bi & 1;
                 const half8_t A_now = A_pre, Ab_now = Ab_pre;
                 if (TM_PREFETCH && bi < TM_PER_WAVE) {
-                    A_pre = *reinterpret_cast<const half8_t *>(colp + 16 * (bi + 1) * TM_COL_PITCH);
-                    Ab_pre = *reinterpret_cast<const half8_t *>(colp + (16 * bi + 8) * TM_COL_PITCH);
+                    A_pre = *reinterpret_cast<const half8_t *>(colp + 16 * (bi + 1) * TM_POS_PITCH);
+                    Ab_pre = *reinterpret_cast<const half8_t *>(colp + (16 * bi + 8) * TM_POS_PITCH);
                 }
                 if ((bi == 0 ? u < ntiles : u - 1 < ntiles) && bi <= cnt && cnt > 0) {      // some tile of this wave uses the block (wave-uniform)
-                    const half8_t A = TM_PREFETCH ? A_now : *reinterpret_cast<const half8_t *>(colp + 16 * bi * TM_COL_PITCH);
+                    const half8_t A = TM_PREFETCH ? A_now : *reinterpret_cast<const half8_t *>(colp + 16 * bi * TM_POS_PITCH);
                     f32x4 cv = {0.f, 0.f, 0.f, 0.f};
 #ifndef TM_DBG_NOMFMA
                     cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, TBh, cv, 0, 0, 0);
@@ -821,7 +837,7 @@ __global__ __launch_bounds__(TM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     if (t < ntiles && ti < cnt) {   // wave-uniform
                         // x = X (mean - b - theta_1): the taps carry X, the accumulator starts at -X theta_1 - X (b - 128)
                         // (the centre pixels: columns 16t + l16 = positions 16t + 8 + l16, this lane's window rows)
-                        const half8_t Ab = TM_PREFETCH ? Ab_now : *reinterpret_cast<const half8_t *>(colp + (16 * ti + 8) * TM_COL_PITCH);
+                        const half8_t Ab = TM_PREFETCH ? Ab_now : *reinterpret_cast<const half8_t *>(colp + (16 * ti + 8) * TM_POS_PITCH);
                         const half8_t XH = as_half8(xh[0], xh[1], xh[2], xh[3]);
 #ifndef TM_DBG_NOMFMA
                         // (the preset ahead of the block's column pass, two independent MFMAs in flight: 232 against 226 us, dropped)
