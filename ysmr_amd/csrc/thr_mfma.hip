@@ -43,10 +43,12 @@
 //   barrier
 //   blur   step s+1: s_raw[(s+1) & 1] -> tile block (s+1) & 1
 //   barrier
+// The tile (blurred pixels - 128 as f16, a ring of two 16-row blocks) lies in LDS as four planes, one per octet of its 32 rows:
+// TM_PLANES below.
 //
 // Error bound: the comment at walk_bound() (bottom of this file): 0.0423 gray levels for cv2's sigma-2 taps with any image,
 // of which 0.031 is the f16 rounding of the intermediate (half an ulp at |v1| < 128); EPS = 1.875 / 39.375 = 0.0476.
-// MEASURED: tests/test_gpu_detect.py (47 cases, every geometry class, noise and synthetic video, the bench's and the 4K launch
+// MEASURED: tests/test_gpu_detect.py (48 cases, every geometry class, noise and synthetic video, the bench's and the 4K launch
 // shapes) byte for byte against the oracle; scripts/sim/thr_single_f16.py models the same arithmetic in numpy: worst
 // |model - real| 0.037 on the bench clip, ~35 undecided pixels per 1.13-Mpx frame (4 at round 4's EPS = 1/256).
 #include "common.h"
