@@ -984,13 +984,36 @@ struct WindowOut {
     uint32_t fbase;      // flat index of the frame's first pixel
 };
 
+// A component whose table row is still to be written: its slot comes back from an atomic (a round trip of 1-2 us), and the
+// wave does not wait for it -- the row is written when the NEXT component is found (or behind the wave's last item), by
+// which time the slot has arrived.  Wave-uniform but for `idx` (lane 0's).
+struct PendingComp {
+    int idx;
+    int f;
+    uint32_t root;
+    int x0, x1, y0, y1, euler4;
+    bool valid;
+};
+__device__ __forceinline__ void flush_component(PendingComp &pc, int lane, const CompTables &t)
+{
+    if (pc.valid && lane == 0 && pc.idx < t.max_det) {
+        const size_t s = (size_t)pc.f * t.max_det + pc.idx;
+        t.roots[s] = (int32_t)pc.root;
+        t.bbox_tmp[s * 4 + 0] = pc.x0; t.bbox_tmp[s * 4 + 1] = pc.x1;
+        t.bbox_tmp[s * 4 + 2] = pc.y0; t.bbox_tmp[s * 4 + 3] = pc.y1;
+        t.euler_tmp[s] = pc.euler4;
+    }
+    pc.valid = false;
+}
+
 // One component C of the final mask (rows in lanes, columns of the slice that starts at frame column sx0;
 // wave-uniform box in slice coordinates): label map, mask, tables.
 __device__ __forceinline__ void window_component(const WindowOut &o, uint32_t c, const WindowBox &b, int sx0, int lane, int f,
-                                                 const CompTables &t)
+                                                 const CompTables &t, PendingComp &pc)
 {
-    int idx = 0;   // slot of the component in the frame's tables: requested first, needed last (the atomic's round trip
-    if (lane == 0) idx = atomicAdd(&t.nroots[(size_t)f * NR_STRIDE], 1);   // is the longest wait of an island)
+    flush_component(pc, lane, t);
+    int idx = 0;   // slot of the component in the frame's tables
+    if (lane == 0) idx = atomicAdd(&t.nroots[(size_t)f * NR_STRIDE], 1);
     const int rx = __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)c, b.y0));   // first pixel: top row, leftmost column
     const uint32_t root = (uint32_t)(o.wy0 + b.y0) * (uint32_t)o.W + (uint32_t)(sx0 + rx);
     const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)o.W + (uint32_t)sx0;
@@ -1006,20 +1029,15 @@ __device__ __forceinline__ void window_component(const WindowOut &o, uint32_t c,
     const uint32_t diag = (qa & qd & ~(qb | qc)) | (qb & qc & ~(qa | qd));
     int q = __popc(odd & ~pair) - __popc(odd & pair) - 2 * __popc(diag);
     const int euler4 = WAVE_REDUCE(dpp_iadd, q);
-    if (lane == 0) {
-        if (idx < t.max_det) {
-            const size_t s = (size_t)f * t.max_det + idx;
-            t.roots[s] = (int32_t)root;
-            t.bbox_tmp[s * 4 + 0] = sx0 + b.x0; t.bbox_tmp[s * 4 + 1] = sx0 + b.x1;
-            t.bbox_tmp[s * 4 + 2] = o.wy0 + b.y0; t.bbox_tmp[s * 4 + 3] = o.wy0 + b.y1;
-            t.euler_tmp[s] = euler4;
-        }
-    }
+    pc.idx = idx; pc.f = f; pc.root = root;
+    pc.x0 = sx0 + b.x0; pc.x1 = sx0 + b.x1; pc.y0 = o.wy0 + b.y0; pc.y1 = o.wy0 + b.y1;
+    pc.euler4 = euler4;
+    pc.valid = true;
 }
 
 // The islands a window's core holds a pixel of (see above).  T / M: thresh / marker rows of the window.
 __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const WindowOut &o, int lane, int f, uint8_t *cf,
-                                               const PixelList &pl, const CompTables &t)
+                                               const PixelList &pl, const CompTables &t, PendingComp &pc)
 {
     const uint64_t core_rows = (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) ? 0x0000FFFFFFFF0000ull : 0ull;
     const uint64_t A = T | M;
@@ -1084,7 +1102,7 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
         }
         const int sx0 = o.wx0 + sh;   // frame column of the slice's column 0
         if (whole) {
-            window_component(o, F, b, sx0, lane, f, t);
+            window_component(o, F, b, sx0, lane, f, t, pc);
         } else {
             while (true) {
                 const unsigned long long rr = __ballot(R != 0u);
@@ -1093,7 +1111,7 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
                 const int cx0 = __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)R, cy0));
                 const uint32_t C = flood8(lane == cy0 ? (1u << cx0) : 0u, R);
                 R &= ~C;
-                window_component(o, C, box_of(C), sx0, lane, f, t);
+                window_component(o, C, box_of(C), sx0, lane, f, t, pc);
             }
         }
     }
@@ -1136,6 +1154,8 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
     }
     // (static dealing: handing further items out by a ticket counter per group of blocks, requested an item ahead,
     // was slower -- 61 against 55 us -- and 230 us with the eight counters on one cache line)
+    PendingComp pc;
+    pc.valid = false;
     for (long long j = first; j < count; j += step) {
         const long long it = offset + j;
         const int f = (int)(it / per_frame) * f_mul + f_add, rem = (int)(it % per_frame);
@@ -1229,7 +1249,7 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
 #ifdef WIN_DBG_STAGE_ONLY
             if (T == 0x123456789ull) o.labels[0] = 1;
 #else
-            window_islands(T, M, o, lane, f, cf, pl, t);
+            window_islands(T, M, o, lane, f, cf, pl, t, pc);
 #endif
         }
         if constexpr (WIN_GROUP != 4) {
@@ -1237,6 +1257,7 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
             __builtin_amdgcn_wave_barrier();
         }
     }
+    flush_component(pc, lane, t);
 }
 
 // Pass B: 4-connected components of the `thresh` bit (the mask of binary_propagation).
@@ -1395,6 +1416,9 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *l
         n = t.max_det;
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) atomicMax(t.max_roots, n);
+    // (the grid is sized for max_det: a workgroup whose roots do not exist leaves before the histogram -- six of the eight per
+    // frame on the bench stream; 3 us of the chain)
+    if ((int)blockIdx.y * (RANK_THREADS / 4) >= n) return;
     const int32_t *roots = t.roots + (size_t)f * t.max_det;
     // rank of a root = roots in the bands of image rows below its own + roots of its own band with a larger index:
     // a histogram over the bands, a suffix sum, the roots bucketed by band in LDS, and each root compared with its
