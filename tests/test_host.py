@@ -68,6 +68,29 @@ def test_csv_wire_format(tmp_path):
     assert open(csv_path).read().endswith("5,2,1.5,2.5,1.0,2.0,3.0\n")
 
 
+def test_previous_list_is_removed_small_at_once_large_beside_the_run(tmp_path):
+    """save_list(first_call) without 'rename previous result .csv' (helper_file.py:1434-1445: os.remove): the name holds a
+    header-only file when it returns, whatever the old list's size; a large one is unlinked by a thread that
+    wait_for_removals (track_bacteria's last step) joins."""
+    import os
+    from ysmr_amd import helper_file as hf
+    video = tmp_path / "clip.npy"
+    video.write_bytes(b"")
+    csv_path = str(tmp_path / "clip_list.csv")
+    for size in (100, hf._REMOVE_ASIDE_FROM + 1):
+        with open(csv_path, "wb") as fh:
+            fh.write(b"x" * size)
+        old, got = hf.save_list(path=str(video), result_folder=str(tmp_path), first_call=True, rename_old_list=False)
+        assert old is False and got == csv_path and open(csv_path).read() == hf.CSV_HEADER
+        hf.wait_for_removals()
+        assert sorted(os.listdir(tmp_path)) == ["clip.npy", "clip_list.csv"] and not hf._REMOVALS
+    # 'rename previous result .csv': the old list stays, under a dated name (helper_file.py:1437-1442)
+    with open(csv_path, "wb") as fh:
+        fh.write(b"y" * (hf._REMOVE_ASIDE_FROM + 1))
+    old, got = hf.save_list(path=str(video), result_folder=str(tmp_path), first_call=True, rename_old_list=True)
+    assert old and os.path.getsize(old) == hf._REMOVE_ASIDE_FROM + 1 and open(csv_path).read() == hf.CSV_HEADER
+
+
 def test_reshape_result():
     from ysmr_amd.helper_file import reshape_result
     assert reshape_result(((1.0, 2.0), (3.0, 4.0), -45.0)) == ((1.0, 2.0), (3.0, 4.0, -45.0))
@@ -569,6 +592,36 @@ def test_csv_written_by_the_formatting_threads_equals_the_one_buffer_form(tmp_pa
                 assert length2 == len(want) and path2.read_bytes() == want
                 ref = rows_to_dataframe(rows, via_pandas=via)
                 assert df2.equals(ref) and list(df2.dtypes) == list(ref.dtypes)
+
+
+def test_frame_feed_threads_run_next_to_the_gpu_and_the_caller_stays_where_it_was(monkeypatch):
+    """DeviceFrameFeed(near_gpu=True): the CPUs of the GPU's NUMA node as far as this thread may use them (frames.cpus_near_gpu),
+    taken on for the allocation of the staging buffers only (frames._ThreadOn restores the caller's mask)."""
+    import os
+    import threading
+    from ysmr_amd import dist, frames
+    mine = sorted(os.sched_getaffinity(0))
+    monkeypatch.setattr(dist, "pci_bus_id", lambda index=0: "0000:c1:00.0")
+    frames._NODE_CPUS.clear()
+    monkeypatch.setattr(dist, "local_cpus", lambda bus_id, sysfs_root="/sys": set(mine[:4]) | {100000} if len(mine) >= 4 else None)
+    if len(mine) >= 4:
+        assert frames.cpus_near_gpu("cuda:0") == set(mine[:4])
+        seen = {}
+        with frames._ThreadOn(set(mine[:4])):
+            seen["inside"] = os.sched_getaffinity(0)
+            th = threading.Thread(target=lambda: seen.__setitem__("child", os.sched_getaffinity(0)))
+            th.start(); th.join()
+        assert seen["inside"] == set(mine[:4]) and seen["child"] == set(mine[:4])      # (threads inherit the mask)
+        assert os.sched_getaffinity(0) == set(mine)
+    frames._NODE_CPUS.clear()
+    monkeypatch.setattr(dist, "local_cpus", lambda bus_id, sysfs_root="/sys": set(mine[:3]))
+    assert frames.cpus_near_gpu("cuda:0") is None                                       # fewer than four: left alone
+    frames._NODE_CPUS.clear()
+    monkeypatch.setattr(dist, "local_cpus", lambda bus_id, sysfs_root="/sys": None)
+    assert frames.cpus_near_gpu("cuda:0") is None
+    with frames._ThreadOn(None):
+        assert os.sched_getaffinity(0) == set(mine)
+    frames._NODE_CPUS.clear()
 
 
 def test_gc_freeze_is_counted_across_overlapping_passes():

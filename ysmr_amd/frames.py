@@ -377,6 +377,51 @@ class Cv2Video:
         self._cap.release()
 
 
+_NODE_CPUS = {}      # GPU index -> CPUs of its NUMA node (sysfs; asked once per process)
+
+
+def cpus_near_gpu(device):
+    """The CPUs of the NUMA node the GPU hangs off that this thread may use (None: unknown, or fewer than four)."""
+    try:
+        import torch
+        from . import dist
+        index = torch.device(device).index or 0
+        if index not in _NODE_CPUS:
+            _NODE_CPUS[index] = dist.local_cpus(dist.pci_bus_id(index))
+        cpus = _NODE_CPUS[index]
+        if not cpus:
+            return None
+        cpus = cpus & os.sched_getaffinity(0)
+        return cpus if len(cpus) >= 4 else None
+    except (AttributeError, OSError, ValueError):
+        return None
+
+
+class _ThreadOn:
+    """``with _ThreadOn(cpus):`` -- the calling THREAD runs on ``cpus`` inside the block (Linux: sched_setaffinity(0) is the
+    calling thread's mask, and the threads it starts inherit it), and on what it was allowed before afterwards."""
+
+    def __init__(self, cpus):
+        self.cpus, self.before = cpus, None
+
+    def __enter__(self):
+        if self.cpus:
+            try:
+                self.before = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, self.cpus)
+            except (AttributeError, OSError):
+                self.before = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.before is not None:
+            try:
+                os.sched_setaffinity(0, self.before)
+            except OSError:
+                pass
+        return False
+
+
 class DeviceFrameFeed:
     """Batches of a video as device tensors, read and uploaded ahead of their use.
 
@@ -385,27 +430,28 @@ class DeviceFrameFeed:
     while the consumer works on earlier batches.  Iterating yields ``(frames_dev, first_frame, count,
     slot)``; the consumer's stream already waits for the upload.  When the kernels that read
     ``frames_dev`` have been issued, the consumer calls ``release(slot, event)`` with an event recorded
-    behind them: the slot's device buffer is overwritten only after that event."""
+    behind them: the slot's device buffer is overwritten only after that event.
 
-    def __init__(self, video, batch, device, depth=3, readers=16):
+    ``near_gpu``: the staging buffers are allocated, and the producer and its readers run, on the CPUs of the GPU's own NUMA node
+    (the caller's threads are left where they are).  On a two-socket host the copy into pinned memory and the DMA out of it
+    otherwise cross the sockets' link half of the time: reads 50-60 GB/s and uploads 35-45 while both run, against 85-90 and
+    56 (`scripts/feed_copy_timeline.py`)."""
+
+    def __init__(self, video, batch, device, depth=3, readers=16, pieces=4, near_gpu=True):
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
 
         import torch
         self.video, self.B, self.device, self.depth = video, int(batch), torch.device(device), int(depth)
+        self.pieces = max(1, int(pieces))
         shape = (self.B, video.height, video.width) + ((3,) if video.channels == 3 else ())
         # uncompressed AVI: the stored frames (bottom-up, padded rows, palette indices) go to the device as they are
         # and are unpacked there; every other source delivers finished frames
         self._raw = getattr(video, "raw_layout", None)
-        if self._raw is not None:
-            raw_bytes, _, _, _, palette = self._raw
-            self._pinned = [torch.empty((self.B, raw_bytes), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
-            self._raw_dev = [torch.empty((self.B, raw_bytes), dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
-            self._palette = None if palette is None else torch.from_numpy(np.ascontiguousarray(palette)).to(self.device)
-        else:
-            self._pinned = [torch.empty(shape, dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
-        self._dev = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
+        self._cpus = cpus_near_gpu(self.device) if near_gpu else None
+        with _ThreadOn(self._cpus):      # (pinned pages are the calling thread's node's)
+            self._allocate(shape)
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._uploaded = [None] * self.depth     # event: H2D copy out of pinned[slot] finished
         self._released = [None] * self.depth     # event posted by the consumer (or True: never used / free)
@@ -418,10 +464,27 @@ class DeviceFrameFeed:
         self._thread = threading.Thread(target=self._produce, name="ysmr-frame-feed", daemon=True)
         self._thread.start()
 
+    def _allocate(self, shape):
+        import torch
+        video = self.video
+        if self._raw is not None:
+            raw_bytes, _, _, _, palette = self._raw
+            self._pinned = [torch.empty((self.B, raw_bytes), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
+            self._raw_dev = [torch.empty((self.B, raw_bytes), dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
+            self._palette = None if palette is None else torch.from_numpy(np.ascontiguousarray(palette)).to(self.device)
+        else:
+            self._pinned = [torch.empty(shape, dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
+        self._dev = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
+
     def _produce(self):
         import torch
         try:
             torch.cuda.set_device(self.device)
+            if self._cpus:
+                try:
+                    os.sched_setaffinity(0, self._cpus)      # this thread, and the readers it starts
+                except OSError:
+                    pass
             i = 0
             # (every frame the source HOLDS, which need not be the number it reports: track_bacteria applies the
             # reference's rule to the difference)
@@ -436,30 +499,42 @@ class DeviceFrameFeed:
                 if self._uploaded[slot] is not None:
                     self._uploaded[slot].synchronize()          # staging buffer free again
                 host = self._pinned[slot].numpy()
-                if self._raw is not None:
-                    n = self.video.read_raw_into(f0, self.B, host, self._pool)
-                elif hasattr(self.video, "read_into"):
-                    n = self.video.read_into(f0, self.B, host, self._pool)
-                else:
-                    got = self.video.read(f0, self.B)
-                    n = got.shape[0]
-                    host[:n] = got
+                # A batch is read and uploaded in `pieces` parts: the upload of a part starts when the part has been read, not
+                # when the batch has (the first batch of a 1228 x 922 file is 280 MB: 5 ms of reading before the first byte
+                # crossed the bus, 4 of the 73 ms a 1920-frame file takes)
+                step = max(1, -(-self.B // self.pieces))
+                n = 0
+                for c0 in range(0, self.B, step):
+                    want = min(step, self.B - c0)
+                    if self._raw is not None:
+                        got = self.video.read_raw_into(f0 + c0, want, host[c0:c0 + want], self._pool)
+                    elif hasattr(self.video, "read_into"):
+                        got = self.video.read_into(f0 + c0, want, host[c0:c0 + want], self._pool)
+                    else:
+                        part = self.video.read(f0 + c0, want)
+                        got = part.shape[0]
+                        host[c0:c0 + got] = part
+                    if got:
+                        with torch.cuda.stream(self._copy_stream):
+                            if released is not True:
+                                self._copy_stream.wait_event(released)  # the kernels that read this device buffer are done
+                                released = True
+                            dst = self._raw_dev[slot] if self._raw is not None else self._dev[slot]
+                            dst[c0:c0 + got].copy_(self._pinned[slot][c0:c0 + got], non_blocking=True)
+                    n += got
+                    if got < want:
+                        break
                 if n == 0:
                     break
                 with torch.cuda.stream(self._copy_stream):
-                    if released is not True:
-                        self._copy_stream.wait_event(released)  # the kernels that read this device buffer are done
                     if self._raw is not None:
                         from . import _lib
                         raw_bytes, bpp, stride, bottom_up, _ = self._raw
-                        self._raw_dev[slot][:n].copy_(self._pinned[slot][:n], non_blocking=True)
                         _lib.check(_lib.lib().ysmr_unpack_dib_batch(
                             self._copy_stream.cuda_stream, self._raw_dev[slot].data_ptr(), n, raw_bytes, self.video.height,
                             self.video.width, bpp, stride, int(bottom_up),
                             None if self._palette is None else self._palette.data_ptr(), self._dev[slot].data_ptr()),
                             "ysmr_unpack_dib_batch")
-                    else:
-                        self._dev[slot][:n].copy_(self._pinned[slot][:n], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self._copy_stream)
                 self._uploaded[slot] = ev

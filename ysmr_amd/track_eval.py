@@ -26,7 +26,7 @@ from . import _lib
 from .detect import Detector, MeanGrayState, mean_gray_params, threshold_params
 from .frames import DeviceFrameFeed, open_video
 from .helper_file import (COLOR_BGR2GRAY, RowStream, create_results_folder, get_configs, get_loggers, rows_to_csv_bytes, rows_to_csv_file, rows_to_csv_file_and_dataframe, rows_device_to_csv_file_and_dataframe,
-                          rows_to_dataframe, save_list)
+                          rows_to_dataframe, save_list, wait_for_removals)
 from .tracker import DeviceTracker, rows_to_numpy, sort_rows
 
 __all__ = ["track_bacteria", "TrackingPipeline", "select_tracks", "evaluate_tracks"]
@@ -350,39 +350,42 @@ def track_bacteria(video_path, settings=None, result_folder=None, batch=None, ma
     logger.info("Starting with file {}".format(video_path))
     old_list, list_name = save_list(path=video_path, result_folder=result_folder, first_call=True,
                                     rename_old_list=settings["rename previous result .csv"])
-    # The reference flips the sign of the offset IN the caller's dict for dark-on-bright videos
-    # (track_eval.py:132), so a dict reused across files alternates; kept for drop-in parity.
-    # threshold_params() applies the same sign change internally, from the value seen on entry.
-    offset_on_entry = settings["threshold offset for detection"]
-    if not settings["white bacteria on dark background"]:
-        settings["threshold offset for detection"] = offset_on_entry * -1
-    local = dict(settings)
-    local["threshold offset for detection"] = offset_on_entry
+    try:
+        # The reference flips the sign of the offset IN the caller's dict for dark-on-bright videos
+        # (track_eval.py:132), so a dict reused across files alternates; kept for drop-in parity.
+        # threshold_params() applies the same sign change internally, from the value seen on entry.
+        offset_on_entry = settings["threshold offset for detection"]
+        if not settings["white bacteria on dark background"]:
+            settings["threshold offset for detection"] = offset_on_entry * -1
+        local = dict(settings)
+        local["threshold offset for detection"] = offset_on_entry
 
-    frame_height, frame_width = video.height, video.width
-    # frames per batch when nobody names a number: ~256 MB of frames, between 16 and 256 frames (248 at 1228 x 922, 32 at 4K).
-    # A batch's fixed costs -- one link launch, the detection kernels' starts, the reader's calls -- are paid per batch
-    # (a 1920-frame 1228 x 922 file: 114-119 ms at 64 frames per batch, 99 ms at 256, scripts/e2e_batches.py); three pinned
-    # staging buffers and two detectors' outputs of that many frames are what it costs in memory.
-    batch = int(batch or settings.get("hip frames per batch") or auto_batch(frame_height, frame_width, video.channels))
-    max_det = int(max_det or settings.get("hip max detections per frame") or DEFAULT_MAX_DET)
-    capacity = int(capacity or settings.get("hip max tracks") or DEFAULT_CAPACITY)
-    while True:
-        outcome = _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_det, capacity, device,
-                               settings, logger, list_name if settings.get("hip persist rows") else None)
-        if outcome[0] == "overflow" and 2 * max(max_det, capacity) <= LIMIT_MAX:
-            max_det, capacity = 2 * max_det, max(2 * capacity, max_det)
-            logger.warning("More objects than the device buffers hold in file {}: running it again with "
-                           "max_det = {}, capacity = {}".format(video_path, max_det, capacity))
-            continue
-        if outcome[0] == "overflow":
-            logger.critical("File {} holds more objects per frame than the largest device buffers ({}); "
-                            "not analysed".format(video_path, LIMIT_MAX))
-        break
-    video.close()
-    _, sorted_rows, frames_done, error_during_read, t_start, t_frames = outcome
-    return _finish(video_path, settings, logger, sorted_rows, frames_done, frame_count, error_during_read, old_list,
-                   list_name, fps_of_file, frame_height, frame_width, t_start, t_frames)
+        frame_height, frame_width = video.height, video.width
+        # frames per batch when nobody names a number: ~256 MB of frames, between 16 and 256 frames (248 at 1228 x 922, 32 at 4K).
+        # A batch's fixed costs -- one link launch, the detection kernels' starts, the reader's calls -- are paid per batch
+        # (a 1920-frame 1228 x 922 file: 114-119 ms at 64 frames per batch, 99 ms at 256, scripts/e2e_batches.py); three pinned
+        # staging buffers and two detectors' outputs of that many frames are what it costs in memory.
+        batch = int(batch or settings.get("hip frames per batch") or auto_batch(frame_height, frame_width, video.channels))
+        max_det = int(max_det or settings.get("hip max detections per frame") or DEFAULT_MAX_DET)
+        capacity = int(capacity or settings.get("hip max tracks") or DEFAULT_CAPACITY)
+        while True:
+            outcome = _device_pass(video, video_path, frame_count, fps_of_file, local, batch, max_det, capacity, device,
+                                   settings, logger, list_name if settings.get("hip persist rows") else None)
+            if outcome[0] == "overflow" and 2 * max(max_det, capacity) <= LIMIT_MAX:
+                max_det, capacity = 2 * max_det, max(2 * capacity, max_det)
+                logger.warning("More objects than the device buffers hold in file {}: running it again with "
+                               "max_det = {}, capacity = {}".format(video_path, max_det, capacity))
+                continue
+            if outcome[0] == "overflow":
+                logger.critical("File {} holds more objects per frame than the largest device buffers ({}); "
+                                "not analysed".format(video_path, LIMIT_MAX))
+            break
+        video.close()
+        _, sorted_rows, frames_done, error_during_read, t_start, t_frames = outcome
+        return _finish(video_path, settings, logger, sorted_rows, frames_done, frame_count, error_during_read, old_list,
+                       list_name, fps_of_file, frame_height, frame_width, t_start, t_frames)
+    finally:
+        wait_for_removals()   # (a large previous list is unlinked beside the run: helper_file._remove_previous_list)
 
 
 def usable_cpus():
