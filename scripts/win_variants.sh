@@ -7,7 +7,7 @@ if [ "$1" = build ]; then
   while [ $# -gt 1 ]; do
     name=$1; flags=$2; shift 2
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -I$R/include $flags -c $C/detect.hip -o /tmp/var_$name.o &&
-    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/scripts/var_$name.so /tmp/var_$name.o $C/common.o $C/meangray.o $C/track.o $C/rows.o $C/select.o $C/evaluate.o $C/ingest.o && echo built $name
+    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/scripts/var_$name.so /tmp/var_$name.o $C/common.o $C/meangray.o $C/track.o $C/rows.o $C/select.o $C/evaluate.o $C/ingest.o $C/thr_mfma.o && echo built $name
   done
   exit 0
 fi
