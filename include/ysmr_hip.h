@@ -117,11 +117,11 @@ int ysmr_file_read(int fd, void *dst, size_t n, long long offset, int threads);
 size_t ysmr_detect_workspace_bytes(int batch, int height, int width, int max_det);
 
 /* Call once after allocating a workspace, again if the output buffers used with it were written by anyone else,
- * and after a detection call that returned an error.  The workspace keeps the component tables of the previous
- * ysmr_components_batch / ysmr_detect_batch call (first pixel and bounding box of every component); when the next
- * call gets the same labels_dev / mask_dev, batch, geometry and max_det it zeroes the label map and the mask
- * inside those boxes instead of the whole maps.  A workspace whose first 256 bytes are zero (this call) makes the
- * next call clear everything. */
+ * and after a detection call that returned an error.  The workspace keeps a record of where the previous
+ * ysmr_components_batch / ysmr_detect_batch call may have written the label map and the mask (a word per 32-pixel
+ * row segment, left by the labelling kernel); when the next call gets the same labels_dev / mask_dev, batch,
+ * geometry and max_det it zeroes the two maps there -- and only where that call does not write them again -- instead
+ * of the whole maps.  A workspace whose first 256 bytes are zero (this call) makes the next call clear everything. */
 int ysmr_detect_workspace_init(void *stream, void *workspace_dev, size_t workspace_bytes);
 
 /* a1-a3 fused.  frames_dev: u8 [batch][height][width][channels], channels 1 (gray) or 3 (BGR).

@@ -690,10 +690,11 @@ __device__ __forceinline__ uint32_t chunk_byte(const uint4 &v, int i)
 // k_bbox_euler, one lane per listed pixel.  The list has room for 1/8 of the batch; a denser residue makes
 // the passes fall back to walking every pixel (`count` keeps counting past `cap`, which is how they know), and
 // then everything k_windows settled is done again by them (k_residue).
-// The workspace remembers, across calls, the components of the previous call (first pixel and bounding box
-// of each): if the next call gets the same buffers and geometry, clearing the label map and the final mask
-// inside those boxes replaces a dense memset (362 MB per 64-frame batch at 1228x922 -- more HBM traffic
-// than the threshold kernel itself).
+// The workspace remembers, across calls, where the previous call may have written (round 5: one word per core and
+// row, left by k_windows, WIN_CLEARS below; before that the components' bounding boxes, still the WIN_CLEARS_N=0
+// build): if the next call gets the same buffers and geometry, zeroing the label map and the final mask there
+// replaces a dense memset (362 MB per 64-frame batch at 1228x922 -- more HBM traffic than the threshold kernel
+// itself).
 constexpr unsigned long long WS_MAGIC = 0x59534D5248495032ull;   // "YSMRHIP2"
 constexpr int WS_BIG = 16;              // components too large for the per-component clear that a header can name
 constexpr int WS_BIG_AREA = 64 * 64;    // bounding-box area from which a component counts as large
@@ -705,7 +706,7 @@ struct WsHeader {
     uint32_t fault;              // YSMR_WS_FAULT_RESIDUE_STALL (written by a TEST into its own workspace): the next call's
                                  // barrier kernel behaves as if one workgroup never became resident; cleared by that call
     uint32_t count[2];           // [0] residue pixels found (may exceed cap: list incomplete)
-    uint32_t pad;                // ticket counter of k_clear
+    uint32_t old_bits_valid;     // written by k_clear for k_windows: the header vouched, `oldbits` describes what is to be zeroed
     int32_t batch, H, W, max_det;
     uint32_t dense;              // the tables do not cover everything written (a frame overflowed max_det, or
                                  // more than WS_BIG large components): the next call clears everything
@@ -758,14 +759,23 @@ struct CompTables {
     int max_det;
 };
 
-// Clears the label map and the final mask (both are written sparsely afterwards): only inside the bounding
-// boxes of the previous call's components if the header vouches for these buffers, everything otherwise.  A
+// Clears the label map and the final mask (both are written sparsely afterwards): everything, unless the header
+// vouches for these buffers -- then k_windows does it, core by core (WIN_CLEARS; in a WIN_CLEARS_N=0 build this
+// kernel does, inside the bounding boxes of the previous call's components).  A
 // resident grid instead of hipMemsetAsync: the runtime's fill kernels use grids far larger than the chip
 // holds, and such a grid starves every other stream (the link) until it has drained.
 // (The status words are zeroed here.  The per-call counters are left at zero by k_compact, the last kernel of a
 // call, which also keeps the component counts for this kernel (prev_n) and vouches for the buffers; k_windows,
 // the next launch, marks the header invalid until then, so a chain that was cut short is followed by a full clear.)
 constexpr int CLEAR_BLOCKS = 512;
+// k_windows also CLEARS (round 5, last hours): the previous call's label map and mask are zeroed by the wave that works on a core
+// -- the pixels that call may have written (one word per core and row, left in the workspace by k_windows itself) and this one
+// will not -- instead of by k_clear beforehand (which dirtied the same ~1.45 M lines k_windows dirties again, and had them
+// written back in between: 50-57 us per batch).
+#ifndef WIN_CLEARS_N
+#define WIN_CLEARS_N 1
+#endif
+constexpr bool WIN_CLEARS = WIN_CLEARS_N != 0;
 __device__ __forceinline__ void clear_box(uint32_t *__restrict__ lab, uint8_t *__restrict__ mask, int W, int x0, int x1, int y0,
                                           int y1, int first, int step)
 {
@@ -794,6 +804,11 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
     if (h.magic == WS_MAGIC && h.labels == (unsigned long long)labels && h.mask == (unsigned long long)mask &&
         h.total == total && h.batch == batch && h.H == H && h.W == W && h.max_det == t.max_det && !h.dense &&
         h.n_big <= (uint32_t)WS_BIG) {
+        // k_windows zeroes what the previous call left, core by core, from the words it wrote then (WIN_CLEARS)
+        if (WIN_CLEARS) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) pl.hdr->old_bits_valid = 1u;
+            return;
+        }
         // Work items are (16 consecutive ranks, frame), frame fastest: the populated ranks come first in every
         // frame, so the live items are spread evenly over the waves.  16 lanes per component (one per column of
         // its box), four components at a time, all box loads of an item first; blind stores (test-then-store is a
@@ -831,7 +846,9 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
                       t.bbox[s * 4 + 1], t.bbox[s * 4 + 2], t.bbox[s * 4 + 3], (int)tid, (int)stride);
         }
     } else {
-        // (nobody reads the counters on this path, and every block takes it -- the header is not written here)
+        // (nobody reads the counters on this path, and every block takes it -- the header's fields that say whether it
+        // vouches are not written here)
+        if (blockIdx.x == 0 && threadIdx.x == 0) pl.hdr->old_bits_valid = 0u;
         if (blockIdx.x == 0) {
             for (int i = threadIdx.x; i < n_counters; i += 256) t.nroots[i] = 0;
             for (int i = threadIdx.x; i < batch; i += 256) t.prev_n[i] = 0;
@@ -1036,8 +1053,11 @@ __device__ __forceinline__ void window_component(const WindowOut &o, uint32_t c,
 }
 
 // The islands a window's core holds a pixel of (see above).  T / M: thresh / marker rows of the window.
+// keep: the core's pixels (bit j = core column j; rows = lanes 16..47) that are somebody's to write in this call -- the small
+// islands, whoever owns them (the owner writes the final mask's pixels and zeroes the others), and the listed pixels of the
+// large ones (the residue passes write those).
 __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const WindowOut &o, int lane, int f, uint8_t *cf,
-                                               const PixelList &pl, const CompTables &t, PendingComp &pc)
+                                               const PixelList &pl, const CompTables &t, PendingComp &pc, uint32_t &keep)
 {
     const uint64_t core_rows = (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) ? 0x0000FFFFFFFF0000ull : 0ull;
     const uint64_t A = T | M;
@@ -1064,6 +1084,7 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
             const uint64_t F64 = flood8(lane == sy ? (1ull << sx) : 0ull, A);
             todo &= ~F64;
             const uint64_t E = F64 & core_rows;
+            keep |= (uint32_t)(E >> WIN_MARGIN);
             const uint32_t cnt = (uint32_t)__popcll(E);
             const unsigned long long below = (1ull << lane) - 1ull;
             uint32_t before = 0, total = 0;
@@ -1088,6 +1109,8 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
             continue;
         }
         todo &= ~((uint64_t)F << sh);
+        // (what of a small island lies in this core is its owner's to write, all of it: `keep`)
+        keep |= (uint32_t)(((uint64_t)F << sh) >> WIN_MARGIN);      // slice column k = window column sh + k = core column sh + k - 16
         if (sy != b.y0 || __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)F, b.y0)) != WIN_MARGIN) continue;   // first pixel in another core: not ours
         // the island is settled here
         const uint32_t thresh = __builtin_amdgcn_alignbit((uint32_t)(T >> 32), (uint32_t)T, sh) & F;
@@ -1104,6 +1127,16 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
         if (whole) {
             window_component(o, F, b, sx0, lane, f, t, pc);
         } else {
+            if (WIN_CLEARS) {
+                // the island's pixels outside the final mask: zero, whatever the previous call left there (the cores' waves
+                // leave a small island to its owner)
+                const uint32_t row = (uint32_t)(o.wy0 + lane) * (uint32_t)o.W + (uint32_t)sx0;
+                for (uint32_t rest = F & ~R; rest; rest &= rest - 1) {
+                    const uint32_t p = row + (uint32_t)__builtin_ctz(rest);
+                    o.labels[p] = 0u;
+                    if (o.mask) o.mask[p] = 0;
+                }
+            }
             while (true) {
                 const unsigned long long rr = __ballot(R != 0u);
                 if (!rr) break;
@@ -1117,13 +1150,48 @@ __device__ __forceinline__ void window_islands(uint64_t T, uint64_t M, const Win
     }
 }
 
+// 16 bytes of row y from column xs on, zeros where the frame is not (any alignment: W need not be a multiple of 4)
+__device__ __forceinline__ uint4 load16_clipped(const uint8_t *cf, int y, int xs, int H, int W)
+{
+    uint4 vj = make_uint4(0, 0, 0, 0);
+    if (y >= 0 && y < H && xs < W && xs + 16 > 0) {
+        const uint8_t *src = cf + (size_t)y * W + xs;
+        if (xs >= 0 && xs + 16 <= W) {
+            __builtin_memcpy(&vj, src, 16);
+        } else if (xs >= 0 && W >= 16) {
+            // the chunk sticks out of the row on the right: the row's last 16 bytes, shifted down.  (A loop
+            // of guarded byte loads here was a chain of round trips in every item of the last column group,
+            // and those items were the kernel's duration.)
+            uint4 l;
+            __builtin_memcpy(&l, src - (xs + 16 - W), 16);
+            const int drop = xs + 16 - W, a = drop >> 2, b = drop & 3;   // 1..15 bytes
+            const uint32_t e0 = a == 0 ? l.x : a == 1 ? l.y : a == 2 ? l.z : l.w;
+            const uint32_t e1 = a == 0 ? l.y : a == 1 ? l.z : a == 2 ? l.w : 0u;
+            const uint32_t e2 = a == 0 ? l.z : a == 1 ? l.w : 0u;
+            const uint32_t e3 = a == 0 ? l.w : 0u;
+            vj = make_uint4(__builtin_amdgcn_alignbyte(e1, e0, b), __builtin_amdgcn_alignbyte(e2, e1, b),
+                            __builtin_amdgcn_alignbyte(e3, e2, b), __builtin_amdgcn_alignbyte(0u, e3, b));
+        } else {   // frames narrower than 16 pixels
+            uint32_t d[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; ++k)
+                if (xs + k >= 0 && xs + k < W) d[k >> 2] |= (uint32_t)src[k] << (8 * (k & 3));
+            vj = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+    }
+    return vj;
+}
+
 // Work item of a wave: WIN_GROUP cores side by side = 64 rows x 160 columns of class bytes, turned into row masks
 // through the wave's own slice of LDS (adjacent lanes load adjacent 16-byte chunks of a row; lane = row reads the
 // words back): no block barrier, the waves of a block do not wait for each other.
 __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint32_t *__restrict__ labels,
-                                                 uint8_t *__restrict__ mask, Geo g, int batch, PixelList pl, CompTables t)
+                                                 uint8_t *__restrict__ mask, Geo g, int batch, PixelList pl, CompTables t,
+                                                 uint32_t *__restrict__ oldbits)
 {
     DET_RING(4);
+    // (k_clear's word: the header vouched for these buffers, so the words this kernel left in `oldbits` in the previous call
+    // say where the label map and the mask may be non-zero; otherwise k_clear has zeroed everything)
+    const bool use_old = WIN_CLEARS && pl.hdr->old_bits_valid != 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // (k_clear, the previous launch, was the last reader of these)
         pl.hdr->magic = 0;
         pl.hdr->dense = 0;
@@ -1161,6 +1229,20 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
         const int f = (int)(it / per_frame) * f_mul + f_add, rem = (int)(it % per_frame);
         const int Y0 = rem / groups_x * WIN_CORE, X0 = rem % groups_x * SPAN;
         uint8_t *cf = cls + (size_t)f * g.HW;
+        // what the previous call may have left in the label map and the mask inside this item's cores: one word per core and row
+        // (rows in lanes 16..47, the cores' rows of the window), written by this kernel in that call (`keep` below)
+        static_assert(WIN_GROUP % 4 == 0, "a row's words are loaded four at a time");
+        uint32_t oldw[WIN_GROUP];
+#pragma unroll
+        for (int k = 0; k < WIN_GROUP; ++k) oldw[k] = 0u;
+        uint32_t *item_bits = oldbits + ((size_t)f * per_frame + rem) * (WIN_CORE * WIN_GROUP) + (size_t)(lane - WIN_MARGIN) * WIN_GROUP;   // (lanes 16..47)
+        if (use_old && lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) {
+#pragma unroll
+            for (int k = 0; k < WIN_GROUP / 4; ++k) {
+                const uint4 q = reinterpret_cast<const uint4 *>(item_bits)[k];
+                oldw[4 * k] = q.x; oldw[4 * k + 1] = q.y; oldw[4 * k + 2] = q.z; oldw[4 * k + 3] = q.w;
+            }
+        }
         constexpr int PARTS = WIN_GROUP == 4 ? 2 : 3, PER_PART = ROUNDS / PARTS;
         static_assert(ROUNDS % PARTS == 0, "equal part-batches of loads");
 #pragma unroll 1
@@ -1171,32 +1253,7 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
             const int j = jj + half * PER_PART;
             const int q = lane + 64 * j, r = q / WIN_HALVES, c = q - r * WIN_HALVES;
             const int y = Y0 - WIN_MARGIN + r, xs = X0 - WIN_MARGIN + 16 * c;
-            uint4 &vj = v[jj];
-            vj = make_uint4(0, 0, 0, 0);
-            if (y >= 0 && y < H && xs < W && xs + 16 > 0) {
-                const uint8_t *src = cf + (size_t)y * W + xs;
-                if (xs >= 0 && xs + 16 <= W) {
-                    __builtin_memcpy(&vj, src, 16);   // (any alignment: W need not be a multiple of 4)
-                } else if (xs >= 0 && W >= 16) {
-                    // the chunk sticks out of the row on the right: the row's last 16 bytes, shifted down.  (A loop
-                    // of guarded byte loads here was a chain of round trips in every item of the last column group,
-                    // and those items were the kernel's duration.)
-                    uint4 l;
-                    __builtin_memcpy(&l, src - (xs + 16 - W), 16);
-                    const int drop = xs + 16 - W, a = drop >> 2, b = drop & 3;   // 1..15 bytes
-                    const uint32_t e0 = a == 0 ? l.x : a == 1 ? l.y : a == 2 ? l.z : l.w;
-                    const uint32_t e1 = a == 0 ? l.y : a == 1 ? l.z : a == 2 ? l.w : 0u;
-                    const uint32_t e2 = a == 0 ? l.z : a == 1 ? l.w : 0u;
-                    const uint32_t e3 = a == 0 ? l.w : 0u;
-                    vj = make_uint4(__builtin_amdgcn_alignbyte(e1, e0, b), __builtin_amdgcn_alignbyte(e2, e1, b),
-                                      __builtin_amdgcn_alignbyte(e3, e2, b), __builtin_amdgcn_alignbyte(0u, e3, b));
-                } else {   // frames narrower than 16 pixels
-                    uint32_t d[4] = {0, 0, 0, 0};
-                    for (int k = 0; k < 16; ++k)
-                        if (xs + k >= 0 && xs + k < W) d[k >> 2] |= (uint32_t)src[k] << (8 * (k & 3));
-                    vj = make_uint4(d[0], d[1], d[2], d[3]);
-                }
-            }
+            v[jj] = load16_clipped(cf, y, xs, H, W);
         }
 #pragma unroll
         for (int jj = 0; jj < PER_PART; ++jj) {
@@ -1244,13 +1301,31 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
             }
             const uint64_t T = (uint64_t)t_lo | ((uint64_t)t_hi << 32), M = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
             const uint64_t core_rows = (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) ? 0x0000FFFFFFFF0000ull : 0ull;
-            if (__ballot(((T | M) & core_rows) != 0ull) == 0ull) continue;
-            o.wx0 = X0 + cx * WIN_CORE - WIN_MARGIN;
+            uint32_t keep = 0u;
+            if (__ballot(((T | M) & core_rows) != 0ull) != 0ull) {
+                o.wx0 = X0 + cx * WIN_CORE - WIN_MARGIN;
 #ifdef WIN_DBG_STAGE_ONLY
-            if (T == 0x123456789ull) o.labels[0] = 1;
+                if (T == 0x123456789ull) o.labels[0] = 1;
 #else
-            window_islands(T, M, o, lane, f, cf, pl, t, pc);
+                window_islands(T, M, o, lane, f, cf, pl, t, pc, keep);
 #endif
+            }
+            if (WIN_CLEARS) {
+                if (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) item_bits[cx] = keep;   // for the next call
+                // the previous call's pixels of this core that nobody writes in this one: zero in the label map and in the mask
+                uint32_t old_cx = oldw[0];
+#pragma unroll
+                for (int k = 1; k < WIN_GROUP; ++k) old_cx = cx == k ? oldw[k] : old_cx;
+                const uint32_t z = old_cx & ~keep;
+                if (__ballot(z != 0u) != 0ull) {
+                    const uint32_t row = (uint32_t)(Y0 + lane - WIN_MARGIN) * (uint32_t)W + (uint32_t)(X0 + cx * WIN_CORE);   // (lanes 16..47 only: z is zero elsewhere)
+                    for (uint32_t rest = z; rest; rest &= rest - 1) {
+                        const uint32_t p = row + (uint32_t)__builtin_ctz(rest);
+                        o.labels[p] = 0u;
+                        if (o.mask) o.mask[p] = 0;
+                    }
+                }
+            }
         }
         if constexpr (WIN_GROUP != 4) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the cores' reads of the words before the next item's writes
@@ -1383,6 +1458,7 @@ __device__ __forceinline__ void pass_flatten(const uint8_t *__restrict__ cls, ui
             }
         } else {
             L[p] = 0u;
+            if (mask) mask[flat] = 0;   // (k_windows left the listed pixels to this pass: WIN_CLEARS)
         }
     }
 }
@@ -2334,7 +2410,7 @@ struct Workspace {
     int32_t *nroots, *roots, *order, *bbox, *euler4, *nested, *n_holed, *max_roots, *prev_n, *bbox_tmp, *euler_tmp;
     int2 *holed;
     PixelList pixels;
-    uint32_t *arena_used;
+    uint32_t *arena_used, *oldbits;
     float *det_tmp, *arena;
     uint32_t arena_floats;
     size_t bytes;
@@ -2371,6 +2447,12 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     if (arena_floats > 0x7FFFFFFFull) arena_floats = 0x7FFFFFFFull;
     w.arena_floats = (uint32_t)arena_floats;
     w.arena = (float *)take(sizeof(float) * arena_floats);
+    // k_windows' words for the next call's clearing: per work item (WIN_GROUP cores side by side) 32 rows x WIN_GROUP words
+    {
+        constexpr int SPAN = WIN_GROUP * WIN_CORE;
+        const size_t items = (size_t)batch * ((H + WIN_CORE - 1) / WIN_CORE) * ((W + SPAN - 1) / SPAN);
+        w.oldbits = (uint32_t *)take(sizeof(uint32_t) * items * WIN_CORE * WIN_GROUP);
+    }
     w.bytes = off;
     return w;
 }
@@ -2567,7 +2649,7 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
         long long wblocks = std::min<long long>((items + 3) / 4, window_blocks);
         if (wblocks >= 8) wblocks &= ~7ll;   // (a multiple of 8: the kernel deals its items to the XCDs)
         hipLaunchKernelGGL(k_windows, dim3((unsigned)wblocks), tb, 0, st, cls_dev, labels, mask_dev, g,
-                           batch, w.pixels, t);
+                           batch, w.pixels, t, w.oldbits);
     }
     if (batch >= RESF_MIN_BATCH)
         hipLaunchKernelGGL(k_residue_frames, dim3(batch), dim3(RESF_THREADS), 0, st, cls_dev, labels, mask_dev, g, batch, w.pixels, t,
