@@ -1855,13 +1855,11 @@ __global__ __launch_bounds__(RESF_THREADS) void k_residue_frames(uint8_t *cls, u
 // whose first pixel has such a cell as its west neighbour lies in a hole and is not a detection.
 // Cell states: 0 foreground, 1 reached background, 2 unreached background.
 // ------------------------------------------------------------------------------------------
-constexpr int NEST_LDS_CELLS = 48 * 1024;
-
+// (s_cell / lds_cells: the workgroup's LDS for the window -- k_geometry's own arrays, which its nesting workgroups do not use)
 __device__ void nested_component(const uint32_t *__restrict__ labels, const Geo &g, const CompTables &t, int idx,
                                  const int2 *holed, float *arena, uint32_t arena_floats, uint32_t *arena_used,
-                                 int32_t *status)
+                                 int32_t *status, uint8_t *s_cell, int lds_cells)
 {
-    __shared__ uint8_t s_cell[NEST_LDS_CELLS];
     __shared__ int s_changed;
     __shared__ uint32_t s_off;
     const int f = holed[idx].x, k = holed[idx].y;
@@ -1872,7 +1870,7 @@ __device__ void nested_component(const uint32_t *__restrict__ labels, const Geo 
     const uint32_t *L = labels + (size_t)f * g.HW;
     const int W = g.W, H = g.H;
     uint8_t *cell = s_cell;
-    if (cells > NEST_LDS_CELLS) {
+    if (cells > lds_cells) {
         if (threadIdx.x == 0) {
             uint32_t need = (uint32_t)(cells + 3) / 4;
             uint32_t off = atomicAdd(arena_used, need);
@@ -1930,20 +1928,10 @@ __device__ void nested_component(const uint32_t *__restrict__ labels, const Geo 
     }
 }
 
-// Resident grid over the queued components (usually a handful; see k_clear for why not one block
-// per queue slot).
+// The queued components (usually a handful) are worked on by the first NEST_BLOCKS workgroups of k_geometry's launch (round 5:
+// nothing in k_geometry depends on the outcome -- k_compact drops the nested components -- and as a launch of its own,
+// between k_rank and k_geometry, this was 10-16 us of the labelling chain for a handful of dependent loads).
 constexpr int NEST_BLOCKS = 128;
-__global__ __launch_bounds__(256) void k_nested(const uint32_t *__restrict__ labels, Geo g, CompTables t,
-                                                const int32_t *n_holed, const int2 *holed, float *arena,
-                                                uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
-{
-    DET_RING(12);
-    const int nh = min(*n_holed, HOLED_CAP);
-    for (int idx = blockIdx.x; idx < nh; idx += gridDim.x) {
-        nested_component(labels, g, t, idx, holed, arena, arena_floats, arena_used, status);
-        __syncthreads();
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // k_geometry: a6, a 16-lane group per component (column scan), then its lane 0 (hull, calipers)
@@ -2155,20 +2143,17 @@ __device__ __forceinline__ void column_extent2(const uint32_t *L, int W, int xa,
 
 __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g, const CompTables &t, int f, int k,
                                float *det_tmp, float *arena, uint32_t arena_floats, uint32_t *arena_used,
-                               int32_t *status)
+                               int32_t *status, float *lds, int (*s_top)[GEO_COLS], int (*s_bot)[GEO_COLS])
 {
-    __shared__ float lds[GEO_COMPS * GEO_LDS_STRIDE];
-    __shared__ int s_top[GEO_COMPS][GEO_COLS], s_bot[GEO_COMPS][GEO_COLS];
     GEOSTAMP(0);
     const int grp = threadIdx.x / GEO_GROUP, sub = threadIdx.x % GEO_GROUP;
     // (the component's table entries are requested beside the count that says whether rank k exists, not behind it: the
     // kernel is a chain of round trips per component, and this was one of them)
     const size_t o = (size_t)f * t.max_det + min(k, t.max_det - 1);
     const int n_f = t.nroots[(size_t)f * NR_STRIDE];
-    const bool nested = t.nested[o] != 0;
     const int order = t.order[o];
     const int4 box = *reinterpret_cast<const int4 *>(t.bbox + o * 4);
-    const bool live = k < min(n_f, t.max_det) && !nested;
+    const bool live = k < min(n_f, t.max_det);   // (nested components too: the nesting workgroups of this launch are still at it)
     uint32_t want = 0;
     int minx = 0, maxx = -1, miny = 0, maxy = -1;
     if (live) {
@@ -2304,15 +2289,28 @@ __device__ void geometry_group(const uint32_t *__restrict__ labels, const Geo &g
 constexpr int GEO_BLOCKS = 512;
 __global__ __launch_bounds__(GEO_THREADS) void k_geometry(const uint32_t *__restrict__ labels, Geo g, CompTables t,
                                                           int batch, float *det_tmp, float *arena,
-                                                          uint32_t arena_floats, uint32_t *arena_used, int32_t *status)
+                                                          uint32_t arena_floats, uint32_t *arena_used, int32_t *status,
+                                                          const int32_t *n_holed, const int2 *holed)
 {
     DET_RING(13);
+    __shared__ float lds[GEO_COMPS * GEO_LDS_STRIDE];
+    __shared__ int s_top[GEO_COMPS][GEO_COLS], s_bot[GEO_COMPS][GEO_COLS];
+    static_assert(GEO_THREADS == 256, "nested_component strides by 256 threads");
+    if (blockIdx.x < (unsigned)NEST_BLOCKS) {      // RETR_EXTERNAL nesting: the components with holes, one workgroup each
+        const int nh = min(*n_holed, HOLED_CAP);
+        for (int idx = blockIdx.x; idx < nh; idx += NEST_BLOCKS) {
+            nested_component(labels, g, t, idx, holed, arena, arena_floats, arena_used, status, reinterpret_cast<uint8_t *>(lds),
+                             (int)sizeof(lds));
+            __syncthreads();
+        }
+        return;
+    }
     const int most = min(*t.max_roots, t.max_det);
     const long long items = (long long)((most + GEO_COMPS - 1) / GEO_COMPS) * batch;
-    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+    for (long long it = blockIdx.x - NEST_BLOCKS; it < items; it += gridDim.x - NEST_BLOCKS) {
         const int kb = (int)(it / batch), f = (int)(it - (long long)kb * batch);
         geometry_group(labels, g, t, f, kb * GEO_COMPS + threadIdx.x / GEO_GROUP, det_tmp, arena, arena_floats,
-                       arena_used, status);
+                       arena_used, status, lds, s_top, s_bot);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (this item's LDS reads before the next item's writes, wave by wave)
         __builtin_amdgcn_wave_barrier();
     }
@@ -2660,11 +2658,8 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     YSMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rank, dim3(batch, (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) < 32 ? (max_det + RANK_THREADS / 4 - 1) / (RANK_THREADS / 4) : 32), dim3(RANK_THREADS), 0, st, t, labels, g.HW,
                        width, height, status_dev, w.pixels.hdr, w.n_holed, w.holed);
-    hipLaunchKernelGGL(k_nested, dim3(NEST_BLOCKS), dim3(256), 0, st, labels, g, t, w.n_holed, w.holed, w.arena,
-                       w.arena_floats, w.arena_used, status_dev);
-    YSMR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_geometry, dim3(geo_blocks), dim3(GEO_THREADS), 0, st,
-                       labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev);
+    hipLaunchKernelGGL(k_geometry, dim3(geo_blocks + NEST_BLOCKS), dim3(GEO_THREADS), 0, st,
+                       labels, g, t, batch, w.det_tmp, w.arena, w.arena_floats, w.arena_used, status_dev, w.n_holed, w.holed);
     hipLaunchKernelGGL(k_compact, dim3(batch), dim3(COMPACT_THREADS), 0, st, t, w.det_tmp, det_dev, det_count_dev, anchors_dev, w.pixels,
                        reinterpret_cast<const uint8_t *>(labels), mask_dev, g.total, batch, height, width,
                        (cv_flavour & YSMR_CV_ANGLE_PRE451) != 0);
