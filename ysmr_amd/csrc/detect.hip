@@ -3,7 +3,7 @@
 // of 4); 4-connected hysteresis + 8-connected component labelling, for small islands of foreground in
 // registers as 64 x 64 bit windows (k_windows) and for the rest on a lock-free union-find that lives in
 // the label map (k_residue: pass_union4 .. pass_bbox_euler); RETR_EXTERNAL ordering / nesting (k_rank,
-// k_nested); per-component minAreaRect (k_geometry, k_compact).
+// nested_component in k_geometry's launch); per-component minAreaRect (k_geometry, k_compact).
 // Reference call sites: ysmr/track_eval.py:180-303.
 //
 // All kernels are batched over frames (detection is frame-parallel) and launched as RESIDENT grids
@@ -1470,7 +1470,7 @@ __device__ __forceinline__ void pass_flatten(const uint8_t *__restrict__ cls, ui
 // Rank of every root among its frame's roots (descending pixel index = findContours order); four
 // lanes share a root and split the comparisons.  A component takes its box and Euler number along to its rank
 // (k_windows / pass_bbox_euler filed them under the slot the root was appended at), gets its root's label back
-// (pass_tag_roots), and is queued for k_nested if it has holes.
+// (pass_tag_roots), and is queued for nested_component if it has holes.
 constexpr int RANK_THREADS = 1024;
 constexpr int RANK_BANDS = 2048;      // bands of image rows (LDS histogram)
 constexpr int RANK_BUCKET = 8192;     // roots of a frame the banded ranking holds in LDS
@@ -1567,7 +1567,7 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(CompTables t, uint32_t *l
             t.nested[o] = 0;
             labels[(size_t)f * HW + (uint32_t)mine] = (uint32_t)mine + 1u;
             // components whose Euler number is not 1 have holes and may enclose other components (RETR_EXTERNAL
-            // skips those): queued for k_nested
+            // skips those): queued for nested_component
             if (e4 != 4) {
                 const int at = atomicAdd(n_holed, 1);
                 if (at < HOLED_CAP) holed[at] = make_int2(f, rank);
@@ -2439,7 +2439,7 @@ Workspace carve(void *base, int batch, int H, int W, int max_det)
     w.bbox_tmp = (int32_t *)take(sizeof(int32_t) * bm * 4);
     w.euler_tmp = (int32_t *)take(sizeof(int32_t) * bm);
     w.det_tmp = (float *)take(sizeof(float) * bm * 5);
-    // scratch arena shared by k_geometry (hulls wider than the LDS fast path) and k_nested (windows
+    // scratch arena shared by k_geometry (hulls wider than the LDS fast path) and its nesting workgroups (windows
     // larger than LDS): room for 16 full-width hulls per frame, and at least one full-frame window
     size_t arena_floats = (size_t)batch * std::max<size_t>(16 * 5 * (2 * (size_t)W + 3), ((size_t)(H + 2) * (W + 2) + 3) / 4);
     if (arena_floats > 0x7FFFFFFFull) arena_floats = 0x7FFFFFFFull;
