@@ -350,6 +350,8 @@ def main():
                 "threshold_us_per_64_frames": sum(ms) / len(ms) * 1e3 * 64.0 / B,
                 "components_us_per_64_frames": (sum(e0.elapsed_time(e1) for e0, e1, _ in chain_events) / len(chain_events) * 1e3 * 64.0 / B) if chain_events else None,
                 "threshold_us_per_batch": stats_us([m * 1e3 for m in ms]),
+                # in launch order (two per step): a launch at twice the others' time had a workgroup wait for a compute unit
+                "threshold_us_by_launch": [round(m * 1e3) for m in ms],
                 "components_us_per_batch": stats_us([e0.elapsed_time(e1) * 1e3 for e0, e1, _ in chain_events]),
                 "link_us_per_frame": stats_us([e0.elapsed_time(e1) * 1e3 / n for e0, e1, n, _ in link_events]),
                 "link_host_issue_us_per_frame": stats_us([h * 1e6 / n for _, _, n, h in link_events]),

@@ -2048,6 +2048,28 @@ __global__ void k_peek(TrackerDev t, int32_t *ids, double *xy, int32_t *gone, in
 
 }  // namespace
 
+// One wave that waits `ticks` x 10 ns (the 100 MHz realtime counter), in front of every launch of the batch link.  In the pipeline the
+// event behind a link launch releases two things at the same instant: the NEXT link launch (same stream) and the detection of the
+// batch whose buffers that launch was reading -- the threshold kernel's 248 workgroups, one per free compute unit, 31 per XCD.  A link
+// workgroup that takes its seat while those 248 are being placed, on an XCD where the previous launch's unit is not free yet, leaves
+// that XCD one unit short: one threshold workgroup then waits for another to finish its frame, and the launch takes 372-379 us instead
+// of 203 -- none in most runs, every eighth launch in some (profiles/r05_thr_launch_outliers.log: always at a link boundary; with a
+// 3 us wait here EVERY launch, with 6 us one run in eight, with 10 us none).  The wait lets the 248 sit down first; the link's
+// workgroup then finds its XCD's spare unit.  12 us per launch of up to 256 frames (0.8 % of the link's time at the bench's size).
+#ifndef BL_PAUSE_TICKS_N
+#define BL_PAUSE_TICKS_N 1200
+#endif
+constexpr int BL_PAUSE_TICKS = BL_PAUSE_TICKS_N;
+__global__ __launch_bounds__(64) void k_pause(int ticks)
+{
+    unsigned long long t0, t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    do {
+        __builtin_amdgcn_s_sleep(8);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    } while (t - t0 < (unsigned long long)ticks);
+}
+
 extern "C" {
 
 int ysmr_gsff_gains(double fps, int n_min, double n_max, int n_f, int32_t *n_i_out, double *gains_out)
@@ -2393,6 +2415,7 @@ int ysmr_tracker_run(ysmr_tracker *t, void *stream, const float *det_dev, const 
             ka.t = t->d; ka.bd = bd; ka.det_all = det; ka.det_count = det_count_dev + f0; ka.batch = nb;
             ka.frame0 = first_frame_index + f0; ka.rows = rows_dev; ka.rows_capacity = (long long)rows_capacity;
             ka.row_count = (long long *)row_count_dev; ka.gains = t->bgains_dev;
+            if (BL_PAUSE_TICKS > 0) hipLaunchKernelGGL(k_pause, dim3(1), dim3(64), 0, (hipStream_t)stream, BL_PAUSE_TICKS);
             hipLaunchKernelGGL(k_batch, dim3(1), dim3(BL_THREADS), t->batch_lds, (hipStream_t)stream, ka);
             YSMR_LAUNCH_CHECK();
         }
