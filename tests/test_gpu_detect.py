@@ -590,6 +590,34 @@ def test_detector_reuse_clears_what_the_previous_call_wrote(torch_cuda, oracle):
     _compare(oracle, clips[0], got, p, max_det=8192)
 
 
+def test_detector_without_a_final_mask_call_after_call(torch_cuda):
+    """mask_dev = NULL (Detector(want_mask=False)): the label map is cleared and written the same way call after call -- the
+    record of where the previous call wrote lives in the workspace, not in the mask -- and everything but the mask equals a
+    detector's that keeps one, on clips that differ from call to call (a shorter batch in between: that call clears in full)."""
+    torch = torch_cuda
+    from ysmr_amd.detect import Detector, threshold_params
+    from ysmr_amd.synth import SyntheticVideo
+    p = threshold_params(True, 5, 2.0)
+    h, w = 200, 312
+    with_mask = Detector(4, h, w, max_det=4096, params=p)
+    without = Detector(4, h, w, max_det=4096, params=p, want_mask=False)
+    rng = np.random.default_rng(3)
+    clips = [SyntheticVideo(h, w, 60, seed=15).frames(4), SyntheticVideo(h, w, 25, seed=16).frames(4),
+             SyntheticVideo(h, w, 40, seed=17).frames(2), SyntheticVideo(h, w, 30, seed=18).frames(4),
+             rng.integers(0, 256, (4, h, w), dtype=np.uint8), SyntheticVideo(h, w, 30, seed=19).frames(4)]
+    for k, frames in enumerate(clips):
+        dev = torch.from_numpy(frames).cuda()
+        a, b = with_mask.detect(dev), without.detect(dev)
+        torch.cuda.synchronize()
+        assert b.mask is None and a.mask is not None
+        for name in ("cls", "labels", "det_count", "anchors", "status"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), f"call {k}: {name}"
+        n = a.det_count.cpu().numpy()
+        for f in range(frames.shape[0]):
+            assert torch.equal(a.det[f, :n[f]], b.det[f, :n[f]]), f"call {k} frame {f}: det"
+        assert torch.equal((a.labels != 0), (a.mask != 0))
+
+
 # ---- mean-gray branch ('adaptive double threshold' < 0; track_eval.py:219-253) -------------------
 @pytest.mark.parametrize("channels", [1, 3])
 @pytest.mark.parametrize("white", [True, False])

@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
         uint32_t oldw[WIN_GROUP];
 #pragma unroll
         for (int k = 0; k < WIN_GROUP; ++k) oldw[k] = 0u;
-        uint32_t *item_bits = oldbits + ((size_t)f * per_frame + rem) * (WIN_CORE * WIN_GROUP) + (size_t)(lane - WIN_MARGIN) * WIN_GROUP;   // (lanes 16..47)
+        uint32_t *item_bits = oldbits + ((size_t)f * per_frame + rem) * (WIN_CORE * WIN_GROUP) + (size_t)((lane - WIN_MARGIN) & (WIN_CORE - 1)) * WIN_GROUP;   // (used by lanes 16..47: the core's rows)
         if (use_old && lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) {
 #pragma unroll
             for (int k = 0; k < WIN_GROUP / 4; ++k) {
