@@ -1243,6 +1243,9 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
                 oldw[4 * k] = q.x; oldw[4 * k + 1] = q.y; oldw[4 * k + 2] = q.z; oldw[4 * k + 3] = q.w;
             }
         }
+        uint32_t old_any = 0u;      // bit k: the previous call left something in core k (most cores of most items: nothing)
+#pragma unroll
+        for (int k = 0; k < WIN_GROUP; ++k) old_any |= (__ballot(oldw[k] != 0u) != 0ull ? 1u : 0u) << k;
         constexpr int PARTS = WIN_GROUP == 4 ? 2 : 3, PER_PART = ROUNDS / PARTS;
         static_assert(ROUNDS % PARTS == 0, "equal part-batches of loads");
 #pragma unroll 1
@@ -1302,7 +1305,11 @@ __global__ __launch_bounds__(256) void k_windows(uint8_t *__restrict__ cls, uint
             const uint64_t T = (uint64_t)t_lo | ((uint64_t)t_hi << 32), M = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
             const uint64_t core_rows = (lane >= WIN_MARGIN && lane < WIN_MARGIN + WIN_CORE) ? 0x0000FFFFFFFF0000ull : 0ull;
             uint32_t keep = 0u;
-            if (__ballot(((T | M) & core_rows) != 0ull) != 0ull) {
+            const bool has_class = __ballot(((T | M) & core_rows) != 0ull) != 0ull;
+            // nothing here now and nothing before: the core's words stay zero (a call that does not go by the words writes them all:
+            // what it finds there may be anything)
+            if (use_old && !has_class && !((old_any >> cx) & 1u)) continue;
+            if (has_class) {
                 o.wx0 = X0 + cx * WIN_CORE - WIN_MARGIN;
 #ifdef WIN_DBG_STAGE_ONLY
                 if (T == 0x123456789ull) o.labels[0] = 1;
