@@ -36,21 +36,25 @@ def wave_ends():
 
 def report(title, ev, keep):
     by = {}
-    ends = wave_ends()
-    newest = max(fr for _, ph, fr in ev if ph == 4)
+    # (k_track_lanes, the per-track half since round 5, carries no stamps: its time is then the interval between k_link's end and
+    # the next k_link's entry)
+    order = ORDER if any(ph == 4 for _, ph, _ in ev) else [p for p in ORDER if p >= 9]
     for t, ph, fr in ev:
         if ph in PH and keep(fr): by.setdefault(fr, {})[ph] = t
-    for fr in by:                      # (the per-wave slots hold the last 64 frames only)
-        if fr > newest - 60: by[fr][8] = int(ends[fr & 63])
+    if order is ORDER:
+        ends = wave_ends()
+        newest = max(fr for _, ph, fr in ev if ph == 4)
+        for fr in by:                      # (the per-wave slots hold the last 64 frames only)
+            if fr > newest - 60: by[fr][8] = int(ends[fr & 63])
     rows = []
     for fr in sorted(by):
         d, nx = by[fr], by.get(fr + 1)
-        if all(p in d for p in ORDER) and nx and 9 in nx:
-            ts = [d[p] for p in ORDER] + [nx[9]]
+        if all(p in d for p in order) and nx and 9 in nx:
+            ts = [d[p] for p in order] + [nx[9]]
             rows.append(np.diff(ts))
     r = np.array(rows) / 100.0          # s_memrealtime ticks at 100 MHz
     print(f"{title}: {len(r)} frames; median / mean / p90 us")
-    names = [f"{PH[a]} -> {PH[b]}" for a, b in zip(ORDER, ORDER[1:])] + ["track last block done -> next link entry"]
+    names = [f"{PH[a]} -> {PH[b]}" for a, b in zip(order, order[1:])] + [("track last block done" if order is ORDER else "link end (k_track_lanes, unstamped)") + " -> next link entry"]
     for i, nm in enumerate(names):
         print(f"  {nm:44s} {np.median(r[:, i]):7.2f} {r[:, i].mean():7.2f} {np.percentile(r[:, i], 90):7.2f}")
     tot = r.sum(axis=1)
