@@ -590,6 +590,36 @@ def test_detector_reuse_clears_what_the_previous_call_wrote(torch_cuda, oracle):
     _compare(oracle, clips[0], got, p, max_det=8192)
 
 
+def test_many_large_components_call_after_call(torch_cuda, oracle):
+    """More large components (boxes of 64 x 64 pixels and more) per batch than the workspace header once had names for (16): the
+    record k_windows leaves covers components of any size, so such batches are cleared like any other -- discs and rings of
+    radius 34..60 at other places in every call, label map and mask against scipy / the oracle in full."""
+    import torch
+    from scipy import ndimage
+    from ysmr_amd.detect import Detector
+    rng = np.random.default_rng(5)
+    b, h, w, max_det = 3, 300, 420, 256
+    det = Detector(b, h, w, max_det=max_det)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for call in range(4):
+        cls = np.zeros((b, h, w), np.uint8)
+        for f in range(b):
+            for _ in range(9):
+                cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(34, 61)
+                d = np.hypot(yy - cy, xx - cx)
+                cls[f][(d < r) & ((rng.random() < 0.5) | (d > r - 3))] |= 1
+            cls[f][(rng.random((h, w)) < 0.002) & (cls[f] > 0)] |= 2
+        res = det.components(cls=torch.from_numpy(cls).cuda())
+        torch.cuda.synchronize()
+        assert int(res.status.max().item()) == 0
+        for f in range(b):
+            ref_mask = ndimage.binary_propagation((cls[f] & 2) != 0, mask=(cls[f] & 1) != 0)
+            np.testing.assert_array_equal(res.mask[f].cpu().numpy() > 0, ref_mask, err_msg=f"call {call} frame {f}")
+            labels, rects, anchors, n = oracle.components(ref_mask.astype(np.uint8), max_det=max_det)
+            np.testing.assert_array_equal(res.labels[f].cpu().numpy(), labels, err_msg=f"call {call} frame {f}")
+            assert int(res.det_count[f].item()) == n
+
+
 def test_detector_without_a_final_mask_call_after_call(torch_cuda):
     """mask_dev = NULL (Detector(want_mask=False)): the label map is cleared and written the same way call after call -- the
     record of where the previous call wrote lives in the workspace, not in the mask -- and everything but the mask equals a

@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void k_clear(PixelList pl, CompTables t, uint8
     const size_t HW = (size_t)H * W;
     if (h.magic == WS_MAGIC && h.labels == (unsigned long long)labels && h.mask == (unsigned long long)mask &&
         h.total == total && h.batch == batch && h.H == H && h.W == W && h.max_det == t.max_det && !h.dense &&
-        h.n_big <= (uint32_t)WS_BIG) {
+        (WIN_CLEARS || h.n_big <= (uint32_t)WS_BIG)) {      // (the boxes' limit: k_windows' words cover components of any size)
         // k_windows zeroes what the previous call left, core by core, from the words it wrote then (WIN_CLEARS)
         if (WIN_CLEARS) {
             if (blockIdx.x == 0 && threadIdx.x == 0) pl.hdr->old_bits_valid = 1u;
