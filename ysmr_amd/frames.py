@@ -466,7 +466,6 @@ class DeviceFrameFeed:
 
     def _allocate(self, shape):
         import torch
-        video = self.video
         if self._raw is not None:
             raw_bytes, _, _, _, palette = self._raw
             self._pinned = [torch.empty((self.B, raw_bytes), dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
