@@ -906,6 +906,10 @@ constexpr int WIN_HALVES = 2 * (WIN_GROUP + 1);                  // 16-pixel hal
 #define WINDOW_BLOCKS_N 1024
 #endif
 constexpr int WINDOW_BLOCKS = WINDOW_BLOCKS_N;
+#ifndef WINDOW_BLOCKS_FREE_N
+#define WINDOW_BLOCKS_FREE_N 8192
+#endif
+constexpr int WINDOW_BLOCKS_FREE = WINDOW_BLOCKS_FREE_N;   // k_windows' grid where no per-frame link kernel runs beside it (components_batch)
 
 __device__ __forceinline__ uint64_t row_above(uint64_t v)   // lane r: the mask of lane r-1 (0 into lane 0)
 {
@@ -2640,7 +2644,15 @@ int ysmr_components_batch(void *stream, int batch, int height, int width, void *
     // (the LDS reserve matters to k_frame, the one-launch link, which tables of more than 2456 detections do not use
     // and which the caller announces with YSMR_BESIDE_LINK)
     const bool small_tables = max_det <= 2456 && (cv_flavour & YSMR_BESIDE_LINK);
-    const unsigned window_blocks = kn.collect_blocks > 0 ? (unsigned)kn.collect_blocks : (unsigned)(small_tables ? WINDOW_BLOCKS : 2 * WINDOW_BLOCKS);
+    // k_windows' grid.  Beside the per-frame link kernels (one-launch or split) it stays a RESIDENT grid that leaves them their LDS
+    // and wave slots.  Beside the batch link -- one workgroup that has long been seated -- or with no link at all, a wave per work item
+    // and the dispatcher hands the workgroups out as units become free: the work items differ (a core with twenty islands, a core
+    // with none), and 2048 resident workgroups with 4.4 items per wave ended as late as the unluckiest of them (round 5, last hours:
+    // 293 -> 267-270 us of labelling chain per 256 frames with 7168-8192 workgroups, scripts/sweep_window_blocks.sh; the link's
+    // time does not change)
+    const bool per_frame_link = (cv_flavour & (YSMR_BESIDE_LINK | YSMR_BESIDE_SPLIT_LINK)) != 0;
+    const unsigned window_blocks = kn.collect_blocks > 0 ? (unsigned)kn.collect_blocks
+                                   : (unsigned)(small_tables ? WINDOW_BLOCKS : (per_frame_link ? 2 * WINDOW_BLOCKS : WINDOW_BLOCKS_FREE));
     const unsigned sparse_blocks = kn.sparse_blocks > 0 ? (unsigned)kn.sparse_blocks : (unsigned)SPARSE_BLOCKS;
     const unsigned clear_blocks = kn.clear_blocks > 0 ? (unsigned)kn.clear_blocks : (unsigned)CLEAR_BLOCKS;
     const unsigned geo_blocks = kn.geo_blocks > 0 ? (unsigned)kn.geo_blocks : (unsigned)(small_tables ? GEO_BLOCKS : 3 * GEO_BLOCKS);
