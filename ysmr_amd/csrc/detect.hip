@@ -8,7 +8,9 @@
 //
 // All kernels are batched over frames (detection is frame-parallel) and launched as RESIDENT grids
 // that stride over their work (a grid larger than the chip holds starves every other HIP stream,
-// i.e. the link, until it has drained).  Only k_threshold_strip, k_windows and the dense fallback of
+// i.e. the per-frame link kernels, until it has drained) -- except k_windows where no such kernel runs
+// beside it (the batch link is one workgroup that has long been seated): there it is a wave per work
+// item, handed out by the dispatcher.  Only k_threshold_strip, k_windows and the dense fallback of
 // k_clear touch every pixel.
 //
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
